@@ -1,0 +1,120 @@
+"""ctypes binding of libhumor_amd.so (C ABI: include/humor_amd.h).
+
+The product path loads humor_amd/csrc/libhumor_amd.so -- the hipcc/gfx950 build -- and raises if it is missing
+or if the device is not a gfx950: there is no CPU or PyTorch fallback for the kernels.
+(`load(path)` exists so the CPU-only test tier can bind the host SIMT-emulator build of the same sources.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, 'csrc', 'libhumor_amd.so')
+
+HA_OK = 0
+ABI_VERSION = 1
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int32)
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [('n_linear', C.c_int), ('in_dim', C.c_int), ('skip_dim', C.c_int), ('out_dims', C.c_int * 8),
+                ('w', C.c_void_p * 8), ('b', C.c_void_p * 8), ('gn_gamma', C.c_void_p * 8), ('gn_beta', C.c_void_p * 8)]
+
+
+_SIGS = {
+    'ha_last_error': (C.c_char_p, []),
+    'ha_abi_version': (C.c_int, []),
+    'ha_device_arch': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    'ha_smpl_model_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
+    'ha_smpl_model_destroy': (C.c_int, [C.c_void_p]),
+    'ha_smpl_model_info': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    'ha_smpl_model_define_subset': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    'ha_smpl_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]),
+    'ha_smpl_workspace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'ha_smpl_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
+    'ha_lbs_skin': (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),
+    'ha_rodrigues_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_rodrigues_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_rotmat_to_aa_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_rotmat_to_aa_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_humor_net_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(MlpDesc), C.POINTER(MlpDesc)]),
+    'ha_humor_net_destroy': (C.c_int, [C.c_void_p]),
+    'ha_humor_rollout_workspace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    'ha_humor_rollout_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p]),
+    'ha_humor_rollout_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
+}
+
+
+class HumorAmdError(RuntimeError):
+    pass
+
+
+class Lib:
+    """Thin checked wrapper: every C entry point becomes a method that raises HumorAmdError on non-zero status."""
+
+    def __init__(self, path, emulator=False):
+        if not os.path.exists(path):
+            raise HumorAmdError(
+                f'{path} not found: build the gfx950 extension first (python -m humor_amd.build, or '
+                f'__graft_entry__.build()).  humor_amd has no CPU/PyTorch fallback for its kernels.')
+        self.path = path
+        self.emulator = emulator
+        self._dll = C.CDLL(path)
+        missing = []
+        for name, (res, args) in _SIGS.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        self.missing = missing
+        if self._dll.ha_abi_version() != ABI_VERSION:
+            raise HumorAmdError(f'{path}: ABI version mismatch')
+
+    def exports(self, name):
+        return name not in self.missing
+
+    def call(self, name, *args):
+        rc = getattr(self._dll, name)(*args)
+        if rc != HA_OK:
+            msg = self._dll.ha_last_error()
+            raise HumorAmdError(f'{name} failed (status {rc}): {msg.decode() if msg else "?"}')
+
+    def device_arch(self, device):
+        buf = C.create_string_buffer(128)
+        self.call('ha_device_arch', int(device), buf, 128)
+        return buf.value.decode()
+
+
+_lib = None
+
+
+def load(path, emulator=False):
+    return Lib(path, emulator=emulator)
+
+
+def get_lib():
+    """The product library (gfx950 build).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        _lib = Lib(DEFAULT_LIB)
+    return _lib
+
+
+def ptr(t):
+    """Raw data pointer of a contiguous tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'humor_amd kernels need contiguous tensors'
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(t):
+    """The current HIP stream of the tensor's device as void* (0 for host/emulator tensors)."""
+    if t.is_cuda:
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)

@@ -1,0 +1,292 @@
+"""Drop-in replacement for the reference's ``BodyModel`` (humor/body_model/body_model.py:11-115) whose arithmetic
+runs in libhumor_amd.so (gfx950 HIP kernels) instead of the smplx package.
+
+Same constructor and ``forward`` signature, same output object (attributes ``v, f, betas, Jtr, pose_body,
+full_pose, pose_hand``), differentiable w.r.t. ``root_orient, pose_body, pose_hand, betas, trans``.
+
+Extensions that do not change the reference semantics:
+  * any N <= anything works (the reference needs N == batch_size only because smplx bakes default parameters);
+  * ``vertex_subset=ids``: ``v`` is then ``[N, len(ids), 3]`` (those vertices, in that order) instead of all
+    6890 -- the fitting losses consume 43 ``KEYPT_VERTS`` + the 21 selector vertices, and the
+    wave-per-frame kernel evaluates exactly those;
+  * model constants are packed/uploaded once per (file, num_betas, device) and shared by later constructions
+    (run_fitting.py:351 builds a fresh BodyModel per batch).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+# smplx/vertex_ids.py (release 0.1.28), 'smplh' table, in VertexJointSelector order:
+# face (nose, reye, leye, rear, lear), feet (L big/small/heel, R big/small/heel), left-hand tips, right-hand tips
+# (thumb, index, middle, ring, pinky).  See oracle/lbs_restated.py for the name -> id table.
+SMPLH_SELECTOR_VERTS = [332, 6260, 2800, 4071, 583,
+                        3216, 3226, 3387, 6617, 6624, 6787,
+                        2746, 2319, 2445, 2556, 2673,
+                        6191, 5782, 5905, 6016, 6133]
+SMPLX_SELECTOR_VERTS = [9120, 9929, 9448, 616, 6,
+                        5770, 5780, 8846, 8463, 8474, 8635,
+                        5361, 4933, 5058, 5169, 5286,
+                        8079, 7669, 7794, 7905, 8022]
+NUM_JOINTS = {'smpl': 23, 'smplh': 51, 'smplx': 54}   # smplx.{SMPL,SMPLH,SMPLX}.NUM_JOINTS (root excluded)
+NUM_HAND_JOINTS = 15
+SHAPE_SPACE_DIM = 300
+
+
+class Struct(object):
+    def __init__(self, **kwargs):
+        for key, val in kwargs.items():
+            setattr(self, key, val)
+
+
+class _Handle:
+    """Owns one ha_smpl_model (per file/num_betas/device)."""
+
+    def __init__(self, lib, device_index, data, num_betas):
+        self.lib = lib
+        self.ptr = C.c_void_p()
+        f32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        v_template = f32(data['v_template'])
+        shapedirs = f32(np.asarray(data['shapedirs'])[:, :, :num_betas])
+        posedirs = f32(data['posedirs'])
+        J_regressor = f32(data['J_regressor'])
+        weights = f32(data['weights'])
+        kintree = np.asarray(data['kintree_table'])
+        parents = np.ascontiguousarray(kintree[0].astype(np.int64).astype(np.int32))
+        parents[0] = -1
+        self.V, self.J, self.NB = v_template.shape[0], J_regressor.shape[0], shapedirs.shape[2]
+        assert posedirs.shape == (self.V, 3, (self.J - 1) * 9), 'posedirs must be [V,3,(J-1)*9]'
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        lib.call('ha_smpl_model_create', C.byref(self.ptr), device_index, self.V, self.J, self.NB,
+                 vp(v_template), vp(shapedirs), vp(posedirs), vp(J_regressor), vp(weights), vp(parents))
+        self.subsets = {}     # tuple(ids) -> slot
+        self.faces = torch.from_numpy(np.asarray(data['f']).astype(np.int64))
+
+    def info(self, what):
+        out = C.c_int()
+        self.lib.call('ha_smpl_model_info', self.ptr, what, C.byref(out))
+        return out.value
+
+    def subset_slot(self, ids):
+        key = tuple(int(i) for i in ids)
+        if key not in self.subsets:
+            slot = len(self.subsets) + 1
+            if slot > 7:
+                raise _lib.HumorAmdError('at most 7 vertex subsets per SMPL model handle')
+            arr = np.ascontiguousarray(np.array(key, dtype=np.int32))
+            self.lib.call('ha_smpl_model_define_subset', self.ptr, slot, arr.ctypes.data_as(C.c_void_p), len(key))
+            self.subsets[key] = slot
+        return self.subsets[key]
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.call('ha_smpl_model_destroy', self.ptr)
+        except Exception:
+            pass
+
+
+_HANDLES = {}
+
+
+def _get_handle(lib, path, num_betas, device_index):
+    st = os.stat(path)
+    key = (lib.path, os.path.realpath(path), st.st_mtime_ns, num_betas, device_index)
+    if key not in _HANDLES:
+        data = np.load(path, encoding='latin1', allow_pickle=True)
+        _HANDLES[key] = _Handle(lib, device_index, data, num_betas)
+    return _HANDLES[key]
+
+
+class _SmplFunction(torch.autograd.Function):
+    """(pose [N,J*3], betas [N,NB], transl [N,3]) -> (v, Jtr).  cfg selects dense / subset evaluation."""
+
+    @staticmethod
+    def forward(ctx, pose, betas, transl, cfg):
+        h, lib = cfg['handle'], cfg['handle'].lib
+        N = pose.shape[0]
+        pose, betas, transl = pose.contiguous(), betas.contiguous(), transl.contiguous()
+        st = _lib.stream_ptr(pose)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=pose.device)
+        joints = new(N, h.J, 3)
+        n_sel = len(cfg['selector'])
+        if cfg['mode'] == 'dense':
+            verts = new(N, h.V, 3)
+            A = new(N, h.J, 12)
+            nv, nc = C.c_int64(), C.c_int64()
+            lib.call('ha_smpl_workspace', h.ptr, N, cfg['n_active'], C.byref(nv), C.byref(nc))
+            ws_v, ws_c = new(nv.value), new(nc.value)
+            lib.call('ha_smpl_forward', h.ptr, 0, N, cfg['n_active'], _lib.ptr(pose), _lib.ptr(betas), _lib.ptr(transl),
+                     _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(A), _lib.ptr(ws_v), _lib.ptr(ws_c), cfg['algo'], st)
+            if n_sel:
+                joints = torch.cat([joints, verts.index_select(1, cfg['selector_t'].to(verts.device))], dim=1)
+            v_out = verts
+        else:
+            nS = len(cfg['subset_all'])
+            vs = new(N, nS, 3)
+            lib.call('ha_smpl_forward', h.ptr, cfg['slot_all'], N, cfg['n_active'], _lib.ptr(pose), _lib.ptr(betas),
+                     _lib.ptr(transl), _lib.ptr(vs), _lib.ptr(joints), None, None, None, 1, st)
+            if n_sel:
+                joints = torch.cat([joints, vs[:, :n_sel]], dim=1)
+            v_out = vs[:, n_sel:].contiguous()
+        ctx.cfg = cfg
+        ctx.save_for_backward(pose, betas)
+        ctx.set_materialize_grads(False)
+        return v_out, joints
+
+    @staticmethod
+    def backward(ctx, g_v, g_joints):
+        cfg = ctx.cfg
+        h, lib = cfg['handle'], cfg['handle'].lib
+        pose, betas = ctx.saved_tensors
+        N = pose.shape[0]
+        n_sel = len(cfg['selector'])
+        if g_v is None and g_joints is None:
+            return None, None, None, None
+        dev = pose.device
+        g_j52 = g_extra = None
+        if g_joints is not None:
+            g_joints = g_joints.contiguous()
+            g_j52 = g_joints[:, :h.J].contiguous()
+            if n_sel:
+                g_extra = g_joints[:, h.J:]
+        if cfg['mode'] == 'dense':
+            if g_v is not None:
+                slot, g_set = 0, g_v.contiguous()
+                if g_extra is not None:
+                    g_set = g_set.clone()
+                    g_set.index_add_(1, cfg['selector_t'].to(dev), g_extra)
+            elif g_extra is not None:
+                slot, g_set = cfg['slot_sel'], g_extra.contiguous()
+            else:
+                slot, g_set = 0, None
+        else:
+            slot = cfg['slot_all']
+            nS = len(cfg['subset_all'])
+            g_set = torch.zeros(N, nS, 3, dtype=torch.float32, device=dev)
+            if g_extra is not None:
+                g_set[:, :n_sel] = g_extra
+            if g_v is not None:
+                g_set[:, n_sel:] = g_v
+        g_pose = torch.empty_like(pose)
+        g_betas = torch.empty_like(betas)
+        g_transl = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        lib.call('ha_smpl_backward', h.ptr, slot, N, cfg['n_active'], _lib.ptr(pose), _lib.ptr(betas),
+                 _lib.ptr(g_set) if g_set is not None else None, _lib.ptr(g_j52) if g_j52 is not None else None,
+                 _lib.ptr(g_pose), _lib.ptr(g_betas), _lib.ptr(g_transl), _lib.stream_ptr(pose))
+        return g_pose, g_betas, g_transl, None
+
+
+class _BmShim(nn.Module):
+    """Stands in for ``BodyModel.bm`` (the smplx layer): the reference reads ``bm.faces_tensor`` (body_model.py:95)."""
+
+    def __init__(self, faces):
+        super().__init__()
+        self.register_buffer('faces_tensor', faces, persistent=False)
+
+
+class BodyModel(nn.Module):
+    '''
+    SMPL / SMPL+H / SMPL-X body model evaluated by the MI355X kernels.  Interface of
+    humor/body_model/body_model.py:11-115.
+    '''
+
+    def __init__(self, bm_path, num_betas=10, batch_size=1, num_expressions=10, use_vtx_selector=False,
+                 model_type='smplh', vertex_subset=None, algo=0, _lib_override=None):
+        super(BodyModel, self).__init__()
+        assert model_type in ['smpl', 'smplh', 'smplx']
+        if '.npz' not in bm_path:
+            raise _lib.HumorAmdError('humor_amd.BodyModel reads the .npz body-model format (as the reference does for SMPL+H)')
+        if model_type == 'smplx':
+            raise NotImplementedError('SMPL-X (expression / jaw / eye blend terms) is not on the fitting path')
+        self.use_vtx_selector = use_vtx_selector
+        self.model_type = model_type
+        self.num_joints = NUM_JOINTS[model_type]
+        self.num_betas = num_betas
+        self.batch_size = batch_size
+        self.bm_path = bm_path
+        self._lib = _lib_override
+        self._algo = algo
+        self._handles = {}
+        self._selector = list(SMPLH_SELECTOR_VERTS) if use_vtx_selector else []
+        self._subset = None if vertex_subset is None else [int(i) for i in vertex_subset]
+        faces = torch.from_numpy(np.asarray(np.load(bm_path, encoding='latin1', allow_pickle=True)['f']).astype(np.int64))
+        self.bm = _BmShim(faces)
+
+    # ------------------------------------------------------------------------------------------------
+    def _handle_for(self, device):
+        lib = self._lib if self._lib is not None else _lib.get_lib()
+        if device.type == 'cuda':
+            index = device.index if device.index is not None else torch.cuda.current_device()
+        elif lib.emulator:
+            index = 0
+        else:
+            raise _lib.HumorAmdError('humor_amd.BodyModel runs on the GPU only: move the inputs to a CUDA(HIP) device '
+                                     '(there is no CPU fallback)')
+        key = (device.type, index)
+        if key not in self._handles:
+            self._handles[key] = _get_handle(lib, self.bm_path, self.num_betas, index)
+        return self._handles[key]
+
+    def forward(self, root_orient=None, pose_body=None, pose_hand=None, pose_jaw=None, pose_eye=None, betas=None,
+                trans=None, dmpls=None, expression=None, return_dict=False, **kwargs):
+        '''
+        Note dmpls are not supported.
+        '''
+        assert (dmpls is None)
+        given = [t for t in (root_orient, pose_body, pose_hand, betas, trans) if t is not None]
+        if not given:
+            raise ValueError('BodyModel.forward needs at least one tensor argument')
+        N = max(t.shape[0] for t in given)
+        ref = given[0]
+        zeros = lambda d: torch.zeros(N, d, dtype=torch.float32, device=ref.device)
+        h = self._handle_for(ref.device)
+        nbody = 3 * (min(h.J, 22) - 1)
+        root_orient = zeros(3) if root_orient is None else root_orient
+        pose_body = zeros(nbody) if pose_body is None else pose_body
+        betas = zeros(h.NB) if betas is None else betas
+        trans_in = zeros(3) if trans is None else trans
+        has_hands = self.model_type in ['smplh', 'smplx']
+        nhand = 2 * NUM_HAND_JOINTS * 3 if has_hands else 0
+        rest = h.J * 3 - 3 - nbody - nhand       # SMPL's two hand joints live in body_pose (69 values)
+        if pose_hand is None:
+            n_active = 1 + nbody // 3
+            full_pose = torch.cat([root_orient, pose_body, zeros(nhand + rest)], dim=1)
+            pose_hand_out = zeros(nhand) if has_hands else None
+        else:
+            n_active = h.J
+            full_pose = torch.cat([root_orient, pose_body, pose_hand] + ([zeros(rest)] if rest else []), dim=1)
+            pose_hand_out = pose_hand
+        if betas.shape[0] != N:
+            betas = betas.expand(N, -1)
+
+        if self._subset is None:
+            cfg = dict(mode='dense')
+        else:
+            subset_all = self._selector + self._subset
+            cfg = dict(mode='subset', subset_all=subset_all, slot_all=h.subset_slot(subset_all))
+        cfg.update(handle=h, n_active=n_active, selector=self._selector, algo=self._algo)
+        if self._selector:
+            cfg['selector_t'] = torch.tensor(self._selector, dtype=torch.long)
+            cfg['slot_sel'] = h.subset_slot(self._selector)
+        v, joints = _SmplFunction.apply(full_pose.float(), betas.float(), trans_in.float(), cfg)
+
+        out = {
+            'v': v,
+            'f': self.bm.faces_tensor,
+            'betas': betas,
+            'Jtr': joints,
+            'pose_body': pose_body,
+            'full_pose': full_pose,
+        }
+        if has_hands:
+            out['pose_hand'] = pose_hand_out
+        if not self.use_vtx_selector:
+            out['Jtr'] = out['Jtr'][:, :self.num_joints + 1]
+        if not return_dict:
+            out = Struct(**out)
+        return out

@@ -1,0 +1,55 @@
+// Packed SMPL(+H) model constants, resident in HBM (one copy per device, ~100 MB incl. both posedirs layouts).
+#pragma once
+#include "common.h"
+
+namespace ha {
+
+constexpr int kMaxSubsets = 8;
+constexpr int kMaxJoints = 64;   // one lane per joint in the wave-per-frame kernels
+constexpr int kChunk = 64;       // vertices per wave chunk
+
+// The per-frame blend coefficient vector c (length Kfull = NB + 1 + P) is ordered so that the part that is
+// non-zero when trailing joints have zero pose is a prefix:
+//   c[0..NB-1] = betas,  c[NB] = 1 (template),  c[NB+1+k] = pose_feature[k] = (R_{1+k/9} - I)[k%9]
+// and the blend matrix rows follow the same order: shapedirs rows, the template row, posedirs rows.
+// v_posed[v, comp] = sum_k c[k] * Pd[k][v][comp]
+struct VertexSet {
+  int n = 0;          // vertices in the set
+  int npad = 0;       // padded to a multiple of kChunk
+  int nchunks = 0;
+  // wave-per-frame layout: [nchunks][Kfull][3][64]
+  float* Pd_v = nullptr;
+  // skinning weights / joint indices, general form: [nchunks][nnz][64]
+  float* w = nullptr;
+  int32_t* idx = nullptr;
+  int32_t* ids = nullptr;   // [n] vertex ids (device); nullptr for slot 0
+};
+
+}  // namespace ha
+
+struct ha_smpl_model {
+  int device = 0;
+  int V = 0, J = 0, NB = 0, P = 0;
+  int Kfull = 0;      // NB + 1 + P
+  int Kfull_pad = 0;  // even
+  int Vpad = 0;       // multiple of 64
+  int nnz = 0;        // max skinning influences per vertex
+  int depth = 0;      // max tree depth (root = 0)
+  // joint constants (device)
+  float* Jt = nullptr;        // [J,3]   J_regressor @ v_template
+  float* Js = nullptr;        // [J,3,NB] J_regressor @ shapedirs
+  int32_t* parents = nullptr; // [J], parents[0] = -1
+  int32_t* jdepth = nullptr;  // [J]
+  int32_t* child_start = nullptr;  // [J+1] CSR of children (deterministic parent-side accumulation in backward)
+  int32_t* child_idx = nullptr;    // [J]
+  // dense (slot 0) extras
+  float* Pd_m = nullptr;      // MFMA B-operand layout [Vpad/32][Kfull_pad/2][3][64]
+  float4* w4 = nullptr;       // [V] (nnz <= 4 fast path)
+  uint32_t* idx4 = nullptr;   // [V] 4 x uint8 joint ids
+  ha::VertexSet sets[ha::kMaxSubsets];
+  // host copies kept for defining subsets later
+  std::string* host_blob = nullptr;  // unused placeholder (keeps struct trivially extendable)
+  float* h_Pd = nullptr;      // [Kfull][V][3] host, blend matrix rows in coefficient order
+  float* h_w = nullptr;       // [V][nnz] host
+  int32_t* h_idx = nullptr;   // [V][nnz] host
+};

@@ -1,0 +1,159 @@
+/*
+ * humor_amd.h -- C ABI of libhumor_amd.so: the MI355X (gfx950) hot path of HuMoR test-time optimisation.
+ *
+ * The reference (davrempe/humor) has no FFI for this path: the boundary is three Python classes
+ * (BodyModel / HumorModel / MotionOptimizer).  This header is what those classes bind
+ * instead of the chain of ATen ops they run today; every entry point names the reference interface it
+ * replaces.  Conventions:
+ *   - plain C, no torch types; all tensor arguments are raw DEVICE pointers to contiguous row-major fp32
+ *     (int32 for index tables) unless marked HOST; the caller owns every buffer;
+ *   - the library owns only opaque handles (model constants packed for the kernels, resident in HBM);
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous w.r.t. the host and never
+ *     synchronises the device (no hidden hipDeviceSynchronize, safe under stream capture);
+ *   - every function returns an int status: 0 = HA_OK, otherwise an HA_ERR_* code; ha_last_error()
+ *     returns a thread-local message.  Nothing aborts: the Python layer raises RuntimeError so the
+ *     reference's skip-the-batch handling (humor/fitting/run_fitting.py:437-439) keeps working;
+ *   - one host thread per device (the multi-GPU runner is one process per GPU).
+ */
+#ifndef HUMOR_AMD_H
+#define HUMOR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HA_OK 0
+#define HA_ERR_INVALID_ARG 1   /* bad shape / null pointer / unsupported size */
+#define HA_ERR_HIP 2           /* a HIP runtime call or kernel launch failed */
+#define HA_ERR_UNSUPPORTED 3   /* valid request this build cannot serve */
+
+const char* ha_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int ha_abi_version(void);
+/* Writes the device's gcnArchName (e.g. "gfx950:sramecc+:xnack-") into buf. */
+int ha_device_arch(int device, char* buf, int buflen);
+
+/* ------------------------------------------------------------------------------------------------
+ * SMPL / SMPL+H body model  (replaces smplx==0.1.28 `lbs`, `SMPLH.forward`, `VertexJointSelector` as
+ * called by humor/body_model/body_model.py:61-68, 78-91, and the gathers of
+ * humor/fitting/motion_optimizer.py:1093-1100)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ha_smpl_model ha_smpl_model;
+
+/* Packs and uploads the model constants.  All array arguments are HOST pointers in the layout of the
+ * reference's model.npz (body_model.py:37-48): v_template[V,3], shapedirs[V,3,NB], posedirs[V,3,P]
+ * with P=(J-1)*9, J_regressor[J,V], weights[V,J] (dense; packed to <=max-nnz-per-row sparse form),
+ * parents[J] (parents[0] ignored / treated as root).  `device` is the HIP device ordinal. */
+int ha_smpl_model_create(ha_smpl_model** out, int device, int V, int J, int NB,
+                         const float* v_template, const float* shapedirs, const float* posedirs,
+                         const float* J_regressor, const float* weights, const int32_t* parents);
+int ha_smpl_model_destroy(ha_smpl_model* m);
+/* Queries: what = 0:V 1:J 2:NB 3:max skinning influences per vertex 4:tree depth 5:V padded (multiple of 64)
+ *          6:number of vertex subsets defined 7:P (pose-blend basis size) */
+int ha_smpl_model_info(const ha_smpl_model* m, int what, int* value);
+
+/* Defines vertex subset `slot` (1..7; slot 0 is "all vertices") from HOST ids[n].  Kernels can then be
+ * asked to evaluate only that subset (the fitting losses consume <=64 of the 6890 vertices:
+ * VertexJointSelector's 21 + KEYPT_VERTS' 43, body_model/utils.py:17-19). */
+int ha_smpl_model_define_subset(ha_smpl_model* m, int slot, const int32_t* ids, int n);
+
+/* Forward for N frames on vertex subset `slot` (0 = all).
+ *   pose   [N, J*3] axis-angle (global|body|lhand|rhand as SMPLH.forward concatenates them)
+ *   n_active_joints: joints >= n_active are treated as exactly zero pose (R = I, pose feature 0);
+ *                    22 reproduces pose_hand=None of BodyModel.forward, J = general case
+ *   betas  [N, NB]; transl [N,3] or NULL
+ * outputs
+ *   verts  [N, n_subset, 3]  (subset order; slot 0: [N,V,3])
+ *   joints [N, J, 3]         posed joints + transl
+ * optional workspace outputs (NULL to skip), needed by the tiled dense path and for debugging:
+ *   A_out  [N, J, 12]  relative joint transforms (3x4 row-major)
+ * `algo`: 0 = auto, 1 = wave-per-frame VALU kernel, 2 = tiled MFMA pose-blend + streaming skinning
+ *         (slot 0 only; needs ws_vposed [N, Vpad, 3] and ws_coeff [Kc, Npad] from ha_smpl_workspace). */
+int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_active_joints,
+                    const float* pose, const float* betas, const float* transl,
+                    float* verts, float* joints, float* A_out,
+                    float* ws_vposed, float* ws_coeff, int algo, void* stream);
+
+/* Element counts (floats) of the algo-2 workspaces for N frames: *vposed = N*Vpad*3, *coeff = Kc*Npad. */
+int ha_smpl_workspace(const ha_smpl_model* m, int N, int n_active_joints, int64_t* vposed, int64_t* coeff);
+
+/* Backward of ha_smpl_forward for subset `slot`.  Forward intermediates are recomputed from
+ * (pose, betas), nothing needs to be stashed.
+ *   g_verts  [N, n_subset, 3] or NULL;  g_joints [N, J, 3] or NULL
+ * outputs (each may be NULL): g_pose [N, J*3] (entries of joints >= n_active are written as 0),
+ *   g_betas [N, NB], g_transl [N, 3]. */
+int ha_smpl_backward(const ha_smpl_model* m, int slot, int N, int n_active_joints,
+                     const float* pose, const float* betas,
+                     const float* g_verts, const float* g_joints,
+                     float* g_pose, float* g_betas, float* g_transl, void* stream);
+
+/* The streaming linear-blend-skinning kernel on its own (the HBM-roofline kernel):
+ * verts[n,v,:] = (sum_i w[v,i] * A[n, idx[v,i]]) * [v_posed[n,v,:]; 1] + transl[n].
+ * v_posed is [N, Vpad, 3] (Vpad from ha_smpl_model_info what=5), verts is [N, V, 3]. */
+int ha_lbs_skin(const ha_smpl_model* m, int N, const float* v_posed, const float* A, const float* transl,
+                float* verts, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rotation conversions (replace humor/utils/transforms.py:139-170 batch_rodrigues and :243-389
+ * rotation_matrix_to_angle_axis, forward and backward)
+ * ---------------------------------------------------------------------------------------------- */
+int ha_rodrigues_fwd(int n, const float* aa /*[n,3]*/, float* R /*[n,9]*/, void* stream);
+int ha_rodrigues_bwd(int n, const float* aa, const float* gR /*[n,9]*/, float* g_aa /*[n,3]*/, void* stream);
+int ha_rotmat_to_aa_fwd(int n, const float* R /*[n,9]*/, float* aa /*[n,3]*/, void* stream);
+int ha_rotmat_to_aa_bwd(int n, const float* R, const float* g_aa, float* gR, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * HuMoR CVAE roll-out (replaces HumorModel.roll_out / sample_step / prior / decode / MLP.forward /
+ * apply_world2local_trans, humor/models/humor_model.py:407-498, 696-772, 785-1059, 1206-1241, and
+ * compute_world2aligned_mat, humor/utils/transforms.py:17-42) for the fitting configuration:
+ * in_rot_rep='mat', out_rot_rep='aa', steps_in=1, 'smpl+joints(+contacts)', conditional prior.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ha_humor_net ha_humor_net;
+
+/* One MLP = Linear -> [GroupNorm(16) -> ReLU -> (cat z) -> Linear]*.  HOST arrays, reference
+ * state_dict layout: w[i] is [out_i, in_i (+skip)] row-major, gamma/beta are the GroupNorm affine of
+ * the activation feeding Linear i (i >= 1). */
+typedef struct ha_mlp_desc {
+  int n_linear;              /* number of Linear layers (<= 8) */
+  int in_dim;                /* input width of Linear 0 (including the skip part) */
+  int skip_dim;              /* width of the input tail re-concatenated before every later Linear (0 = none) */
+  int out_dims[8];
+  const float* w[8];
+  const float* b[8];
+  const float* gn_gamma[8];  /* index i>=1: affine of GroupNorm before Linear i */
+  const float* gn_beta[8];
+} ha_mlp_desc;
+
+/* decoder: [339+48] -> 1024 -> 1024 -> 512 -> 216 with z skip; prior: 339 -> 1024 x4 -> 96. */
+int ha_humor_net_create(ha_humor_net** out, int device, const ha_mlp_desc* decoder, const ha_mlp_desc* prior);
+int ha_humor_net_destroy(ha_humor_net* net);
+
+/* Floats of stash needed per (sequence, step) for the backward pass, and total workspace floats for
+ * a roll-out of B sequences x S steps. */
+int ha_humor_rollout_workspace(const ha_humor_net* net, int B, int S, int64_t* stash_floats);
+
+/* Forward roll-out.
+ *   past_in0 [B,339]  initial (canonical-frame) input state, layout: trans3|trans_vel3|rootR9|root_vel3|
+ *                     bodyR189|joints66|joints_vel66
+ *   z_seq    [B,S,48]
+ * outputs
+ *   world    [B,S,348] world-frame predicted states (past_in layout + 9 contact logits)
+ *   prior_mu [B,S,48], prior_var [B,S,48] (NULL to skip the prior network, G10)
+ *   stash    workspace kept for ha_humor_rollout_backward */
+int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, const float* past_in0, const float* z_seq,
+                             float* world, float* prior_mu, float* prior_var, float* stash, void* stream);
+
+/* Backward roll-out: given gradients of the outputs, produce gradients of the inputs.
+ *   g_world [B,S,348], g_prior_mu / g_prior_var [B,S,48] (NULL = zero)
+ * outputs g_past_in0 [B,339], g_z_seq [B,S,48].  `stash` is the forward's, consumed read-only except
+ * for scratch regions reserved by ha_humor_rollout_workspace. */
+int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float* z_seq,
+                              const float* g_world, const float* g_prior_mu, const float* g_prior_var,
+                              float* stash, float* g_past_in0, float* g_z_seq, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HUMOR_AMD_H */

@@ -1,0 +1,82 @@
+"""Shared SMPL parity checks: the same assertions run against the host SIMT-emulator build (CPU tier, tiny sizes)
+and against the gfx950 build on a real MI355X (GPU tier, through the C ABI)."""
+import numpy as np
+import torch
+
+from conftest import golden
+from humor_amd.body_model import BodyModel
+from oracle import lbs_restated as L
+
+from humor_amd.tables import KEYPT_VERTS   # noqa: E402  (body_model/utils.py:17-19)
+
+FWD_TOL = 1e-4      # north_star: fp32 vertices within 1e-4
+GRAD_RTOL = 2e-4    # gradients: relative to the largest reference gradient entry
+
+
+def make_inputs(N, seed, device, hands=False):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(device).requires_grad_(True)
+    d = dict(root_orient=mk(N, 3, sc=0.5), pose_body=mk(N, 63, sc=0.4), betas=mk(N, 16), trans=mk(N, 3))
+    if hands:
+        d['pose_hand'] = mk(N, 90, sc=0.3)
+    return d
+
+
+def oracle_forward(ds, inputs, selector):
+    N = inputs['betas'].shape[0]
+    layer = L.SMPLHLayer(data_struct=ds, num_betas=16, batch_size=N, vertex_ids=L.VERTEX_IDS_SMPLH if selector else None)
+    cpu = {k: v.detach().cpu().requires_grad_(True) for k, v in inputs.items()}
+    kw = dict(betas=cpu['betas'], global_orient=cpu['root_orient'], body_pose=cpu['pose_body'], transl=cpu['trans'])
+    if 'pose_hand' in cpu:
+        kw.update(left_hand_pose=cpu['pose_hand'][:, :45], right_hand_pose=cpu['pose_hand'][:, 45:])
+    return layer(**kw), cpu
+
+
+def check_forward_backward(lib, npz, ds, N, device, seed=0, hands=False, selector=True, subset=None, algo=0, dense_grad=False):
+    inputs = make_inputs(N, seed, device, hands)
+    ref, cpu = oracle_forward(ds, inputs, selector)
+    bm = BodyModel(npz, num_betas=16, batch_size=N, use_vtx_selector=selector, vertex_subset=subset, algo=algo,
+                   _lib_override=lib)
+    out = bm(**inputs)
+    ref_v = ref.vertices if subset is None else ref.vertices[:, subset]
+    assert out.v.shape == ref_v.shape and out.Jtr.shape == ref.joints.shape
+    dv = (out.v.detach().cpu() - ref_v).abs().max().item()
+    dj = (out.Jtr.detach().cpu() - ref.joints).abs().max().item()
+    assert dv < FWD_TOL and dj < FWD_TOL, (dv, dj)
+    # backward: joints always, vertices when a subset is used or a dense gradient is requested
+    g = torch.Generator().manual_seed(seed + 100)
+    gJ = torch.randn(ref.joints.shape, generator=g)
+    loss_ref = (ref.joints * gJ).sum()
+    loss = (out.Jtr * gJ.to(device)).sum()
+    if subset is not None or dense_grad:
+        gV = torch.randn(ref_v.shape, generator=g)
+        loss_ref = loss_ref + (ref_v * gV).sum()
+        loss = loss + (out.v * gV.to(device)).sum()
+    keys = list(inputs.keys())
+    g_ref = torch.autograd.grad(loss_ref, [cpu[k] for k in keys])
+    g_our = torch.autograd.grad(loss, [inputs[k] for k in keys])
+    for k, a, b in zip(keys, g_ref, g_our):
+        scale = max(1.0, a.abs().max().item())
+        err = (a - b.cpu()).abs().max().item()
+        assert err < GRAD_RTOL * scale, (k, err, scale)
+    return dv, dj
+
+
+def check_golden(lib, npz, device):
+    gd = golden('smpl_bodymodel.npz')
+    t = lambda k: torch.tensor(gd[k]).to(device).requires_grad_(True)
+    inputs = dict(root_orient=t('root_orient'), pose_body=t('pose_body'), betas=t('betas'), trans=t('trans'))
+    N = gd['betas'].shape[0]
+    bm = BodyModel(npz, num_betas=16, batch_size=N, use_vtx_selector=True, _lib_override=lib)
+    out = bm(**inputs)
+    assert np.abs(out.Jtr.detach().cpu().numpy() - gd['Jtr']).max() < FWD_TOL
+    assert np.abs(out.v[:, gd['keep_verts']].detach().cpu().numpy() - gd['v_keep']).max() < FWD_TOL
+    # the fitting-style subset evaluation and its gradients
+    bm2 = BodyModel(npz, num_betas=16, use_vtx_selector=True, vertex_subset=gd['keypt_verts'].tolist(), _lib_override=lib)
+    o2 = bm2(**inputs)
+    assert np.abs(o2.v.detach().cpu().numpy() - gd['v_keypt']).max() < FWD_TOL
+    loss = (o2.Jtr * torch.tensor(gd['gJ']).to(device)).sum() + (o2.v * torch.tensor(gd['gV']).to(device)).sum()
+    grads = torch.autograd.grad(loss, [inputs[k] for k in ('root_orient', 'pose_body', 'betas', 'trans')])
+    for k, gr in zip(('g_root', 'g_body', 'g_betas', 'g_trans'), grads):
+        scale = max(1.0, np.abs(gd[k]).max())
+        assert np.abs(gr.cpu().numpy() - gd[k]).max() < GRAD_RTOL * scale, k

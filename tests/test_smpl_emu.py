@@ -1,0 +1,39 @@
+"""CPU tier: the SMPL kernel sources executed by the host SIMT emulator (tests/simt_emu) against the oracle.
+Tiny sizes (one OS thread per work-item); the real parity tests are tests/test_smpl_gpu.py."""
+import pytest
+import torch
+
+import smpl_checks as SC
+
+CPU = torch.device('cpu')
+
+
+def test_emu_frame_kernel_dense(emu_lib, smplh_npz, smplh_struct):
+    SC.check_forward_backward(emu_lib, smplh_npz, smplh_struct, N=5, device=CPU, algo=1)
+
+
+def test_emu_subset_fwd_bwd(emu_lib, smplh_npz, smplh_struct):
+    SC.check_forward_backward(emu_lib, smplh_npz, smplh_struct, N=6, device=CPU, subset=SC.KEYPT_VERTS)
+
+
+def test_emu_hands_dense_grad(emu_lib, smplh_npz, smplh_struct):
+    SC.check_forward_backward(emu_lib, smplh_npz, smplh_struct, N=3, device=CPU, hands=True, selector=False, algo=1, dense_grad=True)
+
+
+def test_emu_golden(emu_lib, smplh_npz):
+    SC.check_golden(emu_lib, smplh_npz, CPU)
+
+
+@pytest.mark.slow
+def test_emu_mfma_dense_path(emu_lib, smplh_npz, smplh_struct):
+    # MFMA fragment maps + streaming skinning kernel (window straddling two frames, ragged tail)
+    SC.check_forward_backward(emu_lib, smplh_npz, smplh_struct, N=3, device=CPU, algo=2)
+
+
+def test_no_cpu_fallback(smplh_npz):
+    """The product BodyModel must refuse CPU tensors instead of silently computing somewhere else."""
+    from humor_amd.body_model import BodyModel
+    from humor_amd._lib import HumorAmdError
+    bm = BodyModel(smplh_npz, num_betas=16)
+    with pytest.raises((HumorAmdError, RuntimeError)):
+        bm(root_orient=torch.zeros(1, 3), pose_body=torch.zeros(1, 63), betas=torch.zeros(1, 16), trans=torch.zeros(1, 3))

@@ -1,0 +1,76 @@
+"""GPU tier (-m gpu): SMPL parity on a real MI355X, through the C ABI of the gfx950 build."""
+import numpy as np
+import pytest
+import torch
+
+import smpl_checks as SC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('N', [1, 2, 7, 64, 130])
+@pytest.mark.parametrize('algo', [1, 2])
+def test_dense_forward_backward(gpu_lib, smplh_npz, smplh_struct, dev, N, algo):
+    SC.check_forward_backward(gpu_lib, smplh_npz, smplh_struct, N=N, device=dev, seed=N, algo=algo)
+
+
+@pytest.mark.parametrize('N', [1, 5, 60, 257])
+def test_subset_forward_backward(gpu_lib, smplh_npz, smplh_struct, dev, N):
+    SC.check_forward_backward(gpu_lib, smplh_npz, smplh_struct, N=N, device=dev, seed=N + 1, subset=SC.KEYPT_VERTS)
+
+
+def test_hands_and_dense_gradient(gpu_lib, smplh_npz, smplh_struct, dev):
+    SC.check_forward_backward(gpu_lib, smplh_npz, smplh_struct, N=9, device=dev, hands=True, selector=False, algo=1, dense_grad=True)
+    SC.check_forward_backward(gpu_lib, smplh_npz, smplh_struct, N=9, device=dev, hands=True, selector=True, algo=2, dense_grad=True)
+
+
+def test_golden_vectors(gpu_lib, smplh_npz, dev):
+    SC.check_golden(gpu_lib, smplh_npz, dev)
+
+
+def test_full_size_properties(gpu_lib, smplh_npz, smplh_struct, dev):
+    """BASELINE config C4 size (32 x 60 frames): size-independent properties instead of an oracle run."""
+    from humor_amd.body_model import BodyModel
+    N = 32 * 60
+    inp = {k: v.detach() for k, v in SC.make_inputs(N, 3, dev).items()}
+    bm1 = BodyModel(smplh_npz, num_betas=16, use_vtx_selector=True, algo=1)
+    bm2 = BodyModel(smplh_npz, num_betas=16, use_vtx_selector=True, algo=2)
+    o1, o2 = bm1(**inp), bm2(**inp)
+    assert torch.isfinite(o2.v).all()
+    # the two independent kernels (VALU wave-per-frame vs MFMA + streaming skinning) agree
+    assert (o1.v - o2.v).abs().max().item() < 1e-4 and (o1.Jtr - o2.Jtr).abs().max().item() < 1e-5
+    # subset evaluation == gather of the dense result
+    bm3 = BodyModel(smplh_npz, num_betas=16, use_vtx_selector=True, vertex_subset=SC.KEYPT_VERTS)
+    o3 = bm3(**inp)
+    assert (o3.v - o2.v[:, SC.KEYPT_VERTS]).abs().max().item() < 1e-5
+    # translation equivariance
+    shift = torch.tensor([[0.5, -1.0, 2.0]], device=dev)
+    o4 = bm2(**{**inp, 'trans': inp['trans'] + shift})
+    assert (o4.v - (o2.v + shift[:, None])).abs().max().item() < 1e-5
+    # rigid root rotation: |v - root joint| is invariant to root_orient
+    o5 = bm2(**{**inp, 'root_orient': inp['root_orient'] + 0.3})
+    d2 = (o2.v - o2.Jtr[:, :1]).norm(dim=2)
+    d5 = (o5.v - o5.Jtr[:, :1]).norm(dim=2)
+    assert (d2 - d5).abs().max().item() < 1e-4
+    # zero pose/shape -> template + trans
+    z = lambda d: torch.zeros(8, d, device=dev)
+    o6 = bm2(root_orient=z(3), pose_body=z(63), betas=z(16), trans=inp['trans'][:8])
+    vt = torch.tensor(smplh_struct.v_template, device=dev)
+    assert (o6.v - (vt[None] + inp['trans'][:8, None])).abs().max().item() < 1e-5
+    # spot-check 4 frames of the big batch against the oracle
+    sel = [0, 777, 1500, N - 1]
+    ref, _ = SC.oracle_forward(smplh_struct, {k: v[sel] for k, v in inp.items()}, True)
+    assert (o2.v[sel].cpu() - ref.vertices).abs().max().item() < 1e-4
+
+
+def test_errors_are_exceptions(gpu_lib, smplh_npz, dev):
+    """Shape errors surface as Python exceptions (run_fitting.py:437-439 relies on catching them)."""
+    import ctypes as C
+    from humor_amd._lib import HumorAmdError
+    with pytest.raises(HumorAmdError):
+        gpu_lib.call('ha_smpl_forward', None, 0, 1, 22, None, None, None, None, None, None, None, None, 0, None)
