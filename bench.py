@@ -64,15 +64,31 @@ class HotPath:
         self.bm_dense = BodyModel(npz, num_betas=16, batch_size=N, use_vtx_selector=True)
         self.obs_j = torch.randn(N, 73, 3, generator=g).to(dev)
         self.obs_v = torch.randn(N, len(KEYPT_VERTS), 3, generator=g).to(dev)
+        # motion prior roll-out: 32 sequences x 59 steps, latent sequence + initial state are the optimisation variables
+        from humor_amd.humor_model import HumorModel
+        self.hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts',
+                             steps_in=1)
+        self.hm.load_state_dict(synth.humor_state_dict(seed=0))
+        self.hm = self.hm.to(dev).eval()
+        for p_ in self.hm.parameters():
+            p_.requires_grad_(False)
+        from oracle.make_golden import canonical_state   # input generator only (oracle is never the timed path)
+        self.past0 = canonical_state(B_SEQ, g).to(dev).requires_grad_(True)
+        self.z = (0.5 * torch.randn(B_SEQ, T_SEQ - 1, 48, generator=g)).to(dev).requires_grad_(True)
+        self.obs_w = torch.randn(B_SEQ, T_SEQ - 1, 348, generator=g).to(dev)
 
     def step(self):
         """One hot-path evaluation: SMPL (the 64 vertices + 73 joints the losses consume) forward, a joints/keypoint
         data term, backward to pose/shape/translation."""
-        for t in (self.root, self.body, self.trans, self.betas_seq):
+        for t in (self.root, self.body, self.trans, self.betas_seq, self.past0, self.z):
             t.grad = None
         betas = self.betas_seq.unsqueeze(1).expand(B_SEQ, T_SEQ, 16).reshape(self.N, 16)
         out = self.bm_fit(root_orient=self.root, pose_body=self.body, betas=betas, trans=self.trans)
         loss = (out.Jtr - self.obs_j).square().sum() + (out.v - self.obs_v).square().sum()
+        pred, (pm, pv) = self.hm.roll_out(self.past0, None, T_SEQ - 1, z_seq=self.z, return_prior=True)
+        world = torch.cat([pred[k] for k in ('trans', 'trans_vel', 'root_orient', 'root_orient_vel', 'pose_body', 'joints',
+                                              'joints_vel', 'contacts')], dim=2)
+        loss = loss + (world - self.obs_w).square().sum() + ((self.z - pm).square() / pv).sum()
         loss.backward()
         return loss
 

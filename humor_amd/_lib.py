@@ -26,6 +26,7 @@ _SIGS = {
     'ha_last_error': (C.c_char_p, []),
     'ha_abi_version': (C.c_int, []),
     'ha_device_arch': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    'ha_tune_set': (C.c_int, [C.c_char_p, C.c_int]),
     'ha_smpl_model_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     'ha_smpl_model_destroy': (C.c_int, [C.c_void_p]),
     'ha_smpl_model_info': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

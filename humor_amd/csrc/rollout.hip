@@ -1,0 +1,1121 @@
+// HuMoR CVAE roll-out on gfx950: packed-weight fp32-MFMA MLP layers with fused GroupNorm+ReLU prologues (forward)
+// and fused GroupNorm/ReLU adjoint prologues (backward), per-step "glue" kernels (residual composition with Rodrigues,
+// heading alignment, both frame changes, world-transform accumulation) forward and backward, and the rotation
+// conversion kernels.  Replaces the per-step chain of ~120 ATen launches of HumorModel.roll_out
+// (humor/models/humor_model.py:785-1017; prior :407-418, decode :445-498, MLP :1206-1241,
+// apply_world2local_trans :696-772; compute_world2aligned_mat humor/utils/transforms.py:17-42).
+//
+// Data layout: every activation lives transposed in 32-row tiles, X^T[tile][channel][32 rows], so that the A
+// operand of v_mfma_f32_32x32x2_f32 (lane l <-> row l&31, k = l>>5) is a fully coalesced 256-byte read and an
+// output tile's four consecutive rows per lane are one 16-byte store.  Weights are re-packed once into the B
+// operand's lane order.  A wave owns a 64-channel K-slice (= GroupNorm groups, so the statistics are lane-local +
+// one cross-half shuffle); NW waves of a block split K further and reduce through LDS; blocks split K across the
+// chip and the consumer layer's prologue sums those partial slabs (the launch-boundary reduce).
+#include <string.h>
+
+#include <vector>
+
+#include "rot_math.h"
+
+namespace ha {
+
+constexpr int D_IN = 339, D_RAW = 216, D_STATE = 348, ZD = 48, NJT = 22, NBODY = 21;
+constexpr int NW = 4;            // waves per block in the layer kernel
+constexpr int SLICE = 64;        // channels per wave K-slice
+constexpr int MAXL = 8;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PackedLayer {
+  int Cin = 0, skip = 0, Nout = 0;
+  int nslices_f = 0, main_slices = 0, ntiles_f = 0, nsplit_f = 0, Nout_pad = 0;
+  int nslices_b = 0, ntiles_b = 0, nsplit_b = 0, Nin_pad = 0;
+  int group = 0;
+  float* Wf = nullptr;   // [ntiles_f][nslices_f][32][64]
+  float* Wb = nullptr;   // [ntiles_b][nslices_b][32][64]
+  float* bias = nullptr;
+  float* gamma = nullptr;  // GroupNorm affine of the activation feeding this layer (Cin channels)
+  float* beta = nullptr;
+};
+
+}  // namespace ha
+
+struct ha_humor_net {
+  int device = 0;
+  int n_dec = 0, n_pri = 0;
+  ha::PackedLayer dec[ha::MAXL], pri[ha::MAXL];
+};
+
+namespace ha {
+
+// One (layer, direction) unit of work inside a launch.
+struct LayerTask {
+  const float* Wp; const float* bias;
+  int ntiles, nslices, main_slices, Nout, Nout_pad;
+  const float* src; int nsplit_src; int Csrc;       // A operand main part: partial slabs [nsplit][RT][Csrc][32]
+  const float* skip; int skip_dim;                  // raw tail part [RT][skip_dim][32]
+  int mode;                                         // 0 raw, 1 GN+ReLU (fwd), 3 GN+ReLU adjoint (bwd)
+  const float* gamma; const float* beta; int group;
+  const float* hsrc; int nsplit_h; int Ch;          // mode 3: forward pre-activation slabs of the same channels ([..][Ch][32])
+  float* dst;                                       // [nsplit_dst][RT][Nout_pad][32]
+  int nblocks;                                      // ntiles * nsplit_dst
+};
+
+struct LayerLaunch {
+  LayerTask t[2];
+  int ntasks;
+  int RT;
+};
+
+// sums `nsplit` partial slabs of element (channel c, row) of tile rt
+__device__ __forceinline__ float slab_sum(const float* base, int nsplit, int RT, int C, int rt, int c, int row) {
+  const size_t stride = (size_t)RT * C * 32;
+  const float* p = base + ((size_t)rt * C + c) * 32 + row;
+  float v = p[0];
+  for (int s = 1; s < nsplit; ++s) v += p[(size_t)s * stride];
+  return v;
+}
+
+__global__ __launch_bounds__(NW * 64) void mlp_layer_kernel(LayerLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // NW * 1024 floats
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int b = blockIdx.x;
+  int ti = 0;
+  if (L.ntasks > 1 && b >= L.t[0].nblocks) { b -= L.t[0].nblocks; ti = 1; }
+  const LayerTask& T = L.t[ti];
+  const int tile = b % T.ntiles, ks = b / T.ntiles;
+  const int slice = ks * NW + wave;
+  const bool active = slice < T.nslices;
+  const int row = lane & 31, hi = lane >> 5;
+
+  // B operand: this wave's 64 x 32 weight panel, resident in registers for all row tiles
+  float bw[32];
+  if (active) {
+    const float* wp = T.Wp + ((size_t)tile * T.nslices + slice) * 32 * 64 + lane;
+#pragma unroll
+    for (int kp = 0; kp < 32; ++kp) bw[kp] = wp[kp * 64];
+  }
+  const bool is_main = slice < T.main_slices;
+  const int cbase = is_main ? slice * SLICE : (slice - T.main_slices) * SLICE;
+
+  for (int rt = 0; rt < L.RT; ++rt) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (active) {
+      float a[32];
+      if (!is_main) {
+#pragma unroll
+        for (int kp = 0; kp < 32; ++kp) {
+          const int c = cbase + 2 * kp + hi;
+          a[kp] = c < T.skip_dim ? T.skip[((size_t)rt * T.skip_dim + c) * 32 + row] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int kp = 0; kp < 32; ++kp) {
+          const int c = cbase + 2 * kp + hi;
+          a[kp] = c < T.Csrc ? slab_sum(T.src, T.nsplit_src, L.RT, T.Csrc, rt, c, row) : 0.f;
+        }
+        if (T.mode != 0) {
+          // GroupNorm over groups of T.group (64 or 32) channels: lane holds 32 channels of its row (one parity),
+          // the other parity lives in lane^32.
+          const int ng = SLICE / T.group;          // 1 or 2 groups in this slice
+          const int per = 32 / ng;                 // kp entries per group
+          float h[32];
+          if (T.mode == 3) {
+#pragma unroll
+            for (int kp = 0; kp < 32; ++kp) {
+              const int c = cbase + 2 * kp + hi;
+              h[kp] = slab_sum(T.hsrc, T.nsplit_h, L.RT, T.Ch, rt, c, row);
+            }
+          } else {
+#pragma unroll
+            for (int kp = 0; kp < 32; ++kp) h[kp] = a[kp];
+          }
+          float mean[2], rstd[2];
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            if (g < ng) {
+              float s1 = 0.f;
+#pragma unroll
+              for (int kp = 0; kp < 32; ++kp)
+                if (kp / per == g || ng == 1) s1 += h[kp];
+              s1 += __shfl_xor(s1, 32);
+              const float mu = s1 / (float)T.group;
+              float s2 = 0.f;
+#pragma unroll
+              for (int kp = 0; kp < 32; ++kp)
+                if (kp / per == g || ng == 1) { const float d = h[kp] - mu; s2 = fmaf(d, d, s2); }
+              s2 += __shfl_xor(s2, 32);
+              mean[g] = mu;
+              rstd[g] = rsqrtf(s2 / (float)T.group + 1e-5f);
+            }
+          }
+          if (T.mode == 1) {
+#pragma unroll
+            for (int kp = 0; kp < 32; ++kp) {
+              const int c = cbase + 2 * kp + hi;
+              const int g = ng == 1 ? 0 : kp / per;
+              const float y = (h[kp] - mean[g]) * rstd[g] * T.gamma[c] + T.beta[c];
+              a[kp] = fmaxf(y, 0.f);
+            }
+          } else {
+            // adjoint: da -> dh through ReLU and GroupNorm
+            float dxh[32], xh[32];
+            float m1[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
+#pragma unroll
+            for (int kp = 0; kp < 32; ++kp) {
+              const int c = cbase + 2 * kp + hi;
+              const int g = ng == 1 ? 0 : kp / per;
+              const float gam = T.gamma[c];
+              xh[kp] = (h[kp] - mean[g]) * rstd[g];
+              const float y = xh[kp] * gam + T.beta[c];
+              const float dy = y > 0.f ? a[kp] : 0.f;
+              dxh[kp] = dy * gam;
+              m1[g] += dxh[kp];
+              m2[g] = fmaf(dxh[kp], xh[kp], m2[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              m1[g] += __shfl_xor(m1[g], 32);
+              m2[g] += __shfl_xor(m2[g], 32);
+              m1[g] /= (float)T.group;
+              m2[g] /= (float)T.group;
+            }
+#pragma unroll
+            for (int kp = 0; kp < 32; ++kp) {
+              const int g = ng == 1 ? 0 : kp / per;
+              a[kp] = rstd[g] * (dxh[kp] - m1[g] - xh[kp] * m2[g]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int kp = 0; kp < 32; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], bw[kp], acc, 0, 0, 0);
+    }
+    // cross-wave K reduction through LDS, then one 16-byte store per (lane, row quad)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) smem[(wave * 16 + i) * 64 + lane] = acc[i];
+    __syncthreads();
+    {
+      const int l2 = threadIdx.x & 63, rq = threadIdx.x >> 6;   // NW == 4 row quads of 4 registers
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += smem[(w * 16 + rq * 4 + e) * 64 + l2];
+        o[e] = v;
+      }
+      const int n = tile * 32 + (l2 & 31);
+      if (ks == 0 && T.bias && n < T.Nout) {
+        const float bv = T.bias[n];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += bv;
+      }
+      float* dst = T.dst + (((size_t)ks * L.RT + rt) * T.Nout_pad + n) * 32 + 8 * rq + 4 * (l2 >> 5);
+      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// glue kernels: one wave per sequence (row); lane j < 22 owns joint j, lanes 1..21 also body rotation j-1,
+// lane 0 the root quantities.
+// ---------------------------------------------------------------------------------------------------
+struct GlueParams {
+  int B, S, t, RT;
+  // forward stash
+  const float* xT;          // [RT][D_IN][32]   input state of step t (transposed)
+  float* xT_next;           // [RT][D_IN][32]
+  const float* dec_out; int dec_nsplit; int dec_pad;   // decoder raw output slabs [nsplit][RT][dec_pad][32]
+  const float* pri_out; int pri_nsplit; int pri_pad;   // prior output slabs
+  const float* Gs;          // [RT*32][12] accumulated world transform at step t: G (9) | gt (3)
+  float* Gs_next;
+  const float* t2j;         // [RT*32][3]
+  float* world;             // [B][S][348]
+  float* prior_mu; float* prior_var;   // [B][S][48] or null
+  // backward
+  const float* g_world;     // [B][S][348] or null
+  const float* g_prior_mu; const float* g_prior_var;
+  float* g_dec_out;         // [RT][dec_pad][32] adjoint of the decoder raw output
+  float* g_pri_out;         // [RT][pri_pad][32]
+  const float* gx_dir_in;   // [RT][D_IN][32] direct part of dL/dx_{t+1} (from glue_bwd(t+1)); null at t = S-1
+  float* gx_dir_out;        // [RT][D_IN][32] direct part of dL/dx_t
+  const float* gxp_pri; int gxp_pri_nsplit; int gxp_pri_pad;   // step t+1 layer-0 input-gradient slabs (prior)
+  const float* gxp_dec; int gxp_dec_nsplit; int gxp_dec_pad;   // (decoder; columns >= D_IN are dz)
+  float* carry;             // [RT*32][16]: gG (9) | ggt (3) | g_t2j (3) | pad
+  // dz collection of step t+1: decoder layer input-gradient slabs, z columns at `zoff`
+  const float* dz_src[MAXL]; int dz_nsplit[MAXL]; int dz_pad[MAXL]; int dz_off[MAXL]; int dz_n;
+  float* g_z;               // [B][S][48]
+  float* g_past0;           // [B][D_IN] (final collect only)
+};
+
+__device__ __forceinline__ float tsum(const float* base, int nsplit, int RT, int C, int rt, int c, int row) {
+  return base ? slab_sum(base, nsplit, RT, C, rt, c, row) : 0.f;
+}
+
+struct PredState {
+  // lane-local pieces of the decoder prediction (local frame) and what is needed to differentiate it
+  float pj[3], jv[3];       // joint position / velocity (lane j < 22)
+  float dB[9], Bin[9], pB[9];   // body rotation j-1 (lanes 1..21): delta, input, product
+  float ptrans[3], ptvel[3], prvel[3], dR[9], Rin[9], pR[9];   // lane 0
+  float raw_aa_b[3], raw_aa_r[3];
+};
+
+__device__ __forceinline__ void glue_predict(const GlueParams& p, int rt, int rr, int lane, PredState& s) {
+  auto X = [&](int c) { return p.xT[((size_t)rt * D_IN + c) * 32 + rr]; };
+  auto RAW = [&](int c) { return slab_sum(p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, rt, c, rr); };
+  const int j = lane;
+  if (j < NJT) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      s.pj[c] = RAW(75 + 3 * j + c) + X(207 + 3 * j + c);
+      s.jv[c] = RAW(141 + 3 * j + c) + X(273 + 3 * j + c);
+    }
+  }
+  if (j >= 1 && j < NJT) {
+    const int bidx = j - 1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s.raw_aa_b[c] = RAW(12 + 3 * bidx + c);
+    rodrigues(s.raw_aa_b, s.dB);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s.Bin[i] = X(18 + 9 * bidx + i);
+    mat3_mul(s.dB, s.Bin, s.pB);
+  }
+  if (j == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      s.ptrans[c] = RAW(c) + X(c);
+      s.ptvel[c] = RAW(3 + c) + X(3 + c);
+      s.raw_aa_r[c] = RAW(6 + c);
+      s.prvel[c] = RAW(9 + c) + X(15 + c);
+    }
+    rodrigues(s.raw_aa_r, s.dR);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s.Rin[i] = X(6 + i);
+    mat3_mul(s.dR, s.Rin, s.pR);
+  }
+}
+
+__global__ __launch_bounds__(64) void glue_fwd_kernel(GlueParams p) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int rt = r >> 5, rr = r & 31;
+  const bool valid = r < p.B;
+  float* XN = p.xT_next + (size_t)rt * D_IN * 32 + rr;
+  if (!valid) {
+    for (int c = lane; c < D_IN; c += 64) XN[(size_t)c * 32] = 0.f;
+    return;
+  }
+  PredState s;
+  glue_predict(p, rt, rr, lane, s);
+  // heading alignment from the predicted root orientation (lane 0), broadcast
+  W2A wa;
+  if (lane == 0) w2a_fwd(s.pR, wa);
+  float W[9], ptr[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) W[i] = __shfl(wa.W[i], 0);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ptr[c] = __shfl(s.ptrans[c], 0);
+  float G[9], gt[3], t2j[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) G[i] = p.Gs[(size_t)r * 12 + i];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { gt[c] = p.Gs[(size_t)r * 12 + 9 + c]; t2j[c] = p.t2j[(size_t)r * 3 + c]; }
+  const float wt[3] = {-ptr[0], -ptr[1], 0.f};
+  float* WO = p.world + ((size_t)r * p.S + p.t) * D_STATE;
+
+  if (lane < NJT) {
+    const int j = lane;
+    float q[3], o[3];
+    // next input: W (pj + wt + t2j) - t2j ; W jv
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = s.pj[c] + wt[c] + t2j[c];
+    mat3_vec(W, q, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) XN[(size_t)(207 + 3 * j + c) * 32] = o[c] - t2j[c];
+    mat3_vec(W, s.jv, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) XN[(size_t)(273 + 3 * j + c) * 32] = o[c];
+    // world: G^T (pj + t2j) - t2j - gt ; G^T jv
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = s.pj[c] + t2j[c];
+    mat3_tvec(G, q, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) WO[207 + 3 * j + c] = o[c] - t2j[c] - gt[c];
+    mat3_tvec(G, s.jv, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) WO[273 + 3 * j + c] = o[c];
+    if (j >= 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        XN[(size_t)(18 + 9 * (j - 1) + i) * 32] = s.pB[i];
+        WO[18 + 9 * (j - 1) + i] = s.pB[i];
+      }
+    }
+  }
+  if (lane == 0) {
+    float q[3], o[3], M[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = s.ptrans[c] + wt[c];
+    mat3_vec(W, q, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) XN[(size_t)c * 32] = o[c];
+    mat3_vec(W, s.ptvel, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) XN[(size_t)(3 + c) * 32] = o[c];
+    mat3_mul(W, s.pR, M);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) XN[(size_t)(6 + i) * 32] = M[i];
+    mat3_vec(W, s.prvel, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) XN[(size_t)(15 + c) * 32] = o[c];
+    // world
+    float wtr[3];
+    mat3_tvec(G, s.ptrans, wtr);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { wtr[c] -= gt[c]; WO[c] = wtr[c]; }
+    mat3_tvec(G, s.ptvel, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) WO[3 + c] = o[c];
+    mat3_tmul(G, s.pR, M);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) WO[6 + i] = M[i];
+    mat3_tvec(G, s.prvel, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) WO[15 + c] = o[c];
+    // accumulate the world transform
+    mat3_mul(G, W, M);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p.Gs_next[(size_t)r * 12 + i] = M[i];
+    p.Gs_next[(size_t)r * 12 + 9] = -wtr[0];
+    p.Gs_next[(size_t)r * 12 + 10] = -wtr[1];
+    p.Gs_next[(size_t)r * 12 + 11] = 0.f;
+  }
+  if (lane >= 32 && lane < 32 + 9) {
+    const int c = lane - 32;
+    WO[339 + c] = slab_sum(p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, rt, 207 + c, rr);
+  }
+  if (p.prior_mu && lane < ZD) {
+    const float mu = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, lane, rr);
+    const float lv = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, ZD + lane, rr);
+    p.prior_mu[((size_t)r * p.S + p.t) * ZD + lane] = mu;
+    p.prior_var[((size_t)r * p.S + p.t) * ZD + lane] = expf(lv);
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// a (x) b accumulated into M (3x3): M[i][k] += a_i b_k
+__device__ __forceinline__ void outer_acc(float M[9], const float a[3], const float b[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) M[i * 3 + k] = fmaf(a[i], b[k], M[i * 3 + k]);
+}
+
+// Backward of step t.  Also collects dL/dz of step t+1 (its decoder backward has completed) and, when
+// p.t == -1 ("final collect"), only assembles dL/dpast_in0 and dL/dz_0.
+__global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int rt = r >> 5, rr = r & 31;
+  if (r >= p.B) return;
+  const bool last = p.t == p.S - 1;      // no step t+1 behind this one
+  const bool final_collect = p.t < 0;
+
+  // ---- total adjoint of x_{t+1}: direct part + layer-0 input-gradient slabs of step t+1 -------------
+  auto GXN = [&](int c) -> float {
+    if (last) return 0.f;
+    float v = p.gx_dir_in[((size_t)rt * D_IN + c) * 32 + rr];
+    v += tsum(p.gxp_pri, p.gxp_pri_nsplit, p.RT, p.gxp_pri_pad, rt, c, rr);
+    v += tsum(p.gxp_dec, p.gxp_dec_nsplit, p.RT, p.gxp_dec_pad, rt, c, rr);
+    return v;
+  };
+  // ---- dz of step t+1 ---------------------------------------------------------------------------------
+  if (!last && p.g_z && lane < ZD) {
+    float v = 0.f;
+    for (int i = 0; i < p.dz_n; ++i) v += slab_sum(p.dz_src[i], p.dz_nsplit[i], p.RT, p.dz_pad[i], rt, p.dz_off[i] + lane, rr);
+    p.g_z[((size_t)r * p.S + (p.t + 1)) * ZD + lane] = v;
+  }
+  float* carry = p.carry + (size_t)r * 16;
+  if (final_collect) {
+    // dL/dpast_in0 = adjoint of x_0 ; t2j = -(x0[207], x0[208], 0)
+    for (int c = lane; c < D_IN; c += 64) {
+      float v = GXN(c);
+      if (c == 207) v -= carry[12];
+      if (c == 208) v -= carry[13];
+      p.g_past0[(size_t)r * D_IN + c] = v;
+    }
+    return;
+  }
+
+  PredState s;
+  glue_predict(p, rt, rr, lane, s);
+  W2A wa;
+  if (lane == 0) w2a_fwd(s.pR, wa);
+  float W[9], ptr[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) W[i] = __shfl(wa.W[i], 0);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ptr[c] = __shfl(s.ptrans[c], 0);
+  float G[9], gt[3], t2j[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) G[i] = p.Gs[(size_t)r * 12 + i];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { gt[c] = p.Gs[(size_t)r * 12 + 9 + c]; t2j[c] = p.t2j[(size_t)r * 3 + c]; }
+  const float wt[3] = {-ptr[0], -ptr[1], 0.f};
+
+  // incoming carried adjoints of (G', gt') = state after this step
+  float gGn[9], ggtn[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) gGn[i] = last ? 0.f : carry[i];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ggtn[c] = last ? 0.f : carry[9 + c];
+  float g_t2j_acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) g_t2j_acc[c] = last ? 0.f : carry[12 + c];
+
+  const float* GW = p.g_world ? p.g_world + ((size_t)r * p.S + p.t) * D_STATE : nullptr;
+  auto gw = [&](int c) { return GW ? GW[c] : 0.f; };
+
+  // lane-local partial sums of the wave-shared adjoints
+  float gW[9], gG[9], ggt[3] = {0.f, 0.f, 0.f}, gwt[3] = {0.f, 0.f, 0.f}, gt2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { gW[i] = 0.f; gG[i] = 0.f; }
+
+  float* GD = p.g_dec_out + (size_t)rt * p.dec_pad * 32 + rr;      // adjoint of decoder raw output, channel stride 32
+  float* GX = p.gx_dir_out + (size_t)rt * D_IN * 32 + rr;
+
+  if (lane < NJT) {
+    const int j = lane;
+    float g[3], q[3], o[3], gpj[3] = {0.f, 0.f, 0.f}, gjv[3] = {0.f, 0.f, 0.f};
+    // world joints: wj = G^T (pj + t2j) - t2j - gt
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { g[c] = gw(207 + 3 * j + c); q[c] = s.pj[c] + t2j[c]; }
+    mat3_vec(G, g, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gpj[c] += o[c]; gt2[c] += o[c] - g[c]; ggt[c] -= g[c]; }
+    outer_acc(gG, q, g);
+    // world joint velocities: G^T jv
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = gw(273 + 3 * j + c);
+    mat3_vec(G, g, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gjv[c] += o[c];
+    outer_acc(gG, s.jv, g);
+    // next-input joints: W (pj + wt + t2j) - t2j
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { g[c] = GXN(207 + 3 * j + c); q[c] = s.pj[c] + wt[c] + t2j[c]; }
+    mat3_tvec(W, g, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gpj[c] += o[c]; gwt[c] += o[c]; gt2[c] += o[c] - g[c]; }
+    outer_acc(gW, g, q);
+    // next-input joint velocities: W jv
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = GXN(273 + 3 * j + c);
+    mat3_tvec(W, g, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gjv[c] += o[c];
+    outer_acc(gW, g, s.jv);
+    // residual composition: pj = raw + x
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      GD[(size_t)(75 + 3 * j + c) * 32] = gpj[c];
+      GX[(size_t)(207 + 3 * j + c) * 32] = gpj[c];
+      GD[(size_t)(141 + 3 * j + c) * 32] = gjv[c];
+      GX[(size_t)(273 + 3 * j + c) * 32] = gjv[c];
+    }
+    if (j >= 1) {
+      // body rotation: pB = dB * Bin goes unchanged to both outputs
+      const int bidx = j - 1;
+      float gpB[9], gdB[9], gBin[9], gaa[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gpB[i] = gw(18 + 9 * bidx + i) + GXN(18 + 9 * bidx + i);
+      mat3_mult(gpB, s.Bin, gdB);      // gdB = gpB * Bin^T
+      mat3_tmul(s.dB, gpB, gBin);      // gBin = dB^T * gpB
+      rodrigues_bwd(s.raw_aa_b, gdB, gaa);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) GD[(size_t)(12 + 3 * bidx + c) * 32] = gaa[c];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) GX[(size_t)(18 + 9 * bidx + i) * 32] = gBin[i];
+    }
+  }
+  // root pieces (lane 0) contribute to the shared adjoints before the reduction
+  float gptrans[3] = {0.f, 0.f, 0.f}, gptvel[3] = {0.f, 0.f, 0.f}, gprvel[3] = {0.f, 0.f, 0.f}, gpR[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) gpR[i] = 0.f;
+  if (lane == 0) {
+    float g[3], o[3], q[3];
+    // carried: gt' = (-wtrans.x, -wtrans.y, 0)
+    float gwtr[3] = {gw(0) - ggtn[0], gw(1) - ggtn[1], gw(2)};
+    // wtrans = G^T ptrans - gt
+    mat3_vec(G, gwtr, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gptrans[c] += o[c]; ggt[c] -= gwtr[c]; }
+    outer_acc(gG, s.ptrans, gwtr);
+    // wtvel = G^T ptvel
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = gw(3 + c);
+    mat3_vec(G, g, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gptvel[c] += o[c];
+    outer_acc(gG, s.ptvel, g);
+    // wR = G^T pR : gpR += G gwR ; gG += pR gwR^T
+    float gwR[9], M[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gwR[i] = gw(6 + i);
+    mat3_mul(G, gwR, M);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gpR[i] += M[i];
+    mat3_mult(s.pR, gwR, M);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gG[i] += M[i];
+    // wrvel = G^T prvel
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = gw(15 + c);
+    mat3_vec(G, g, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gprvel[c] += o[c];
+    outer_acc(gG, s.prvel, g);
+    // G' = G W : gG += gG' W^T ; gW += G^T gG'
+    mat3_mult(gGn, W, M);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gG[i] += M[i];
+    mat3_tmul(G, gGn, M);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gW[i] += M[i];
+    // next input: trans' = W (ptrans + wt)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { g[c] = GXN(c); q[c] = s.ptrans[c] + wt[c]; }
+    mat3_tvec(W, g, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gptrans[c] += o[c]; gwt[c] += o[c]; }
+    outer_acc(gW, g, q);
+    // tvel' = W ptvel
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = GXN(3 + c);
+    mat3_tvec(W, g, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gptvel[c] += o[c];
+    outer_acc(gW, g, s.ptvel);
+    // R' = W pR : gpR += W^T gR' ; gW += gR' pR^T
+    float gRn[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gRn[i] = GXN(6 + i);
+    mat3_tmul(W, gRn, M);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gpR[i] += M[i];
+    mat3_mult(gRn, s.pR, M);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gW[i] += M[i];
+    // rvel' = W prvel
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = GXN(15 + c);
+    mat3_tvec(W, g, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gprvel[c] += o[c];
+    outer_acc(gW, g, s.prvel);
+  }
+  // wave reduction of the shared adjoints
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { gW[i] = wave_sum(gW[i]); gG[i] = wave_sum(gG[i]); }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { ggt[c] = wave_sum(ggt[c]); gwt[c] = wave_sum(gwt[c]); gt2[c] = wave_sum(gt2[c]); }
+
+  if (lane == 0) {
+    // wt = (-ptrans.x, -ptrans.y, 0)
+    gptrans[0] -= gwt[0];
+    gptrans[1] -= gwt[1];
+    // W = world2aligned(pR)
+    float g0, g3;
+    w2a_bwd(wa, gW, g0, g3);
+    gpR[0] += g0;
+    gpR[3] += g3;
+    // pR = dR * Rin
+    float gdR[9], gRin[9], gaa[3];
+    mat3_mult(gpR, s.Rin, gdR);
+    mat3_tmul(s.dR, gpR, gRin);
+    rodrigues_bwd(s.raw_aa_r, gdR, gaa);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      GD[(size_t)c * 32] = gptrans[c];        GX[(size_t)c * 32] = gptrans[c];
+      GD[(size_t)(3 + c) * 32] = gptvel[c];   GX[(size_t)(3 + c) * 32] = gptvel[c];
+      GD[(size_t)(6 + c) * 32] = gaa[c];
+      GD[(size_t)(9 + c) * 32] = gprvel[c];   GX[(size_t)(15 + c) * 32] = gprvel[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) GX[(size_t)(6 + i) * 32] = gRin[i];
+    // carry to step t-1
+#pragma unroll
+    for (int i = 0; i < 9; ++i) carry[i] = gG[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { carry[9 + c] = ggt[c]; carry[12 + c] = g_t2j_acc[c] + gt2[c]; }
+  }
+  // contacts pass straight through; padded decoder channels get zero
+  if (lane >= 32 && lane < 32 + 9) GD[(size_t)(207 + lane - 32) * 32] = gw(339 + lane - 32);
+  for (int c = D_RAW + lane; c < p.dec_pad; c += 64) GD[(size_t)c * 32] = 0.f;
+  // prior output adjoint: (g_mu, g_var * var)
+  if (p.g_pri_out) {
+    float* GP = p.g_pri_out + (size_t)rt * p.pri_pad * 32 + rr;
+    if (lane < ZD) {
+      const size_t o = ((size_t)r * p.S + p.t) * ZD + lane;
+      GP[(size_t)lane * 32] = p.g_prior_mu ? p.g_prior_mu[o] : 0.f;
+      // var = exp(logvar): d/dlogvar = g_var * var (recomputed from the stashed prior output slabs)
+      const float var = expf(slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, ZD + lane, rr));
+      GP[(size_t)(ZD + lane) * 32] = p.g_prior_var ? p.g_prior_var[o] * var : 0.f;
+    }
+    for (int c = 2 * ZD + lane; c < p.pri_pad; c += 64) GP[(size_t)c * 32] = 0.f;
+  }
+}
+
+// [B][S][48] -> [S][RT][48][32] (zero-padded rows) ; [B][339] -> [RT][339][32]
+__global__ void transpose_in_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int S, int C, int RT) {
+  const size_t total = (size_t)S * RT * C * 32;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int rr = (int)(i & 31);
+    const size_t q = i >> 5;
+    const int c = (int)(q % C);
+    const size_t q2 = q / C;
+    const int rt = (int)(q2 % RT);
+    const int s = (int)(q2 / RT);
+    const int r = rt * 32 + rr;
+    dst[i] = r < B ? src[((size_t)r * S + s) * C + c] : 0.f;
+  }
+}
+
+__global__ void init_state_kernel(const float* __restrict__ past0, float* __restrict__ Gs, float* __restrict__ t2j, int B, int rows) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float I[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+  for (int i = 0; i < 12; ++i) Gs[(size_t)r * 12 + i] = I[i];
+  t2j[(size_t)r * 3 + 0] = r < B ? -past0[(size_t)r * D_IN + 207] : 0.f;
+  t2j[(size_t)r * 3 + 1] = r < B ? -past0[(size_t)r * D_IN + 208] : 0.f;
+  t2j[(size_t)r * 3 + 2] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rotation conversion kernels
+// ---------------------------------------------------------------------------------------------------
+__global__ void rodrigues_fwd_kernel(int n, const float* __restrict__ aa, float* __restrict__ R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float r[3] = {aa[(size_t)i * 3], aa[(size_t)i * 3 + 1], aa[(size_t)i * 3 + 2]};
+  float M[9];
+  rodrigues(r, M);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = M[k];
+}
+__global__ void rodrigues_bwd_kernel(int n, const float* __restrict__ aa, const float* __restrict__ gR, float* __restrict__ g_aa) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float r[3] = {aa[(size_t)i * 3], aa[(size_t)i * 3 + 1], aa[(size_t)i * 3 + 2]};
+  float g[9], o[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g[k] = gR[(size_t)i * 9 + k];
+  rodrigues_bwd(r, g, o);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g_aa[(size_t)i * 3 + k] = o[k];
+}
+__global__ void rotmat_to_aa_fwd_kernel(int n, const float* __restrict__ R, float* __restrict__ aa) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float M[9], o[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) M[k] = R[(size_t)i * 9 + k];
+  rotmat_to_aa(M, o);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) aa[(size_t)i * 3 + k] = o[k];
+}
+__global__ void rotmat_to_aa_bwd_kernel(int n, const float* __restrict__ R, const float* __restrict__ g_aa, float* __restrict__ gR) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float M[9], g[3], o[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) M[k] = R[(size_t)i * 9 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g[k] = g_aa[(size_t)i * 3 + k];
+  rotmat_to_aa_bwd(M, g, o);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) gR[(size_t)i * 9 + k] = o[k];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side: weight packing, stash layout, orchestration
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+static int upload_vec(T** dst, const std::vector<T>& src) {
+  *dst = nullptr;
+  if (src.empty()) return HA_OK;
+  HA_CHECK_HIP(hipMalloc((void**)dst, src.size() * sizeof(T)));
+  HA_CHECK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return HA_OK;
+}
+
+static int pack_layer(PackedLayer& L, const float* W, const float* bias, const float* gamma, const float* beta, int Cin,
+                      int skip, int Nout, bool has_gn) {
+  L.Cin = Cin; L.skip = skip; L.Nout = Nout;
+  L.main_slices = ceil_div(Cin, SLICE);
+  L.nslices_f = L.main_slices + ceil_div(skip, SLICE);
+  L.ntiles_f = ceil_div(Nout, 32);
+  L.Nout_pad = L.ntiles_f * 32;
+  L.nsplit_f = ceil_div(L.nslices_f, NW);
+  L.nslices_b = ceil_div(Nout, SLICE);
+  L.ntiles_b = ceil_div(Cin + skip, 32);
+  L.Nin_pad = L.ntiles_b * 32;
+  L.nsplit_b = ceil_div(L.nslices_b, NW);
+  L.group = has_gn ? Cin / 16 : 0;
+  const int Kin = Cin + skip;
+  // forward pack: lane l of (tile, slice, kp) <-> W[n = tile*32 + (l&31)][k], k = channel of the slice
+  std::vector<float> wf((size_t)L.ntiles_f * L.nslices_f * 32 * 64, 0.f);
+  for (int tile = 0; tile < L.ntiles_f; ++tile)
+    for (int sl = 0; sl < L.nslices_f; ++sl)
+      for (int kp = 0; kp < 32; ++kp)
+        for (int l = 0; l < 64; ++l) {
+          const int n = tile * 32 + (l & 31);
+          const int cc = 2 * kp + (l >> 5);
+          int k;
+          if (sl < L.main_slices) { const int c = sl * SLICE + cc; k = c < Cin ? c : -1; }
+          else { const int c = (sl - L.main_slices) * SLICE + cc; k = c < skip ? Cin + c : -1; }
+          if (n < Nout && k >= 0) wf[(((size_t)tile * L.nslices_f + sl) * 32 + kp) * 64 + l] = W[(size_t)n * Kin + k];
+        }
+  // backward pack: A = dh [rows, Nout channels], output columns = input channels (main then skip)
+  std::vector<float> wb((size_t)L.ntiles_b * L.nslices_b * 32 * 64, 0.f);
+  for (int tile = 0; tile < L.ntiles_b; ++tile)
+    for (int sl = 0; sl < L.nslices_b; ++sl)
+      for (int kp = 0; kp < 32; ++kp)
+        for (int l = 0; l < 64; ++l) {
+          const int n = tile * 32 + (l & 31);                 // input channel
+          const int k = sl * SLICE + 2 * kp + (l >> 5);       // output channel
+          if (n < Kin && k < Nout) wb[(((size_t)tile * L.nslices_b + sl) * 32 + kp) * 64 + l] = W[(size_t)k * Kin + n];
+        }
+  int rc;
+  if ((rc = upload_vec(&L.Wf, wf)) != HA_OK) return rc;
+  if ((rc = upload_vec(&L.Wb, wb)) != HA_OK) return rc;
+  std::vector<float> bv(bias, bias + Nout);
+  if ((rc = upload_vec(&L.bias, bv)) != HA_OK) return rc;
+  if (has_gn) {
+    std::vector<float> gv(gamma, gamma + Cin), bev(beta, beta + Cin);
+    if ((rc = upload_vec(&L.gamma, gv)) != HA_OK) return rc;
+    if ((rc = upload_vec(&L.beta, bev)) != HA_OK) return rc;
+  }
+  return HA_OK;
+}
+
+static int pack_mlp(PackedLayer* out, const ha_mlp_desc* d, const char* name) {
+  HA_REQUIRE(d->n_linear >= 1 && d->n_linear <= MAXL, "%s: n_linear=%d out of range", name, d->n_linear);
+  int cin = d->in_dim - d->skip_dim;
+  for (int i = 0; i < d->n_linear; ++i) {
+    HA_REQUIRE(d->w[i] && d->b[i], "%s: layer %d weights missing", name, i);
+    const bool gn = i > 0;
+    if (gn) {
+      HA_REQUIRE(d->gn_gamma[i] && d->gn_beta[i], "%s: layer %d GroupNorm affine missing", name, i);
+      HA_REQUIRE(cin % 16 == 0 && (cin / 16 == 64 || cin / 16 == 32), "%s: hidden width %d needs GroupNorm groups of 32 or 64 channels", name, cin);
+    }
+    int rc = pack_layer(out[i], d->w[i], d->b[i], d->gn_gamma[i], d->gn_beta[i], cin, d->skip_dim, d->out_dims[i], gn);
+    if (rc != HA_OK) return rc;
+    cin = d->out_dims[i];
+  }
+  return HA_OK;
+}
+
+// Offsets (in floats) into the caller-owned stash.
+struct StashLayout {
+  int RT = 0;
+  size_t zT = 0, t2j = 0, per_step = 0, steps = 0;
+  size_t off_x = 0, off_G = 0;
+  size_t off_pri[MAXL], off_dec[MAXL];
+  // backward scratch
+  size_t gx_dir[2], carry = 0, g_dec_out = 0, g_pri_out = 0;
+  size_t bwd_pri[MAXL], bwd_dec[MAXL];
+  size_t total = 0;
+};
+
+static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
+  L.RT = ceil_div(B, 32);
+  const size_t RT = L.RT;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
+  L.zT = take((size_t)S * RT * ZD * 32);
+  L.t2j = take(RT * 32 * 3);
+  // per-step region
+  size_t p = 0;
+  auto ptake = [&](size_t n) { size_t r = p; p += (n + 63) / 64 * 64; return r; };
+  L.off_x = ptake(RT * D_IN * 32);
+  L.off_G = ptake(RT * 32 * 12);
+  for (int i = 0; i < net->n_pri; ++i) L.off_pri[i] = ptake((size_t)net->pri[i].nsplit_f * RT * net->pri[i].Nout_pad * 32);
+  for (int i = 0; i < net->n_dec; ++i) L.off_dec[i] = ptake((size_t)net->dec[i].nsplit_f * RT * net->dec[i].Nout_pad * 32);
+  L.per_step = p;
+  L.steps = take(p * (size_t)(S + 1));
+  L.gx_dir[0] = take(RT * D_IN * 32);
+  L.gx_dir[1] = take(RT * D_IN * 32);
+  L.carry = take(RT * 32 * 16);
+  L.g_dec_out = take(RT * net->dec[net->n_dec - 1].Nout_pad * 32);
+  L.g_pri_out = take(RT * net->pri[net->n_pri - 1].Nout_pad * 32);
+  for (int i = 0; i < net->n_pri; ++i) L.bwd_pri[i] = take((size_t)net->pri[i].nsplit_b * RT * net->pri[i].Nin_pad * 32);
+  for (int i = 0; i < net->n_dec; ++i) L.bwd_dec[i] = take((size_t)net->dec[i].nsplit_b * RT * net->dec[i].Nin_pad * 32);
+  L.total = o;
+}
+
+static void fwd_task(LayerTask& T, const PackedLayer& L, const float* src, int nsplit_src, const float* skip, float* dst) {
+  memset(&T, 0, sizeof(T));
+  T.Wp = L.Wf; T.bias = L.bias;
+  T.ntiles = L.ntiles_f; T.nslices = L.nslices_f; T.main_slices = L.main_slices; T.Nout = L.Nout; T.Nout_pad = L.Nout_pad;
+  T.src = src; T.nsplit_src = nsplit_src; T.Csrc = L.Cin;
+  T.skip = skip; T.skip_dim = L.skip;
+  T.mode = L.group ? 1 : 0;
+  T.gamma = L.gamma; T.beta = L.beta; T.group = L.group ? L.group : 64;
+  T.dst = dst;
+  T.nblocks = L.ntiles_f * L.nsplit_f;
+}
+
+// backward through layer L: A = dh (adjoint of L's raw output), output = adjoint of L's input activation slabs.
+// `Lnext_gn` describes the GroupNorm that follows L (i.e. the consumer layer's gamma/beta/group) when dh has to be
+// derived from the consumer's input-gradient slabs (mode 3); null when dh is given directly (mode 0).
+static void bwd_task(LayerTask& T, const PackedLayer& L, const float* dsrc, int nsplit_d, int dC, const PackedLayer* Lnext_gn,
+                     const float* hsrc, int nsplit_h, float* dst) {
+  memset(&T, 0, sizeof(T));
+  T.Wp = L.Wb; T.bias = nullptr;
+  T.ntiles = L.ntiles_b; T.nslices = L.nslices_b; T.main_slices = L.nslices_b; T.Nout = L.Cin + L.skip; T.Nout_pad = L.Nin_pad;
+  T.src = dsrc; T.nsplit_src = nsplit_d; T.Csrc = dC;
+  T.mode = Lnext_gn ? 3 : 0;
+  if (Lnext_gn) { T.gamma = Lnext_gn->gamma; T.beta = Lnext_gn->beta; T.group = Lnext_gn->group; }
+  else T.group = 64;
+  T.hsrc = hsrc; T.nsplit_h = nsplit_h; T.Ch = L.Nout_pad;
+  T.dst = dst;
+  T.nblocks = L.ntiles_b * L.nsplit_b;
+}
+
+static int launch_layers(LayerLaunch& LL, hipStream_t st) {
+  int blocks = 0;
+  for (int i = 0; i < LL.ntasks; ++i) blocks += LL.t[i].nblocks;
+  hipLaunchKernelGGL(mlp_layer_kernel, dim3(blocks), dim3(NW * 64), NW * 1024 * sizeof(float), st, LL);
+  HA_LAUNCH_CHECK();
+  return HA_OK;
+}
+
+}  // namespace ha
+
+using namespace ha;
+
+extern "C" int ha_humor_net_create(ha_humor_net** out, int device, const ha_mlp_desc* decoder, const ha_mlp_desc* prior) {
+  HA_REQUIRE(out && decoder && prior, "ha_humor_net_create: null argument");
+  HA_REQUIRE(decoder->in_dim == D_IN + ZD && decoder->skip_dim == ZD && decoder->out_dims[decoder->n_linear - 1] == D_RAW,
+             "ha_humor_net_create: decoder must map [339+48] -> 216 with a 48-d latent skip (got in=%d skip=%d)", decoder->in_dim, decoder->skip_dim);
+  HA_REQUIRE(prior->in_dim == D_IN && prior->skip_dim == 0 && prior->out_dims[prior->n_linear - 1] == 2 * ZD,
+             "ha_humor_net_create: prior must map 339 -> 96");
+  DeviceGuard guard(device);
+  HA_REQUIRE(guard.ok, "ha_humor_net_create: cannot select device %d", device);
+  ha_humor_net* net = new ha_humor_net();
+  net->device = device;
+  net->n_dec = decoder->n_linear;
+  net->n_pri = prior->n_linear;
+  int rc;
+  if ((rc = pack_mlp(net->dec, decoder, "decoder")) != HA_OK || (rc = pack_mlp(net->pri, prior, "prior")) != HA_OK) {
+    ha_humor_net_destroy(net);
+    return rc;
+  }
+  *out = net;
+  return HA_OK;
+}
+
+extern "C" int ha_humor_net_destroy(ha_humor_net* net) {
+  if (!net) return HA_OK;
+  DeviceGuard guard(net->device);
+  for (PackedLayer* arr : {net->dec, net->pri})
+    for (int i = 0; i < MAXL; ++i) {
+      void* ptrs[] = {arr[i].Wf, arr[i].Wb, arr[i].bias, arr[i].gamma, arr[i].beta};
+      for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    }
+  delete net;
+  return HA_OK;
+}
+
+extern "C" int ha_humor_rollout_workspace(const ha_humor_net* net, int B, int S, int64_t* stash_floats) {
+  HA_REQUIRE(net && stash_floats, "ha_humor_rollout_workspace: null argument");
+  HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_workspace: B and S must be >= 1");
+  StashLayout L;
+  make_layout(net, B, S, L);
+  *stash_floats = (int64_t)L.total;
+  return HA_OK;
+}
+
+extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, const float* past_in0, const float* z_seq,
+                                        float* world, float* prior_mu, float* prior_var, float* stash, void* stream) {
+  HA_REQUIRE(net && past_in0 && z_seq && world && stash, "ha_humor_rollout_forward: null argument");
+  HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_forward: B and S must be >= 1");
+  HA_REQUIRE((prior_mu == nullptr) == (prior_var == nullptr), "ha_humor_rollout_forward: prior_mu and prior_var go together");
+  DeviceGuard guard(net->device);
+  hipStream_t st = (hipStream_t)stream;
+  StashLayout L;
+  make_layout(net, B, S, L);
+  const int RT = L.RT, rows = RT * 32;
+  auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
+
+  hipLaunchKernelGGL(transpose_in_kernel, dim3(256), dim3(256), 0, st, z_seq, stash + L.zT, B, S, ZD, RT);
+  HA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, step_ptr(0) + L.off_x, B, 1, D_IN, RT);
+  HA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
+  HA_LAUNCH_CHECK();
+
+  const bool with_prior = prior_mu != nullptr;
+  const int nl = net->n_dec > net->n_pri ? net->n_dec : net->n_pri;
+  for (int t = 0; t < S; ++t) {
+    float* sp = step_ptr(t);
+    const float* zT = stash + L.zT + (size_t)t * RT * ZD * 32;
+    for (int l = 0; l < nl; ++l) {
+      LayerLaunch LL;
+      memset(&LL, 0, sizeof(LL));
+      LL.RT = RT;
+      if (l < net->n_dec) {
+        const PackedLayer& P = net->dec[l];
+        const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
+        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : net->dec[l - 1].nsplit_f, zT, sp + L.off_dec[l]);
+      }
+      if (with_prior && l < net->n_pri) {
+        const PackedLayer& P = net->pri[l];
+        const float* src = l == 0 ? sp + L.off_x : sp + L.off_pri[l - 1];
+        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : net->pri[l - 1].nsplit_f, nullptr, sp + L.off_pri[l]);
+      }
+      if (LL.ntasks == 0) continue;
+      int rc = launch_layers(LL, st);
+      if (rc != HA_OK) return rc;
+    }
+    GlueParams g;
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.S = S; g.t = t; g.RT = RT;
+    g.xT = sp + L.off_x;
+    g.xT_next = step_ptr(t + 1) + L.off_x;
+    const PackedLayer& DL = net->dec[net->n_dec - 1];
+    g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = DL.nsplit_f; g.dec_pad = DL.Nout_pad;
+    const PackedLayer& PL = net->pri[net->n_pri - 1];
+    g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = PL.nsplit_f; g.pri_pad = PL.Nout_pad;
+    g.Gs = sp + L.off_G;
+    g.Gs_next = step_ptr(t + 1) + L.off_G;
+    g.t2j = stash + L.t2j;
+    g.world = world;
+    g.prior_mu = prior_mu; g.prior_var = prior_var;
+    hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(64), 0, st, g);
+    HA_LAUNCH_CHECK();
+  }
+  return HA_OK;
+}
+
+extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float* z_seq, const float* g_world,
+                                         const float* g_prior_mu, const float* g_prior_var, float* stash, float* g_past_in0,
+                                         float* g_z_seq, void* stream) {
+  HA_REQUIRE(net && stash && g_past_in0 && g_z_seq, "ha_humor_rollout_backward: null argument");
+  HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_backward: B and S must be >= 1");
+  (void)z_seq;
+  DeviceGuard guard(net->device);
+  hipStream_t st = (hipStream_t)stream;
+  StashLayout L;
+  make_layout(net, B, S, L);
+  const int RT = L.RT, rows = RT * 32;
+  auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
+  const bool with_prior = g_prior_mu != nullptr || g_prior_var != nullptr;
+  const PackedLayer& DL = net->dec[net->n_dec - 1];
+  const PackedLayer& PL = net->pri[net->n_pri - 1];
+
+  auto fill_glue = [&](GlueParams& g, int t) {
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.S = S; g.t = t; g.RT = RT;
+    g.t2j = stash + L.t2j;
+    g.carry = stash + L.carry;
+    g.g_z = g_z_seq;
+    g.g_past0 = g_past_in0;
+    // step t+1 products (consumed when t < S-1)
+    g.gx_dir_in = stash + L.gx_dir[(t + 1) & 1];
+    g.gx_dir_out = stash + L.gx_dir[t & 1];
+    g.gxp_dec = stash + L.bwd_dec[0]; g.gxp_dec_nsplit = net->dec[0].nsplit_b; g.gxp_dec_pad = net->dec[0].Nin_pad;
+    if (with_prior) { g.gxp_pri = stash + L.bwd_pri[0]; g.gxp_pri_nsplit = net->pri[0].nsplit_b; g.gxp_pri_pad = net->pri[0].Nin_pad; }
+    g.dz_n = net->n_dec;
+    for (int i = 0; i < net->n_dec; ++i) {
+      g.dz_src[i] = stash + L.bwd_dec[i]; g.dz_nsplit[i] = net->dec[i].nsplit_b; g.dz_pad[i] = net->dec[i].Nin_pad;
+      g.dz_off[i] = net->dec[i].Cin;
+    }
+    if (t >= 0) {
+      float* sp = step_ptr(t);
+      g.xT = sp + L.off_x;
+      g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = DL.nsplit_f; g.dec_pad = DL.Nout_pad;
+      g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = PL.nsplit_f; g.pri_pad = PL.Nout_pad;
+      g.Gs = sp + L.off_G;
+      g.g_world = g_world;
+      g.g_prior_mu = g_prior_mu; g.g_prior_var = g_prior_var;
+      g.g_dec_out = stash + L.g_dec_out;
+      g.g_pri_out = with_prior ? stash + L.g_pri_out : nullptr;
+    }
+  };
+
+  for (int t = S - 1; t >= 0; --t) {
+    GlueParams g;
+    fill_glue(g, t);
+    hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(64), 0, st, g);
+    HA_LAUNCH_CHECK();
+    (void)0;
+    float* sp = step_ptr(t);
+    const int nl = net->n_dec > net->n_pri ? net->n_dec : net->n_pri;
+    for (int l = nl - 1; l >= 0; --l) {
+      LayerLaunch LL;
+      memset(&LL, 0, sizeof(LL));
+      LL.RT = RT;
+      if (l < net->n_dec) {
+        const PackedLayer& P = net->dec[l];
+        if (l == net->n_dec - 1)
+          bwd_task(LL.t[LL.ntasks++], P, stash + L.g_dec_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_dec[l]);
+        else
+          bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_dec[l + 1], net->dec[l + 1].nsplit_b, net->dec[l + 1].Nin_pad, &net->dec[l + 1],
+                   sp + L.off_dec[l], P.nsplit_f, stash + L.bwd_dec[l]);
+      }
+      if (with_prior && l < net->n_pri) {
+        const PackedLayer& P = net->pri[l];
+        if (l == net->n_pri - 1)
+          bwd_task(LL.t[LL.ntasks++], P, stash + L.g_pri_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_pri[l]);
+        else
+          bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_pri[l + 1], net->pri[l + 1].nsplit_b, net->pri[l + 1].Nin_pad, &net->pri[l + 1],
+                   sp + L.off_pri[l], P.nsplit_f, stash + L.bwd_pri[l]);
+      }
+      if (LL.ntasks == 0) continue;
+      int rc = launch_layers(LL, st);
+      if (rc != HA_OK) return rc;
+    }
+  }
+  GlueParams g;
+  fill_glue(g, -1);
+  hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(64), 0, st, g);
+  HA_LAUNCH_CHECK();
+  return HA_OK;
+}
+
+// ---- rotation conversions -------------------------------------------------------------------------
+#define HA_ROT_ENTRY(NAME, KERNEL, ...)                                                   \
+  do {                                                                                    \
+    HA_REQUIRE(n >= 0, NAME ": n must be >= 0");                                          \
+    if (n == 0) return HA_OK;                                                             \
+    hipLaunchKernelGGL(KERNEL, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, n, __VA_ARGS__); \
+    HA_LAUNCH_CHECK();                                                                    \
+    return HA_OK;                                                                         \
+  } while (0)
+
+extern "C" int ha_rodrigues_fwd(int n, const float* aa, float* R, void* stream) {
+  HA_REQUIRE(aa && R, "ha_rodrigues_fwd: null argument");
+  HA_ROT_ENTRY("ha_rodrigues_fwd", rodrigues_fwd_kernel, aa, R);
+}
+extern "C" int ha_rodrigues_bwd(int n, const float* aa, const float* gR, float* g_aa, void* stream) {
+  HA_REQUIRE(aa && gR && g_aa, "ha_rodrigues_bwd: null argument");
+  HA_ROT_ENTRY("ha_rodrigues_bwd", rodrigues_bwd_kernel, aa, gR, g_aa);
+}
+extern "C" int ha_rotmat_to_aa_fwd(int n, const float* R, float* aa, void* stream) {
+  HA_REQUIRE(R && aa, "ha_rotmat_to_aa_fwd: null argument");
+  HA_ROT_ENTRY("ha_rotmat_to_aa_fwd", rotmat_to_aa_fwd_kernel, R, aa);
+}
+extern "C" int ha_rotmat_to_aa_bwd(int n, const float* R, const float* g_aa, float* gR, void* stream) {
+  HA_REQUIRE(R && g_aa && gR, "ha_rotmat_to_aa_bwd: null argument");
+  HA_ROT_ENTRY("ha_rotmat_to_aa_bwd", rotmat_to_aa_bwd_kernel, R, g_aa, gR);
+}

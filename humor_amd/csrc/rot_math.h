@@ -1,0 +1,177 @@
+// Rotation conversions used on the roll-out path (device + host), fp32.
+#pragma once
+#include "common.h"
+
+namespace ha {
+
+// ---------------------------------------------------------------------------------------------------
+// rotation matrix -> axis-angle, restating rotation_matrix_to_angle_axis (humor/utils/transforms.py:243-389):
+// transpose, 4-way masked quaternion extraction (masks on m22 < 1e-6, m00 > m11, m00 < -m11), q *= 0.5/sqrt(t),
+// two_theta = 2 atan2(+-s, +-c), k = two_theta / s (2 when s^2 == 0), NaN -> 0.
+// `br` returns the selected branch, `q` the quaternion (w,x,y,z) for the backward pass.
+// ---------------------------------------------------------------------------------------------------
+struct QuatBranch {
+  int br;
+  float n[4];   // un-normalised numerators
+  float t;      // branch trace term
+};
+
+HA_HD void rot_to_quat_branch(const float R[9], QuatBranch& o) {
+  // m = R^T : m[i][j] = R[j][i]
+  const float m00 = R[0], m01 = R[3], m02 = R[6];
+  const float m10 = R[1], m11 = R[4], m12 = R[7];
+  const float m20 = R[2], m21 = R[5], m22 = R[8];
+  const bool d2 = m22 < 1e-6f, d01 = m00 > m11, d0n1 = m00 < -m11;
+  if (d2 && d01) {
+    o.br = 0; o.t = 1.f + m00 - m11 - m22;
+    o.n[0] = m12 - m21; o.n[1] = o.t; o.n[2] = m01 + m10; o.n[3] = m20 + m02;
+  } else if (d2) {
+    o.br = 1; o.t = 1.f - m00 + m11 - m22;
+    o.n[0] = m20 - m02; o.n[1] = m01 + m10; o.n[2] = o.t; o.n[3] = m12 + m21;
+  } else if (d0n1) {
+    o.br = 2; o.t = 1.f - m00 - m11 + m22;
+    o.n[0] = m01 - m10; o.n[1] = m20 + m02; o.n[2] = m12 + m21; o.n[3] = o.t;
+  } else {
+    o.br = 3; o.t = 1.f + m00 + m11 + m22;
+    o.n[0] = o.t; o.n[1] = m12 - m21; o.n[2] = m20 - m02; o.n[3] = m01 - m10;
+  }
+}
+
+HA_HD void rotmat_to_aa(const float R[9], float aa[3]) {
+  QuatBranch b;
+  rot_to_quat_branch(R, b);
+  const float sc = 0.5f / sqrtf(b.t);
+  const float q0 = b.n[0] * sc, q1 = b.n[1] * sc, q2 = b.n[2] * sc, q3 = b.n[3] * sc;
+  const float s2 = q1 * q1 + q2 * q2 + q3 * q3;
+  const float s = sqrtf(s2);
+  const float tt = 2.0f * (q0 < 0.0f ? atan2f(-s, -q0) : atan2f(s, q0));
+  const float k = s2 > 0.0f ? tt / s : 2.0f;
+  aa[0] = q1 * k; aa[1] = q2 * k; aa[2] = q3 * k;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (aa[i] != aa[i]) aa[i] = 0.f;
+}
+
+HA_HD void rotmat_to_aa_bwd(const float R[9], const float g_aa_in[3], float gR[9]) {
+  QuatBranch b;
+  rot_to_quat_branch(R, b);
+  const float ist = 1.0f / sqrtf(b.t);
+  const float sc = 0.5f * ist;
+  const float q[4] = {b.n[0] * sc, b.n[1] * sc, b.n[2] * sc, b.n[3] * sc};
+  const float s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const float s = sqrtf(s2);
+  const float tt = 2.0f * (q[0] < 0.0f ? atan2f(-s, -q[0]) : atan2f(s, q[0]));
+  const float k = s2 > 0.0f ? tt / s : 2.0f;
+  float g_aa[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float a = q[i + 1] * k;
+    g_aa[i] = (a != a) ? 0.f : g_aa_in[i];      // aa[isnan] = 0 cuts the gradient
+  }
+  float gq[4] = {0.f, g_aa[0] * k, g_aa[1] * k, g_aa[2] * k};
+  if (s2 > 0.0f) {
+    const float gk = g_aa[0] * q[1] + g_aa[1] * q[2] + g_aa[2] * q[3];
+    const float gtt = gk / s;
+    float gs = -gk * tt / s2;
+    const float den = s2 + q[0] * q[0];
+    gs += gtt * 2.0f * q[0] / den;
+    gq[0] = -gtt * 2.0f * s / den;
+    const float gs2 = gs / (2.0f * s);
+    gq[1] += 2.0f * q[1] * gs2; gq[2] += 2.0f * q[2] * gs2; gq[3] += 2.0f * q[3] * gs2;
+  }
+  // q_i = 0.5 n_i t^-1/2
+  float gn[4];
+  float gt = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    gn[i] = gq[i] * sc;
+    gt += gq[i] * b.n[i];
+  }
+  gt *= -0.25f * ist * ist * ist;
+  // gradient w.r.t. m (= R^T) entries
+  float gm[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) gm[i] = 0.f;
+  // indices into gm: m_ij -> i*3+j
+  if (b.br == 0) {
+    gt += gn[1];
+    gm[5] += gn[0]; gm[7] -= gn[0];           // m12 - m21
+    gm[1] += gn[2]; gm[3] += gn[2];           // m01 + m10
+    gm[6] += gn[3]; gm[2] += gn[3];           // m20 + m02
+    gm[0] += gt; gm[4] -= gt; gm[8] -= gt;
+  } else if (b.br == 1) {
+    gt += gn[2];
+    gm[6] += gn[0]; gm[2] -= gn[0];           // m20 - m02
+    gm[1] += gn[1]; gm[3] += gn[1];           // m01 + m10
+    gm[5] += gn[3]; gm[7] += gn[3];           // m12 + m21
+    gm[0] -= gt; gm[4] += gt; gm[8] -= gt;
+  } else if (b.br == 2) {
+    gt += gn[3];
+    gm[1] += gn[0]; gm[3] -= gn[0];           // m01 - m10
+    gm[6] += gn[1]; gm[2] += gn[1];           // m20 + m02
+    gm[5] += gn[2]; gm[7] += gn[2];           // m12 + m21
+    gm[0] -= gt; gm[4] -= gt; gm[8] += gt;
+  } else {
+    gt += gn[0];
+    gm[5] += gn[1]; gm[7] -= gn[1];           // m12 - m21
+    gm[6] += gn[2]; gm[2] -= gn[2];           // m20 - m02
+    gm[1] += gn[3]; gm[3] -= gn[3];           // m01 - m10
+    gm[0] += gt; gm[4] += gt; gm[8] += gt;
+  }
+  // m = R^T
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gR[j * 3 + i] = gm[i * 3 + j];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// heading alignment, compute_world2aligned_mat (humor/utils/transforms.py:17-42)
+// ---------------------------------------------------------------------------------------------------
+struct W2A {
+  float W[9];
+  float rx, ry, nrm, u, xp, angle, s, az;
+};
+
+HA_HD void w2a_fwd(const float pR[9], W2A& o) {
+  o.rx = -pR[0];
+  o.ry = -pR[3];
+  o.nrm = sqrtf(o.rx * o.rx + o.ry * o.ry);
+  o.u = o.rx / (o.nrm + 1e-6f);
+  o.xp = fminf(fmaxf(o.u, -1.0f), 1.0f);
+  o.angle = acosf(o.xp);
+  // axis = cross((rx, ry, 0), (1, 0, 0)) = (0, 0, -ry)
+  o.s = -o.ry / (fabsf(o.ry) + 1e-6f);
+  o.az = o.s * o.angle;
+  const float aa[3] = {0.f, 0.f, o.az};
+  rodrigues(aa, o.W);
+}
+
+// returns gradient w.r.t. pR[0] and pR[3] (the only entries W depends on)
+HA_HD void w2a_bwd(const W2A& o, const float gW[9], float& g_p0, float& g_p3) {
+  const float aa[3] = {0.f, 0.f, o.az};
+  float gaa[3];
+  rodrigues_bwd(aa, gW, gaa);
+  const float g_az = gaa[2];
+  const float g_s = o.angle * g_az;
+  const float g_angle = o.s * g_az;
+  const float g_xp = -g_angle / sqrtf(1.0f - o.xp * o.xp);
+  const float g_u = (o.u >= -1.0f && o.u <= 1.0f) ? g_xp : 0.f;
+  const float d = o.nrm + 1e-6f;
+  float g_rx = g_u / d;
+  float g_ry = 0.f;
+  const float g_nrm = -g_u * o.rx / (d * d);
+  if (o.nrm > 0.f) {
+    g_rx += g_nrm * o.rx / o.nrm;
+    g_ry += g_nrm * o.ry / o.nrm;
+  }
+  const float ar = fabsf(o.ry), da = ar + 1e-6f;
+  const float sgn = o.ry > 0.f ? 1.f : (o.ry < 0.f ? -1.f : 0.f);
+  // s = -ry / (|ry| + 1e-6)
+  const float ds = -(da - o.ry * sgn) / (da * da);
+  g_ry += g_s * ds;
+  g_p0 = -g_rx;
+  g_p3 = -g_ry;
+}
+
+}  // namespace ha

@@ -35,6 +35,15 @@ void set_error(const char* fmt, ...) {
 
 }  // namespace ha
 
+namespace ha {
+int g_skin_variant = 2;   // 0: LDS-staged window, 1: + hoisted weight loads, 2: direct 48-byte per-thread path; +4: non-temporal stores
+}
+extern "C" int ha_tune_set(const char* key, int value) {
+  HA_REQUIRE(key, "ha_tune_set: null key");
+  if (strcmp(key, "skin_variant") == 0) { ha::g_skin_variant = value; return HA_OK; }
+  ha::set_error("ha_tune_set: unknown key '%s'", key);
+  return HA_ERR_INVALID_ARG;
+}
 extern "C" const char* ha_last_error(void) { return ha::g_err; }
 extern "C" int ha_abi_version(void) { return 1; }
 extern "C" int ha_device_arch(int device, char* buf, int buflen) {
@@ -748,7 +757,7 @@ constexpr int kSkinVerts = 1024;
 __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__ v_posed, const float* __restrict__ A,
                                                        const float* __restrict__ transl, const float4* __restrict__ w4,
                                                        const uint32_t* __restrict__ idx4, float* __restrict__ verts,
-                                                       int N, int V, int J) {
+                                                       int N, int V, int J, int hoist) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_v = smem;                      // 3072 floats
   float* s_A = smem + kSkinVerts * 3;     // 2 frames x J x 12 floats
@@ -785,8 +794,21 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__
       }
     }
   }
-  __syncthreads();
   const long long frame1_start = (long long)(n0 + 1) * V;
+  float4 hw[4];
+  uint32_t hid[4];
+  if (hoist) {
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+      const long long gv = gv0 + tid + 256 * sidx;
+      const int fr = gv >= frame1_start ? 1 : 0;
+      int v = (int)(gv - (long long)(n0 + fr) * V);
+      if (gv >= total) v = 0;
+      hw[sidx] = w4[v];
+      hid[sidx] = idx4[v];
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int sidx = 0; sidx < 4; ++sidx) {
     const int lv = tid + 256 * sidx;
@@ -795,8 +817,8 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__
       const int fr = gv >= frame1_start ? 1 : 0;
       const int n = n0 + fr;
       const int v = (int)(gv - (long long)n * V);
-      const float4 wv = w4[v];
-      const uint32_t id = idx4[v];
+      const float4 wv = hoist ? hw[sidx] : w4[v];
+      const uint32_t id = hoist ? hid[sidx] : idx4[v];
       const float x = s_v[lv * 3], y = s_v[lv * 3 + 1], z = s_v[lv * 3 + 2];
       const float4* Af = reinterpret_cast<const float4*>(s_A + fr * J * 12);
       const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
@@ -833,6 +855,114 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__
           if (fl + e < total3) verts[fl + e] = s_v[i * 4 + e];
       }
     }
+  }
+}
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ void store4(float* dst, float a, float b, float c, float d) {
+  vf4 v = {a, b, c, d};
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<vf4*>(dst));
+  else *reinterpret_cast<vf4*>(dst) = v;
+}
+
+__device__ __forceinline__ void skin_one(const float* s_A, int J, int fr, float4 wv, uint32_t id, float x, float y, float z,
+                                         float tx, float ty, float tz, float& ox, float& oy, float& oz) {
+  const float4* Af = reinterpret_cast<const float4*>(s_A + fr * J * 12);
+  const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int jq = (id >> (8 * q)) & 0xff;
+    const float4 a0 = Af[jq * 3], a1 = Af[jq * 3 + 1], a2 = Af[jq * 3 + 2];
+    r0.x = fmaf(wq[q], a0.x, r0.x); r0.y = fmaf(wq[q], a0.y, r0.y); r0.z = fmaf(wq[q], a0.z, r0.z); r0.w = fmaf(wq[q], a0.w, r0.w);
+    r1.x = fmaf(wq[q], a1.x, r1.x); r1.y = fmaf(wq[q], a1.y, r1.y); r1.z = fmaf(wq[q], a1.z, r1.z); r1.w = fmaf(wq[q], a1.w, r1.w);
+    r2.x = fmaf(wq[q], a2.x, r2.x); r2.y = fmaf(wq[q], a2.y, r2.y); r2.z = fmaf(wq[q], a2.z, r2.z); r2.w = fmaf(wq[q], a2.w, r2.w);
+  }
+  // T = [R00 R01 R02 R10 | R11 R12 R20 R21 | R22 t0 t1 t2]
+  ox = fmaf(r0.x, x, fmaf(r0.y, y, fmaf(r0.z, z, r2.y))) + tx;
+  oy = fmaf(r0.w, x, fmaf(r1.x, y, fmaf(r1.y, z, r2.z))) + ty;
+  oz = fmaf(r1.z, x, fmaf(r1.w, y, fmaf(r2.x, z, r2.w))) + tz;
+}
+
+// Variant 2: no LDS staging of the vertices.  Thread i owns global vertices 4i..4i+3 = 48 contiguous bytes = three 16-byte
+// loads / stores (a wave's three instructions together cover 3072 contiguous bytes); only A goes through LDS.
+template <bool NT>
+__global__ __launch_bounds__(256) void lbs_skin_direct_kernel(const float* __restrict__ v_posed, const float* __restrict__ A,
+                                                              const float* __restrict__ transl, const float4* __restrict__ w4,
+                                                              const uint32_t* __restrict__ idx4, float* __restrict__ verts,
+                                                              int N, int V, int J) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_A = smem;   // 2 frames x J x 12
+  const int tid = threadIdx.x;
+  const long long total = (long long)N * V;
+  const long long gv0 = (long long)blockIdx.x * kSkinVerts;
+  const int n0 = (int)(gv0 / V);
+  const long long total3 = total * 3;
+  const long long gvt = gv0 + 4 * tid;          // this thread's first vertex
+  const long long fl = gvt * 3;                 // first float (multiple of 4)
+  // issue every global load up front
+  float f[12];
+  const bool full = fl + 11 < total3;
+  if (full) {
+    const float4* src = reinterpret_cast<const float4*>(v_posed + fl);
+    const float4 a = src[0], b = src[1], c = src[2];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    f[8] = c.x; f[9] = c.y; f[10] = c.z; f[11] = c.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 12; ++e) f[e] = fl + e < total3 ? v_posed[fl + e] : 0.f;
+  }
+  const long long frame1_start = (long long)(n0 + 1) * V;
+  float4 wv[4];
+  uint32_t id[4];
+  int frs[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long gv = gvt + k;
+    const int fr = gv >= frame1_start ? 1 : 0;
+    int v = (int)(gv - (long long)(n0 + fr) * V);
+    if (gv >= total) v = 0;
+    frs[k] = fr;
+    wv[k] = w4[v];
+    id[k] = idx4[v];
+  }
+  float tl[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  if (transl) {
+#pragma unroll
+    for (int fr = 0; fr < 2; ++fr)
+      if (n0 + fr < N) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tl[fr][c] = transl[(size_t)(n0 + fr) * 3 + c];
+      }
+  }
+  {
+    const int per = J * 3;
+    const float4* A4 = reinterpret_cast<const float4*>(A);
+    float4* sA4 = reinterpret_cast<float4*>(s_A);
+    for (int i = tid; i < 2 * per; i += 256) {
+      const int fr = i / per;
+      if (n0 + fr < N) sA4[i] = A4[(size_t)(n0 + fr) * per + (i - fr * per)];
+    }
+  }
+  __syncthreads();
+  float o[12];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int fr = frs[k];
+    skin_one(s_A, J, fr, wv[k], id[k], f[3 * k], f[3 * k + 1], f[3 * k + 2], tl[fr][0], tl[fr][1], tl[fr][2], o[3 * k], o[3 * k + 1],
+             o[3 * k + 2]);
+  }
+  if (full) {
+    float* dst = verts + fl;
+    store4<NT>(dst, o[0], o[1], o[2], o[3]);
+    store4<NT>(dst + 4, o[4], o[5], o[6], o[7]);
+    store4<NT>(dst + 8, o[8], o[9], o[10], o[11]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 12; ++e)
+      if (fl + e < total3) verts[fl + e] = o[e];
   }
 }
 
@@ -878,8 +1008,20 @@ extern "C" int ha_lbs_skin(const ha_smpl_model* m, int N, const float* v_posed, 
   const long long total = (long long)N * m->V;
   const int blocks = (int)((total + kSkinVerts - 1) / kSkinVerts);
   const size_t lds = (size_t)(kSkinVerts * 3 + 2 * m->J * 12) * sizeof(float);
-  hipLaunchKernelGGL(lbs_skin_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, v_posed, A, transl, m->w4, m->idx4,
-                     verts, N, m->V, m->J);
+  const int variant = g_skin_variant & 3;
+  const bool nt = (g_skin_variant & 4) != 0;
+  if (variant == 2) {
+    const size_t lds2 = (size_t)(2 * m->J * 12) * sizeof(float);
+    if (nt)
+      hipLaunchKernelGGL(lbs_skin_direct_kernel<true>, dim3(blocks), dim3(256), lds2, (hipStream_t)stream, v_posed, A, transl, m->w4,
+                         m->idx4, verts, N, m->V, m->J);
+    else
+      hipLaunchKernelGGL(lbs_skin_direct_kernel<false>, dim3(blocks), dim3(256), lds2, (hipStream_t)stream, v_posed, A, transl, m->w4,
+                         m->idx4, verts, N, m->V, m->J);
+  } else {
+    hipLaunchKernelGGL(lbs_skin_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, v_posed, A, transl, m->w4, m->idx4,
+                       verts, N, m->V, m->J, variant);
+  }
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

@@ -1,0 +1,340 @@
+"""Drop-in replacement for the reference's ``HumorModel`` on the fitting path (humor/models/humor_model.py:102-1203).
+
+Keeps the constructor signature, the parameter naming (``encoder|decoder|prior_net.net.<idx>.{weight,bias}``, so the
+reference checkpoint loads with ``load_state_dict``), the attributes the optimiser reads (``latent_size``,
+``use_conditional_prior``, ``model_data_config``, ``in_rot_rep``, ``data_names`` ...) and the methods it calls:
+``roll_out`` (the autoregressive hot loop -> one C-ABI call forward, one backward, no per-step Python),
+``infer_global_seq`` / ``prior`` / ``posterior`` / ``decode`` / ``sample_step`` / ``split_output`` / ``prepare_input``.
+
+The roll-out kernels implement the configuration the fitting pipeline uses (in_rot_rep='mat', out_rot_rep='aa',
+steps_in=1, 'smpl+joints(+contacts)', output_delta=True).  Other configurations raise NotImplementedError instead of
+silently running somewhere else.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .tables import SMPL_JOINTS
+
+IN_ROT_REPS = ['aa', '6d', 'mat']
+OUT_ROT_REPS = ['aa', '6d', '9d']
+ROT_REP_SIZE = {'aa': 3, '6d': 6, 'mat': 9, '9d': 9}
+NUM_SMPL_JOINTS = len(SMPL_JOINTS)
+NUM_BODY_JOINTS = NUM_SMPL_JOINTS - 1
+
+# humor/datasets/amass_utils.py:28-91 (state vector composition)
+_DATA_NAMES = ['trans', 'trans_vel', 'root_orient', 'root_orient_vel', 'pose_body', 'pose_body_vel', 'joints',
+               'joints_vel', 'joints_orient_vel', 'verts', 'verts_vel', 'contacts']
+_RETURN_CONFIGS = {
+    'smpl+joints': {'trans', 'trans_vel', 'root_orient', 'root_orient_vel', 'pose_body', 'joints', 'joints_vel'},
+    'smpl+joints+contacts': {'trans', 'trans_vel', 'root_orient', 'root_orient_vel', 'pose_body', 'joints', 'joints_vel', 'contacts'},
+}
+
+
+def data_name_list(return_config):
+    if return_config not in _RETURN_CONFIGS:
+        raise NotImplementedError(f"model_data_config '{return_config}' is not supported by humor_amd (fitting uses smpl+joints+contacts)")
+    return [k for k in _DATA_NAMES if k in _RETURN_CONFIGS[return_config]]
+
+
+def data_dim(dname, rot_rep_size=9):
+    if dname in ['trans', 'trans_vel', 'root_orient_vel']:
+        return 3
+    if dname == 'root_orient':
+        return rot_rep_size
+    if dname == 'pose_body':
+        return NUM_BODY_JOINTS * rot_rep_size
+    if dname in ['joints', 'joints_vel']:
+        return NUM_SMPL_JOINTS * 3
+    if dname == 'contacts':
+        return 9
+    raise ValueError(dname)
+
+
+class MLP(nn.Module):
+    """Parameter container with the reference's module indexing (Linear@0, then GroupNorm@3k-2, ReLU@3k-1, Linear@3k);
+    ``forward`` is the plain PyTorch evaluation used off the hot path (posterior inference once per fit)."""
+
+    def __init__(self, layers=[3, 128, 128, 3], nonlinearity=nn.ReLU, use_gn=True, skip_input_idx=None):
+        super(MLP, self).__init__()
+        in_size, out_channels = layers[0], layers[1:]
+        mods = [nn.Linear(in_size, out_channels[0])]
+        skip_size = 0 if skip_input_idx is None else (in_size - skip_input_idx)
+        for li in range(1, len(out_channels)):
+            if use_gn:
+                mods.append(nn.GroupNorm(16, out_channels[li - 1]))
+            mods.extend([nonlinearity(), nn.Linear(out_channels[li - 1] + skip_size, out_channels[li])])
+        self.net = nn.ModuleList(mods)
+        self.skip_input_idx = skip_input_idx
+
+    def forward(self, x):
+        skip_in = x[:, self.skip_input_idx:] if self.skip_input_idx is not None else None
+        for i, layer in enumerate(self.net):
+            if skip_in is not None and i > 0 and isinstance(layer, nn.Linear):
+                x = torch.cat([x, skip_in], dim=1)
+            x = layer(x)
+        return x
+
+    def describe(self):
+        """(n_linear, in_dim, skip_dim, out_dims, [(w,b)], [(gamma,beta) or None]) for packing."""
+        lin = [m for m in self.net if isinstance(m, nn.Linear)]
+        gns = [m for m in self.net if isinstance(m, nn.GroupNorm)]
+        skip = 0 if self.skip_input_idx is None else lin[0].in_features - self.skip_input_idx
+        return lin, gns, skip
+
+
+class _NetHandle:
+    def __init__(self, lib, device_index, decoder, prior):
+        self.lib = lib
+        self.ptr = C.c_void_p()
+        keep = []
+
+        def desc(mlp):
+            lin, gns, skip = mlp.describe()
+            if len(gns) != len(lin) - 1:
+                raise NotImplementedError('humor_amd roll-out kernels expect GroupNorm before every hidden Linear')
+            d = _lib.MlpDesc()
+            d.n_linear, d.in_dim, d.skip_dim = len(lin), lin[0].in_features, skip
+            for i, l in enumerate(lin):
+                w = l.weight.detach().float().cpu().contiguous()
+                b = l.bias.detach().float().cpu().contiguous()
+                keep.extend([w, b])
+                d.out_dims[i] = l.out_features
+                d.w[i], d.b[i] = w.data_ptr(), b.data_ptr()
+                if i > 0:
+                    g = gns[i - 1].weight.detach().float().cpu().contiguous()
+                    be = gns[i - 1].bias.detach().float().cpu().contiguous()
+                    keep.extend([g, be])
+                    d.gn_gamma[i], d.gn_beta[i] = g.data_ptr(), be.data_ptr()
+            return d
+        dd, dp = desc(decoder), desc(prior)
+        lib.call('ha_humor_net_create', C.byref(self.ptr), device_index, C.byref(dd), C.byref(dp))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.call('ha_humor_net_destroy', self.ptr)
+        except Exception:
+            pass
+
+
+class _RolloutFunction(torch.autograd.Function):
+    """(past_in0 [B,339], z_seq [B,S,48]) -> (world [B,S,348], prior_mu [B,S,48], prior_var [B,S,48])."""
+
+    @staticmethod
+    def forward(ctx, past_in0, z_seq, handle, want_prior):
+        lib = handle.lib
+        past_in0, z_seq = past_in0.contiguous().float(), z_seq.contiguous().float()
+        B, S = z_seq.shape[0], z_seq.shape[1]
+        dev = past_in0.device
+        n = C.c_int64()
+        lib.call('ha_humor_rollout_workspace', handle.ptr, B, S, C.byref(n))
+        stash = torch.empty(n.value, dtype=torch.float32, device=dev)
+        world = torch.empty(B, S, 348, dtype=torch.float32, device=dev)
+        pm = torch.empty(B, S, 48, dtype=torch.float32, device=dev) if want_prior else None
+        pv = torch.empty(B, S, 48, dtype=torch.float32, device=dev) if want_prior else None
+        lib.call('ha_humor_rollout_forward', handle.ptr, B, S, _lib.ptr(past_in0), _lib.ptr(z_seq), _lib.ptr(world),
+                 _lib.ptr(pm), _lib.ptr(pv), _lib.ptr(stash), _lib.stream_ptr(past_in0))
+        ctx.handle, ctx.stash, ctx.dims, ctx.want_prior = handle, stash, (B, S), want_prior
+        ctx.save_for_backward(z_seq)
+        ctx.set_materialize_grads(False)
+        if want_prior:
+            return world, pm, pv
+        return world, None, None
+
+    @staticmethod
+    def backward(ctx, g_world, g_pm, g_pv):
+        handle, (B, S) = ctx.handle, ctx.dims
+        lib = handle.lib
+        z_seq, = ctx.saved_tensors
+        dev = z_seq.device
+        c = lambda t: None if t is None else t.contiguous().float()
+        g_world, g_pm, g_pv = c(g_world), c(g_pm), c(g_pv)
+        g_past = torch.empty(B, 339, dtype=torch.float32, device=dev)
+        g_z = torch.empty(B, S, 48, dtype=torch.float32, device=dev)
+        lib.call('ha_humor_rollout_backward', handle.ptr, B, S, _lib.ptr(z_seq), _lib.ptr(g_world), _lib.ptr(g_pm), _lib.ptr(g_pv),
+                 _lib.ptr(ctx.stash), _lib.ptr(g_past), _lib.ptr(g_z), _lib.stream_ptr(z_seq))
+        return g_past, g_z, None, None
+
+
+class HumorModel(nn.Module):
+
+    def __init__(self, in_rot_rep='aa', out_rot_rep='aa', latent_size=48, steps_in=1, conditional_prior=True,
+                 output_delta=True, posterior_arch='mlp', decoder_arch='mlp', prior_arch='mlp',
+                 model_data_config='smpl+joints+contacts', detach_sched_samp=True, model_use_smpl_joint_inputs=False,
+                 model_smpl_batch_size=1, _lib_override=None):
+        super(HumorModel, self).__init__()
+        if out_rot_rep not in OUT_ROT_REPS:
+            raise Exception('Not a valid output rotation representation: %s' % (out_rot_rep))
+        if in_rot_rep not in IN_ROT_REPS:
+            raise Exception('Not a valid input rotation representation: %s' % (in_rot_rep))
+        if 'mlp' not in (posterior_arch, decoder_arch, prior_arch) or {posterior_arch, decoder_arch, prior_arch} != {'mlp'}:
+            raise Exception('Only mlp architectures exist')
+        if model_use_smpl_joint_inputs:
+            raise NotImplementedError('model_use_smpl_joint_inputs is a training-time option outside the fitting path')
+        self.ignore_keys = []
+        self.steps_in, self.steps_out, self.out_step_size = steps_in, 1, 1
+        self.detach_sched_samp = detach_sched_samp
+        self.output_delta = output_delta
+        self.out_rot_rep, self.in_rot_rep = out_rot_rep, in_rot_rep
+        self.posterior_arch, self.decoder_arch, self.prior_arch = posterior_arch, decoder_arch, prior_arch
+        self.data_names = data_name_list(model_data_config)
+        self.aux_in_data_names = self.aux_out_data_names = None
+        self.pred_contacts = False
+        if 'contacts' in model_data_config:
+            self.data_names.remove('contacts')
+            self.aux_out_data_names = ['contacts']
+            self.pred_contacts = True
+        self.need_trans2joint = 'joints' in self.data_names
+        self.model_data_config = model_data_config
+        self.input_rot_dim = ROT_REP_SIZE[in_rot_rep]
+        self.input_dim_list = [data_dim(d, self.input_rot_dim) for d in self.data_names]
+        self.input_data_dim = sum(self.input_dim_list)
+        self.output_rot_dim = ROT_REP_SIZE[out_rot_rep]
+        self.output_dim_list = [data_dim(d, self.output_rot_dim) for d in self.data_names]
+        self.delta_output_dim_list = [data_dim(d, 9) for d in self.data_names]
+        if self.pred_contacts:
+            self.output_dim_list.append(9)
+            self.delta_output_dim_list.append(9)
+        self.output_data_dim = sum(self.output_dim_list)
+        self.latent_size = latent_size
+        past_dim = steps_in * self.input_data_dim
+        self.encoder = MLP([past_dim + self.input_data_dim, 1024, 1024, 1024, 1024, latent_size * 2])
+        self.decoder = MLP([past_dim + latent_size, 1024, 1024, 512, self.output_data_dim], skip_input_idx=past_dim)
+        self.use_conditional_prior = conditional_prior
+        if conditional_prior:
+            self.prior_net = MLP([past_dim, 1024, 1024, 1024, 1024, latent_size * 2])
+        self.use_smpl_joint_inputs = False
+        self.smpl_batch_size = model_smpl_batch_size
+        self._lib = _lib_override
+        self._net_handles = {}
+
+    # ------------------------------------------------------------------------------------------------
+    # single-step API (PyTorch ops; off the hot path)
+    # ------------------------------------------------------------------------------------------------
+    def prior(self, past_in):
+        out = self.prior_net(past_in)
+        return out[:, :self.latent_size], torch.exp(out[:, self.latent_size:])
+
+    def posterior(self, past_in, t_in):
+        out = self.encoder(torch.cat([past_in, t_in], dim=1))
+        return out[:, :self.latent_size], torch.exp(out[:, self.latent_size:])
+
+    def rsample(self, mu, var):
+        return mu + torch.randn_like(mu) * torch.sqrt(var)
+
+    def infer_step(self, past_in, t_in):
+        qm, qv = self.posterior(past_in, t_in)
+        if self.use_conditional_prior:
+            pm, pv = self.prior(past_in)
+        else:
+            pm, pv = torch.zeros_like(qm), torch.ones_like(qv)
+        return (pm, pv), (qm, qv)
+
+    def infer(self, x_past, x_t):
+        B = x_past.size(0)
+        return self.infer_step(x_past.reshape(B, -1), x_t.reshape(B, -1))
+
+    def split_output(self, decoder_out, convert_rots=True):
+        B = decoder_out.size(0)
+        decoder_out = decoder_out.reshape(B, self.steps_out, -1)
+        names = self.data_names + (self.aux_out_data_names or [])
+        dims = self.delta_output_dim_list if self.output_delta else self.output_dim_list
+        out, s = {}, 0
+        for n, d in zip(names, dims):
+            out[n] = decoder_out[:, :, s:s + d]
+            s += d
+        if convert_rots and not self.output_delta:
+            raise NotImplementedError('output_delta=False models are outside the fitting path')
+        return out
+
+    def prepare_input(self, data_in, device, data_out=None, return_input_dict=False, return_global_dict=False):
+        """Concatenates per-key data [B,T,...] into x_past [B,T,steps_in,D] (humor_model.py:233-314, input side)."""
+        if data_out is not None or return_global_dict:
+            raise NotImplementedError('training-side prepare_input (data_out / global dict) is outside the fitting path')
+        parts = []
+        for k in self.data_names:
+            cur = data_in[k].to(device)
+            parts.append(cur.reshape(cur.size(0), cur.size(1), self.steps_in, -1))
+        x_past = torch.cat(parts, dim=3)
+        if return_input_dict:
+            return x_past, {k: v for k, v in zip(self.data_names, parts)}
+        return x_past
+
+    # ------------------------------------------------------------------------------------------------
+    # roll-out (hot path)
+    # ------------------------------------------------------------------------------------------------
+    def _check_rollout_config(self):
+        if not (self.in_rot_rep == 'mat' and self.out_rot_rep == 'aa' and self.steps_in == 1 and self.output_delta
+                and self.input_data_dim == 339):
+            raise NotImplementedError("humor_amd roll-out kernels implement in_rot_rep='mat', out_rot_rep='aa', steps_in=1, "
+                                      "output_delta=True, 'smpl+joints(+contacts)' (the fitting configuration)")
+        if not self.use_conditional_prior:
+            raise NotImplementedError('roll-out kernels expect the conditional prior network')
+
+    def _net_handle(self, device):
+        lib = self._lib if self._lib is not None else _lib.get_lib()
+        if device.type == 'cuda':
+            index = device.index if device.index is not None else torch.cuda.current_device()
+        elif lib.emulator:
+            index = 0
+        else:
+            raise _lib.HumorAmdError('HumorModel.roll_out runs on the GPU only (no CPU fallback): move the model inputs to a HIP device')
+        ver = tuple(p._version for p in self.parameters())
+        key = (device.type, index)
+        cached = self._net_handles.get(key)
+        if cached is None or cached[0] != ver:
+            self._net_handles[key] = (ver, _NetHandle(lib, index, self.decoder, self.prior_net))
+        return self._net_handles[key][1]
+
+    def roll_out(self, x_past, init_input_dict, num_steps, use_mean=False, z_seq=None, return_prior=False, gender=None,
+                 betas=None, return_z=False, canonicalize_input=False, uncanonicalize_output=False):
+        '''
+        Rolls the model out from the initial state with the given latent sequence (humor_model.py:785-1017).
+        Returns a dict of world-frame [B, num_steps, D] tensors (rotations as matrices), optionally (prior mean, var).
+        '''
+        self._check_rollout_config()
+        if canonicalize_input:
+            raise NotImplementedError('canonicalize_input=True: canonicalise with MotionOptimizer / ops first (fitting calls roll_out with the default)')
+        if z_seq is None:
+            raise NotImplementedError('sampling roll-out (z_seq=None) is not on the fitting path; pass z_seq')
+        if x_past is not None:
+            past_in = x_past.reshape(x_past.size(0), -1)
+        else:
+            past_in = torch.cat([init_input_dict[k][:, -1, :] for k in self.data_names], dim=1)
+        z_seq = z_seq[:, :num_steps]
+        handle = self._net_handle(past_in.device)
+        world, pm, pv = _RolloutFunction.apply(past_in, z_seq, handle, bool(return_prior))
+        out, s = {}, 0
+        for n, d in zip(self.data_names, self.delta_output_dim_list):
+            out[n] = world[:, :, s:s + d]
+            s += d
+        if self.pred_contacts:
+            out['contacts'] = world[:, :, s:s + 9]
+        if return_z:
+            out['z'] = z_seq
+        if return_prior:
+            return out, (pm, pv)
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    # posterior inference over a whole sequence (once per fit; PyTorch ops, all T-1 pairs batched)
+    # ------------------------------------------------------------------------------------------------
+    def infer_global_seq(self, global_seq, full_forward_pass=False):
+        '''
+        Canonicalises every consecutive frame pair (t, t+1) into frame t's aligned coordinate system and evaluates
+        prior and posterior for all pairs at once (humor_model.py:1061-1165 does the same with a Python loop over t).
+        '''
+        if full_forward_pass:
+            raise NotImplementedError('full_forward_pass=True is a training/eval option outside the fitting path')
+        if self.steps_in != 1 or self.in_rot_rep != 'mat':
+            raise NotImplementedError("infer_global_seq implements steps_in=1, in_rot_rep='mat'")
+        from .frames import canonicalize_pairs
+        x_past, x_t = canonicalize_pairs(global_seq, self.data_names)      # [B*(T-1), D] each
+        B, T = global_seq['trans'].shape[0], global_seq['trans'].shape[1]
+        (pm, pv), (qm, qv) = self.infer_step(x_past, x_t)
+        r = lambda a: a.reshape(B, T - 1, -1)
+        return (r(pm), r(pv)), (r(qm), r(qv))

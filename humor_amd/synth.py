@@ -77,7 +77,8 @@ def make_smplh_npz(seed=0, num_verts=NUM_VERTS, num_betas=NUM_BETAS, dtype=np.fl
     P = (NUM_JOINTS - 1) * 9
 
     # vertices: points scattered around bones (segment joint->parent), radius by body part
-    bone_of_vert = rng.randint(0, NUM_JOINTS, size=num_verts)
+    # vertex ids are grouped by body part, as in the real SMPL topology (neighbouring ids share skinning joints)
+    bone_of_vert = np.sort(rng.randint(0, NUM_JOINTS, size=num_verts))
     t = rng.rand(num_verts, 1)
     par = np.where(parents[bone_of_vert] < 0, bone_of_vert, parents[bone_of_vert])
     centre = J[bone_of_vert] * t + J[par] * (1.0 - t)

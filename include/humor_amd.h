@@ -34,6 +34,8 @@ const char* ha_last_error(void);
 int ha_abi_version(void);
 /* Writes the device's gcnArchName (e.g. "gfx950:sramecc+:xnack-") into buf. */
 int ha_device_arch(int device, char* buf, int buflen);
+/* Development knob for kernel variants (A/B measurements); keys: "skin_variant". Process-wide. */
+int ha_tune_set(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------
  * SMPL / SMPL+H body model  (replaces smplx==0.1.28 `lbs`, `SMPLH.forward`, `VertexJointSelector` as
@@ -70,13 +72,13 @@ int ha_smpl_model_define_subset(ha_smpl_model* m, int slot, const int32_t* ids, 
  * optional workspace outputs (NULL to skip), needed by the tiled dense path and for debugging:
  *   A_out  [N, J, 12]  relative joint transforms (3x4 row-major)
  * `algo`: 0 = auto, 1 = wave-per-frame VALU kernel, 2 = tiled MFMA pose-blend + streaming skinning
- *         (slot 0 only; needs ws_vposed [N, Vpad, 3] and ws_coeff [Kc, Npad] from ha_smpl_workspace). */
+ *         (slot 0 only; needs A_out, ws_vposed [N,V,3](+4) and ws_coeff [Kc, Npad] sized by ha_smpl_workspace). */
 int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_active_joints,
                     const float* pose, const float* betas, const float* transl,
                     float* verts, float* joints, float* A_out,
                     float* ws_vposed, float* ws_coeff, int algo, void* stream);
 
-/* Element counts (floats) of the algo-2 workspaces for N frames: *vposed = N*Vpad*3, *coeff = Kc*Npad. */
+/* Element counts (floats) of the algo-2 workspaces for N frames: *vposed = N*V*3 + 4, *coeff = Kc_pad*Npad. */
 int ha_smpl_workspace(const ha_smpl_model* m, int N, int n_active_joints, int64_t* vposed, int64_t* coeff);
 
 /* Backward of ha_smpl_forward for subset `slot`.  Forward intermediates are recomputed from
@@ -91,7 +93,7 @@ int ha_smpl_backward(const ha_smpl_model* m, int slot, int N, int n_active_joint
 
 /* The streaming linear-blend-skinning kernel on its own (the HBM-roofline kernel):
  * verts[n,v,:] = (sum_i w[v,i] * A[n, idx[v,i]]) * [v_posed[n,v,:]; 1] + transl[n].
- * v_posed is [N, Vpad, 3] (Vpad from ha_smpl_model_info what=5), verts is [N, V, 3]. */
+ * v_posed and verts are [N, V, 3] (v_posed allocated with the +4 floats ha_smpl_workspace reports). */
 int ha_lbs_skin(const ha_smpl_model* m, int N, const float* v_posed, const float* A, const float* transl,
                 float* verts, void* stream);
 

@@ -16,6 +16,15 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'slow: long-running CPU test')
 
 
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get('HUMOR_AMD_SLOW', '0') == '1':
+        return
+    skip = pytest.mark.skip(reason='slow SIMT-emulator test: set HUMOR_AMD_SLOW=1')
+    for item in items:
+        if 'slow' in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope='session')
 def smplh_npz(tmp_path_factory):
     """Seed-0 synthetic SMPL+H model file (same bytes on every machine)."""

@@ -1,0 +1,133 @@
+"""Shared roll-out / rotation parity checks (emulator tier on CPU, gfx950 build on the GPU)."""
+import numpy as np
+import torch
+
+from conftest import golden
+from humor_amd import ops, synth
+from humor_amd.humor_model import HumorModel
+from oracle import humor_restated as H
+from oracle import lbs_restated as L
+
+KEYS = ['trans', 'trans_vel', 'root_orient', 'root_orient_vel', 'pose_body', 'joints', 'joints_vel', 'contacts']
+FWD_TOL = 1e-4      # north_star: fp32 latents / states within 1e-4
+GRAD_RTOL = 1e-3    # relative to the largest reference gradient entry (chain of S steps)
+
+
+def canonical_state(B, gen):
+    r = lambda *s: torch.randn(*s, generator=gen)
+    trans = torch.cat([torch.zeros(B, 2), 0.9 + 0.1 * r(B, 1)], 1)
+    R_root = L.batch_rodrigues(0.3 * r(B, 3)).reshape(B, 9)
+    R_body = L.batch_rodrigues(0.3 * r(B * 21, 3)).reshape(B, 189)
+    joints = 0.3 * r(B, 66)
+    joints[:, :2] = 0
+    return torch.cat([trans, 0.3 * r(B, 3), R_root, 0.3 * r(B, 3), R_body, joints, 0.3 * r(B, 66)], 1)
+
+
+def make_model(lib, device, seed=0, weight_scale=1.0):
+    sd = synth.humor_state_dict(seed=seed, weight_scale=weight_scale)
+    hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1,
+                    _lib_override=lib)
+    hm.load_state_dict(sd)
+    return hm.to(device).eval(), sd
+
+
+def world_of(out):
+    return torch.cat([out[k] for k in KEYS], 2)
+
+
+def check_rollout(lib, device, B, S, seed=0, with_prior=True, weight_scale=1.0, fwd_tol=FWD_TOL):
+    hm, sd = make_model(lib, device, seed=seed, weight_scale=weight_scale)
+    g = torch.Generator().manual_seed(seed + 5)
+    past_c = canonical_state(B, g).requires_grad_(True)
+    z_c = torch.randn(B, S, 48, generator=g).requires_grad_(True)
+    past = past_c.detach().to(device).requires_grad_(True)
+    z = z_c.detach().to(device).requires_grad_(True)
+    res = hm.roll_out(past, None, S, z_seq=z, return_prior=with_prior)
+    out, (pm, pv) = res if with_prior else (res, (None, None))
+    world = world_of(out)
+    w_ref, (pm_r, pv_r) = H.roll_out(sd, past_c, z_c)
+    err = (world.detach().cpu() - w_ref).abs().max().item()
+    assert err < fwd_tol, err
+    gw = torch.randn(w_ref.shape, generator=g)
+    loss, loss_ref = (world * gw.to(device)).sum(), (w_ref * gw).sum()
+    if with_prior:
+        assert (pm.detach().cpu() - pm_r).abs().max().item() < fwd_tol
+        assert ((pv.detach().cpu() - pv_r).abs() / pv_r.abs().clamp(min=1.0)).max().item() < fwd_tol
+        gm, gv = torch.randn(pm_r.shape, generator=g), torch.randn(pv_r.shape, generator=g)
+        loss = loss + (pm * gm.to(device)).sum() + (pv * gv.to(device)).sum()
+        loss_ref = loss_ref + (pm_r * gm).sum() + (pv_r * gv).sum()
+    g_our = torch.autograd.grad(loss, [past, z])
+    g_ref = torch.autograd.grad(loss_ref, [past_c, z_c])
+    for name, a, b in zip(('g_past_in0', 'g_z'), g_ref, g_our):
+        scale = max(1.0, a.abs().max().item())
+        e = (a - b.cpu()).abs().max().item()
+        assert e < GRAD_RTOL * scale, (name, e, scale)
+    # contact labels (the only thresholded output) must be bit-exact away from the decision boundary (G11)
+    logits_ref = w_ref[:, :, 339:348].detach()
+    lab = (torch.sigmoid(world[:, :, 339:348].detach().cpu()) > 0.5)
+    lab_ref = torch.sigmoid(logits_ref) > 0.5
+    far = logits_ref.abs() > 1e-4
+    assert (lab[far] == lab_ref[far]).all()
+    return err
+
+
+def check_rollout_golden(lib, device):
+    gd = golden('rollout.npz')
+    hm, _ = make_model(lib, device, seed=int(gd['weight_seed']))
+    past = torch.tensor(gd['past0']).to(device).requires_grad_(True)
+    z = torch.tensor(gd['z']).to(device).requires_grad_(True)
+    out, (pm, pv) = hm.roll_out(past, None, z.shape[1], z_seq=z, return_prior=True)
+    world = world_of(out)
+    assert np.abs(world.detach().cpu().numpy() - gd['world']).max() < FWD_TOL
+    assert np.abs(pm.detach().cpu().numpy() - gd['prior_mu']).max() < FWD_TOL
+    assert np.abs(pv.detach().cpu().numpy() - gd['prior_var']).max() < FWD_TOL
+    t = lambda k: torch.tensor(gd[k]).to(device)
+    loss = (world * t('gw')).sum() + (pm * t('gm')).sum() + (pv * t('gv')).sum()
+    g0, gz = torch.autograd.grad(loss, [past, z])
+    assert np.abs(g0.cpu().numpy() - gd['g_past0']).max() < 2e-3 * max(1.0, np.abs(gd['g_past0']).max())
+    assert np.abs(gz.cpu().numpy() - gd['g_z']).max() < 2e-3 * max(1.0, np.abs(gd['g_z']).max())
+    aa_root = ops.rotation_matrix_to_angle_axis(out['root_orient'].reshape(-1, 3, 3), _lib_override=lib)
+    assert np.abs(aa_root.detach().cpu().numpy().reshape(gd['aa_root'].shape) - gd['aa_root']).max() < FWD_TOL
+
+
+def check_rotations_golden(lib, device):
+    gd = golden('rotations.npz')
+    aa = torch.tensor(gd['aa']).to(device).requires_grad_(True)
+    Rm = ops.batch_rodrigues(aa, _lib_override=lib)
+    assert np.abs(Rm.detach().cpu().numpy() - gd['R']).max() < 1e-6
+    g_aa = torch.autograd.grad((Rm * torch.tensor(gd['gR']).to(device)).sum(), aa)[0].cpu().numpy()
+    ok = np.isfinite(gd['g_aa']).all(axis=1) & (np.abs(gd['aa']).sum(axis=1) > 0)   # skip the exact-zero rows (1/1.7e-8 scaling)
+    assert np.abs(g_aa[ok] - gd['g_aa'][ok]).max() < 1e-3 * max(1.0, np.abs(gd['g_aa'][ok]).max())
+    Rin = torch.tensor(gd['R']).to(device).requires_grad_(True)
+    back = ops.rotation_matrix_to_angle_axis(Rin, _lib_override=lib)
+    assert np.abs(back.detach().cpu().numpy() - gd['aa_back']).max() < 1e-5
+    g_R = torch.autograd.grad((back * torch.tensor(gd['gb']).to(device)).sum(), Rin)[0].cpu().numpy()
+    # the reference gradient is ill-conditioned at theta ~ 0 and theta ~ pi (G3): compare well-conditioned rows
+    ang = np.linalg.norm(gd['aa_back'], axis=1)
+    good = (ang > 0.2) & (ang < 2.6) & np.isfinite(gd['g_Rin']).all(axis=(1, 2))
+    assert np.abs(g_R[good] - gd['g_Rin'][good]).max() < 1e-3 * max(1.0, np.abs(gd['g_Rin'][good]).max())
+
+
+def check_rot_random(lib, device, n=4096, seed=0):
+    """rotation kernels against the oracle on random, well-conditioned inputs (fwd + bwd)."""
+    g = torch.Generator().manual_seed(seed)
+    aa_c = (1.0 * torch.randn(n, 3, generator=g)).requires_grad_(True)
+    aa = aa_c.detach().to(device).requires_grad_(True)
+    R_ref = L.batch_rodrigues(aa_c)
+    Rm = ops.batch_rodrigues(aa, _lib_override=lib)
+    assert (Rm.detach().cpu() - R_ref).abs().max().item() < 1e-6
+    gR = torch.randn(n, 3, 3, generator=g)
+    ga = torch.autograd.grad((Rm * gR.to(device)).sum(), aa)[0].cpu()
+    ga_ref = torch.autograd.grad((R_ref * gR).sum(), aa_c)[0]
+    assert (ga - ga_ref).abs().max().item() < 1e-4 * max(1.0, ga_ref.abs().max().item())
+    Rc = R_ref.detach().clone().requires_grad_(True)
+    Rd = Rc.detach().to(device).requires_grad_(True)
+    b_ref = H.rot_to_aa(Rc)
+    b = ops.rotation_matrix_to_angle_axis(Rd, _lib_override=lib)
+    assert (b.detach().cpu() - b_ref).abs().max().item() < 1e-5
+    gb = torch.randn(n, 3, generator=g)
+    gr = torch.autograd.grad((b * gb.to(device)).sum(), Rd)[0].cpu()
+    gr_ref = torch.autograd.grad((b_ref * gb).sum(), Rc)[0]
+    ang = b_ref.detach().norm(dim=1)
+    good = (ang > 0.2) & (ang < 2.6)
+    assert (gr[good] - gr_ref[good]).abs().max().item() < 1e-3 * max(1.0, gr_ref[good].abs().max().item())

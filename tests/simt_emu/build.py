@@ -23,7 +23,7 @@ def build(force=False):
         [os.path.join(HERE, 'include', 'hip', 'hip_runtime.h'), os.path.join(ROOT, 'include', 'humor_amd.h')]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
-    cmd = [CLANG, '-x', 'c++', '-std=c++20', '-O1', '-g0', '-fPIC', '-shared', '-pthread', '-ffp-contract=off',
+    cmd = [CLANG, '-x', 'c++', '-std=c++20', '-O2', '-g0', '-fPIC', '-shared', '-pthread', '-ffp-contract=off',
            '-Wno-unknown-attributes', '-Wno-ignored-attributes', '-Wno-pass-failed',
            '-I', os.path.join(HERE, 'include'), '-o', OUT] + srcs
     subprocess.check_call(cmd)

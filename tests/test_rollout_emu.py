@@ -1,0 +1,28 @@
+"""CPU tier: roll-out / rotation kernel sources executed by the host SIMT emulator against the oracle."""
+import pytest
+import torch
+
+import rollout_checks as RC
+
+CPU = torch.device('cpu')
+
+
+def test_emu_rotation_kernels(emu_lib):
+    RC.check_rot_random(emu_lib, CPU, n=512)
+    RC.check_rotations_golden(emu_lib, CPU)
+
+
+@pytest.mark.slow
+def test_emu_rollout_two_steps(emu_lib):
+    # MFMA layer kernel (all four prologue modes), glue forward/backward, dz / past_in0 collection
+    RC.check_rollout(emu_lib, CPU, B=2, S=2)
+
+
+def test_rollout_refuses_cpu():
+    from humor_amd._lib import HumorAmdError
+    from humor_amd.humor_model import HumorModel
+    hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', model_data_config='smpl+joints+contacts')
+    with pytest.raises((HumorAmdError, RuntimeError)):
+        hm.roll_out(torch.zeros(2, 339), None, 2, z_seq=torch.zeros(2, 2, 48))
+    with pytest.raises(NotImplementedError):
+        HumorModel(in_rot_rep='aa', out_rot_rep='aa').roll_out(torch.zeros(2, 300), None, 2, z_seq=torch.zeros(2, 2, 48))
