@@ -67,13 +67,121 @@ struct LayerLaunch {
   int RT;
 };
 
-// sums `nsplit` partial slabs of element (channel c, row) of tile rt
+constexpr int MAXSPLIT = 6;   // K-slices / NW never exceeds this for the supported layer widths
+
+// sums `nsplit` (<= MAXSPLIT) partial slabs of element (channel c, row) of tile rt.  All loads are unconditional (clamped
+// slab index, zero weight beyond nsplit) so they issue back-to-back instead of one round trip per slab.
 __device__ __forceinline__ float slab_sum(const float* base, int nsplit, int RT, int C, int rt, int c, int row) {
   const size_t stride = (size_t)RT * C * 32;
   const float* p = base + ((size_t)rt * C + c) * 32 + row;
-  float v = p[0];
-  for (int s = 1; s < nsplit; ++s) v += p[(size_t)s * stride];
+  float t[MAXSPLIT];
+#pragma unroll
+  for (int s = 0; s < MAXSPLIT; ++s) t[s] = p[(size_t)(s < nsplit ? s : 0) * stride];
+  float v = t[0];
+#pragma unroll
+  for (int s = 1; s < MAXSPLIT; ++s) v += s < nsplit ? t[s] : 0.f;
   return v;
+}
+
+// A wave's 64-channel x 32-row fragment of a slab stack: element kp of lane l is (channel cbase + 2 kp + (l>>5), row l&31),
+// i.e. p[kp * 64] with p = slab + (rt*C + cbase)*32 + lane.  All NS x 32 loads are issued back-to-back (independent), then
+// summed in split order -- the layer is latency-bound, so the loads must not be serialised by a runtime loop.
+template <int NS>
+__device__ __forceinline__ void load_frag(const float* p, size_t stride, float (&a)[32]) {
+  float part[NS][32];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int kp = 0; kp < 32; ++kp) part[s][kp] = p[(size_t)s * stride + kp * 64];
+#pragma unroll
+  for (int kp = 0; kp < 32; ++kp) {
+    float v = part[0][kp];
+#pragma unroll
+    for (int s = 1; s < NS; ++s) v += part[s][kp];
+    a[kp] = v;
+  }
+}
+
+__device__ __forceinline__ void load_frag_n(const float* base, int nsplit, int RT, int C, int rt, int cbase, int lane, float (&a)[32]) {
+  const size_t stride = (size_t)RT * C * 32;
+  if (cbase + SLICE <= C) {
+    const float* p = base + ((size_t)rt * C + cbase) * 32 + lane;
+    switch (nsplit) {
+      case 1: load_frag<1>(p, stride, a); return;
+      case 2: load_frag<2>(p, stride, a); return;
+      case 3: load_frag<3>(p, stride, a); return;
+      case 4: load_frag<4>(p, stride, a); return;
+      case 5: load_frag<5>(p, stride, a); return;
+      default: break;
+    }
+  }
+  const int row = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int kp = 0; kp < 32; ++kp) {
+    const int c = cbase + 2 * kp + hi;
+    a[kp] = c < C ? slab_sum(base, nsplit, RT, C, rt, c, row) : 0.f;
+  }
+}
+
+// per-row GroupNorm statistics of the lane's fragment; NG groups (1 or 2) per 64-channel slice
+template <int NG>
+__device__ __forceinline__ void gn_stats(const float (&h)[32], float inv_n, float (&mean)[2], float (&rstd)[2]) {
+  constexpr int PER = 32 / NG;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int kp = 0; kp < PER; ++kp) s1 += h[g * PER + kp];
+    s1 += __shfl_xor(s1, 32);
+    const float mu = s1 * inv_n;
+    float s2 = 0.f;
+#pragma unroll
+    for (int kp = 0; kp < PER; ++kp) { const float d = h[g * PER + kp] - mu; s2 = fmaf(d, d, s2); }
+    s2 += __shfl_xor(s2, 32);
+    mean[g] = mu;
+    rstd[g] = rsqrtf(s2 * inv_n + 1e-5f);
+  }
+}
+
+template <int NG>
+__device__ __forceinline__ void gn_apply(int mode, const float* gamma, const float* beta, int cbase, int hi, float inv_n,
+                                         const float (&h)[32], float (&a)[32]) {
+  constexpr int PER = 32 / NG;
+  float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+  gn_stats<NG>(h, inv_n, mean, rstd);
+  float gam[32], bet[32];
+#pragma unroll
+  for (int kp = 0; kp < 32; ++kp) { gam[kp] = gamma[cbase + 2 * kp + hi]; bet[kp] = beta[cbase + 2 * kp + hi]; }
+  if (mode == 1) {
+#pragma unroll
+    for (int kp = 0; kp < 32; ++kp) {
+      const int g = kp / PER;
+      a[kp] = fmaxf((h[kp] - mean[g]) * rstd[g] * gam[kp] + bet[kp], 0.f);
+    }
+  } else {
+    // adjoint: a holds da; through ReLU and GroupNorm -> dh
+    float dxh[32], xh[32];
+    float m1[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int kp = 0; kp < 32; ++kp) {
+      const int g = kp / PER;
+      xh[kp] = (h[kp] - mean[g]) * rstd[g];
+      const float y = xh[kp] * gam[kp] + bet[kp];
+      dxh[kp] = (y > 0.f ? a[kp] : 0.f) * gam[kp];
+      m1[g] += dxh[kp];
+      m2[g] = fmaf(dxh[kp], xh[kp], m2[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      m1[g] = (m1[g] + __shfl_xor(m1[g], 32)) * inv_n;
+      m2[g] = (m2[g] + __shfl_xor(m2[g], 32)) * inv_n;
+    }
+#pragma unroll
+    for (int kp = 0; kp < 32; ++kp) {
+      const int g = kp / PER;
+      a[kp] = rstd[g] * (dxh[kp] - m1[g] - xh[kp] * m2[g]);
+    }
+  }
 }
 
 __global__ __launch_bounds__(NW * 64) void mlp_layer_kernel(LayerLaunch L) {
@@ -86,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_layer_kernel(LayerLaunch L) {
   const int tile = b % T.ntiles, ks = b / T.ntiles;
   const int slice = ks * NW + wave;
   const bool active = slice < T.nslices;
-  const int row = lane & 31, hi = lane >> 5;
+  const int hi = lane >> 5;
 
   // B operand: this wave's 64 x 32 weight panel, resident in registers for all row tiles
   float bw[32];
@@ -105,89 +213,21 @@ __global__ __launch_bounds__(NW * 64) void mlp_layer_kernel(LayerLaunch L) {
     if (active) {
       float a[32];
       if (!is_main) {
-#pragma unroll
-        for (int kp = 0; kp < 32; ++kp) {
-          const int c = cbase + 2 * kp + hi;
-          a[kp] = c < T.skip_dim ? T.skip[((size_t)rt * T.skip_dim + c) * 32 + row] : 0.f;
-        }
+        load_frag_n(T.skip, 1, L.RT, T.skip_dim, rt, cbase, lane, a);
       } else {
-#pragma unroll
-        for (int kp = 0; kp < 32; ++kp) {
-          const int c = cbase + 2 * kp + hi;
-          a[kp] = c < T.Csrc ? slab_sum(T.src, T.nsplit_src, L.RT, T.Csrc, rt, c, row) : 0.f;
-        }
+        load_frag_n(T.src, T.nsplit_src, L.RT, T.Csrc, rt, cbase, lane, a);
         if (T.mode != 0) {
-          // GroupNorm over groups of T.group (64 or 32) channels: lane holds 32 channels of its row (one parity),
+          // GroupNorm over groups of T.group (64 or 32) channels: the lane holds 32 channels of its row (one parity),
           // the other parity lives in lane^32.
-          const int ng = SLICE / T.group;          // 1 or 2 groups in this slice
-          const int per = 32 / ng;                 // kp entries per group
           float h[32];
-          if (T.mode == 3) {
-#pragma unroll
-            for (int kp = 0; kp < 32; ++kp) {
-              const int c = cbase + 2 * kp + hi;
-              h[kp] = slab_sum(T.hsrc, T.nsplit_h, L.RT, T.Ch, rt, c, row);
-            }
-          } else {
+          if (T.mode == 3) load_frag_n(T.hsrc, T.nsplit_h, L.RT, T.Ch, rt, cbase, lane, h);
+          else {
 #pragma unroll
             for (int kp = 0; kp < 32; ++kp) h[kp] = a[kp];
           }
-          float mean[2], rstd[2];
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            if (g < ng) {
-              float s1 = 0.f;
-#pragma unroll
-              for (int kp = 0; kp < 32; ++kp)
-                if (kp / per == g || ng == 1) s1 += h[kp];
-              s1 += __shfl_xor(s1, 32);
-              const float mu = s1 / (float)T.group;
-              float s2 = 0.f;
-#pragma unroll
-              for (int kp = 0; kp < 32; ++kp)
-                if (kp / per == g || ng == 1) { const float d = h[kp] - mu; s2 = fmaf(d, d, s2); }
-              s2 += __shfl_xor(s2, 32);
-              mean[g] = mu;
-              rstd[g] = rsqrtf(s2 / (float)T.group + 1e-5f);
-            }
-          }
-          if (T.mode == 1) {
-#pragma unroll
-            for (int kp = 0; kp < 32; ++kp) {
-              const int c = cbase + 2 * kp + hi;
-              const int g = ng == 1 ? 0 : kp / per;
-              const float y = (h[kp] - mean[g]) * rstd[g] * T.gamma[c] + T.beta[c];
-              a[kp] = fmaxf(y, 0.f);
-            }
-          } else {
-            // adjoint: da -> dh through ReLU and GroupNorm
-            float dxh[32], xh[32];
-            float m1[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
-#pragma unroll
-            for (int kp = 0; kp < 32; ++kp) {
-              const int c = cbase + 2 * kp + hi;
-              const int g = ng == 1 ? 0 : kp / per;
-              const float gam = T.gamma[c];
-              xh[kp] = (h[kp] - mean[g]) * rstd[g];
-              const float y = xh[kp] * gam + T.beta[c];
-              const float dy = y > 0.f ? a[kp] : 0.f;
-              dxh[kp] = dy * gam;
-              m1[g] += dxh[kp];
-              m2[g] = fmaf(dxh[kp], xh[kp], m2[g]);
-            }
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-              m1[g] += __shfl_xor(m1[g], 32);
-              m2[g] += __shfl_xor(m2[g], 32);
-              m1[g] /= (float)T.group;
-              m2[g] /= (float)T.group;
-            }
-#pragma unroll
-            for (int kp = 0; kp < 32; ++kp) {
-              const int g = ng == 1 ? 0 : kp / per;
-              a[kp] = rstd[g] * (dxh[kp] - m1[g] - xh[kp] * m2[g]);
-            }
-          }
+          const float inv_n = 1.0f / (float)T.group;
+          if (T.group == SLICE) gn_apply<1>(T.mode, T.gamma, T.beta, cbase, hi, inv_n, h, a);
+          else gn_apply<2>(T.mode, T.gamma, T.beta, cbase, hi, inv_n, h, a);
         }
       }
 #pragma unroll
@@ -264,9 +304,44 @@ struct PredState {
   float raw_aa_b[3], raw_aa_r[3];
 };
 
-__device__ __forceinline__ void glue_predict(const GlueParams& p, int rt, int rr, int lane, PredState& s) {
-  auto X = [&](int c) { return p.xT[((size_t)rt * D_IN + c) * 32 + rr]; };
-  auto RAW = [&](int c) { return slab_sum(p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, rt, c, rr); };
+// LDS staging of one row's vectors: every lane issues its (independent) loads back-to-back, one barrier, then the
+// per-joint math reads LDS.  (The kernels are pure latency: a runtime slab loop per element would serialise ~100 L2/HBM
+// round trips per lane.)
+constexpr int S_X = 0, S_RAW = 352, S_GXN = 576, S_GW = 928, S_TOTAL = 1280;
+
+template <int NC>   // NC = ceil(channels / 64)
+__device__ __forceinline__ void stage_slabs(float* dst, const float* base, int nsplit, int RT, int C, int nch, int rt, int rr,
+                                            int lane, bool accumulate) {
+  float v[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) v[i] = 0.f;
+  if (base) {
+    const size_t stride = (size_t)RT * C * 32;
+    float t[MAXSPLIT][NC];
+#pragma unroll
+    for (int sidx = 0; sidx < MAXSPLIT; ++sidx) {
+      const float* p = base + (size_t)(sidx < nsplit ? sidx : 0) * stride + (size_t)rt * C * 32 + rr;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        t[sidx][i] = p[(size_t)(c < nch ? c : 0) * 32];
+      }
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < MAXSPLIT; ++sidx)
+#pragma unroll
+      for (int i = 0; i < NC; ++i) v[i] += sidx < nsplit ? t[sidx][i] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) dst[c] = accumulate ? dst[c] + v[i] : v[i];
+  }
+}
+
+__device__ __forceinline__ void glue_predict(const float* sX, const float* sRAW, int lane, PredState& s) {
+  auto X = [&](int c) { return sX[c]; };
+  auto RAW = [&](int c) { return sRAW[c]; };
   const int j = lane;
   if (j < NJT) {
 #pragma unroll
@@ -308,8 +383,14 @@ __global__ __launch_bounds__(64) void glue_fwd_kernel(GlueParams p) {
     for (int c = lane; c < D_IN; c += 64) XN[(size_t)c * 32] = 0.f;
     return;
   }
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sX = smem + S_X;
+  float* sRAW = smem + S_RAW;
+  stage_slabs<6>(sX, p.xT, 1, p.RT, D_IN, D_IN, rt, rr, lane, false);
+  stage_slabs<4>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, lane, false);
+  __syncthreads();
   PredState s;
-  glue_predict(p, rt, rr, lane, s);
+  glue_predict(sX, sRAW, lane, s);
   // heading alignment from the predicted root orientation (lane 0), broadcast
   W2A wa;
   if (lane == 0) w2a_fwd(s.pR, wa);
@@ -395,7 +476,7 @@ __global__ __launch_bounds__(64) void glue_fwd_kernel(GlueParams p) {
   }
   if (lane >= 32 && lane < 32 + 9) {
     const int c = lane - 32;
-    WO[339 + c] = slab_sum(p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, rt, 207 + c, rr);
+    WO[339 + c] = sRAW[207 + c];
   }
   if (p.prior_mu && lane < ZD) {
     const float mu = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, lane, rr);
@@ -428,14 +509,27 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
   const bool last = p.t == p.S - 1;      // no step t+1 behind this one
   const bool final_collect = p.t < 0;
 
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sX = smem + S_X;
+  float* sRAW = smem + S_RAW;
+  float* sGXN = smem + S_GXN;
+  float* sGW = smem + S_GW;
   // ---- total adjoint of x_{t+1}: direct part + layer-0 input-gradient slabs of step t+1 -------------
-  auto GXN = [&](int c) -> float {
-    if (last) return 0.f;
-    float v = p.gx_dir_in[((size_t)rt * D_IN + c) * 32 + rr];
-    v += tsum(p.gxp_pri, p.gxp_pri_nsplit, p.RT, p.gxp_pri_pad, rt, c, rr);
-    v += tsum(p.gxp_dec, p.gxp_dec_nsplit, p.RT, p.gxp_dec_pad, rt, c, rr);
-    return v;
-  };
+  if (last) {
+    for (int c = lane; c < D_IN; c += 64) sGXN[c] = 0.f;
+  } else {
+    stage_slabs<6>(sGXN, p.gx_dir_in, 1, p.RT, D_IN, D_IN, rt, rr, lane, false);
+    stage_slabs<6>(sGXN, p.gxp_pri, p.gxp_pri_nsplit, p.RT, p.gxp_pri_pad, D_IN, rt, rr, lane, true);
+    stage_slabs<6>(sGXN, p.gxp_dec, p.gxp_dec_nsplit, p.RT, p.gxp_dec_pad, D_IN, rt, rr, lane, true);
+  }
+  if (!final_collect) {
+    stage_slabs<6>(sX, p.xT, 1, p.RT, D_IN, D_IN, rt, rr, lane, false);
+    stage_slabs<4>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, lane, false);
+    const float* GWp = p.g_world ? p.g_world + ((size_t)r * p.S + p.t) * D_STATE : nullptr;
+    for (int c = lane; c < D_STATE; c += 64) sGW[c] = GWp ? GWp[c] : 0.f;
+  }
+  __syncthreads();
+  auto GXN = [&](int c) -> float { return sGXN[c]; };
   // ---- dz of step t+1 ---------------------------------------------------------------------------------
   if (!last && p.g_z && lane < ZD) {
     float v = 0.f;
@@ -455,7 +549,7 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
   }
 
   PredState s;
-  glue_predict(p, rt, rr, lane, s);
+  glue_predict(sX, sRAW, lane, s);
   W2A wa;
   if (lane == 0) w2a_fwd(s.pR, wa);
   float W[9], ptr[3];
@@ -480,8 +574,7 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) g_t2j_acc[c] = last ? 0.f : carry[12 + c];
 
-  const float* GW = p.g_world ? p.g_world + ((size_t)r * p.S + p.t) * D_STATE : nullptr;
-  auto gw = [&](int c) { return GW ? GW[c] : 0.f; };
+  auto gw = [&](int c) { return sGW[c]; };
 
   // lane-local partial sums of the wave-shared adjoints
   float gW[9], gG[9], ggt[3] = {0.f, 0.f, 0.f}, gwt[3] = {0.f, 0.f, 0.f}, gt2[3] = {0.f, 0.f, 0.f};
@@ -769,6 +862,7 @@ static int pack_layer(PackedLayer& L, const float* W, const float* bias, const f
   L.Nin_pad = L.ntiles_b * 32;
   L.nsplit_b = ceil_div(L.nslices_b, NW);
   L.group = has_gn ? Cin / 16 : 0;
+  HA_REQUIRE(L.nsplit_f <= MAXSPLIT && L.nsplit_b <= MAXSPLIT, "layer %dx%d needs more than %d K-splits", Nout, Cin + skip, MAXSPLIT);
   const int Kin = Cin + skip;
   // forward pack: lane l of (tile, slice, kp) <-> W[n = tile*32 + (l&31)][k], k = channel of the slice
   std::vector<float> wf((size_t)L.ntiles_f * L.nslices_f * 32 * 64, 0.f);
@@ -1001,7 +1095,7 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
     g.t2j = stash + L.t2j;
     g.world = world;
     g.prior_mu = prior_mu; g.prior_var = prior_var;
-    hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(64), S_TOTAL * sizeof(float), st, g);
     HA_LAUNCH_CHECK();
   }
   return HA_OK;
@@ -1056,7 +1150,7 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
   for (int t = S - 1; t >= 0; --t) {
     GlueParams g;
     fill_glue(g, t);
-    hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(64), S_TOTAL * sizeof(float), st, g);
     HA_LAUNCH_CHECK();
     (void)0;
     float* sp = step_ptr(t);
@@ -1088,7 +1182,7 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
   }
   GlueParams g;
   fill_glue(g, -1);
-  hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(64), 0, st, g);
+  hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(64), S_TOTAL * sizeof(float), st, g);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
