@@ -1,0 +1,321 @@
+"""Loss assembly of the fitting closures: same class name, constructor, stage methods (``root_fit`` / ``smpl_fit`` /
+``motion_fit``), weight keys and per-term values as the reference's ``FittingLoss``
+(humor/fitting/fitting_loss.py:20-517), written for the GPU:
+
+  * masked terms multiply by the visibility mask instead of boolean-mask indexing (no dynamic shapes, no host
+    sync; invisible = +-inf observations contribute exactly 0, as in the reference, G6);
+  * ``stats_dict`` holds device tensors -- nothing here calls ``.item()``;
+  * the overlap-consistency terms take an optional ``halo`` so a rank can evaluate the pair (b-1, b) when b-1 lives
+    on the neighbouring rank (humor_amd/distributed.py).
+
+Host-side PyTorch: ~60 small element-wise/reduction launches per closure; the HIP kernels are below it (SMPL, roll-out,
+rotation conversions).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.distributions import Categorical, MixtureSameFamily, MultivariateNormal
+
+from .tables import OP_NUM_JOINTS, SMPL_PARENTS
+
+CONTACT_HEIGHT_THRESH = 0.08   # fitting_loss.py:18
+
+
+def gmof(res, sigma):
+    """Geman-McClure robust function (fitting_utils.py:250-258)."""
+    x2 = res ** 2
+    s2 = sigma ** 2
+    return (s2 * x2) / (s2 + x2)
+
+
+def perspective_projection(points, focal_length, camera_center):
+    """Pinhole projection with identity extrinsics (fitting_utils.py:647-676 with R = I, t = 0).
+    points [N,K,3], focal_length [N,2], camera_center [N,2] -> [N,K,2]."""
+    proj = points[:, :, :2] / points[:, :, 2:3]
+    return proj * focal_length.unsqueeze(1) + camera_center.unsqueeze(1)
+
+
+def _masked_sq(obs, pred):
+    """0.5 * sum over visible entries of (obs - pred)^2; entries whose observation is +-inf are invisible."""
+    vis = torch.isfinite(obs)
+    diff = torch.where(vis, obs - pred, torch.zeros_like(pred))
+    return 0.5 * torch.sum(diff * diff)
+
+
+class FittingLoss(nn.Module):
+    '''
+    Functions to compute all needed losses for fitting.
+    '''
+
+    def __init__(self, loss_weights, init_motion_prior=None, smpl2op_map=None, ignore_op_joints=None, cam_f=None,
+                 cam_cent=None, robust_loss='none', robust_tuning_const=4.6851, joints2d_sigma=100, use_chamfer=False):
+        super(FittingLoss, self).__init__()
+        self.all_stage_loss_weights = loss_weights
+        self.cur_stage_idx = 0
+        self.loss_weights = self.all_stage_loss_weights[self.cur_stage_idx]
+        self.smpl2op_map = None if smpl2op_map is None else torch.as_tensor(list(smpl2op_map), dtype=torch.long)
+        self.ignore_op_joints = ignore_op_joints
+        self.cam_f, self.cam_cent = cam_f, cam_cent
+        self.joints2d_sigma = joints2d_sigma
+        self.can_reproj = self.smpl2op_map is not None and cam_f is not None and cam_cent is not None
+        if self.can_reproj:
+            self.cam_f = self.cam_f.reshape((-1, 1, 2))
+            self.cam_cent = self.cam_cent.reshape((-1, 1, 2))
+        if use_chamfer:
+            raise NotImplementedError('point-cloud (chamfer) fitting is outside the BASELINE configs (SURVEY.md 8(f) rank 1)')
+        total = {k: sum(w[k] for w in self.all_stage_loss_weights) for k in self.loss_weights}
+        self.init_motion_prior = None
+        if init_motion_prior is not None and total['init_motion_prior'] > 0.0:
+            w, mu, cov = init_motion_prior['gmm']
+            self.init_motion_prior = {'gmm': MixtureSameFamily(Categorical(w), MultivariateNormal(mu, covariance_matrix=cov))}
+        if robust_loss not in ['none', 'bisquare', 'gm']:
+            raise ValueError('Not a valid robust loss: %s' % robust_loss)
+        self.robust_loss = robust_loss
+        self.robust_tuning_const = robust_tuning_const
+        self.cur_optim_step = 0
+        self._op_conf_mask = None
+
+    def set_stage(self, idx):
+        ''' Sets the current stage index. Determines which loss weights are used '''
+        self.cur_stage_idx = idx
+        self.loss_weights = self.all_stage_loss_weights[idx]
+
+    def forward(self):
+        pass
+
+    # ------------------------------------------------------------------------------------------------
+    # stage objectives
+    # ------------------------------------------------------------------------------------------------
+    def root_fit(self, observed_data, pred_data, halo=None):
+        '''
+        For fitting just global root trans/orientation. Only data terms, no priors (fitting_loss.py:94-181).
+        '''
+        W = self.loss_weights
+        stats = dict()
+        loss = 0.0
+        if 'joints3d' in observed_data and 'joints3d' in pred_data and W['joints3d'] > 0.0:
+            cur = self.joints3d_loss(observed_data['joints3d'], pred_data['joints3d'])
+            loss = loss + W['joints3d'] * cur
+            stats['joints3d'] = cur
+        if 'verts3d' in observed_data and 'verts3d' in pred_data and W['verts3d'] > 0.0:
+            cur = self.verts3d_loss(observed_data['verts3d'], pred_data['verts3d'])
+            loss = loss + W['verts3d'] * cur
+            stats['verts3d'] = cur
+        if 'points3d' in observed_data and 'points3d' in pred_data and W['points3d'] > 0.0:
+            raise NotImplementedError('points3d (chamfer) term: SURVEY.md 8(f) rank 1, not in the BASELINE configs')
+        if 'joints2d' in observed_data and 'joints3d' in pred_data and 'joints3d_extra' in pred_data and W['joints2d'] > 0.0:
+            if not self.can_reproj:
+                raise RuntimeError('Must provide camera intrinsics and SMPL to OpenPose joint map to use re-projection loss!')
+            cur = self.joints2d_loss(observed_data['joints2d'], pred_data['joints3d'], pred_data['joints3d_extra'])
+            loss = loss + W['joints2d'] * cur
+            stats['joints2d'] = cur
+        if 'seq_interval' in observed_data and 'verts3d' in pred_data and W['rgb_overlap_consist'] > 0.0:
+            pos, vel = self.overlap_verts_loss(observed_data['seq_interval'], pred_data['verts3d'], halo)
+            loss = loss + W['rgb_overlap_consist'] * pos + W['rgb_overlap_consist'] * vel
+            stats['rgb_overlap_consist_verts3d_pos'] = pos
+            stats['rgb_overlap_consist_verts3d_vel'] = vel
+            if 'prev_batch_overlap_res' in observed_data and (halo is None or halo.get('first', True)):
+                prev = observed_data['prev_batch_overlap_res']
+                cur_ov = int(prev['seq_interval'][1] - observed_data['seq_interval'][0, 0])
+                T_pred = pred_data['verts3d'].size(1)
+                ov_len = min(T_pred, cur_ov)
+                prev_pos = prev['verts3d'][-cur_ov:][:ov_len]
+                cur_pos = pred_data['verts3d'][0, :ov_len]
+                p = self.verts3d_loss(prev_pos, cur_pos)
+                v = 0.0
+                if cur_ov > 1:
+                    v = self.verts3d_loss(prev_pos[1:] - prev_pos[:-1], cur_pos[1:] - cur_pos[:-1])
+                loss = loss + W['rgb_overlap_consist'] * p + W['rgb_overlap_consist'] * v
+                stats['rgb_overlap_xbatch_verts3d_pos'] = p
+                stats['rgb_overlap_xbatch_verts3d_vel'] = v
+        return loss, stats
+
+    def overlap_verts_loss(self, seq_interval, verts3d, halo=None):
+        """Consistency of the overlapping frames of consecutive sub-sequences (fitting_loss.py:135-157).
+        verts3d [Bl,T,43,3] are the local sequences; with `halo`, halo['prev_tail'] [T,43,3] is the full predicted
+        verts3d of the sequence before the first local one (None on the first rank) and seq_interval is already the
+        local slice extended by that predecessor's interval in row 0."""
+        pos = verts3d.new_zeros(())
+        vel = verts3d.new_zeros(())
+        iv = seq_interval
+        if halo is not None and halo.get('prev_tail') is not None:
+            seqs = [halo['prev_tail']] + [verts3d[b] for b in range(verts3d.size(0))]
+        else:
+            seqs = [verts3d[b] for b in range(verts3d.size(0))]
+        for b in range(1, len(seqs)):
+            ov = int(iv[b - 1, 1] - iv[b, 0])
+            prev_pos = seqs[b - 1][-ov:] if ov > 0 else seqs[b - 1][:0]
+            cur_pos = seqs[b][:ov]
+            pos = pos + self.verts3d_loss(prev_pos, cur_pos)
+            if ov > 1:
+                vel = vel + self.verts3d_loss(prev_pos[1:] - prev_pos[:-1], cur_pos[1:] - cur_pos[:-1])
+        return pos, vel
+
+    def smpl_fit(self, observed_data, pred_data, nsteps, halo=None):
+        '''
+        For fitting full shape and pose of SMPL (fitting_loss.py:183-224).  nsteps scales single-step terms.
+        '''
+        W = self.loss_weights
+        loss, stats = self.root_fit(observed_data, pred_data, halo=halo)
+        if 'latent_pose' in pred_data and W['pose_prior'] > 0.0:
+            cur = torch.sum(pred_data['latent_pose'] ** 2)
+            loss = loss + W['pose_prior'] * cur
+            stats['pose_prior'] = cur
+        if 'betas' in pred_data and W['shape_prior'] > 0.0:
+            cur = torch.sum(pred_data['betas'] ** 2)
+            loss = loss + W['shape_prior'] * nsteps * cur
+            stats['shape_prior'] = cur
+        if W['joints3d_smooth'] > 0.0:
+            cur = self.joints3d_smooth_loss(pred_data['joints3d'])
+            loss = loss + W['joints3d_smooth'] * cur
+            stats['joints3d_smooth'] = cur
+        if 'seq_interval' in observed_data and 'betas' in pred_data and W['rgb_overlap_consist'] > 0.0:
+            betas = pred_data['betas']
+            if halo is not None and halo.get('prev_betas') is not None:
+                betas = torch.cat([halo['prev_betas'].unsqueeze(0), betas], dim=0)
+            cur = self.joints3d_loss(betas[:-1], betas[1:])
+            loss = loss + W['rgb_overlap_consist'] * cur
+            stats['rgb_overlap_consist_betas'] = cur
+            if 'prev_batch_overlap_res' in observed_data and (halo is None or halo.get('first', True)):
+                cur = self.joints3d_loss(pred_data['betas'][0], observed_data['prev_batch_overlap_res']['betas'])
+                loss = loss + W['rgb_overlap_consist'] * cur
+                stats['rgb_overlap_xbatch_betas'] = cur
+        return loss, stats
+
+    def motion_fit(self, observed_data, pred_data, cam_pred_data, nsteps, cond_prior=None, init_motion_scale=1.0, halo=None):
+        '''
+        For fitting full shape and pose of SMPL with the motion prior (fitting_loss.py:226-309).
+        pred_data lives in the prior (canonical) frame, cam_pred_data in the camera frame.
+        '''
+        W = self.loss_weights
+        loss, stats = self.smpl_fit(observed_data, cam_pred_data, nsteps, halo=halo)
+        if 'latent_motion' in pred_data and W['motion_prior'] > 0.0:
+            cur = self.motion_prior_loss(pred_data['latent_motion'], cond_prior=cond_prior)
+            loss = loss + W['motion_prior'] * cur
+            stats['motion_prior'] = cur
+        have_init = all(k in pred_data for k in ('joints3d', 'joints_vel', 'trans_vel', 'root_orient_vel'))
+        if have_init and W['init_motion_prior'] > 0.0:
+            cur = self.init_motion_prior_loss(pred_data['joints3d'][:, 0:1], pred_data['joints_vel'], pred_data['trans_vel'],
+                                              pred_data['root_orient_vel'])
+            loss = loss + W['init_motion_prior'] * init_motion_scale * cur
+            stats['init_motion_prior'] = cur
+        if 'joints3d_rollout' in pred_data and 'joints3d' in pred_data and W['joint_consistency'] > 0.0:
+            cur = 0.5 * torch.sum((pred_data['joints3d'] - pred_data['joints3d_rollout']) ** 2)
+            loss = loss + W['joint_consistency'] * cur
+            stats['joint_consistency'] = cur
+        if 'joints3d_rollout' in pred_data and W['bone_length'] > 0.0:
+            cur = self.bone_length_loss(pred_data['joints3d_rollout'])
+            loss = loss + W['bone_length'] * cur
+            stats['bone_length'] = cur
+        if 'joints3d' in observed_data and 'joints3d_rollout' in pred_data and W['joints3d_rollout'] > 0.0:
+            cur = self.joints3d_loss(observed_data['joints3d'], pred_data['joints3d_rollout'])
+            loss = loss + W['joints3d_rollout'] * cur
+            stats['joints3d_rollout'] = cur
+        if W['contact_vel'] > 0.0 and 'contacts_conf' in pred_data and 'joints3d' in pred_data:
+            cur = self.contact_vel_loss(pred_data['contacts_conf'], pred_data['joints3d'])
+            loss = loss + W['contact_vel'] * cur
+            stats['contact_vel'] = cur
+        if W['contact_height'] > 0.0 and 'contacts_conf' in pred_data and 'joints3d' in pred_data:
+            cur = self.contact_height_loss(pred_data['contacts_conf'], pred_data['joints3d'])
+            loss = loss + W['contact_height'] * cur
+            stats['contact_height'] = cur
+        if W['floor_reg'] > 0.0 and 'floor_plane' in cam_pred_data and 'floor_plane' in observed_data:
+            cur = self.floor_reg_loss(cam_pred_data['floor_plane'], observed_data['floor_plane'])
+            loss = loss + W['floor_reg'] * nsteps * cur
+            stats['floor_reg'] = cur
+        if 'seq_interval' in observed_data and 'floor_plane' in cam_pred_data and W['rgb_overlap_consist'] > 0.0:
+            fp = cam_pred_data['floor_plane']
+            if halo is not None and halo.get('prev_floor') is not None:
+                fp = torch.cat([halo['prev_floor'].unsqueeze(0), fp], dim=0)
+            cur = self.joints3d_loss(fp[:-1], fp[1:])
+            loss = loss + W['rgb_overlap_consist'] * cur
+            stats['rgb_overlap_consist_floor'] = cur
+            if 'prev_batch_overlap_res' in observed_data and (halo is None or halo.get('first', True)):
+                cur = self.floor_reg_loss(cam_pred_data['floor_plane'][0:1],
+                                          observed_data['prev_batch_overlap_res']['floor_plane'].unsqueeze(0))
+                loss = loss + W['rgb_overlap_consist'] * cur
+                stats['rgb_overlap_xbatch_floor'] = cur
+        return loss, stats
+
+    # ------------------------------------------------------------------------------------------------
+    # terms
+    # ------------------------------------------------------------------------------------------------
+    def get_visible_mask(self, obs_data):
+        return torch.logical_not(torch.isinf(obs_data))
+
+    def joints2d_loss(self, joints2d_obs, joints3d_pred, joints3d_extra_pred, cam_t=None, cam_R=None, debug_img=None):
+        '''GMoF re-projection error weighted by squared detection confidence (fitting_loss.py:317-358).'''
+        if cam_t is not None or cam_R is not None:
+            raise NotImplementedError('camera extrinsics are the identity on the fitting path')
+        B, T = joints2d_obs.size(0), joints2d_obs.size(1)
+        full = torch.cat([joints3d_pred, joints3d_extra_pred], dim=2)
+        op = full.index_select(2, self.smpl2op_map.to(full.device)).reshape(B * T, OP_NUM_JOINTS, 3)
+        cam_f = self.cam_f.expand(B, T, 2).reshape(B * T, 2)
+        cam_c = self.cam_cent.expand(B, T, 2).reshape(B * T, 2)
+        pred2d = perspective_projection(op, cam_f, cam_c).reshape(B, T, OP_NUM_JOINTS, 2)
+        conf = joints2d_obs[:, :, :, 2:3]
+        if self.ignore_op_joints is not None:
+            # the reference zeroes these confidences IN PLACE on the observations (G5); same effect, no mutation
+            if self._op_conf_mask is None or self._op_conf_mask.device != conf.device:
+                m = torch.ones(OP_NUM_JOINTS, device=conf.device, dtype=conf.dtype)
+                m[list(self.ignore_op_joints)] = 0.0
+                self._op_conf_mask = m.reshape(1, 1, OP_NUM_JOINTS, 1)
+            conf = conf * self._op_conf_mask
+        err = (conf ** 2) * gmof(pred2d - joints2d_obs[:, :, :, :2], self.joints2d_sigma)
+        return torch.sum(err)
+
+    def joints3d_loss(self, joints3d_obs, joints3d_pred):
+        return _masked_sq(joints3d_obs, joints3d_pred)
+
+    def verts3d_loss(self, verts3d_obs, verts3d_pred):
+        return _masked_sq(verts3d_obs, verts3d_pred)
+
+    def joints3d_smooth_loss(self, joints3d_pred):
+        d = joints3d_pred[:, 1:] - joints3d_pred[:, :-1]
+        return 0.5 * torch.sum(d * d)
+
+    def pose_prior_loss(self, latent_pose_pred):
+        return torch.sum(latent_pose_pred ** 2)
+
+    def shape_prior_loss(self, betas_pred):
+        return torch.sum(betas_pred ** 2)
+
+    def motion_prior_loss(self, latent_motion_pred, cond_prior=None):
+        if cond_prior is None:
+            return torch.sum(latent_motion_pred ** 2)
+        pm, pv = cond_prior
+        return -torch.sum(self.log_normal(latent_motion_pred, pm, pv))
+
+    def init_motion_prior_loss(self, joints, joints_vel, trans_vel, root_orient_vel):
+        B = joints.size(0)
+        state = torch.cat([joints.reshape(B, -1), joints_vel.reshape(B, -1), trans_vel.reshape(B, -1),
+                           root_orient_vel.reshape(B, -1)], dim=-1)
+        return -torch.sum(self.init_motion_prior['gmm'].log_prob(state))
+
+    def joint_consistency_loss(self, smpl_joints3d, rollout_joints3d):
+        return 0.5 * torch.sum((smpl_joints3d - rollout_joints3d) ** 2)
+
+    def bone_length_loss(self, rollout_joints3d):
+        bones = rollout_joints3d[:, :, 1:]
+        parents = rollout_joints3d[:, :, SMPL_PARENTS[1:]]
+        lengths = torch.norm(bones - parents, dim=-1)
+        d = lengths[:, 1:] - lengths[:, :-1]
+        return 0.5 * torch.sum(d * d)
+
+    def contact_vel_loss(self, contacts_conf, joints3d):
+        delta = (joints3d[:, 1:] - joints3d[:, :-1]) ** 2
+        return 0.5 * torch.sum(delta.sum(dim=-1) * contacts_conf[:, 1:])
+
+    def contact_height_loss(self, contacts_conf, joints3d):
+        floor_diff = F.relu(torch.abs(joints3d[:, :, :, 2]) - CONTACT_HEIGHT_THRESH)
+        return torch.sum(floor_diff * contacts_conf)
+
+    def floor_reg_loss(self, pred_floor_plane, obs_floor_plane):
+        obs3 = obs_floor_plane[:, :3] * obs_floor_plane[:, 3:]
+        return 0.5 * torch.sum((pred_floor_plane - obs3) ** 2)
+
+    def log_normal(self, x, m, v):
+        lp = -torch.log(torch.sqrt(v)) - math.log(math.sqrt(2 * math.pi)) - ((x - m) ** 2 / (2 * v))
+        return torch.sum(lp, dim=-1)

@@ -1,0 +1,570 @@
+"""``MotionOptimizer`` with the reference's constructor and ``run`` signatures (humor/fitting/motion_optimizer.py:29-676),
+driving the MI355X kernels: the 3-stage L-BFGS schedule, optimisation variables, closures and result dictionaries are the
+reference's; what each closure evaluates goes through libhumor_amd.so:
+
+  * SMPL: only the rows that exist and only the 43 + 21 vertices the losses read -- no expansion of single frames to the
+    full B*T batch, no zero padding, no dense 6890-vertex output (values are identical because the
+    reference slices those rows/vertices back out, motion_optimizer.py:1075-1100);
+  * roll-out: one forward and one backward C-ABI call (HumorModel.roll_out), R -> axis-angle on the HIP kernel;
+  * per-term logging (a host sync per loss term per closure in the reference, fitting_utils.py:261-272) is off unless
+    ``verbose=True``.
+
+Multi-GPU: pass ``shard=humor_amd.distributed.Shard(B, group)`` -- replicated L-BFGS, closure evaluated on the local slice
+of sub-sequences, one packed all-reduce per closure (humor_amd/distributed.py).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import frames, ops
+from .body_model import BodyModel
+from .fitting_loss import FittingLoss
+from .tables import (CONTACT_INDS, KEYPT_VERTS, OP_EDGE_LIST, OP_IGNORE_JOINTS, SMPL_JOINTS, SMPLH_TO_OPENPOSE25)
+
+LINE_SEARCH = 'strong_wolfe'
+J_BODY = len(SMPL_JOINTS) - 1
+CONTACT_THRESH = 0.5
+
+
+class MotionOptimizer():
+    ''' Fits SMPL shape and motion to observation sequence '''
+
+    def __init__(self, device, body_model, num_betas, batch_size, seq_len, observed_modalities, loss_weights, pose_prior,
+                 motion_prior=None, init_motion_prior=None, optim_floor=False, camera_matrix=None, robust_loss_type='none',
+                 robust_tuning_const=4.6851, joint2d_sigma=100, stage3_tune_init_state=True, stage3_tune_init_num_frames=15,
+                 stage3_tune_init_freeze_start=30, stage3_tune_init_freeze_end=50, stage3_contact_refine_only=False,
+                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False):
+        B, T = batch_size, seq_len
+        self.device = device
+        self.batch_size, self.seq_len = B, T
+        self.num_betas = num_betas
+        self.optim_floor = optim_floor
+        self.stage3_tune_init_state = stage3_tune_init_state
+        self.stage3_tune_init_num_frames = stage3_tune_init_num_frames
+        self.stage3_tune_init_freeze_start = stage3_tune_init_freeze_start
+        self.stage3_tune_init_freeze_end = stage3_tune_init_freeze_end
+        self.stage3_contact_refine_only = stage3_contact_refine_only
+        self.im_dim = im_dim
+        self.shard = shard
+        self.verbose = verbose
+        self.closure_evals = 0
+        if motion_prior is None:
+            raise ValueError('Need the motion prior to use all-implicit parameterization!')
+        if use_chamfer or 'points3d' in observed_modalities:
+            raise NotImplementedError('point-cloud fitting (chamfer) is outside the BASELINE configs (SURVEY.md 8(f))')
+
+        # the body model evaluates only what the losses consume; share the packed constants with the model we were given
+        self.body_model = body_model
+        if isinstance(body_model, BodyModel):
+            self.fit_bm = BodyModel(body_model.bm_path, num_betas=num_betas, batch_size=B * T,
+                                    use_vtx_selector=body_model.use_vtx_selector, model_type=body_model.model_type,
+                                    vertex_subset=KEYPT_VERTS, _lib_override=body_model._lib)
+        else:
+            raise TypeError('humor_amd.MotionOptimizer needs a humor_amd.BodyModel')
+
+        # optimisation variables (motion_optimizer.py:70-84)
+        self.pose_prior = pose_prior
+        self.latent_pose_dim = pose_prior.latentD
+        self.latent_pose = torch.zeros((B, T, self.latent_pose_dim), device=device)
+        self.trans = torch.zeros((B, T, 3), device=device)
+        self.root_orient = torch.zeros((B, T, 3), device=device)
+        self.root_orient[:, :, 0] = np.pi
+        self.betas = torch.zeros((B, num_betas), device=device)
+        self.motion_prior = motion_prior
+        self.init_motion_prior = init_motion_prior
+        self.latent_motion = None
+        self.latent_motion_dim = motion_prior.latent_size
+        self.cond_prior = motion_prior.use_conditional_prior
+        self.trans_vel = self.root_orient_vel = self.joints_vel = None
+        self.init_fidx = np.zeros((B), dtype=np.int64)
+
+        self.cam_f = self.cam_center = None
+        if optim_floor:
+            if camera_matrix is None:
+                raise ValueError('Must have camera intrinsics (camera_matrix) to optimize the floor plane!')
+            self.floor_plane = torch.zeros((B, 3), device=device)
+            self.floor_plane[:, 2] = 1.0
+            self.cam2prior_R = torch.eye(3, device=device).reshape(1, 3, 3).expand(B, 3, 3)
+            self.cam2prior_t = torch.zeros((B, 3), device=device)
+            self.cam2prior_root_height = torch.zeros((B, 1), device=device)
+            self.cam_f = torch.stack([camera_matrix[:, 0, 0], camera_matrix[:, 1, 1]], dim=1)
+            self.cam_center = torch.stack([camera_matrix[:, 0, 2], camera_matrix[:, 1, 2]], dim=1)
+        self.use_camera = self.cam_f is not None
+
+        self.smpl2op_map = list(SMPLH_TO_OPENPOSE25)
+        cam_f, cam_c = self.cam_f, self.cam_center
+        if shard is not None and cam_f is not None:
+            cam_f, cam_c = shard.sl(cam_f), shard.sl(cam_c)
+        self.fitting_loss = FittingLoss(loss_weights, self.init_motion_prior, self.smpl2op_map, OP_IGNORE_JOINTS, cam_f, cam_c,
+                                        robust_loss_type, robust_tuning_const, joints2d_sigma=joint2d_sigma,
+                                        use_chamfer=use_chamfer).to(device)
+
+    # ------------------------------------------------------------------------------------------------
+    # small helpers
+    # ------------------------------------------------------------------------------------------------
+    def _local(self, x):
+        """This rank's slice of a per-sequence tensor (identity without sharding)."""
+        return x if self.shard is None else self.shard.sl(x)
+
+    def _local_obs(self, observed_data, nsteps=None):
+        out = {}
+        for k, v in observed_data.items():
+            if k == 'prev_batch_overlap_res':
+                out[k] = v
+            elif k == 'seq_interval':
+                if self.shard is None or self.shard.rank == 0:
+                    out[k] = self._local(v)
+                else:
+                    out[k] = v[self.shard.b0 - 1:self.shard.b1]
+            else:
+                v = self._local(v)
+                out[k] = v[:, :nsteps] if nsteps is not None else v
+        return out
+
+    def _halo(self, pred_verts3d, betas, floor_plane, active):
+        """Differentiable exchange of each rank's LAST sequence (predicted key vertices, betas, floor) -> the halo the
+        consistency terms of this rank's FIRST sequence need."""
+        if self.shard is None:
+            return None
+        if not active:
+            return {'first': self.shard.rank == 0, 'prev_tail': None, 'prev_betas': None, 'prev_floor': None}
+        from .distributed import all_gather_with_grad
+        T = pred_verts3d.size(1)
+        fp = floor_plane[-1] if floor_plane is not None else pred_verts3d.new_zeros(3)
+        packed = torch.cat([pred_verts3d[-1].reshape(-1), betas[-1].reshape(-1), fp.reshape(-1)])
+        allg = all_gather_with_grad(packed, self.shard.group)
+        # every rank must run the gather's backward collective, also the ones whose loss does not read the halo
+        halo = {'first': self.shard.rank == 0, 'prev_tail': None, 'prev_betas': None, 'prev_floor': None, 'dep': 0.0 * allg.sum()}
+        if self.shard.rank > 0:
+            prev = allg[self.shard.rank - 1]
+            n = T * len(KEYPT_VERTS) * 3
+            halo['prev_tail'] = prev[:n].reshape(T, len(KEYPT_VERTS), 3)
+            halo['prev_betas'] = prev[n:n + self.num_betas]
+            if floor_plane is not None:
+                halo['prev_floor'] = prev[n + self.num_betas:n + self.num_betas + 3]
+        return halo
+
+    @staticmethod
+    def _with_dep(loss, halo):
+        return loss + halo['dep'] if halo is not None and 'dep' in halo else loss
+
+    def _finish_closure(self, loss, params, stats=None):
+        loss.backward()
+        self.closure_evals += 1
+        if self.shard is not None:
+            from .distributed import allreduce_loss_and_grads
+            loss = allreduce_loss_and_grads(loss, params, self.shard.group)
+        if self.verbose and stats is not None:
+            print('LOSS: %f' % loss.item(), {k: float(v) for k, v in stats.items()})
+        return loss
+
+    # ------------------------------------------------------------------------------------------------
+    def initialize(self, observed_data):
+        '''Floor from the observation; depth from the focal length and bone-length ratio (motion_optimizer.py:141-199).'''
+        if not self.optim_floor:
+            return
+        fp = observed_data['floor_plane']
+        self.floor_plane = (fp[:, :3] * fp[:, 3:]).to(torch.float).clone().detach()
+        self.floor_plane.requires_grad = True
+        if 'joints2d' in observed_data:
+            body_pose = self.latent2pose(self.latent_pose[:, :1])
+            pred, _ = self.smpl_results(self.trans[:, :1], self.root_orient[:, :1], body_pose, self.betas)
+            full = torch.cat([pred['joints3d'], pred['joints3d_extra']], dim=2)
+            j3d_op = full[:, 0][:, self.smpl2op_map]                       # [B,25,3] (pose is constant over time here)
+            j2d = observed_data['joints2d'][:, :, :, :2]
+            conf = observed_data['joints2d'][:, :, :, 2]
+            best = torch.max(torch.sum(conf > 0.0, dim=2), dim=1)[1]
+            e0 = [p[0] for p in OP_EDGE_LIST]
+            e1 = [p[1] for p in OP_EDGE_LIST]
+            bone3d = torch.norm(j3d_op[:, e0] - j3d_op[:, e1], dim=2)     # [B,E]
+            ar = torch.arange(self.batch_size, device=j2d.device)
+            j2b, cb = j2d[ar, best], conf[ar, best]
+            bone2d = torch.norm(j2b[:, e0] - j2b[:, e1], dim=2)
+            minconf = torch.min(cb[:, e0], cb[:, e1])
+            mean3d = torch.mean(bone3d, dim=1)
+            mean2d = torch.mean(bone2d * (minconf > 0.0), dim=1)
+            init_z = self.cam_f[:, 0] * (mean3d / mean2d)
+            self.trans[:, :, 2] = init_z.unsqueeze(1).expand(self.batch_size, self.seq_len).detach()
+
+    # ------------------------------------------------------------------------------------------------
+    def run(self, observed_data, data_fps=30, lr=1.0, num_iter=[30, 70, 70], lbfgs_max_iter=20, stages_res_out=None,
+            fit_gender='neutral'):
+        if len(num_iter) != 3:
+            raise ValueError('Must have num iters for 3 stages! But %d stages were given!' % len(num_iter))
+        per_stage_outputs = {}
+        T = self.seq_len
+        self.initialize(observed_data)
+        obs_local = self._local_obs(observed_data)
+        has_overlap = 'seq_interval' in observed_data
+
+        # ---- Stage I: global root translation and orientation -----------------------------------------
+        self.fitting_loss.set_stage(0)
+        self.trans.requires_grad = True
+        self.root_orient.requires_grad = True
+        self.betas.requires_grad = False
+        self.latent_pose.requires_grad = False
+        params = [self.trans, self.root_orient]
+        optim = torch.optim.LBFGS(params, max_iter=lbfgs_max_iter, lr=lr, line_search_fn=LINE_SEARCH)
+        for i in range(num_iter[0]):
+            self.fitting_loss.cur_optim_step = i
+
+            def closure():
+                optim.zero_grad()
+                loss, stats = self._stage1_objective(obs_local, has_overlap)
+                return self._finish_closure(loss, params, stats)
+            optim.step(closure)
+        per_stage_outputs['stage1'] = self._stage_snapshot(stages_res_out, 'stage1_results.npz')
+
+        # ---- Stage II: full pose and shape ------------------------------------------------------------
+        self.fitting_loss.set_stage(1)
+        self.betas.requires_grad = True
+        self.latent_pose.requires_grad = True
+        params = [self.trans, self.root_orient, self.betas, self.latent_pose]
+        optim = torch.optim.LBFGS(params, max_iter=lbfgs_max_iter, lr=lr, line_search_fn=LINE_SEARCH)
+        for i in range(num_iter[1]):
+            def closure():
+                optim.zero_grad()
+                loss, stats = self._stage2_objective(obs_local, has_overlap)
+                return self._finish_closure(loss, params, stats)
+            optim.step(closure)
+        per_stage_outputs['stage2'] = self._stage_snapshot(stages_res_out, 'stage2_results.npz')
+
+        # ---- Stage III set-up -------------------------------------------------------------------------
+        self.fitting_loss.set_stage(2)
+        og_overlap_w = self.fitting_loss.loss_weights['rgb_overlap_consist']
+        with torch.no_grad():
+            cur_body_pose = self.latent2pose(self.latent_pose)
+            if self.optim_floor:
+                init_smpl, _ = self.smpl_results(self.trans, self.root_orient, cur_body_pose, self.betas)
+                ar = np.arange(self.batch_size)
+                self.cam2prior_R, self.cam2prior_t, self.cam2prior_root_height = frames.compute_cam2prior(
+                    self.floor_plane, self.trans[ar, self.init_fidx],
+                    ops.batch_rodrigues(self.root_orient[ar, self.init_fidx], _lib_override=self.fit_bm._lib),
+                    init_smpl['joints3d'][ar, self.init_fidx])
+            self.latent_motion = self.infer_latent_motion(self.trans, self.root_orient, cur_body_pose, self.betas, data_fps).detach()
+            vel_trans, vel_root = self.trans, self.root_orient
+            if self.optim_floor:
+                pd = self.apply_cam2prior({'trans': self.trans, 'root_orient': self.root_orient}, self.cam2prior_R, self.cam2prior_t,
+                                          self.cam2prior_root_height, cur_body_pose, self.betas, self.init_fidx)
+                vel_trans, vel_root = pd['trans'], pd['root_orient']
+            tv, jv, rv = self.estimate_velocities(vel_trans, vel_root, cur_body_pose, self.betas, data_fps)
+        self.latent_motion.requires_grad = True
+        self.trans_vel = tv[:, :1].detach().clone().requires_grad_(True)
+        self.joints_vel = jv[:, :1].detach().clone().requires_grad_(True)
+        self.root_orient_vel = rv[:, :1].detach().clone().requires_grad_(True)
+        prior_opt_params = [self.trans_vel, self.joints_vel, self.root_orient_vel]
+        self.trans = self.trans[:, :1].detach().clone().requires_grad_(True)
+        self.root_orient = self.root_orient[:, :1].detach().clone().requires_grad_(True)
+        self.latent_pose = self.latent_pose[:, :1].detach().clone().requires_grad_(True)
+        if self.optim_floor:
+            self.floor_plane.requires_grad = True
+        self.betas.requires_grad = True
+        motion_params = [self.trans, self.root_orient, self.latent_pose, self.betas, self.latent_motion] + prior_opt_params
+        if self.optim_floor:
+            motion_params.append(self.floor_plane)
+
+        with torch.no_grad():
+            rr, cam_rr = self.rollout_latent_motion(self.trans, self.root_orient, self.latent2pose(self.latent_pose), self.betas,
+                                                    prior_opt_params, self.latent_motion, fit_gender=fit_gender)
+            init_pred, _ = self.smpl_results(cam_rr['trans'], cam_rr['root_orient'], cam_rr['pose_body'], self.betas)
+            if 'contacts' in rr:
+                init_pred['contacts'] = rr['contacts']
+        per_stage_outputs['stage3_init'] = init_pred
+
+        mk = lambda ps: torch.optim.LBFGS(ps, max_iter=lbfgs_max_iter, lr=lr, line_search_fn=LINE_SEARCH)
+        motion_optim = mk(motion_params)
+        optim_frozen = optim_refine = None
+        if self.stage3_tune_init_state:
+            frozen_params = [self.latent_motion, self.betas] + ([self.floor_plane] if self.optim_floor else [])
+            optim_frozen, optim_refine = mk(frozen_params), mk(motion_params)
+        n_init = self.stage3_tune_init_num_frames
+        saved_ch = self.fitting_loss.loss_weights['contact_height']
+        saved_cv = self.fitting_loss.loss_weights['contact_vel']
+        init_state_vars = [self.trans, self.root_orient, self.latent_pose, self.trans_vel, self.joints_vel, self.root_orient_vel]
+        init_motion_scale = 1.0
+        obs_init = self._local_obs(observed_data, nsteps=n_init)
+
+        for i in range(num_iter[2]):
+            tune_phase = self.stage3_tune_init_state and i < self.stage3_tune_init_freeze_start
+            if self.stage3_tune_init_state and self.stage3_tune_init_freeze_start <= i < self.stage3_tune_init_freeze_end:
+                motion_optim = optim_frozen
+                for v in init_state_vars:
+                    v.requires_grad = False
+                if self.stage3_contact_refine_only:
+                    self.fitting_loss.loss_weights['contact_height'] = 0.0
+                    self.fitting_loss.loss_weights['contact_vel'] = 0.0
+                init_motion_scale = float(self.seq_len) / n_init
+            elif self.stage3_tune_init_state and i >= self.stage3_tune_init_freeze_end:
+                motion_optim = optim_refine
+                for v in init_state_vars:
+                    v.requires_grad = True
+                self.betas.requires_grad = True
+                if self.optim_floor:
+                    self.floor_plane.requires_grad = True
+                if self.stage3_contact_refine_only:
+                    self.fitting_loss.loss_weights['contact_height'] = saved_ch
+                    self.fitting_loss.loss_weights['contact_vel'] = saved_cv
+                init_motion_scale = float(self.seq_len) / n_init
+            cur_optim = motion_optim
+
+            def closure():
+                cur_optim.zero_grad()
+                loss, stats = self._stage3_objective(obs_local, obs_init, prior_opt_params, tune_phase, n_init, init_motion_scale,
+                                                     og_overlap_w, has_overlap, fit_gender)
+                return self._finish_closure(loss, motion_params, stats)
+            cur_optim.step(closure)
+
+        # ---- final roll-out and results ----------------------------------------------------------------
+        with torch.no_grad():
+            body_pose = self.latent2pose(self.latent_pose)
+            if self.optim_floor:
+                cam_smpl, _ = self.smpl_results(self.trans, self.root_orient, body_pose, self.betas)
+                self.cam2prior_R, self.cam2prior_t, self.cam2prior_root_height = frames.compute_cam2prior(
+                    self.floor_plane, self.trans[:, 0], ops.batch_rodrigues(self.root_orient[:, 0], _lib_override=self.fit_bm._lib),
+                    cam_smpl['joints3d'][:, 0])
+            rr, cam_rr = self.rollout_latent_motion(self.trans, self.root_orient, body_pose, self.betas, prior_opt_params,
+                                                    self.latent_motion, fit_gender=fit_gender)
+            body_pose = rr['pose_body']
+            self.latent_pose = self.pose2latent(body_pose)
+            self.trans, self.root_orient = cam_rr['trans'], cam_rr['root_orient']
+            stage3, _ = self.smpl_results(self.trans, self.root_orient, body_pose, self.betas)
+            stage3['prior_joints3d_rollout' if self.optim_floor else 'joints3d_rollout'] = rr['joints']
+            if 'contacts' in rr:
+                stage3['contacts'] = rr['contacts']
+            if self.optim_floor:
+                stage3['prior_trans'], stage3['prior_root_orient'] = rr['trans'], rr['root_orient']
+        per_stage_outputs['stage3'] = stage3
+        final = self.get_optim_result(body_pose)
+        if 'contacts' in rr:
+            final['contacts'] = rr['contacts']
+        if stages_res_out is not None:
+            self._save_stage(stages_res_out, 'stage3_results.npz', body_pose, contacts=rr.get('contacts'))
+        return final, per_stage_outputs
+
+    def _stage1_objective(self, obs_local, has_overlap):
+        """Stage-1 objective on this rank's sequences (motion_optimizer.py:241-252)."""
+        body_pose = self.latent2pose(self._local(self.latent_pose))
+        pred, _ = self.smpl_results(self._local(self.trans), self._local(self.root_orient), body_pose, self._local(self.betas))
+        halo = self._halo(pred['verts3d'], self._local(self.betas), None,
+                          has_overlap and self.fitting_loss.loss_weights['rgb_overlap_consist'] > 0.0)
+        loss, stats = self.fitting_loss.root_fit(obs_local, pred, halo=halo)
+        return self._with_dep(loss, halo), stats
+
+    def _stage2_objective(self, obs_local, has_overlap):
+        """Stage-2 objective on this rank's sequences (motion_optimizer.py:291-304)."""
+        lp = self._local(self.latent_pose)
+        body_pose = self.latent2pose(lp)
+        pred, _ = self.smpl_results(self._local(self.trans), self._local(self.root_orient), body_pose, self._local(self.betas))
+        pred['latent_pose'] = lp
+        pred['betas'] = self._local(self.betas)
+        halo = self._halo(pred['verts3d'], pred['betas'], None,
+                          has_overlap and self.fitting_loss.loss_weights['rgb_overlap_consist'] > 0.0)
+        loss, stats = self.fitting_loss.smpl_fit(obs_local, pred, self.seq_len, halo=halo)
+        return self._with_dep(loss, halo), stats
+
+    def _stage3_objective(self, obs_local, obs_init, prior_opt_params, tune_phase, n_init, init_motion_scale, og_overlap_w,
+                          has_overlap, fit_gender):
+        """One stage-3 objective evaluation on this rank's sequences (motion_optimizer.py:514-605)."""
+        L = self._local
+        trans, root_orient, betas = L(self.trans), L(self.root_orient), L(self.betas)
+        cur_body_pose = self.latent2pose(L(self.latent_pose))
+        floor = L(self.floor_plane) if self.optim_floor else None
+        cam2prior = None
+        if self.optim_floor:
+            cam_smpl, _ = self.smpl_results(trans, root_orient, cur_body_pose, betas)
+            cam2prior = frames.compute_cam2prior(floor, trans[:, 0], ops.batch_rodrigues(root_orient[:, 0], _lib_override=self.fit_bm._lib),
+                                                 cam_smpl['joints3d'][:, 0])
+            if self.shard is None:
+                self.cam2prior_R, self.cam2prior_t, self.cam2prior_root_height = cam2prior
+        latent_motion = L(self.latent_motion)
+        if tune_phase:
+            latent_motion = latent_motion[:, :(n_init - 1)]
+        local_prior_params = [L(p) for p in prior_opt_params]
+        rr, cam_rr = self.rollout_latent_motion(trans, root_orient, cur_body_pose, betas, local_prior_params, latent_motion,
+                                                return_prior=self.cond_prior, fit_gender=fit_gender, cam2prior=cam2prior)
+        cur_latent_pose = self.pose2latent(rr['pose_body'])
+        pred, _ = self.smpl_results(rr['trans'], rr['root_orient'], rr['pose_body'], betas)
+        pred.update(latent_pose=cur_latent_pose, betas=betas, latent_motion=latent_motion, joints_vel=local_prior_params[1],
+                    trans_vel=local_prior_params[0], root_orient_vel=local_prior_params[2], joints3d_rollout=rr['joints'])
+        if 'contacts' in rr:
+            pred['contacts'], pred['contacts_conf'] = rr['contacts'], rr['contacts_conf']
+        cam_pred = pred
+        if self.optim_floor:
+            cam_pred, _ = self.smpl_results(cam_rr['trans'], cam_rr['root_orient'], rr['pose_body'], betas)
+            cam_pred.update(latent_pose=cur_latent_pose, betas=betas, floor_plane=floor)
+        nsteps, obs = self.seq_len, obs_local
+        if tune_phase:
+            nsteps, obs = n_init, obs_init
+            self.fitting_loss.loss_weights['rgb_overlap_consist'] = 0.0
+        halo = self._halo(cam_pred['verts3d'], betas, floor,
+                          has_overlap and self.fitting_loss.loss_weights['rgb_overlap_consist'] > 0.0)
+        loss, stats = self.fitting_loss.motion_fit(obs, pred, cam_pred, nsteps, cond_prior=rr.get('cond_prior'),
+                                                   init_motion_scale=init_motion_scale, halo=halo)
+        if tune_phase:
+            self.fitting_loss.loss_weights['rgb_overlap_consist'] = og_overlap_w
+        return self._with_dep(loss, halo), stats
+
+    # ------------------------------------------------------------------------------------------------
+    def _stage_snapshot(self, stages_res_out, fname):
+        with torch.no_grad():
+            body_pose = self.latent2pose(self.latent_pose)
+            pred, _ = self.smpl_results(self.trans, self.root_orient, body_pose, self.betas)
+        if stages_res_out is not None:
+            self._save_stage(stages_res_out, fname, body_pose)
+        return pred
+
+    def _save_stage(self, stages_res_out, fname, body_pose, contacts=None):
+        """Per-sequence stage results in the reference's npz layout (motion_optimizer.py:260-270)."""
+        arr = lambda t: t.detach().cpu().numpy()
+        betas, trans, ro, bp = arr(self.betas), arr(self.trans), arr(self.root_orient), arr(body_pose)
+        for b, out_dir in enumerate(stages_res_out):
+            d = dict(betas=betas[b], trans=trans[b], root_orient=ro[b], pose_body=bp[b])
+            if contacts is not None:
+                d['contacts'] = arr(contacts[b])
+            if self.optim_floor:
+                d['floor_plane'] = arr(self.floor_plane[b])
+            np.savez(os.path.join(out_dir, fname), **d)
+
+    def apply_cam2prior(self, data_dict, R, t, root_height, body_pose, betas, key_frame_idx, inverse=False):
+        '''Camera <-> prior frame for trans / root_orient (motion_optimizer.py:678-742).'''
+        lib = self.fit_bm._lib
+        out = {}
+        root_orient, trans = data_dict['root_orient'], data_dict['trans']
+        B, T, _ = root_orient.size()
+        Rm = ops.batch_rodrigues(root_orient.reshape(-1, 3), _lib_override=lib).reshape(B, T, 3, 3)
+        Rt = R.unsqueeze(1)
+        new_R = torch.matmul(Rt.transpose(3, 2), Rm) if inverse else torch.matmul(Rt, Rm)
+        out['root_orient'] = ops.rotation_matrix_to_angle_axis(new_R.reshape(-1, 3, 3), _lib_override=lib).reshape(B, T, 3)
+        ar = torch.arange(B, device=trans.device)
+        kf = torch.as_tensor(key_frame_idx, device=trans.device, dtype=torch.long)
+        if inverse:
+            off = trans[ar, kf].unsqueeze(1) if T > 1 else trans[:, 0:1]
+            tr = torch.matmul(Rt.transpose(3, 2), (trans - off).unsqueeze(-1))[..., 0] - t.unsqueeze(1)
+        else:
+            tr = torch.matmul(Rt, (trans + t.unsqueeze(1)).unsqueeze(-1))[..., 0]
+            smpl, _ = self.smpl_results(tr, out['root_orient'], body_pose, betas)
+            cur_h = smpl['joints3d'][ar, kf, 0, 2:3] if T > 1 else smpl['joints3d'][:, 0, 0, 2:3]
+            dh = root_height - cur_h
+            tr = tr + torch.cat([torch.zeros(B, 2, device=tr.device, dtype=tr.dtype), dh], dim=1).reshape(B, 1, 3)
+        out['trans'] = tr
+        return out
+
+    def estimate_velocities(self, trans, root_orient, body_pose, betas, data_fps, smpl_results=None):
+        B, T, _ = trans.size()
+        h = 1.0 / data_fps
+        if smpl_results is None:
+            smpl_results, _ = self.smpl_results(trans, root_orient, body_pose, betas)
+        trans_vel = frames.estimate_linear_velocity(trans, h)
+        joints_vel = frames.estimate_linear_velocity(smpl_results['joints3d'], h)
+        Rm = ops.batch_rodrigues(root_orient.reshape(-1, 3), _lib_override=self.fit_bm._lib).reshape(B, T, 3, 3)
+        return trans_vel, joints_vel, frames.estimate_angular_velocity(Rm, h)
+
+    def infer_latent_motion(self, trans, root_orient, body_pose, betas, data_fps, full_forward_pass=False):
+        '''Posterior mean of z for every transition of the current SMPL sequence (motion_optimizer.py:802-874).'''
+        B, T, _ = trans.size()
+        lib = self.fit_bm._lib
+        if self.optim_floor:
+            pd = self.apply_cam2prior({'trans': trans, 'root_orient': root_orient}, self.cam2prior_R, self.cam2prior_t,
+                                      self.cam2prior_root_height, body_pose, betas, self.init_fidx)
+            trans, root_orient = pd['trans'], pd['root_orient']
+        smpl, _ = self.smpl_results(trans, root_orient, body_pose, betas)
+        tv, jv, rv = self.estimate_velocities(trans, root_orient, body_pose, betas, data_fps, smpl_results=smpl)
+        seq = {'trans': trans, 'trans_vel': tv,
+               'root_orient': ops.batch_rodrigues(root_orient.reshape(-1, 3), _lib_override=lib).reshape(B, T, 9),
+               'root_orient_vel': rv,
+               'pose_body': ops.batch_rodrigues(body_pose.reshape(-1, 3), _lib_override=lib).reshape(B, T, J_BODY * 9),
+               'joints': smpl['joints3d'].reshape(B, T, -1), 'joints_vel': jv.reshape(B, T, -1)}
+        _, post = self.motion_prior.infer_global_seq(seq, full_forward_pass=full_forward_pass)
+        return post[0]
+
+    def rollout_latent_motion(self, trans, root_orient, body_pose, betas, prior_opt_params, latent_motion, return_prior=False,
+                              return_vel=False, fit_gender='neutral', use_mean=False, num_steps=-1, canonicalize_input=False,
+                              cam2prior=None):
+        '''
+        Initial SMPL state + latent sequence -> full SMPL sequence through the motion prior
+        (motion_optimizer.py:876-1019).  Returns (prior-frame dict, camera-frame dict).
+        '''
+        if latent_motion is None:
+            raise NotImplementedError('sampling roll-out is not on the fitting path')
+        lib = self.fit_bm._lib
+        B, Tm1 = trans.size(0), latent_motion.size(1)
+        cam2prior = cam2prior if cam2prior is not None else ((self.cam2prior_R, self.cam2prior_t, self.cam2prior_root_height)
+                                                              if self.optim_floor else None)
+        if self.optim_floor:
+            pd = self.apply_cam2prior({'trans': trans, 'root_orient': root_orient}, cam2prior[0], cam2prior[1], cam2prior[2],
+                                      body_pose, betas, self.init_fidx[:B])
+            trans, root_orient = pd['trans'], pd['root_orient']
+        trans_vel, joints_vel, root_orient_vel = prior_opt_params
+        smpl0, _ = self.smpl_results(trans, root_orient, body_pose, betas)      # one frame per sequence (B rows)
+        joints = smpl0['joints3d']
+        R_root = ops.batch_rodrigues(root_orient.reshape(-1, 3), _lib_override=lib).reshape(B, 9)
+        R_body = ops.batch_rodrigues(body_pose.reshape(-1, 3), _lib_override=lib).reshape(B, J_BODY * 9)
+        past_in = torch.cat([trans.reshape(B, 3), trans_vel.reshape(B, 3), R_root, root_orient_vel.reshape(B, 3), R_body,
+                             joints.reshape(B, -1), joints_vel.reshape(B, -1)], dim=1)
+        res = self.motion_prior.roll_out(past_in.unsqueeze(1), None, Tm1, z_seq=latent_motion, return_prior=return_prior,
+                                         canonicalize_input=canonicalize_input)
+        pred, prior_out = res if return_prior else (res, None)
+        aa_root = ops.rotation_matrix_to_angle_axis(pred['root_orient'].reshape(-1, 3, 3), _lib_override=lib).reshape(B, Tm1, 3)
+        aa_body = ops.rotation_matrix_to_angle_axis(pred['pose_body'].reshape(-1, 3, 3), _lib_override=lib).reshape(B, Tm1, J_BODY * 3)
+        out = {'trans': torch.cat([trans, pred['trans']], dim=1),
+               'root_orient': torch.cat([root_orient, aa_root], dim=1),
+               'pose_body': torch.cat([body_pose, aa_body], dim=1),
+               'joints': torch.cat([joints, pred['joints'].reshape(B, Tm1, -1, 3)], dim=1)}
+        if return_vel:
+            out['trans_vel'] = torch.cat([trans_vel, pred['trans_vel']], dim=1)
+            out['root_orient_vel'] = torch.cat([root_orient_vel, pred['root_orient_vel']], dim=1)
+            out['joints_vel'] = torch.cat([joints_vel, pred['joints_vel'].reshape(B, Tm1, -1, 3)], dim=1)
+        if return_prior:
+            out['cond_prior'] = prior_out
+        if 'contacts' in pred:
+            conf9 = torch.sigmoid(pred['contacts'])
+            lab9 = (conf9 > CONTACT_THRESH).to(torch.float)
+            conf = torch.zeros((B, Tm1, len(SMPL_JOINTS)), device=conf9.device, dtype=conf9.dtype)
+            lab = torch.zeros_like(conf)
+            conf[:, :, CONTACT_INDS] = conf[:, :, CONTACT_INDS] + conf9
+            lab[:, :, CONTACT_INDS] = lab[:, :, CONTACT_INDS] + lab9
+            out['contacts_conf'] = torch.cat([conf[:, 0:1], conf], dim=1)
+            out['contacts'] = torch.cat([lab[:, 0:1], lab], dim=1)
+        cam = {}
+        if self.optim_floor:
+            cam = self.apply_cam2prior({'trans': out['trans'], 'root_orient': out['root_orient']}, cam2prior[0], cam2prior[1],
+                                       cam2prior[2], out['pose_body'], betas, self.init_fidx[:B], inverse=True)
+        else:
+            cam['trans'], cam['root_orient'] = out['trans'], out['root_orient']
+        cam['pose_body'] = out['pose_body']
+        return out, cam
+
+    def get_optim_result(self, body_pose=None):
+        if body_pose is None:
+            body_pose = self.latent2pose(self.latent_pose)
+        d = lambda t: t.clone().detach()
+        res = {'trans': d(self.trans), 'root_orient': d(self.root_orient), 'pose_body': d(body_pose), 'betas': d(self.betas),
+               'latent_pose': d(self.latent_pose), 'latent_motion': d(self.latent_motion)}
+        if self.optim_floor:
+            res['floor_plane'] = d(frames.parse_floor_plane(self.floor_plane))
+        return res
+
+    def latent2pose(self, latent_pose):
+        '''VPoser latent -> axis-angle body pose.  [B,T,D] -> [B,T,63]'''
+        B, T, _ = latent_pose.size()
+        mats = self.pose_prior.decode(latent_pose.reshape(-1, self.latent_pose_dim), output_type='matrot')
+        return ops.rotation_matrix_to_angle_axis(mats.reshape(B * T * J_BODY, 3, 3), _lib_override=self.fit_bm._lib).reshape(B, T, J_BODY * 3)
+
+    def pose2latent(self, body_pose):
+        B, T, _ = body_pose.size()
+        return self.pose_prior.encode(body_pose.reshape(-1, J_BODY * 3)).mean.reshape(B, T, self.latent_pose_dim)
+
+    def smpl_results(self, trans, root_orient, body_pose, beta):
+        '''
+        SMPL forward for [B,T,.] parameters (T = 1 or any length): joints3d [B,T,22,3], joints3d_extra, verts3d [B,T,43,3].
+        '''
+        B, T, _ = trans.size()
+        betas = beta.reshape(B, 1, self.num_betas).expand(B, T, self.num_betas).reshape(B * T, -1)
+        body = self.fit_bm(pose_body=body_pose.reshape(B * T, -1), pose_hand=None, betas=betas,
+                           root_orient=root_orient.reshape(B * T, -1), trans=trans.reshape(B * T, -1))
+        joints = body.Jtr.reshape(B, T, -1, 3)
+        nj = len(SMPL_JOINTS)
+        pred = {'joints3d': joints[:, :, :nj], 'joints3d_extra': joints[:, :, nj:], 'verts3d': body.v.reshape(B, T, -1, 3),
+                'faces': body.f}
+        return pred, body

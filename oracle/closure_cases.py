@@ -1,0 +1,65 @@
+"""ORACLE (test infrastructure only).  Seeded synthetic fitting problems shared by the golden generator (which runs the
+reference MotionOptimizer on them in the build container) and by the tests (which run humor_amd on the same problems).
+Two cases: 'amass' (3D joint observations, no floor: BASELINE config C2 shape) and 'rgb' (2D OpenPose keypoints,
+floor optimisation, overlapping sub-sequences: C3/C4 shape)."""
+import numpy as np
+import torch
+
+KEYS = ['joints2d', 'joints3d', 'joints3d_rollout', 'verts3d', 'points3d', 'pose_prior', 'shape_prior', 'motion_prior',
+        'init_motion_prior', 'joint_consistency', 'bone_length', 'joints3d_smooth', 'contact_vel', 'contact_height', 'floor_reg',
+        'rgb_overlap_consist']
+
+
+def _weights(stage_vals):
+    return [{k: float(v.get(k, 0.0)) for k in KEYS} for v in stage_vals]
+
+
+# configs/fit_amass_joints.cfg:18-34 and configs/fit_rgb_demo_use_split.cfg:18-40 (per-stage 3-tuples)
+AMASS_WEIGHTS = _weights([
+    {'joints3d': 1.0},
+    {'joints3d': 1.0, 'pose_prior': 0.04, 'shape_prior': 0.05, 'joints3d_smooth': 0.1},
+    {'joints3d': 1.0, 'shape_prior': 0.05, 'motion_prior': 0.01, 'init_motion_prior': 0.01, 'joint_consistency': 1.0,
+     'bone_length': 10.0, 'contact_vel': 1.0, 'contact_height': 1.0}])
+RGB_WEIGHTS = _weights([
+    {'joints2d': 0.001, 'rgb_overlap_consist': 200.0},
+    {'joints2d': 0.001, 'pose_prior': 0.04, 'shape_prior': 0.05, 'joints3d_smooth': 100.0, 'rgb_overlap_consist': 200.0},
+    {'joints2d': 0.001, 'shape_prior': 0.05, 'motion_prior': 0.075, 'init_motion_prior': 0.075, 'joint_consistency': 100.0,
+     'bone_length': 2000.0, 'contact_vel': 100.0, 'contact_height': 10.0, 'floor_reg': 0.167, 'rgb_overlap_consist': 200.0}])
+
+CAM = dict(fx=1060.53, fy=1060.38, cx=951.30, cy=536.77)     # configs/intrinsics_default.json
+
+
+def camera_matrix(B):
+    K = torch.zeros(B, 3, 3)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = CAM['fx'], CAM['fy'], CAM['cx'], CAM['cy'], 1.0
+    return K
+
+
+def make_case(kind, B, T, seed=0):
+    """Observations + a random evaluation point (values of every optimisation variable) for `kind`."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: sc * torch.randn(*s, generator=g)
+    case = {'kind': kind, 'B': B, 'T': T}
+    var = {
+        'trans': torch.cat([r(B, T, 2, sc=0.3), 4.0 + r(B, T, 1, sc=0.3)], 2) if kind == 'rgb' else r(B, T, 3, sc=0.3),
+        'root_orient': torch.tensor([np.pi, 0.0, 0.0]) + r(B, T, 3, sc=0.2),
+        'latent_pose': r(B, T, 32, sc=0.7),
+        'betas': r(B, 16, sc=0.5),
+        'latent_motion': r(B, T - 1, 48, sc=0.5),
+        'trans_vel': r(B, 1, 3, sc=0.3), 'joints_vel': r(B, 1, 22, 3, sc=0.3), 'root_orient_vel': r(B, 1, 3, sc=0.3),
+    }
+    obs = {}
+    if kind == 'amass':
+        obs['joints3d'] = r(B, T, 22, 3, sc=0.5)
+        obs['joints3d'][0, 2, 4] = float('inf')       # an occluded joint
+    else:
+        xy = torch.rand(B, T, 25, 2, generator=g) * torch.tensor([1900.0, 1000.0])
+        conf = torch.rand(B, T, 25, 1, generator=g)
+        conf[:, :, 5] = 0.0
+        obs['joints2d'] = torch.cat([xy, conf], 3)
+        obs['floor_plane'] = torch.tensor([[0.0, -1.0, 0.0, -0.5]]).expand(B, 4).clone()
+        ov = 3
+        obs['seq_interval'] = torch.tensor([[b * (T - ov), b * (T - ov) + T] for b in range(B)])
+        var['floor_plane'] = torch.tensor([[0.02, 0.5, 0.03]]) + r(B, 3, sc=0.02)
+    case['obs'], case['var'] = obs, var
+    return case

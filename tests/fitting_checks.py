@@ -1,0 +1,97 @@
+"""Shared checks of the fitting objectives / MotionOptimizer against the reference-generated golden fixtures
+(tests/golden/closure_*.npz, generator oracle/make_golden_closures.py)."""
+import numpy as np
+import torch
+
+from conftest import golden
+from humor_amd import synth
+from humor_amd.body_model import BodyModel
+from humor_amd.humor_model import HumorModel
+from humor_amd.motion_optimizer import MotionOptimizer
+from oracle import closure_cases as CC
+
+
+def build(lib, device, kind, B, T, npz, shard=None):
+    rgb = kind == 'rgb'
+    bm = BodyModel(npz, num_betas=16, batch_size=B * T, use_vtx_selector=rgb, _lib_override=lib)
+    hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1,
+                    _lib_override=lib)
+    hm.load_state_dict(synth.humor_state_dict(seed=0))
+    hm = hm.to(device).eval()
+    for p in hm.parameters():
+        p.requires_grad_(False)
+    vp = synth.SynthVPoser(seed=0).to(device)
+    w, mu, cov = synth.make_gmm(seed=0)
+    weights = CC.RGB_WEIGHTS if rgb else CC.AMASS_WEIGHTS
+    cam = CC.camera_matrix(B).to(device) if rgb else None
+    return MotionOptimizer(device, bm, 16, B, T, ['joints2d'] if rgb else ['joints3d'], weights, vp, hm,
+                           {'gmm': (w.to(device), mu.to(device), cov.to(device))}, optim_floor=rgb, camera_matrix=cam,
+                           robust_loss_type='bisquare', joint2d_sigma=100, shard=shard)
+
+
+def eval_stage(opt, case, stage, device):
+    var = {k: v.clone().to(device).requires_grad_(True) for k, v in case['var'].items()}
+    obs = {k: v.clone().to(device) for k, v in case['obs'].items()}
+    T = case['T']
+    opt.fitting_loss.set_stage(stage)
+    has_overlap = 'seq_interval' in obs
+    if stage < 2:
+        opt.trans, opt.root_orient, opt.betas, opt.latent_pose = var['trans'], var['root_orient'], var['betas'], var['latent_pose']
+        fn = opt._stage1_objective if stage == 0 else opt._stage2_objective
+        loss, _ = fn(opt._local_obs(obs), has_overlap)
+        wrt = ['trans', 'root_orient'] if stage == 0 else ['trans', 'root_orient', 'betas', 'latent_pose']
+    else:
+        first = {k: var[k][:, :1].detach().clone().requires_grad_(True) for k in ('trans', 'root_orient', 'latent_pose')}
+        opt.trans, opt.root_orient, opt.latent_pose = first['trans'], first['root_orient'], first['latent_pose']
+        opt.betas, opt.latent_motion = var['betas'], var['latent_motion']
+        opt.trans_vel, opt.joints_vel, opt.root_orient_vel = var['trans_vel'], var['joints_vel'], var['root_orient_vel']
+        if opt.optim_floor:
+            opt.floor_plane = var['floor_plane']
+        prior_params = [opt.trans_vel, opt.joints_vel, opt.root_orient_vel]
+        loss, _ = opt._stage3_objective(opt._local_obs(obs), None, prior_params, False, 15, 1.0,
+                                        opt.fitting_loss.loss_weights['rgb_overlap_consist'], has_overlap, 'neutral')
+        var.update(first)
+        wrt = ['trans', 'root_orient', 'latent_pose', 'betas', 'latent_motion', 'trans_vel', 'joints_vel', 'root_orient_vel']
+        if opt.optim_floor:
+            wrt.append('floor_plane')
+    grads = torch.autograd.grad(loss, [var[k] for k in wrt], allow_unused=True)
+    out = {'loss': loss}
+    for k, g in zip(wrt, grads):
+        out['g_' + k] = torch.zeros_like(var[k]) if g is None else g
+    return out
+
+
+def check_objectives(lib, device, npz, kind, loss_rtol=2e-4, grad_rtol=2e-3):
+    gd = golden(f'closure_{kind}.npz')
+    B, T = int(gd['B']), int(gd['T'])
+    case = CC.make_case(kind, B, T, seed=int(gd['seed']))
+    opt = build(lib, device, kind, B, T, npz)
+    for stage in range(3):
+        res = eval_stage(opt, case, stage, device)
+        ref_loss = float(gd[f's{stage}_loss'])
+        assert abs(res['loss'].item() - ref_loss) <= loss_rtol * abs(ref_loss), (kind, stage, res['loss'].item(), ref_loss)
+        for k, v in res.items():
+            if k == 'loss':
+                continue
+            ref = gd[f's{stage}_{k}']
+            got = v.detach().cpu().numpy()
+            if stage == 2 and k in ('g_trans', 'g_root_orient', 'g_latent_pose'):
+                ref = ref[:, :1]       # the reference differentiates w.r.t. the full-length tensor; only frame 0 is used
+            scale = max(1.0, np.abs(ref).max())
+            err = np.abs(got - ref).max()
+            assert err <= grad_rtol * scale, (kind, stage, k, err, scale)
+
+
+def check_short_run(lib, device, npz, kind, tol=5e-2):
+    """The reference's run() for a few L-BFGS iterations vs ours on the same problem (trajectory-level, loose)."""
+    gd = golden(f'closure_{kind}.npz')
+    B, T = int(gd['B']), int(gd['T'])
+    opt = build(lib, device, kind, B, T, npz)
+    obs = {k: v.clone().to(device) for k, v in CC.make_case(kind, B, T, seed=2)['obs'].items()}
+    final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[int(x) for x in gd['run_num_iter']], lbfgs_max_iter=5)
+    d2 = np.abs(stages['stage2']['joints3d'].cpu().numpy() - gd['run_stage2_joints3d']).max()
+    d3 = np.abs(stages['stage3']['joints3d'].cpu().numpy() - gd['run_stage3_joints3d']).max()
+    assert d2 < tol and d3 < 2 * tol, (d2, d3)
+    assert set(final.keys()) >= {'trans', 'root_orient', 'pose_body', 'betas', 'latent_pose', 'latent_motion'}
+    assert final['latent_motion'].shape == (B, T - 1, 48) and final['trans'].shape == (B, T, 3)
+    return d2, d3

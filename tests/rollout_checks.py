@@ -71,6 +71,29 @@ def check_rollout(lib, device, B, S, seed=0, with_prior=True, weight_scale=1.0, 
     return err
 
 
+def check_rollout_conditioned(lib, device, B=32, S=59, seed=3):
+    """Full BASELINE length (59 steps).  With random-init weights the autoregressive chain amplifies rounding error by
+    ~1e4 (measured: the reference-style fp32 CPU evaluation drifts 6e-2 from an fp64 evaluation of the same chain at
+    step 58, tools/rollout_diag.py), so a fixed 1e-4 bound against the fp32 oracle is meaningless there.  Criterion:
+    at every step the HIP result must be as close to the fp64 evaluation as the fp32 oracle is (factor 4 + a 1e-5
+    relative floor), and within 1e-4 absolute over the first steps where the chain is still well conditioned."""
+    hm, sd = make_model(lib, device, seed=seed)
+    g = torch.Generator().manual_seed(seed + 5)
+    past, z = canonical_state(B, g), torch.randn(B, S, 48, generator=g)
+    out, (pm, pv) = hm.roll_out(past.to(device), None, S, z_seq=z.to(device), return_prior=True)
+    world = world_of(out).detach().cpu().double()
+    w32, _ = H.roll_out(sd, past, z)
+    w64, _ = H.roll_out({k: v.double() for k, v in sd.items()}, past.double(), z.double())
+    e_gpu = (world - w64).abs().amax(dim=(0, 2))
+    e_cpu = (w32.double() - w64).abs().amax(dim=(0, 2))
+    scale = w64.abs().amax(dim=(0, 2))
+    assert e_gpu[:5].max().item() < 1e-4
+    running = torch.cummax(e_cpu, dim=0)[0]
+    bound = 4.0 * running + 1e-5 * scale
+    assert (e_gpu <= bound).all(), (e_gpu / bound).max().item()
+    assert torch.isfinite(world).all() and torch.isfinite(pv).all()
+
+
 def check_rollout_golden(lib, device):
     gd = golden('rollout.npz')
     hm, _ = make_model(lib, device, seed=int(gd['weight_seed']))

@@ -1,0 +1,135 @@
+"""CPU tier: host-side fitting logic.
+  * FittingLoss against the reference's FittingLoss (build container only);
+  * stage-1/2 objectives of MotionOptimizer on the SIMT-emulator build vs reference-generated fixtures;
+  * the sharded (2-rank, gloo) closure == the single-process closure (loss and gradient), incl. the overlap halo."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import fitting_checks as FC
+from conftest import ROOT, golden
+from humor_amd import synth, tables
+from humor_amd.fitting_loss import FittingLoss
+from oracle import closure_cases as CC
+from oracle import ref_loader
+
+CPU = torch.device('cpu')
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason='reference tree only exists in the build container')
+def test_fitting_loss_matches_reference():
+    R = ref_loader.load()
+    R.fitting_loss.Logger.log = staticmethod(lambda *a, **k: None)
+    torch.manual_seed(0)
+    B, T = 4, 12
+    stages = CC._weights([
+        {'joints2d': 0.001, 'joints3d': 1.0, 'verts3d': 0.7, 'rgb_overlap_consist': 200.0},
+        {'joints2d': 0.001, 'joints3d': 1.0, 'verts3d': 0.5, 'pose_prior': 0.04, 'shape_prior': 0.05, 'joints3d_smooth': 100., 'rgb_overlap_consist': 200.0},
+        {'joints2d': 0.001, 'joints3d': 0.3, 'joints3d_rollout': 0.2, 'shape_prior': 0.05, 'motion_prior': 0.075, 'init_motion_prior': 0.075,
+         'joint_consistency': 100., 'bone_length': 2000., 'contact_vel': 100., 'contact_height': 10., 'floor_reg': 0.167,
+         'rgb_overlap_consist': 200.0, 'pose_prior': 0.04}])
+    args = dict(init_motion_prior={'gmm': synth.make_gmm()}, smpl2op_map=tables.SMPLH_TO_OPENPOSE25,
+                ignore_op_joints=tables.OP_IGNORE_JOINTS, cam_f=torch.tensor([[1060., 1060.]]).expand(B, 2),
+                cam_cent=torch.tensor([[951., 536.]]).expand(B, 2), robust_loss='bisquare', joints2d_sigma=100)
+    ref, our = R.fitting_loss.FittingLoss(stages, **args), FittingLoss(stages, **args)
+    obs = {'joints3d': torch.randn(B, T, 22, 3), 'verts3d': torch.randn(B, T, 43, 3),
+           'joints2d': torch.cat([torch.rand(B, T, 25, 2) * 1000, torch.rand(B, T, 25, 1)], 3),
+           'floor_plane': torch.tensor([[0., -1., 0., -0.5]]).expand(B, 4).clone(),
+           'seq_interval': torch.tensor([[0, 12], [9, 21], [18, 30], [27, 39]])}
+    obs['joints3d'][0, 3, 5] = float('inf')
+    obs['verts3d'][1, :4] = float('inf')
+    obs['prev_batch_overlap_res'] = {'seq_interval': torch.tensor([-9, 3]), 'verts3d': torch.randn(T, 43, 3), 'betas': torch.randn(16),
+                                     'floor_plane': torch.randn(4)}
+    off = torch.tensor([0, 0, 5.])
+    rg = lambda *s: torch.randn(*s).requires_grad_(True)
+    pred = {'joints3d': (torch.randn(B, T, 22, 3) + off).requires_grad_(True), 'joints3d_extra': (torch.randn(B, T, 51, 3) + off).requires_grad_(True),
+            'verts3d': rg(B, T, 43, 3), 'latent_pose': rg(B, T, 32), 'betas': rg(B, 16), 'latent_motion': rg(B, T - 1, 48),
+            'joints_vel': rg(B, 1, 22, 3), 'trans_vel': rg(B, 1, 3), 'root_orient_vel': rg(B, 1, 3), 'joints3d_rollout': rg(B, T, 22, 3),
+            'contacts_conf': torch.rand(B, T, 22).requires_grad_(True), 'floor_plane': rg(B, 3)}
+    cond = (rg(B, T - 1, 48), (torch.rand(B, T - 1, 48) + 0.5).requires_grad_(True))
+    cp = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+    for st in range(3):
+        ref.set_stage(st)
+        our.set_stage(st)
+        if st == 0:
+            l1, s1 = ref.root_fit(cp(obs), pred)
+            l2, s2 = our.root_fit(cp(obs), pred)
+        elif st == 1:
+            l1, s1 = ref.smpl_fit(cp(obs), pred, T)
+            l2, s2 = our.smpl_fit(cp(obs), pred, T)
+        else:
+            l1, s1 = ref.motion_fit(cp(obs), pred, pred, T, cond_prior=cond, init_motion_scale=4.0)
+            l2, s2 = our.motion_fit(cp(obs), pred, pred, T, cond_prior=cond, init_motion_scale=4.0)
+        assert sorted(s1.keys()) == sorted(s2.keys())
+        assert abs(l1.item() - l2.item()) <= 1e-6 * abs(l1.item())
+        ps = list(pred.values()) + list(cond)
+        g1 = torch.autograd.grad(l1, ps, allow_unused=True)
+        g2 = torch.autograd.grad(l2, ps, allow_unused=True)
+        for a, b in zip(g1, g2):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert (a - b).abs().max() <= 1e-5 * max(1.0, a.abs().max().item())
+
+
+@pytest.mark.parametrize('kind', ['amass', 'rgb'])
+def test_emu_stage12_objectives(emu_lib, smplh_npz, kind):
+    gd = golden(f'closure_{kind}.npz')
+    B, T = int(gd['B']), int(gd['T'])
+    case = CC.make_case(kind, B, T, seed=int(gd['seed']))
+    opt = FC.build(emu_lib, CPU, kind, B, T, smplh_npz)
+    for stage in (0, 1):
+        res = FC.eval_stage(opt, case, stage, CPU)
+        ref_loss = float(gd[f's{stage}_loss'])
+        assert abs(res['loss'].item() - ref_loss) <= 1e-5 * abs(ref_loss)
+        for k, v in res.items():
+            if k != 'loss':
+                ref = gd[f's{stage}_{k}']
+                assert np.abs(v.detach().numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (kind, stage, k)
+
+
+def _sharded_worker(rank, world, port, npz, emu_path, out):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from humor_amd import _lib
+    from humor_amd.distributed import Shard, allreduce_loss_and_grads
+    lib = _lib.load(emu_path, emulator=True)
+    B, T = 4, 8
+    case = CC.make_case('rgb', B, T, seed=1)
+    opt = FC.build(lib, CPU, 'rgb', B, T, npz, shard=Shard(B))
+    results = {}
+    for stage in (0, 1):
+        res = FC.eval_stage(opt, case, stage, CPU)
+        keys = [k for k in res if k != 'loss']
+        params = [torch.zeros_like(res[k]).requires_grad_(True) for k in keys]
+        for p, k in zip(params, keys):
+            p.grad = res[k].clone()
+        loss = allreduce_loss_and_grads(res['loss'], params)
+        results[stage] = {'loss': loss.item(), **{k: p.grad.clone() for k, p in zip(keys, params)}}
+    if rank == 0:
+        torch.save(results, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_closure_equals_single_process(emu_lib, smplh_npz, tmp_path):
+    """world_size-2 gloo: replicated variables, closure on the local slice, packed all-reduce, differentiable halo."""
+    out = str(tmp_path / 'sharded.pt')
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_sharded_worker, args=(2, port, smplh_npz, emu_lib.path, out), nprocs=2, join=True)
+    sharded = torch.load(out)
+    B, T = 4, 8
+    case = CC.make_case('rgb', B, T, seed=1)
+    opt = FC.build(emu_lib, CPU, 'rgb', B, T, smplh_npz)
+    for stage in (0, 1):
+        res = FC.eval_stage(opt, case, stage, CPU)
+        assert abs(res['loss'].item() - sharded[stage]['loss']) <= 1e-5 * abs(res['loss'].item())
+        for k, v in res.items():
+            if k != 'loss':
+                assert (v - sharded[stage][k]).abs().max().item() <= 1e-4 * max(1.0, v.abs().max().item()), (stage, k)
