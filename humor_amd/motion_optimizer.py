@@ -49,6 +49,7 @@ class MotionOptimizer():
         self.shard = shard
         self.verbose = verbose
         self.closure_evals = 0
+        self.loss_trace = None      # set to a list to record (stage, loss) of every closure evaluation (host sync per eval)
         if motion_prior is None:
             raise ValueError('Need the motion prior to use all-implicit parameterization!')
         if use_chamfer or 'points3d' in observed_modalities:
@@ -152,6 +153,8 @@ class MotionOptimizer():
     def _finish_closure(self, loss, params, stats=None):
         loss.backward()
         self.closure_evals += 1
+        if self.loss_trace is not None and self.shard is None:
+            self.loss_trace.append((self.fitting_loss.cur_stage_idx, float(loss)))
         if self.shard is not None:
             from .distributed import allreduce_loss_and_grads
             loss = allreduce_loss_and_grads(loss, params, self.shard.group)

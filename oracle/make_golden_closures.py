@@ -109,7 +109,18 @@ def main():
             opt2 = build_reference(R, kind, B, T, npz)
             obs = {k: v.clone() for k, v in CC.make_case(kind, B, T, seed=2)['obs'].items()}
             num_iter = [2, 2, 2]
+            trace = []
+            for name in ('root_fit', 'smpl_fit', 'motion_fit'):
+                orig = getattr(opt2.fitting_loss, name)
+
+                def wrapped(*a, _orig=orig, _name=name, **k):
+                    loss, st = _orig(*a, **k)
+                    if _name == ('root_fit', 'smpl_fit', 'motion_fit')[opt2.fitting_loss.cur_stage_idx]:
+                        trace.append((opt2.fitting_loss.cur_stage_idx, float(loss)))
+                    return loss, st
+                setattr(opt2.fitting_loss, name, wrapped)
             final, stages = opt2.run(obs, data_fps=30, lr=1.0, num_iter=num_iter, lbfgs_max_iter=5)
+            save['run_trace'] = np.array(trace, dtype=np.float64)
             save['run_num_iter'] = np.array(num_iter)
             for k in ('trans', 'root_orient', 'pose_body', 'betas', 'latent_motion'):
                 save['run_' + k] = final[k].detach().numpy()

@@ -88,7 +88,11 @@ def check_short_run(lib, device, npz, kind, tol=5e-2):
     B, T = int(gd['B']), int(gd['T'])
     opt = build(lib, device, kind, B, T, npz)
     obs = {k: v.clone().to(device) for k, v in CC.make_case(kind, B, T, seed=2)['obs'].items()}
+    opt.loss_trace = []
     final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[int(x) for x in gd['run_num_iter']], lbfgs_max_iter=5)
+    ref_trace = gd['run_trace']
+    for i, (st, ls) in enumerate(opt.loss_trace[:len(ref_trace)]):
+        print(f'closure {i:3d} stage {st} ours {ls:.6f} ref {ref_trace[i][1]:.6f} (stage {int(ref_trace[i][0])})')
     d2 = np.abs(stages['stage2']['joints3d'].cpu().numpy() - gd['run_stage2_joints3d']).max()
     d3 = np.abs(stages['stage3']['joints3d'].cpu().numpy() - gd['run_stage3_joints3d']).max()
     assert d2 < tol and d3 < 2 * tol, (d2, d3)
