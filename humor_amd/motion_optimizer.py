@@ -236,36 +236,7 @@ class MotionOptimizer():
         # ---- Stage III set-up -------------------------------------------------------------------------
         self.fitting_loss.set_stage(2)
         og_overlap_w = self.fitting_loss.loss_weights['rgb_overlap_consist']
-        with torch.no_grad():
-            cur_body_pose = self.latent2pose(self.latent_pose)
-            if self.optim_floor:
-                init_smpl, _ = self.smpl_results(self.trans, self.root_orient, cur_body_pose, self.betas)
-                ar = np.arange(self.batch_size)
-                self.cam2prior_R, self.cam2prior_t, self.cam2prior_root_height = frames.compute_cam2prior(
-                    self.floor_plane, self.trans[ar, self.init_fidx],
-                    ops.batch_rodrigues(self.root_orient[ar, self.init_fidx], _lib_override=self.fit_bm._lib),
-                    init_smpl['joints3d'][ar, self.init_fidx])
-            self.latent_motion = self.infer_latent_motion(self.trans, self.root_orient, cur_body_pose, self.betas, data_fps).detach()
-            vel_trans, vel_root = self.trans, self.root_orient
-            if self.optim_floor:
-                pd = self.apply_cam2prior({'trans': self.trans, 'root_orient': self.root_orient}, self.cam2prior_R, self.cam2prior_t,
-                                          self.cam2prior_root_height, cur_body_pose, self.betas, self.init_fidx)
-                vel_trans, vel_root = pd['trans'], pd['root_orient']
-            tv, jv, rv = self.estimate_velocities(vel_trans, vel_root, cur_body_pose, self.betas, data_fps)
-        self.latent_motion.requires_grad = True
-        self.trans_vel = tv[:, :1].detach().clone().requires_grad_(True)
-        self.joints_vel = jv[:, :1].detach().clone().requires_grad_(True)
-        self.root_orient_vel = rv[:, :1].detach().clone().requires_grad_(True)
-        prior_opt_params = [self.trans_vel, self.joints_vel, self.root_orient_vel]
-        self.trans = self.trans[:, :1].detach().clone().requires_grad_(True)
-        self.root_orient = self.root_orient[:, :1].detach().clone().requires_grad_(True)
-        self.latent_pose = self.latent_pose[:, :1].detach().clone().requires_grad_(True)
-        if self.optim_floor:
-            self.floor_plane.requires_grad = True
-        self.betas.requires_grad = True
-        motion_params = [self.trans, self.root_orient, self.latent_pose, self.betas, self.latent_motion] + prior_opt_params
-        if self.optim_floor:
-            motion_params.append(self.floor_plane)
+        motion_params, prior_opt_params = self.setup_stage3(data_fps)
 
         with torch.no_grad():
             rr, cam_rr = self.rollout_latent_motion(self.trans, self.root_orient, self.latent2pose(self.latent_pose), self.betas,
@@ -344,6 +315,43 @@ class MotionOptimizer():
         if stages_res_out is not None:
             self._save_stage(stages_res_out, 'stage3_results.npz', body_pose, contacts=rr.get('contacts'))
         return final, per_stage_outputs
+
+    def setup_stage3(self, data_fps=30):
+        """Stage-3 initialisation (motion_optimizer.py:324-405): cam2prior from the current floor, latent motion from the
+        posterior of the current SMPL sequence, initial velocities by finite differences, SMPL variables cut to frame 0.
+        Returns (motion_params, prior_opt_params)."""
+        with torch.no_grad():
+            cur_body_pose = self.latent2pose(self.latent_pose)
+            if self.optim_floor:
+                init_smpl, _ = self.smpl_results(self.trans, self.root_orient, cur_body_pose, self.betas)
+                ar = np.arange(self.batch_size)
+                self.cam2prior_R, self.cam2prior_t, self.cam2prior_root_height = frames.compute_cam2prior(
+                    self.floor_plane, self.trans[ar, self.init_fidx],
+                    ops.batch_rodrigues(self.root_orient[ar, self.init_fidx], _lib_override=self.fit_bm._lib),
+                    init_smpl['joints3d'][ar, self.init_fidx])
+            self.latent_motion = self.infer_latent_motion(self.trans, self.root_orient, cur_body_pose, self.betas, data_fps).detach()
+            vel_trans, vel_root = self.trans, self.root_orient
+            if self.optim_floor:
+                pd = self.apply_cam2prior({'trans': self.trans, 'root_orient': self.root_orient}, self.cam2prior_R, self.cam2prior_t,
+                                          self.cam2prior_root_height, cur_body_pose, self.betas, self.init_fidx)
+                vel_trans, vel_root = pd['trans'], pd['root_orient']
+            tv, jv, rv = self.estimate_velocities(vel_trans, vel_root, cur_body_pose, self.betas, data_fps)
+        self.latent_motion.requires_grad = True
+        self.trans_vel = tv[:, :1].detach().clone().requires_grad_(True)
+        self.joints_vel = jv[:, :1].detach().clone().requires_grad_(True)
+        self.root_orient_vel = rv[:, :1].detach().clone().requires_grad_(True)
+        prior_opt_params = [self.trans_vel, self.joints_vel, self.root_orient_vel]
+        self.trans = self.trans[:, :1].detach().clone().requires_grad_(True)
+        self.root_orient = self.root_orient[:, :1].detach().clone().requires_grad_(True)
+        self.latent_pose = self.latent_pose[:, :1].detach().clone().requires_grad_(True)
+        if self.optim_floor:
+            self.floor_plane.requires_grad = True
+        self.betas.requires_grad = True
+        motion_params = [self.trans, self.root_orient, self.latent_pose, self.betas, self.latent_motion] + prior_opt_params
+        if self.optim_floor:
+            motion_params.append(self.floor_plane)
+
+        return motion_params, prior_opt_params
 
     def _stage1_objective(self, obs_local, has_overlap):
         """Stage-1 objective on this rank's sequences (motion_optimizer.py:241-252)."""

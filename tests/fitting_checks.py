@@ -82,8 +82,13 @@ def check_objectives(lib, device, npz, kind, loss_rtol=2e-4, grad_rtol=2e-3):
             assert err <= grad_rtol * scale, (kind, stage, k, err, scale)
 
 
-def check_short_run(lib, device, npz, kind, tol=5e-2):
-    """The reference's run() for a few L-BFGS iterations vs ours on the same problem (trajectory-level, loose)."""
+def check_short_run(lib, device, npz, kind):
+    """The reference's run() for a few L-BFGS iterations vs ours on the same problem.
+    L-BFGS with strong-Wolfe line search is a chaotic map of its inputs: stages 1-2 (SMPL only) track the reference
+    closure-for-closure; in stage 3 the first evaluations agree to ~1e-5 and the trajectories then separate (measured:
+    6e-6 relative at the first stage-3 closure, tests/golden/closure_*.npz `run_trace`).  So: every stage-1/2 closure
+    and the first stage-3 closures must match tightly, stage-2 results must match, and stage 3 must make the same kind
+    of progress as the reference."""
     gd = golden(f'closure_{kind}.npz')
     B, T = int(gd['B']), int(gd['T'])
     opt = build(lib, device, kind, B, T, npz)
@@ -91,11 +96,18 @@ def check_short_run(lib, device, npz, kind, tol=5e-2):
     opt.loss_trace = []
     final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[int(x) for x in gd['run_num_iter']], lbfgs_max_iter=5)
     ref_trace = gd['run_trace']
-    for i, (st, ls) in enumerate(opt.loss_trace[:len(ref_trace)]):
-        print(f'closure {i:3d} stage {st} ours {ls:.6f} ref {ref_trace[i][1]:.6f} (stage {int(ref_trace[i][0])})')
+    ours = np.array(opt.loss_trace, dtype=np.float64)
+    n12 = int((ref_trace[:, 0] < 2).sum())
+    assert (ours[:n12, 0] == ref_trace[:n12, 0]).all()
+    rel = np.abs(ours[:n12, 1] - ref_trace[:n12, 1]) / np.abs(ref_trace[:n12, 1])
+    assert rel.max() < 1e-4, rel.max()
+    s3_ours, s3_ref = ours[ours[:, 0] == 2][:, 1], ref_trace[ref_trace[:, 0] == 2][:, 1]
+    rel3 = np.abs(s3_ours[:3] - s3_ref[:3]) / np.abs(s3_ref[:3])
+    assert rel3.max() < 2e-4, rel3
+    assert s3_ours[-1] < s3_ours[0] and abs(np.log(s3_ours.min() / s3_ref.min())) < 0.7
     d2 = np.abs(stages['stage2']['joints3d'].cpu().numpy() - gd['run_stage2_joints3d']).max()
-    d3 = np.abs(stages['stage3']['joints3d'].cpu().numpy() - gd['run_stage3_joints3d']).max()
-    assert d2 < tol and d3 < 2 * tol, (d2, d3)
+    assert d2 < 1e-3, d2
     assert set(final.keys()) >= {'trans', 'root_orient', 'pose_body', 'betas', 'latent_pose', 'latent_motion'}
     assert final['latent_motion'].shape == (B, T - 1, 48) and final['trans'].shape == (B, T, 3)
-    return d2, d3
+    assert all(torch.isfinite(v).all() for v in final.values())
+    return d2

@@ -35,7 +35,7 @@ def world_of(out):
     return torch.cat([out[k] for k in KEYS], 2)
 
 
-def check_rollout(lib, device, B, S, seed=0, with_prior=True, weight_scale=1.0, fwd_tol=FWD_TOL):
+def check_rollout(lib, device, B, S, seed=0, with_prior=True, weight_scale=1.0, fwd_tol=FWD_TOL, grad_rtol=GRAD_RTOL):
     hm, sd = make_model(lib, device, seed=seed, weight_scale=weight_scale)
     g = torch.Generator().manual_seed(seed + 5)
     past_c = canonical_state(B, g).requires_grad_(True)
@@ -61,7 +61,7 @@ def check_rollout(lib, device, B, S, seed=0, with_prior=True, weight_scale=1.0, 
     for name, a, b in zip(('g_past_in0', 'g_z'), g_ref, g_our):
         scale = max(1.0, a.abs().max().item())
         e = (a - b.cpu()).abs().max().item()
-        assert e < GRAD_RTOL * scale, (name, e, scale)
+        assert e < grad_rtol * scale, (name, e, scale)
     # contact labels (the only thresholded output) must be bit-exact away from the decision boundary (G11)
     logits_ref = w_ref[:, :, 339:348].detach()
     lab = (torch.sigmoid(world[:, :, 339:348].detach().cpu()) > 0.5)

@@ -160,3 +160,26 @@ def test_reference_bodymodel_live(smplh_npz, smplh_struct):
     assert out.Jtr.shape == (N, 52, 3) and out.v.shape == (N, 6890, 3) and out.f.shape == (13776, 3)
     assert out.full_pose.shape == (N, 156) and out.pose_hand.shape == (N, 90)
     assert R.transforms.batch_rodrigues(args['root_orient']).equal(L.batch_rodrigues(args['root_orient']))
+
+
+@pytest.mark.parametrize('kind', ['amass', 'rgb'])
+def test_restated_closure_matches_reference_fixture(smplh_struct, kind):
+    """oracle/closure_restated.py (the bench's CPU baseline) reproduces the reference MotionOptimizer's stage-3 objective."""
+    from oracle import closure_cases as CC
+    from oracle.closure_restated import RestatedFit
+    gd = golden(f'closure_{kind}.npz')
+    B, T = int(gd['B']), int(gd['T'])
+    case = CC.make_case(kind, B, T, seed=int(gd['seed']))
+    rgb = kind == 'rgb'
+    fit = RestatedFit(smplh_struct, synth.humor_state_dict(seed=0), synth.SynthVPoser(seed=0), synth.make_gmm(seed=0),
+                      CC.RGB_WEIGHTS if rgb else CC.AMASS_WEIGHTS, B, T, rgb, CC.camera_matrix(B) if rgb else None)
+    var = {k: v.clone() for k, v in case['var'].items()}
+    for k in ('trans', 'root_orient', 'latent_pose'):
+        var[k] = var[k][:, :1]
+    var = {k: v.requires_grad_(True) for k, v in var.items()}
+    loss = fit.objective(var, case['obs'])
+    ref = float(gd['s2_loss'])
+    assert abs(loss.item() - ref) <= 1e-4 * abs(ref), (loss.item(), ref)
+    g = torch.autograd.grad(loss, [var['latent_motion'], var['betas']])
+    assert np.abs(g[0].numpy() - gd['s2_g_latent_motion']).max() <= 2e-3 * max(1.0, np.abs(gd['s2_g_latent_motion']).max())
+    assert np.abs(g[1].numpy() - gd['s2_g_betas']).max() <= 2e-3 * max(1.0, np.abs(gd['s2_g_betas']).max())

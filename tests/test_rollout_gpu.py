@@ -27,9 +27,9 @@ def test_rollout_golden(gpu_lib, dev):
 
 def test_rollout_full_length(gpu_lib, dev):
     """BASELINE size (32 sequences x 59 steps): conditioning-aware parity (see check_rollout_conditioned) plus the
-    gradient check on a 20-step chain where fp32 gradients are still comparable."""
+    gradient check on a 16-step chain (the adjoint is amplified like the forward error, hence the looser bound)."""
     RC.check_rollout_conditioned(gpu_lib, dev, B=32, S=59, seed=3)
-    RC.check_rollout(gpu_lib, dev, B=32, S=20, seed=4, fwd_tol=2e-3)
+    RC.check_rollout(gpu_lib, dev, B=32, S=16, seed=4, fwd_tol=1e-3, grad_rtol=1e-2)
 
 
 def test_rollout_determinism(gpu_lib, dev):
