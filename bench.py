@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='do not capture the closure into a hipGraph')
     return ap.parse_args()
 
 
@@ -86,7 +87,7 @@ def camera_matrix(B, device):
 class FitClosure:
     """Stage-3 closure of humor_amd.MotionOptimizer on this rank's share of the problem."""
 
-    def __init__(self, dev, npz, world, rank, group):
+    def __init__(self, dev, npz, world, rank, group, use_graphs=True):
         from humor_amd import synth
         from humor_amd.body_model import BodyModel
         from humor_amd.humor_model import HumorModel
@@ -106,7 +107,7 @@ class FitClosure:
         w, mu, cov = synth.make_gmm(seed=0)
         self.opt = MotionOptimizer(dev, bm, 16, B, T_SEQ, ['joints2d'], loss_weights(), synth.SynthVPoser(seed=0).to(dev), hm,
                                    {'gmm': (w.to(dev), mu.to(dev), cov.to(dev))}, optim_floor=True, camera_matrix=camera_matrix(B, dev),
-                                   robust_loss_type='bisquare', joint2d_sigma=100, shard=shard)
+                                   robust_loss_type='bisquare', joint2d_sigma=100, shard=shard, use_graphs=use_graphs)
         o = self.opt
         o.trans, o.root_orient, o.latent_pose, o.betas = init['trans'], init['root_orient'], init['latent_pose'], init['betas']
         o.fitting_loss.set_stage(2)
@@ -115,12 +116,13 @@ class FitClosure:
         self.obs_local = o._local_obs(obs)
         self.og_w = o.fitting_loss.loss_weights['rgb_overlap_consist']
 
+        # the closure exactly as MotionOptimizer.run builds it for the refine phase (whole-closure hipGraph when enabled)
+        self.closure = o.make_closure(
+            lambda: o._stage3_objective(self.obs_local, None, self.prior_params, False, 15, 1.0, self.og_w, True, 'neutral'),
+            self.params, None)
+
     def step(self):
-        o = self.opt
-        for p in self.params:
-            p.grad = None
-        loss, _ = o._stage3_objective(self.obs_local, None, self.prior_params, False, 15, 1.0, self.og_w, True, 'neutral')
-        return o._finish_closure(loss, self.params)
+        return self.closure()
 
 
 def time_events(fn, iters, warm=2):
@@ -231,7 +233,7 @@ def main():
     from humor_amd import synth
     tmp = tempfile.mkdtemp(prefix='humor_amd_bench_')
     npz = synth.write_smplh_npz(os.path.join(tmp, f'model_{rank}.npz'), seed=0)
-    fc = FitClosure(dev, npz, world, rank, None)
+    fc = FitClosure(dev, npz, world, rank, None, use_graphs=not args.eager)
 
     for _ in range(args.warmup):
         fc.step()
@@ -264,6 +266,7 @@ def main():
                                    f'{B_SEQ * world} sub-sequences), joints2d + floor + overlap-consistency, SMPL+H 6890 verts / 52 joints / '
                                    '16 betas, HuMoR 48-d latent, 59-step roll-out; step = one stage-3 closure (fwd+bwd)',
                        'global_batch': B_SEQ * world, 'seq_len': T_SEQ, 'parallelism': f'dp{world} (sub-sequence sharding, replicated L-BFGS)'},
+            'closure_mode': 'eager' if (args.eager or not fc.opt.use_graphs) else 'hipGraph replay (objective + backward + all-reduce captured once)',
             'lbfgs_outer_iters_per_sec_est': round(args.steps * world / dt / 25.0, 3),
             'smpl_verts_per_sec': round(B_SEQ * T_SEQ * V / (ms_dense * 1e-3), 1),
             'smpl_dense_fwd_ms': round(ms_dense, 4),

@@ -123,7 +123,7 @@ class _SmplFunction(torch.autograd.Function):
             lib.call('ha_smpl_forward', h.ptr, 0, N, cfg['n_active'], _lib.ptr(pose), _lib.ptr(betas), _lib.ptr(transl),
                      _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(A), _lib.ptr(ws_v), _lib.ptr(ws_c), cfg['algo'], st)
             if n_sel:
-                joints = torch.cat([joints, verts.index_select(1, cfg['selector_t'].to(verts.device))], dim=1)
+                joints = torch.cat([joints, verts.index_select(1, cfg['selector_t'])], dim=1)
             v_out = verts
         else:
             nS = len(cfg['subset_all'])
@@ -159,7 +159,7 @@ class _SmplFunction(torch.autograd.Function):
                 slot, g_set = 0, g_v.contiguous()
                 if g_extra is not None:
                     g_set = g_set.clone()
-                    g_set.index_add_(1, cfg['selector_t'].to(dev), g_extra)
+                    g_set.index_add_(1, cfg['selector_t'], g_extra)
             elif g_extra is not None:
                 slot, g_set = cfg['slot_sel'], g_extra.contiguous()
             else:
@@ -212,6 +212,7 @@ class BodyModel(nn.Module):
         self._lib = _lib_override
         self._algo = algo
         self._handles = {}
+        self._sel_cache = {}
         self._selector = list(SMPLH_SELECTOR_VERTS) if use_vtx_selector else []
         self._subset = None if vertex_subset is None else [int(i) for i in vertex_subset]
         faces = torch.from_numpy(np.asarray(np.load(bm_path, encoding='latin1', allow_pickle=True)['f']).astype(np.int64))
@@ -271,7 +272,10 @@ class BodyModel(nn.Module):
             cfg = dict(mode='subset', subset_all=subset_all, slot_all=h.subset_slot(subset_all))
         cfg.update(handle=h, n_active=n_active, selector=self._selector, algo=self._algo)
         if self._selector:
-            cfg['selector_t'] = torch.tensor(self._selector, dtype=torch.long)
+            key = str(ref.device)
+            if key not in self._sel_cache:
+                self._sel_cache[key] = torch.tensor(self._selector, dtype=torch.long, device=ref.device)
+            cfg['selector_t'] = self._sel_cache[key]
             cfg['slot_sel'] = h.subset_slot(self._selector)
         v, joints = _SmplFunction.apply(full_pose.float(), betas.float(), trans_in.float(), cfg)
 

@@ -76,6 +76,14 @@ class FittingLoss(nn.Module):
         self.robust_tuning_const = robust_tuning_const
         self.cur_optim_step = 0
         self._op_conf_mask = None
+        self._dev_cache = {}
+
+    def _idx(self, name, values, device):
+        """Index tables as device tensors, created once per device (an H2D copy per closure otherwise)."""
+        key = (name, str(device))
+        if key not in self._dev_cache:
+            self._dev_cache[key] = torch.as_tensor(list(values), dtype=torch.long, device=device)
+        return self._dev_cache[key]
 
     def set_stage(self, idx):
         ''' Sets the current stage index. Determines which loss weights are used '''
@@ -118,7 +126,7 @@ class FittingLoss(nn.Module):
             stats['rgb_overlap_consist_verts3d_vel'] = vel
             if 'prev_batch_overlap_res' in observed_data and (halo is None or halo.get('first', True)):
                 prev = observed_data['prev_batch_overlap_res']
-                cur_ov = int(prev['seq_interval'][1] - observed_data['seq_interval'][0, 0])
+                cur_ov = int(prev['seq_interval'][1]) - int(observed_data['seq_interval'][0, 0])
                 T_pred = pred_data['verts3d'].size(1)
                 ov_len = min(T_pred, cur_ov)
                 prev_pos = prev['verts3d'][-cur_ov:][:ov_len]
@@ -137,15 +145,26 @@ class FittingLoss(nn.Module):
         verts3d [Bl,T,43,3] are the local sequences; with `halo`, halo['prev_tail'] [T,43,3] is the full predicted
         verts3d of the sequence before the first local one (None on the first rank) and seq_interval is already the
         local slice extended by that predecessor's interval in row 0."""
+        iv = seq_interval
+        prev_tail = halo.get('prev_tail') if halo is not None else None
+        nb = verts3d.size(0) + (1 if prev_tail is not None else 0)
+        ovs = [int(iv[b - 1, 1]) - int(iv[b, 0]) for b in range(1, nb)]
         pos = verts3d.new_zeros(())
         vel = verts3d.new_zeros(())
-        iv = seq_interval
-        if halo is not None and halo.get('prev_tail') is not None:
-            seqs = [halo['prev_tail']] + [verts3d[b] for b in range(verts3d.size(0))]
-        else:
-            seqs = [verts3d[b] for b in range(verts3d.size(0))]
+        if not ovs:
+            return pos, vel
+        if all(o == ovs[0] for o in ovs) and ovs[0] > 0:
+            # regular splitting (rgb_dataset.py:74-93): every pair overlaps by the same number of frames -> one batched term
+            ov = ovs[0]
+            allv = verts3d if prev_tail is None else torch.cat([prev_tail.unsqueeze(0), verts3d], dim=0)
+            prev_pos, cur_pos = allv[:-1, -ov:], allv[1:, :ov]
+            pos = self.verts3d_loss(prev_pos, cur_pos)
+            if ov > 1:
+                vel = self.verts3d_loss(prev_pos[:, 1:] - prev_pos[:, :-1], cur_pos[:, 1:] - cur_pos[:, :-1])
+            return pos, vel
+        seqs = ([prev_tail] if prev_tail is not None else []) + [verts3d[b] for b in range(verts3d.size(0))]
         for b in range(1, len(seqs)):
-            ov = int(iv[b - 1, 1] - iv[b, 0])
+            ov = ovs[b - 1]
             prev_pos = seqs[b - 1][-ov:] if ov > 0 else seqs[b - 1][:0]
             cur_pos = seqs[b][:ov]
             pos = pos + self.verts3d_loss(prev_pos, cur_pos)
@@ -251,7 +270,7 @@ class FittingLoss(nn.Module):
             raise NotImplementedError('camera extrinsics are the identity on the fitting path')
         B, T = joints2d_obs.size(0), joints2d_obs.size(1)
         full = torch.cat([joints3d_pred, joints3d_extra_pred], dim=2)
-        op = full.index_select(2, self.smpl2op_map.to(full.device)).reshape(B * T, OP_NUM_JOINTS, 3)
+        op = full.index_select(2, self._idx('smpl2op', self.smpl2op_map.tolist(), full.device)).reshape(B * T, OP_NUM_JOINTS, 3)
         cam_f = self.cam_f.expand(B, T, 2).reshape(B * T, 2)
         cam_c = self.cam_cent.expand(B, T, 2).reshape(B * T, 2)
         pred2d = perspective_projection(op, cam_f, cam_c).reshape(B, T, OP_NUM_JOINTS, 2)
@@ -299,7 +318,7 @@ class FittingLoss(nn.Module):
 
     def bone_length_loss(self, rollout_joints3d):
         bones = rollout_joints3d[:, :, 1:]
-        parents = rollout_joints3d[:, :, SMPL_PARENTS[1:]]
+        parents = rollout_joints3d.index_select(2, self._idx('smpl_parents', SMPL_PARENTS[1:], rollout_joints3d.device))
         lengths = torch.norm(bones - parents, dim=-1)
         d = lengths[:, 1:] - lengths[:, :-1]
         return 0.5 * torch.sum(d * d)

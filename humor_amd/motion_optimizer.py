@@ -34,7 +34,7 @@ class MotionOptimizer():
                  motion_prior=None, init_motion_prior=None, optim_floor=False, camera_matrix=None, robust_loss_type='none',
                  robust_tuning_const=4.6851, joint2d_sigma=100, stage3_tune_init_state=True, stage3_tune_init_num_frames=15,
                  stage3_tune_init_freeze_start=30, stage3_tune_init_freeze_end=50, stage3_contact_refine_only=False,
-                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False):
+                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs=False):
         B, T = batch_size, seq_len
         self.device = device
         self.batch_size, self.seq_len = B, T
@@ -48,6 +48,7 @@ class MotionOptimizer():
         self.im_dim = im_dim
         self.shard = shard
         self.verbose = verbose
+        self.use_graphs = use_graphs and torch.device(device).type == 'cuda'   # whole-closure hipGraph capture
         self.closure_evals = 0
         self.loss_trace = None      # set to a list to record (stage, loss) of every closure evaluation (host sync per eval)
         if motion_prior is None:
@@ -79,6 +80,7 @@ class MotionOptimizer():
         self.cond_prior = motion_prior.use_conditional_prior
         self.trans_vel = self.root_orient_vel = self.joints_vel = None
         self.init_fidx = np.zeros((B), dtype=np.int64)
+        self._contact_idx = torch.as_tensor(CONTACT_INDS, dtype=torch.long, device=device)
 
         self.cam_f = self.cam_center = None
         if optim_floor:
@@ -114,6 +116,7 @@ class MotionOptimizer():
             if k == 'prev_batch_overlap_res':
                 out[k] = v
             elif k == 'seq_interval':
+                v = v.cpu()      # frame intervals are host-side integers (no device sync inside the closure)
                 if self.shard is None or self.shard.rank == 0:
                     out[k] = self._local(v)
                 else:
@@ -145,6 +148,62 @@ class MotionOptimizer():
             if floor_plane is not None:
                 halo['prev_floor'] = prev[n + self.num_betas:n + self.num_betas + 3]
         return halo
+
+    def make_closure(self, objective, params, optim=None):
+        """Returns the L-BFGS closure for `objective()` -> (loss, stats).  With use_graphs the objective, its backward and
+        the gradient all-reduce are captured once into a hipGraph (torch.cuda.graphs) and replayed per evaluation: a
+        closure is ~3000 small launches and otherwise host-bound."""
+        if not self.use_graphs:
+            def closure():
+                for p in params:          # = optim.zero_grad(set_to_none=True) of the reference closures
+                    p.grad = None
+                loss, stats = objective()
+                return self._finish_closure(loss, params, stats)
+            return closure
+        state = {'graph': None, 'loss': None, 'grads': None, 'failed': False}
+
+        def eager():
+            for p in params:
+                p.grad = None
+            loss, stats = objective()
+            return self._finish_closure(loss, params, stats)
+
+        def closure():
+            if state['failed']:
+                return eager()
+            if state['graph'] is None:
+                try:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        for _ in range(2):
+                            eager()
+                    torch.cuda.current_stream().wait_stream(side)
+                    for p in params:
+                        p.grad = None
+                    evals, trace = self.closure_evals, self.loss_trace
+                    self.loss_trace = None
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        loss, _ = objective()
+                        loss = self._finish_closure(loss, params, None)
+                        state['loss'] = loss.detach()
+                    self.closure_evals, self.loss_trace = evals, trace
+                    state['grads'] = [p.grad for p in params]
+                    state['graph'] = g
+                except Exception as e:          # capture is an optimisation: fall back to eager evaluation
+                    print('humor_amd: hipGraph capture of the closure failed (%s: %s); running eagerly' % (type(e).__name__, e))
+                    state['failed'] = True
+                    torch.cuda.synchronize()
+                    return eager()
+            for p, gbuf in zip(params, state['grads']):
+                p.grad = gbuf
+            state['graph'].replay()
+            self.closure_evals += 1
+            if self.loss_trace is not None and self.shard is None:
+                self.loss_trace.append((self.fitting_loss.cur_stage_idx, float(state['loss'])))
+            return state['loss']
+        return closure
 
     @staticmethod
     def _with_dep(loss, halo):
@@ -209,14 +268,11 @@ class MotionOptimizer():
         self.latent_pose.requires_grad = False
         params = [self.trans, self.root_orient]
         optim = torch.optim.LBFGS(params, max_iter=lbfgs_max_iter, lr=lr, line_search_fn=LINE_SEARCH)
+        closure1 = self.make_closure(lambda: self._stage1_objective(obs_local, has_overlap), params, optim)
         for i in range(num_iter[0]):
             self.fitting_loss.cur_optim_step = i
 
-            def closure():
-                optim.zero_grad()
-                loss, stats = self._stage1_objective(obs_local, has_overlap)
-                return self._finish_closure(loss, params, stats)
-            optim.step(closure)
+            optim.step(closure1)
         per_stage_outputs['stage1'] = self._stage_snapshot(stages_res_out, 'stage1_results.npz')
 
         # ---- Stage II: full pose and shape ------------------------------------------------------------
@@ -225,12 +281,9 @@ class MotionOptimizer():
         self.latent_pose.requires_grad = True
         params = [self.trans, self.root_orient, self.betas, self.latent_pose]
         optim = torch.optim.LBFGS(params, max_iter=lbfgs_max_iter, lr=lr, line_search_fn=LINE_SEARCH)
+        closure2 = self.make_closure(lambda: self._stage2_objective(obs_local, has_overlap), params, optim)
         for i in range(num_iter[1]):
-            def closure():
-                optim.zero_grad()
-                loss, stats = self._stage2_objective(obs_local, has_overlap)
-                return self._finish_closure(loss, params, stats)
-            optim.step(closure)
+            optim.step(closure2)
         per_stage_outputs['stage2'] = self._stage_snapshot(stages_res_out, 'stage2_results.npz')
 
         # ---- Stage III set-up -------------------------------------------------------------------------
@@ -258,6 +311,7 @@ class MotionOptimizer():
         init_state_vars = [self.trans, self.root_orient, self.latent_pose, self.trans_vel, self.joints_vel, self.root_orient_vel]
         init_motion_scale = 1.0
         obs_init = self._local_obs(observed_data, nsteps=n_init)
+        closures3 = {}
 
         for i in range(num_iter[2]):
             tune_phase = self.stage3_tune_init_state and i < self.stage3_tune_init_freeze_start
@@ -280,14 +334,15 @@ class MotionOptimizer():
                     self.fitting_loss.loss_weights['contact_height'] = saved_ch
                     self.fitting_loss.loss_weights['contact_vel'] = saved_cv
                 init_motion_scale = float(self.seq_len) / n_init
-            cur_optim = motion_optim
-
-            def closure():
-                cur_optim.zero_grad()
-                loss, stats = self._stage3_objective(obs_local, obs_init, prior_opt_params, tune_phase, n_init, init_motion_scale,
-                                                     og_overlap_w, has_overlap, fit_gender)
-                return self._finish_closure(loss, motion_params, stats)
-            cur_optim.step(closure)
+            # one closure (and one captured graph) per phase: tune-init / frozen-init / refine
+            phase = (tune_phase, motion_optim is optim_frozen, init_motion_scale,
+                     self.fitting_loss.loss_weights['contact_height'], self.fitting_loss.loss_weights['contact_vel'])
+            if phase not in closures3:
+                closures3[phase] = self.make_closure(
+                    lambda tp=tune_phase, ims=init_motion_scale: self._stage3_objective(
+                        obs_local, obs_init, prior_opt_params, tp, n_init, ims, og_overlap_w, has_overlap, fit_gender),
+                    motion_params, None)
+            motion_optim.step(closures3[phase])
 
         # ---- final roll-out and results ----------------------------------------------------------------
         with torch.no_grad():
@@ -447,15 +502,15 @@ class MotionOptimizer():
         Rt = R.unsqueeze(1)
         new_R = torch.matmul(Rt.transpose(3, 2), Rm) if inverse else torch.matmul(Rt, Rm)
         out['root_orient'] = ops.rotation_matrix_to_angle_axis(new_R.reshape(-1, 3, 3), _lib_override=lib).reshape(B, T, 3)
-        ar = torch.arange(B, device=trans.device)
-        kf = torch.as_tensor(key_frame_idx, device=trans.device, dtype=torch.long)
+        # key_frame_idx is the first frame on the fitting path (motion_optimizer.py:109: init_fidx = zeros)
+        assert not np.any(np.asarray(key_frame_idx)), 'non-zero key frames are not supported'
         if inverse:
-            off = trans[ar, kf].unsqueeze(1) if T > 1 else trans[:, 0:1]
+            off = trans[:, 0:1]
             tr = torch.matmul(Rt.transpose(3, 2), (trans - off).unsqueeze(-1))[..., 0] - t.unsqueeze(1)
         else:
             tr = torch.matmul(Rt, (trans + t.unsqueeze(1)).unsqueeze(-1))[..., 0]
             smpl, _ = self.smpl_results(tr, out['root_orient'], body_pose, betas)
-            cur_h = smpl['joints3d'][ar, kf, 0, 2:3] if T > 1 else smpl['joints3d'][:, 0, 0, 2:3]
+            cur_h = smpl['joints3d'][:, 0, 0, 2:3]
             dh = root_height - cur_h
             tr = tr + torch.cat([torch.zeros(B, 2, device=tr.device, dtype=tr.dtype), dh], dim=1).reshape(B, 1, 3)
         out['trans'] = tr
@@ -533,8 +588,8 @@ class MotionOptimizer():
             lab9 = (conf9 > CONTACT_THRESH).to(torch.float)
             conf = torch.zeros((B, Tm1, len(SMPL_JOINTS)), device=conf9.device, dtype=conf9.dtype)
             lab = torch.zeros_like(conf)
-            conf[:, :, CONTACT_INDS] = conf[:, :, CONTACT_INDS] + conf9
-            lab[:, :, CONTACT_INDS] = lab[:, :, CONTACT_INDS] + lab9
+            conf = conf.index_add(2, self._contact_idx, conf9)
+            lab = lab.index_add(2, self._contact_idx, lab9)
             out['contacts_conf'] = torch.cat([conf[:, 0:1], conf], dim=1)
             out['contacts'] = torch.cat([lab[:, 0:1], lab], dim=1)
         cam = {}

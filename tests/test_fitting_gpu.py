@@ -21,3 +21,37 @@ def test_stage_objectives_match_reference(gpu_lib, dev, smplh_npz, kind):
 @pytest.mark.parametrize('kind', ['amass', 'rgb'])
 def test_short_run_matches_reference(gpu_lib, dev, smplh_npz, kind):
     FC.check_short_run(gpu_lib, dev, smplh_npz, kind)
+
+
+def test_graphed_closure_equals_eager(gpu_lib, dev, smplh_npz):
+    """hipGraph replay of the stage-3 closure returns the eager loss and gradients bit-for-bit, call after call."""
+    from oracle import closure_cases as CC
+    B, T = 4, 8
+    case = CC.make_case('rgb', B, T, seed=1)
+    res = {}
+    for graphs in (False, True):
+        opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
+        opt.use_graphs = graphs
+        var = {k: v.clone().to(dev) for k, v in case['var'].items()}
+        obs = {k: v.clone().to(dev) for k, v in case['obs'].items()}
+        opt.fitting_loss.set_stage(2)
+        opt.trans, opt.root_orient, opt.latent_pose = (var[k][:, :1].clone().requires_grad_(True) for k in ('trans', 'root_orient', 'latent_pose'))
+        opt.betas = var['betas'].requires_grad_(True)
+        opt.latent_motion = var['latent_motion'].requires_grad_(True)
+        opt.trans_vel, opt.joints_vel, opt.root_orient_vel = (var[k].requires_grad_(True) for k in ('trans_vel', 'joints_vel', 'root_orient_vel'))
+        opt.floor_plane = var['floor_plane'].requires_grad_(True)
+        prior = [opt.trans_vel, opt.joints_vel, opt.root_orient_vel]
+        params = [opt.trans, opt.root_orient, opt.latent_pose, opt.betas, opt.latent_motion] + prior + [opt.floor_plane]
+        ol = opt._local_obs(obs)
+        closure = opt.make_closure(lambda: opt._stage3_objective(ol, None, prior, False, 15, 1.0, 200.0, True, 'neutral'), params, None)
+        out = []
+        for it in range(3):
+            loss = closure()
+            out.append((loss.item(), [p.grad.clone() for p in params]))
+            with torch.no_grad():
+                opt.latent_motion.add_(0.01)          # the optimiser updates variables in place between evaluations
+        res[graphs] = out
+    for (l0, g0), (l1, g1) in zip(res[False], res[True]):
+        assert abs(l0 - l1) <= 1e-5 * abs(l0)
+        for a, b in zip(g0, g1):
+            assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())

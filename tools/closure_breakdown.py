@@ -14,7 +14,7 @@ from humor_amd import synth                              # noqa: E402
 def main():
     dev = torch.device('cuda:0')
     npz = synth.write_smplh_npz('/tmp/model_bd.npz', seed=0)
-    fc = bench.FitClosure(dev, npz, 1, 0, None)
+    fc = bench.FitClosure(dev, npz, 1, 0, None, use_graphs='--graph' in sys.argv)
     for _ in range(3):
         fc.step()
     torch.cuda.synchronize()
