@@ -266,7 +266,7 @@ def main():
                                    f'{B_SEQ * world} sub-sequences), joints2d + floor + overlap-consistency, SMPL+H 6890 verts / 52 joints / '
                                    '16 betas, HuMoR 48-d latent, 59-step roll-out; step = one stage-3 closure (fwd+bwd)',
                        'global_batch': B_SEQ * world, 'seq_len': T_SEQ, 'parallelism': f'dp{world} (sub-sequence sharding, replicated L-BFGS)'},
-            'closure_mode': 'eager' if (args.eager or not fc.opt.use_graphs) else 'hipGraph replay (objective + backward + all-reduce captured once)',
+            'closure_mode': 'eager' if (args.eager or not fc.opt.use_graphs or getattr(fc.opt, 'graph_failures', 0)) else 'hipGraph replay (objective + backward + all-reduce captured once)',
             'lbfgs_outer_iters_per_sec_est': round(args.steps * world / dt / 25.0, 3),
             'smpl_verts_per_sec': round(B_SEQ * T_SEQ * V / (ms_dense * 1e-3), 1),
             'smpl_dense_fwd_ms': round(ms_dense, 4),

@@ -192,8 +192,9 @@ class MotionOptimizer():
                     state['grads'] = [p.grad for p in params]
                     state['graph'] = g
                 except Exception as e:          # capture is an optimisation: fall back to eager evaluation
-                    print('humor_amd: hipGraph capture of the closure failed (%s: %s); running eagerly' % (type(e).__name__, e))
+                    print('humor_amd: hipGraph capture of the closure failed (%s: %s); running eagerly' % (type(e).__name__, str(e)[:600]))
                     state['failed'] = True
+                    self.graph_failures = getattr(self, 'graph_failures', 0) + 1
                     torch.cuda.synchronize()
                     return eager()
             for p, gbuf in zip(params, state['grads']):
