@@ -16,7 +16,6 @@ import math
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.distributions import Categorical, MixtureSameFamily, MultivariateNormal
 
 from .tables import OP_NUM_JOINTS, SMPL_PARENTS
 
@@ -44,6 +43,26 @@ def _masked_sq(obs, pred):
     return 0.5 * torch.sum(diff * diff)
 
 
+class _GMM:
+    """Gaussian-mixture log-density with the Cholesky factors inverted once at construction.
+    Same value as MixtureSameFamily(Categorical(w), MultivariateNormal(mu, cov)).log_prob (run_fitting.py:248-261,
+    fitting_loss.py:83-87, 416-429), but the per-call work is one batched mat-vec: torch.distributions' batched
+    triangular solve issues host-side pointer-array copies that cannot be captured into a hipGraph."""
+
+    def __init__(self, weights, means, covs):
+        L = torch.linalg.cholesky(covs)
+        eye = torch.eye(covs.shape[-1], dtype=covs.dtype, device=covs.device).expand_as(covs)
+        self.Linv = torch.linalg.solve_triangular(L, eye, upper=False)                   # [K,D,D]
+        self.means = means
+        self.const = (torch.log(weights / weights.sum()) - torch.log(torch.diagonal(L, dim1=-2, dim2=-1)).sum(-1)
+                      - 0.5 * means.shape[-1] * math.log(2 * math.pi))                    # [K]
+
+    def log_prob(self, x):
+        diff = x.unsqueeze(1) - self.means.unsqueeze(0)                                  # [B,K,D]
+        y = torch.einsum('kij,bkj->bki', self.Linv, diff)
+        return torch.logsumexp(self.const.unsqueeze(0) - 0.5 * (y * y).sum(-1), dim=1)
+
+
 class FittingLoss(nn.Module):
     '''
     Functions to compute all needed losses for fitting.
@@ -69,7 +88,7 @@ class FittingLoss(nn.Module):
         self.init_motion_prior = None
         if init_motion_prior is not None and total['init_motion_prior'] > 0.0:
             w, mu, cov = init_motion_prior['gmm']
-            self.init_motion_prior = {'gmm': MixtureSameFamily(Categorical(w), MultivariateNormal(mu, covariance_matrix=cov))}
+            self.init_motion_prior = {'gmm': _GMM(w, mu, cov)}
         if robust_loss not in ['none', 'bisquare', 'gm']:
             raise ValueError('Not a valid robust loss: %s' % robust_loss)
         self.robust_loss = robust_loss
