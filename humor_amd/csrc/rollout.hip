@@ -20,19 +20,23 @@
 namespace ha {
 
 constexpr int D_IN = 339, D_RAW = 216, D_STATE = 348, ZD = 48, NJT = 22, NBODY = 21;
-constexpr int NW = 4;            // waves per block in the layer kernel
-constexpr int SLICE = 64;        // channels per wave K-slice
+constexpr int NWL = 4;           // waves per block in the layer kernel (one per SIMD: the whole 512-register file each)
+constexpr int SPW = 4;           // K-slices per wave: wave w owns slices w, w+4, w+8, w+12
+constexpr int SLICE = 64;        // channels per K-slice
 constexpr int MAXL = 8;
+constexpr int ZKS = ZD / 4;      // k-steps of the latent skip term (48 / 4)
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct PackedLayer {
   int Cin = 0, skip = 0, Nout = 0;
-  int nslices_f = 0, main_slices = 0, ntiles_f = 0, nsplit_f = 0, Nout_pad = 0;
-  int nslices_b = 0, ntiles_b = 0, nsplit_b = 0, Nin_pad = 0;
+  int main_slices = 0, ntiles_f = 0, nsplit_f = 1, Nout_pad = 0;
+  int nslices_b = 0, ntiles_b = 0, nsplit_b = 1, Nin_pad = 0;
   int group = 0;
-  float* Wf = nullptr;   // [ntiles_f][nslices_f][32][64]
-  float* Wb = nullptr;   // [ntiles_b][nslices_b][32][64]
+  int zoff = 0;            // column offset of this layer inside the per-step latent-term buffer
+  float* Wf = nullptr;     // [ntiles_f][main_slices][16][64]   B operand of v_mfma_f32_16x16x4_f32, forward
+  float* Wz = nullptr;     // [ntiles_f][ZKS][64]                latent-skip columns (decoder only)
+  float* Wb = nullptr;     // [ntiles_b][nslices_b][16][64]      adjoint (W^T)
   float* bias = nullptr;
   float* gamma = nullptr;  // GroupNorm affine of the activation feeding this layer (Cin channels)
   float* beta = nullptr;
@@ -43,6 +47,7 @@ struct PackedLayer {
 struct ha_humor_net {
   int device = 0;
   int n_dec = 0, n_pri = 0;
+  int ztot = 0;            // sum of the decoder layers' padded widths
   ha::PackedLayer dec[ha::MAXL], pri[ha::MAXL];
 };
 
@@ -51,14 +56,14 @@ namespace ha {
 // One (layer, direction) unit of work inside a launch.
 struct LayerTask {
   const float* Wp; const float* bias;
-  int ntiles, nslices, main_slices, Nout, Nout_pad;
-  const float* src; int nsplit_src; int Csrc;       // A operand main part: partial slabs [nsplit][RT][Csrc][32]
-  const float* skip; int skip_dim;                  // raw tail part [RT][skip_dim][32]
+  int ntiles, nslices, Nout, Nout_pad;
+  const float* src; int nsplit_src; int Csrc;       // A operand: slabs [nsplit][RT][Csrc][32]
   int mode;                                         // 0 raw, 1 GN+ReLU (fwd), 3 GN+ReLU adjoint (bwd)
   const float* gamma; const float* beta; int group;
   const float* hsrc; int nsplit_h; int Ch;          // mode 3: forward pre-activation slabs of the same channels ([..][Ch][32])
-  float* dst;                                       // [nsplit_dst][RT][Nout_pad][32]
-  int nblocks;                                      // ntiles * nsplit_dst
+  const float* zterm; int zstride;                  // forward: precomputed latent term [RT][zstride][32] (+ column offset applied)
+  float* dst;                                       // [RT][Nout_pad][32]
+  int nblocks;                                      // ntiles
 };
 
 struct LayerLaunch {
@@ -67,7 +72,7 @@ struct LayerLaunch {
   int RT;
 };
 
-constexpr int MAXSPLIT = 6;   // K-slices / NW never exceeds this for the supported layer widths
+constexpr int MAXSPLIT = 1;   // the layer kernel reduces the full K inside a block: every slab stack has exactly one slab
 
 // sums `nsplit` (<= MAXSPLIT) partial slabs of element (channel c, row) of tile rt.  All loads are unconditional (clamped
 // slab index, zero weight beyond nsplit) so they issue back-to-back instead of one round trip per slab.
@@ -83,180 +88,224 @@ __device__ __forceinline__ float slab_sum(const float* base, int nsplit, int RT,
   return v;
 }
 
-// A wave's 64-channel x 32-row fragment of a slab stack: element kp of lane l is (channel cbase + 2 kp + (l>>5), row l&31),
-// i.e. p[kp * 64] with p = slab + (rt*C + cbase)*32 + lane.  All NS x 32 loads are issued back-to-back (independent), then
-// summed in split order -- the layer is latency-bound, so the loads must not be serialised by a runtime loop.
-template <int NS>
-__device__ __forceinline__ void load_frag(const float* p, size_t stride, float (&a)[32]) {
-  float part[NS][32];
-#pragma unroll
-  for (int s = 0; s < NS; ++s)
-#pragma unroll
-    for (int kp = 0; kp < 32; ++kp) part[s][kp] = p[(size_t)s * stride + kp * 64];
-#pragma unroll
-  for (int kp = 0; kp < 32; ++kp) {
-    float v = part[0][kp];
-#pragma unroll
-    for (int s = 1; s < NS; ++s) v += part[s][kp];
-    a[kp] = v;
-  }
-}
+// A wave's fragment of one 64-channel slice for v_mfma_f32_16x16x4_f32: lane l holds, for k-step ks = 0..15, channel
+// cbase + 4 ks + (l>>4) of rows (l&15) [half 0] and 16 + (l&15) [half 1].  In the transposed [C][32] layout that is
+// p[ks*128] and p[ks*128 + 16] with p = slab + (rt*C + cbase)*32 + (l>>4)*32 + (l&15): 64-byte contiguous runs.
+struct Frag {
+  float v[2][16];
+};
 
-__device__ __forceinline__ void load_frag_n(const float* base, int nsplit, int RT, int C, int rt, int cbase, int lane, float (&a)[32]) {
-  const size_t stride = (size_t)RT * C * 32;
+__device__ __forceinline__ void load_frag16(const float* base, int RT, int C, int rt, int cbase, int lane, Frag& f) {
+  const float* p = base + ((size_t)rt * C + cbase) * 32 + (lane >> 4) * 32 + (lane & 15);
   if (cbase + SLICE <= C) {
-    const float* p = base + ((size_t)rt * C + cbase) * 32 + lane;
-    switch (nsplit) {
-      case 1: load_frag<1>(p, stride, a); return;
-      case 2: load_frag<2>(p, stride, a); return;
-      case 3: load_frag<3>(p, stride, a); return;
-      case 4: load_frag<4>(p, stride, a); return;
-      case 5: load_frag<5>(p, stride, a); return;
-      default: break;
-    }
-  }
-  const int row = lane & 31, hi = lane >> 5;
 #pragma unroll
-  for (int kp = 0; kp < 32; ++kp) {
-    const int c = cbase + 2 * kp + hi;
-    a[kp] = c < C ? slab_sum(base, nsplit, RT, C, rt, c, row) : 0.f;
+    for (int ks = 0; ks < 16; ++ks) { f.v[0][ks] = p[ks * 128]; f.v[1][ks] = p[ks * 128 + 16]; }
+  } else {        // ragged last slice (339-wide state input, 216 / 96-wide outputs in the adjoint)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const bool ok = cbase + 4 * ks + (lane >> 4) < C;
+      f.v[0][ks] = ok ? p[ks * 128] : 0.f;
+      f.v[1][ks] = ok ? p[ks * 128 + 16] : 0.f;
+    }
   }
 }
 
-// per-row GroupNorm statistics of the lane's fragment; NG groups (1 or 2) per 64-channel slice
+// GroupNorm(+ReLU) forward (mode 1) or its adjoint (mode 3) on a fragment.  NG groups (1 or 2) per slice; a group's
+// channels of one row live in 4 lanes (l, l^16, l^32, l^48) x the lane's 16/NG k-steps.
 template <int NG>
-__device__ __forceinline__ void gn_stats(const float (&h)[32], float inv_n, float (&mean)[2], float (&rstd)[2]) {
-  constexpr int PER = 32 / NG;
+__device__ __forceinline__ void gn_frag(int mode, const float* gamma, const float* beta, int cbase, int lane, float inv_n,
+                                        const Frag& h, Frag& a) {
+  constexpr int PER = 16 / NG;
+  float gam[16], bet[16];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    float s1 = 0.f;
+  for (int ks = 0; ks < 16; ++ks) { gam[ks] = gamma[cbase + 4 * ks + (lane >> 4)]; bet[ks] = beta[cbase + 4 * ks + (lane >> 4)]; }
 #pragma unroll
-    for (int kp = 0; kp < PER; ++kp) s1 += h[g * PER + kp];
-    s1 += __shfl_xor(s1, 32);
-    const float mu = s1 * inv_n;
-    float s2 = 0.f;
-#pragma unroll
-    for (int kp = 0; kp < PER; ++kp) { const float d = h[g * PER + kp] - mu; s2 = fmaf(d, d, s2); }
-    s2 += __shfl_xor(s2, 32);
-    mean[g] = mu;
-    rstd[g] = rsqrtf(s2 * inv_n + 1e-5f);
-  }
-}
-
-template <int NG>
-__device__ __forceinline__ void gn_apply(int mode, const float* gamma, const float* beta, int cbase, int hi, float inv_n,
-                                         const float (&h)[32], float (&a)[32]) {
-  constexpr int PER = 32 / NG;
-  float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
-  gn_stats<NG>(h, inv_n, mean, rstd);
-  float gam[32], bet[32];
-#pragma unroll
-  for (int kp = 0; kp < 32; ++kp) { gam[kp] = gamma[cbase + 2 * kp + hi]; bet[kp] = beta[cbase + 2 * kp + hi]; }
-  if (mode == 1) {
-#pragma unroll
-    for (int kp = 0; kp < 32; ++kp) {
-      const int g = kp / PER;
-      a[kp] = fmaxf((h[kp] - mean[g]) * rstd[g] * gam[kp] + bet[kp], 0.f);
-    }
-  } else {
-    // adjoint: a holds da; through ReLU and GroupNorm -> dh
-    float dxh[32], xh[32];
-    float m1[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
-#pragma unroll
-    for (int kp = 0; kp < 32; ++kp) {
-      const int g = kp / PER;
-      xh[kp] = (h[kp] - mean[g]) * rstd[g];
-      const float y = xh[kp] * gam[kp] + bet[kp];
-      dxh[kp] = (y > 0.f ? a[kp] : 0.f) * gam[kp];
-      m1[g] += dxh[kp];
-      m2[g] = fmaf(dxh[kp], xh[kp], m2[g]);
-    }
+  for (int rh = 0; rh < 2; ++rh) {
+    float mean[NG], rstd[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      m1[g] = (m1[g] + __shfl_xor(m1[g], 32)) * inv_n;
-      m2[g] = (m2[g] + __shfl_xor(m2[g], 32)) * inv_n;
-    }
+      float s1 = 0.f;
 #pragma unroll
-    for (int kp = 0; kp < 32; ++kp) {
-      const int g = kp / PER;
-      a[kp] = rstd[g] * (dxh[kp] - m1[g] - xh[kp] * m2[g]);
+      for (int i = 0; i < PER; ++i) s1 += h.v[rh][g * PER + i];
+      s1 += __shfl_xor(s1, 16);
+      s1 += __shfl_xor(s1, 32);
+      const float mu = s1 * inv_n;
+      float s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) { const float d = h.v[rh][g * PER + i] - mu; s2 = fmaf(d, d, s2); }
+      s2 += __shfl_xor(s2, 16);
+      s2 += __shfl_xor(s2, 32);
+      mean[g] = mu;
+      rstd[g] = rsqrtf(s2 * inv_n + 1e-5f);
+    }
+    if (mode == 1) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int g = ks / PER;
+        a.v[rh][ks] = fmaxf((h.v[rh][ks] - mean[g]) * rstd[g] * gam[ks] + bet[ks], 0.f);
+      }
+    } else {
+      // adjoint: a holds da -> dh = rstd (dxh - mean(dxh) - xh mean(dxh xh)),  dxh = gamma * da * [y > 0]
+      float m1[NG], m2[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) { m1[g] = 0.f; m2[g] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int g = ks / PER;
+        const float xh = (h.v[rh][ks] - mean[g]) * rstd[g];
+        const float dxh = (xh * gam[ks] + bet[ks] > 0.f ? a.v[rh][ks] : 0.f) * gam[ks];
+        a.v[rh][ks] = dxh;
+        m1[g] += dxh;
+        m2[g] = fmaf(dxh, xh, m2[g]);
+      }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        m1[g] += __shfl_xor(m1[g], 16); m1[g] += __shfl_xor(m1[g], 32);
+        m2[g] += __shfl_xor(m2[g], 16); m2[g] += __shfl_xor(m2[g], 32);
+        m1[g] *= inv_n; m2[g] *= inv_n;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int g = ks / PER;
+        const float xh = (h.v[rh][ks] - mean[g]) * rstd[g];
+        a.v[rh][ks] = rstd[g] * (a.v[rh][ks] - m1[g] - xh * m2[g]);
+      }
     }
   }
 }
 
-__global__ __launch_bounds__(NW * 64) void mlp_layer_kernel(LayerLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // NW * 1024 floats
+// Layer kernel: block = 4 waves = one 16-column output tile over the FULL K (no partial slabs); wave w owns the
+// 64-channel slices w, w+4, w+8, w+12.  All global loads of the wave's slices are issued before any arithmetic
+// (the layer is latency-bound at 32 rows: one memory round trip, then MFMAs).
+__global__ __launch_bounds__(NWL * 64) void mlp_layer_kernel(LayerLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // NWL * 8 * 64 floats (K reduction)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int b = blockIdx.x;
   int ti = 0;
   if (L.ntasks > 1 && b >= L.t[0].nblocks) { b -= L.t[0].nblocks; ti = 1; }
   const LayerTask& T = L.t[ti];
-  const int tile = b % T.ntiles, ks = b / T.ntiles;
-  const int slice = ks * NW + wave;
-  const bool active = slice < T.nslices;
-  const int hi = lane >> 5;
-
-  // B operand: this wave's 64 x 32 weight panel, resident in registers for all row tiles
-  float bw[32];
-  if (active) {
-    const float* wp = T.Wp + ((size_t)tile * T.nslices + slice) * 32 * 64 + lane;
-#pragma unroll
-    for (int kp = 0; kp < 32; ++kp) bw[kp] = wp[kp * 64];
+  const int tile = b;
+  const float inv_n = 1.0f / (float)T.group;
+  // GroupNorm affine of the whole input width staged in LDS once per block (keeps 2 x 16 x SPW values per lane out of the
+  // register file, which is full of in-flight activation / weight loads)
+  float* s_gamma = smem + NWL * 8 * 64;
+  float* s_beta = s_gamma + SPW * NWL * SLICE;
+  if (T.mode != 0) {
+    for (int c = threadIdx.x; c < T.nslices * SLICE; c += NWL * 64) {
+      const bool ok = c < T.Csrc && c < T.Ch + T.Csrc;   // gamma/beta have Cin (= consumer input) entries
+      s_gamma[c] = ok ? T.gamma[c] : 0.f;
+      s_beta[c] = ok ? T.beta[c] : 0.f;
+    }
+    __syncthreads();
   }
-  const bool is_main = slice < T.main_slices;
-  const int cbase = is_main ? slice * SLICE : (slice - T.main_slices) * SLICE;
 
   for (int rt = 0; rt < L.RT; ++rt) {
-    f32x16 acc;
+    f32x4 acc[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    if (active) {
-      float a[32];
-      if (!is_main) {
-        load_frag_n(T.skip, 1, L.RT, T.skip_dim, rt, cbase, lane, a);
-      } else {
-        load_frag_n(T.src, T.nsplit_src, L.RT, T.Csrc, rt, cbase, lane, a);
-        if (T.mode != 0) {
-          // GroupNorm over groups of T.group (64 or 32) channels: the lane holds 32 channels of its row (one parity),
-          // the other parity lives in lane^32.
-          float h[32];
-          if (T.mode == 3) load_frag_n(T.hsrc, T.nsplit_h, L.RT, T.Ch, rt, cbase, lane, h);
-          else {
+    for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
-            for (int kp = 0; kp < 32; ++kp) h[kp] = a[kp];
-          }
-          const float inv_n = 1.0f / (float)T.group;
-          if (T.group == SLICE) gn_apply<1>(T.mode, T.gamma, T.beta, cbase, hi, inv_n, h, a);
-          else gn_apply<2>(T.mode, T.gamma, T.beta, cbase, hi, inv_n, h, a);
+      for (int i = 0; i < 4; ++i) acc[rh][i] = 0.f;
+    // ---- issue every load of this wave's (at most two) slices ----
+    Frag a[SPW], h[SPW];
+    float w[SPW][16];
+#pragma unroll
+    for (int q = 0; q < SPW; ++q) {
+      const int slice = wave + NWL * q;
+      if (slice < T.nslices) {
+        const int cbase = slice * SLICE;
+        const float* wp = T.Wp + ((size_t)tile * T.nslices + slice) * 16 * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) w[q][ks] = wp[ks * 64];
+        load_frag16(T.src, L.RT, T.Csrc, rt, cbase, lane, a[q]);
+        if (T.mode == 3) load_frag16(T.hsrc, L.RT, T.Ch, rt, cbase, lane, h[q]);
+      }
+    }
+    // ---- prologue + MFMA ----
+#pragma unroll
+    for (int q = 0; q < SPW; ++q) {
+      const int slice = wave + NWL * q;
+      if (slice < T.nslices) {
+        const int cbase = slice * SLICE;
+        if (T.mode == 1) {          // forward: normalise the fragment in place (element-wise after the statistics)
+          if (T.group == SLICE) gn_frag<1>(1, s_gamma, s_beta, cbase, lane, inv_n, a[q], a[q]);
+          else gn_frag<2>(1, s_gamma, s_beta, cbase, lane, inv_n, a[q], a[q]);
+        } else if (T.mode == 3) {
+          if (T.group == SLICE) gn_frag<1>(3, s_gamma, s_beta, cbase, lane, inv_n, h[q], a[q]);
+          else gn_frag<2>(3, s_gamma, s_beta, cbase, lane, inv_n, h[q], a[q]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].v[0][ks], w[q][ks], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].v[1][ks], w[q][ks], acc[1], 0, 0, 0);
         }
       }
-#pragma unroll
-      for (int kp = 0; kp < 32; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], bw[kp], acc, 0, 0, 0);
     }
-    // cross-wave K reduction through LDS, then one 16-byte store per (lane, row quad)
+    // ---- cross-wave K reduction through LDS; waves 0/1 finish row halves 0/1 ----
 #pragma unroll
-    for (int i = 0; i < 16; ++i) smem[(wave * 16 + i) * 64 + lane] = acc[i];
+    for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) smem[((wave * 2 + rh) * 4 + i) * 64 + lane] = acc[rh][i];
     __syncthreads();
-    {
-      const int l2 = threadIdx.x & 63, rq = threadIdx.x >> 6;   // NW == 4 row quads of 4 registers
+    if (wave < 2) {
+      const int rh = wave;
       float o[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int i = 0; i < 4; ++i) {
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) v += smem[(w * 16 + rq * 4 + e) * 64 + l2];
-        o[e] = v;
+        for (int ww = 0; ww < NWL; ++ww) v += smem[((ww * 2 + rh) * 4 + i) * 64 + lane];
+        o[i] = v;
       }
-      const int n = tile * 32 + (l2 & 31);
-      if (ks == 0 && T.bias && n < T.Nout) {
+      const int n = tile * 16 + (lane & 15);
+      const int row0 = rh * 16 + 4 * (lane >> 4);
+      if (T.bias && n < T.Nout) {
         const float bv = T.bias[n];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] += bv;
+        for (int i = 0; i < 4; ++i) o[i] += bv;
       }
-      float* dst = T.dst + (((size_t)ks * L.RT + rt) * T.Nout_pad + n) * 32 + 8 * rq + 4 * (l2 >> 5);
-      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      if (T.zterm) {
+        const float4 z = *reinterpret_cast<const float4*>(T.zterm + ((size_t)rt * T.zstride + n) * 32 + row0);
+        o[0] += z.x; o[1] += z.y; o[2] += z.z; o[3] += z.w;
+      }
+      *reinterpret_cast<float4*>(T.dst + ((size_t)rt * T.Nout_pad + n) * 32 + row0) = make_float4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
+  }
+}
+
+// Latent skip term of every decoder layer for ALL steps in one launch (off the dependent chain):
+// zterm[s][rt][zoff_l + n][row] = sum_k z[s][row][k] * W_l[n][Cin_l + k].   One wave per (step, row tile, 16-column tile).
+struct ZTermParams {
+  const float* zT;          // [S][RT][48][32]
+  float* out;               // [S][RT][ztot][32]
+  const float* Wz[MAXL]; int zoff[MAXL]; int ntiles[MAXL]; int nlayers;
+  int S, RT, ztot;
+};
+
+__global__ __launch_bounds__(64) void zterm_kernel(ZTermParams p) {
+  const int lane = threadIdx.x;
+  int t16 = blockIdx.x;                 // tile over the concatenated layer widths
+  const int rt = blockIdx.y, sidx = blockIdx.z;
+  int l = 0;
+  while (l < p.nlayers - 1 && t16 >= p.ntiles[l]) { t16 -= p.ntiles[l]; ++l; }
+  const float* zp = p.zT + ((size_t)sidx * p.RT + rt) * ZD * 32 + (lane >> 4) * 32 + (lane & 15);
+  const float* wp = p.Wz[l] + (size_t)t16 * ZKS * 64 + lane;
+  f32x4 acc[2];
+#pragma unroll
+  for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[rh][i] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < ZKS; ++ks) {
+    const float wv = wp[ks * 64];
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(zp[ks * 128], wv, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(zp[ks * 128 + 16], wv, acc[1], 0, 0, 0);
+  }
+  const int n = p.zoff[l] + t16 * 16 + (lane & 15);
+#pragma unroll
+  for (int rh = 0; rh < 2; ++rh) {
+    float* dst = p.out + (((size_t)sidx * p.RT + rt) * p.ztot + n) * 32 + rh * 16 + 4 * (lane >> 4);
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[rh][0], acc[rh][1], acc[rh][2], acc[rh][3]);
   }
 }
 
@@ -853,42 +902,48 @@ static int pack_layer(PackedLayer& L, const float* W, const float* bias, const f
                       int skip, int Nout, bool has_gn) {
   L.Cin = Cin; L.skip = skip; L.Nout = Nout;
   L.main_slices = ceil_div(Cin, SLICE);
-  L.nslices_f = L.main_slices + ceil_div(skip, SLICE);
-  L.ntiles_f = ceil_div(Nout, 32);
-  L.Nout_pad = L.ntiles_f * 32;
-  L.nsplit_f = ceil_div(L.nslices_f, NW);
+  L.ntiles_f = ceil_div(Nout, 16);
+  L.Nout_pad = L.ntiles_f * 16;
   L.nslices_b = ceil_div(Nout, SLICE);
-  L.ntiles_b = ceil_div(Cin + skip, 32);
-  L.Nin_pad = L.ntiles_b * 32;
-  L.nsplit_b = ceil_div(L.nslices_b, NW);
+  L.ntiles_b = ceil_div(Cin + skip, 16);
+  L.Nin_pad = L.ntiles_b * 16;
+  L.nsplit_f = L.nsplit_b = 1;
   L.group = has_gn ? Cin / 16 : 0;
-  HA_REQUIRE(L.nsplit_f <= MAXSPLIT && L.nsplit_b <= MAXSPLIT, "layer %dx%d needs more than %d K-splits", Nout, Cin + skip, MAXSPLIT);
+  HA_REQUIRE(L.main_slices <= SPW * NWL && L.nslices_b <= SPW * NWL, "layer %dx%d is wider than %d channels", Nout, Cin + skip, SPW * NWL * SLICE);
+  HA_REQUIRE(skip == 0 || skip == ZD, "latent skip width must be %d", ZD);
   const int Kin = Cin + skip;
-  // forward pack: lane l of (tile, slice, kp) <-> W[n = tile*32 + (l&31)][k], k = channel of the slice
-  std::vector<float> wf((size_t)L.ntiles_f * L.nslices_f * 32 * 64, 0.f);
+  // lane l of (tile, slice, ks): k = slice*64 + 4 ks + (l>>4), n = tile*16 + (l&15)
+  std::vector<float> wf((size_t)L.ntiles_f * L.main_slices * 16 * 64, 0.f);
   for (int tile = 0; tile < L.ntiles_f; ++tile)
-    for (int sl = 0; sl < L.nslices_f; ++sl)
-      for (int kp = 0; kp < 32; ++kp)
+    for (int sl = 0; sl < L.main_slices; ++sl)
+      for (int ks = 0; ks < 16; ++ks)
         for (int l = 0; l < 64; ++l) {
-          const int n = tile * 32 + (l & 31);
-          const int cc = 2 * kp + (l >> 5);
-          int k;
-          if (sl < L.main_slices) { const int c = sl * SLICE + cc; k = c < Cin ? c : -1; }
-          else { const int c = (sl - L.main_slices) * SLICE + cc; k = c < skip ? Cin + c : -1; }
-          if (n < Nout && k >= 0) wf[(((size_t)tile * L.nslices_f + sl) * 32 + kp) * 64 + l] = W[(size_t)n * Kin + k];
+          const int n = tile * 16 + (l & 15), k = sl * SLICE + 4 * ks + (l >> 4);
+          if (n < Nout && k < Cin) wf[(((size_t)tile * L.main_slices + sl) * 16 + ks) * 64 + l] = W[(size_t)n * Kin + k];
         }
-  // backward pack: A = dh [rows, Nout channels], output columns = input channels (main then skip)
-  std::vector<float> wb((size_t)L.ntiles_b * L.nslices_b * 32 * 64, 0.f);
+  std::vector<float> wz;
+  if (skip) {
+    wz.assign((size_t)L.ntiles_f * ZKS * 64, 0.f);
+    for (int tile = 0; tile < L.ntiles_f; ++tile)
+      for (int ks = 0; ks < ZKS; ++ks)
+        for (int l = 0; l < 64; ++l) {
+          const int n = tile * 16 + (l & 15), k = 4 * ks + (l >> 4);
+          if (n < Nout) wz[((size_t)tile * ZKS + ks) * 64 + l] = W[(size_t)n * Kin + Cin + k];
+        }
+  }
+  // adjoint: A = dh [rows, Nout channels] (K), output columns = input channels (main then skip)
+  std::vector<float> wb((size_t)L.ntiles_b * L.nslices_b * 16 * 64, 0.f);
   for (int tile = 0; tile < L.ntiles_b; ++tile)
     for (int sl = 0; sl < L.nslices_b; ++sl)
-      for (int kp = 0; kp < 32; ++kp)
+      for (int ks = 0; ks < 16; ++ks)
         for (int l = 0; l < 64; ++l) {
-          const int n = tile * 32 + (l & 31);                 // input channel
-          const int k = sl * SLICE + 2 * kp + (l >> 5);       // output channel
-          if (n < Kin && k < Nout) wb[(((size_t)tile * L.nslices_b + sl) * 32 + kp) * 64 + l] = W[(size_t)k * Kin + n];
+          const int n = tile * 16 + (l & 15);                 // input channel
+          const int k = sl * SLICE + 4 * ks + (l >> 4);       // output channel
+          if (n < Kin && k < Nout) wb[(((size_t)tile * L.nslices_b + sl) * 16 + ks) * 64 + l] = W[(size_t)k * Kin + n];
         }
   int rc;
   if ((rc = upload_vec(&L.Wf, wf)) != HA_OK) return rc;
+  if ((rc = upload_vec(&L.Wz, wz)) != HA_OK) return rc;
   if ((rc = upload_vec(&L.Wb, wb)) != HA_OK) return rc;
   std::vector<float> bv(bias, bias + Nout);
   if ((rc = upload_vec(&L.bias, bv)) != HA_OK) return rc;
@@ -920,7 +975,7 @@ static int pack_mlp(PackedLayer* out, const ha_mlp_desc* d, const char* name) {
 // Offsets (in floats) into the caller-owned stash.
 struct StashLayout {
   int RT = 0;
-  size_t zT = 0, t2j = 0, per_step = 0, steps = 0;
+  size_t zT = 0, zterm = 0, t2j = 0, per_step = 0, steps = 0;
   size_t off_x = 0, off_G = 0;
   size_t off_pri[MAXL], off_dec[MAXL];
   // backward scratch
@@ -935,6 +990,7 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
   L.zT = take((size_t)S * RT * ZD * 32);
+  L.zterm = take((size_t)S * RT * net->ztot * 32);
   L.t2j = take(RT * 32 * 3);
   // per-step region
   size_t p = 0;
@@ -955,39 +1011,39 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   L.total = o;
 }
 
-static void fwd_task(LayerTask& T, const PackedLayer& L, const float* src, int nsplit_src, const float* skip, float* dst) {
+static void fwd_task(LayerTask& T, const PackedLayer& L, const float* src, const float* zterm_step, int ztot, float* dst) {
   memset(&T, 0, sizeof(T));
   T.Wp = L.Wf; T.bias = L.bias;
-  T.ntiles = L.ntiles_f; T.nslices = L.nslices_f; T.main_slices = L.main_slices; T.Nout = L.Nout; T.Nout_pad = L.Nout_pad;
-  T.src = src; T.nsplit_src = nsplit_src; T.Csrc = L.Cin;
-  T.skip = skip; T.skip_dim = L.skip;
+  T.ntiles = L.ntiles_f; T.nslices = L.main_slices; T.Nout = L.Nout; T.Nout_pad = L.Nout_pad;
+  T.src = src; T.nsplit_src = 1; T.Csrc = L.Cin;
   T.mode = L.group ? 1 : 0;
   T.gamma = L.gamma; T.beta = L.beta; T.group = L.group ? L.group : 64;
+  if (L.skip && zterm_step) { T.zterm = zterm_step + (size_t)L.zoff * 32; T.zstride = ztot; }
   T.dst = dst;
-  T.nblocks = L.ntiles_f * L.nsplit_f;
+  T.nblocks = L.ntiles_f;
 }
 
-// backward through layer L: A = dh (adjoint of L's raw output), output = adjoint of L's input activation slabs.
-// `Lnext_gn` describes the GroupNorm that follows L (i.e. the consumer layer's gamma/beta/group) when dh has to be
-// derived from the consumer's input-gradient slabs (mode 3); null when dh is given directly (mode 0).
+// backward through layer L: A = dh (adjoint of L's raw output), output = adjoint of L's input (main channels, then the
+// latent-skip columns).  `Lnext_gn` describes the GroupNorm that follows L (the consumer layer's gamma/beta/group) when dh
+// has to be derived from the consumer's input-gradient slab (mode 3); null when dh is given directly (mode 0).
 static void bwd_task(LayerTask& T, const PackedLayer& L, const float* dsrc, int nsplit_d, int dC, const PackedLayer* Lnext_gn,
                      const float* hsrc, int nsplit_h, float* dst) {
   memset(&T, 0, sizeof(T));
   T.Wp = L.Wb; T.bias = nullptr;
-  T.ntiles = L.ntiles_b; T.nslices = L.nslices_b; T.main_slices = L.nslices_b; T.Nout = L.Cin + L.skip; T.Nout_pad = L.Nin_pad;
+  T.ntiles = L.ntiles_b; T.nslices = L.nslices_b; T.Nout = L.Cin + L.skip; T.Nout_pad = L.Nin_pad;
   T.src = dsrc; T.nsplit_src = nsplit_d; T.Csrc = dC;
   T.mode = Lnext_gn ? 3 : 0;
   if (Lnext_gn) { T.gamma = Lnext_gn->gamma; T.beta = Lnext_gn->beta; T.group = Lnext_gn->group; }
   else T.group = 64;
   T.hsrc = hsrc; T.nsplit_h = nsplit_h; T.Ch = L.Nout_pad;
   T.dst = dst;
-  T.nblocks = L.ntiles_b * L.nsplit_b;
+  T.nblocks = L.ntiles_b;
 }
 
 static int launch_layers(LayerLaunch& LL, hipStream_t st) {
   int blocks = 0;
   for (int i = 0; i < LL.ntasks; ++i) blocks += LL.t[i].nblocks;
-  hipLaunchKernelGGL(mlp_layer_kernel, dim3(blocks), dim3(NW * 64), NW * 1024 * sizeof(float), st, LL);
+  hipLaunchKernelGGL(mlp_layer_kernel, dim3(blocks), dim3(NWL * 64), (NWL * 8 * 64 + 2 * SPW * NWL * SLICE) * sizeof(float), st, LL);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -1013,6 +1069,7 @@ extern "C" int ha_humor_net_create(ha_humor_net** out, int device, const ha_mlp_
     ha_humor_net_destroy(net);
     return rc;
   }
+  for (int i = 0; i < net->n_dec; ++i) { net->dec[i].zoff = net->ztot; net->ztot += net->dec[i].Nout_pad; }
   *out = net;
   return HA_OK;
 }
@@ -1022,7 +1079,7 @@ extern "C" int ha_humor_net_destroy(ha_humor_net* net) {
   DeviceGuard guard(net->device);
   for (PackedLayer* arr : {net->dec, net->pri})
     for (int i = 0; i < MAXL; ++i) {
-      void* ptrs[] = {arr[i].Wf, arr[i].Wb, arr[i].bias, arr[i].gamma, arr[i].beta};
+      void* ptrs[] = {arr[i].Wf, arr[i].Wz, arr[i].Wb, arr[i].bias, arr[i].gamma, arr[i].beta};
       for (void* p : ptrs)
         if (p) (void)hipFree(p);
     }
@@ -1058,11 +1115,21 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
   hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
   HA_LAUNCH_CHECK();
 
+  {
+    // latent skip terms of all steps and decoder layers, off the dependent chain
+    ZTermParams zp;
+    memset(&zp, 0, sizeof(zp));
+    zp.zT = stash + L.zT; zp.out = stash + L.zterm;
+    zp.nlayers = net->n_dec; zp.S = S; zp.RT = RT; zp.ztot = net->ztot;
+    for (int i = 0; i < net->n_dec; ++i) { zp.Wz[i] = net->dec[i].Wz; zp.zoff[i] = net->dec[i].zoff; zp.ntiles[i] = net->dec[i].ntiles_f; }
+    hipLaunchKernelGGL(zterm_kernel, dim3(net->ztot / 16, RT, S), dim3(64), 0, st, zp);
+    HA_LAUNCH_CHECK();
+  }
   const bool with_prior = prior_mu != nullptr;
   const int nl = net->n_dec > net->n_pri ? net->n_dec : net->n_pri;
   for (int t = 0; t < S; ++t) {
     float* sp = step_ptr(t);
-    const float* zT = stash + L.zT + (size_t)t * RT * ZD * 32;
+    const float* zterm_t = stash + L.zterm + (size_t)t * RT * net->ztot * 32;
     for (int l = 0; l < nl; ++l) {
       LayerLaunch LL;
       memset(&LL, 0, sizeof(LL));
@@ -1070,12 +1137,12 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
       if (l < net->n_dec) {
         const PackedLayer& P = net->dec[l];
         const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
-        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : net->dec[l - 1].nsplit_f, zT, sp + L.off_dec[l]);
+        fwd_task(LL.t[LL.ntasks++], P, src, zterm_t, net->ztot, sp + L.off_dec[l]);
       }
       if (with_prior && l < net->n_pri) {
         const PackedLayer& P = net->pri[l];
         const float* src = l == 0 ? sp + L.off_x : sp + L.off_pri[l - 1];
-        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : net->pri[l - 1].nsplit_f, nullptr, sp + L.off_pri[l]);
+        fwd_task(LL.t[LL.ntasks++], P, src, nullptr, 0, sp + L.off_pri[l]);
       }
       if (LL.ntasks == 0) continue;
       int rc = launch_layers(LL, st);

@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace ha
 
 namespace ha {
-int g_skin_variant = 2;   // 0: LDS-staged window, 1: + hoisted weight loads, 2: direct 48-byte per-thread path; +4: non-temporal stores
+int g_skin_variant = 2;   // 0: LDS-staged window, 1: + hoisted weight loads, 2: direct 48-byte per-thread path, 3: frame-pair windows; +4: non-temporal
 }
 extern "C" int ha_tune_set(const char* key, int value) {
   HA_REQUIRE(key, "ha_tune_set: null key");
@@ -966,6 +966,109 @@ __global__ __launch_bounds__(256) void lbs_skin_direct_kernel(const float* __res
   }
 }
 
+// Variant 3: frame-PAIR windows.  V is even (6890), so two consecutive frames form a 16-byte aligned unit of V/2 groups of
+// four vertices whose (frame, vertex) pattern is identical in every pair.  A block owns one 256-group window and walks
+// P consecutive pairs with the per-thread skinning weights held in registers (weight/index traffic / P, one barrier per
+// pair), prefetching the next pair's 48 bytes per thread while the current one is skinned.
+template <bool NT, int P>
+__global__ __launch_bounds__(256) void lbs_skin_pairs_kernel(const float* __restrict__ v_posed, const float* __restrict__ A,
+                                                             const float* __restrict__ transl, const float4* __restrict__ w4,
+                                                             const uint32_t* __restrict__ idx4, float* __restrict__ verts,
+                                                             int N, int V, int J, int nwin) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 buffers x 2 frames x J x 12
+  const int tid = threadIdx.x;
+  const int win = blockIdx.x % nwin, pg = blockIdx.x / nwin;
+  const int ngroups = V / 2;                   // groups of 4 vertices per frame pair
+  const int grp = win * 256 + tid;
+  const bool lane_ok = grp < ngroups;
+  const int q0 = 4 * grp;                      // flat vertex offset inside the pair
+  const int per = J * 3;                       // float4s of A per frame
+  // per-thread constants: the four vertices' frame-in-pair, weights and joints
+  float4 wv[4];
+  uint32_t id[4];
+  int frs[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int q = q0 + k;
+    frs[k] = q >= V ? 1 : 0;
+    const int v = lane_ok ? q - frs[k] * V : 0;
+    wv[k] = w4[v];
+    id[k] = idx4[v];
+  }
+  const int npairs = (N + 1) / 2;
+  const int pair0 = pg * P;
+  auto load_pair = [&](int pair, float (&f)[12]) {
+    const long long fl = ((long long)2 * pair * V + q0) * 3;
+    const bool full = lane_ok && (2 * pair + 1 < N || q0 + 3 < V);
+    if (full) {
+      const vf4* src = reinterpret_cast<const vf4*>(v_posed + fl);
+      vf4 a, b, c;
+      if (NT) { a = __builtin_nontemporal_load(src); b = __builtin_nontemporal_load(src + 1); c = __builtin_nontemporal_load(src + 2); }
+      else { a = src[0]; b = src[1]; c = src[2]; }
+      f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+      f[8] = c.x; f[9] = c.y; f[10] = c.z; f[11] = c.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = lane_ok && 2 * pair + frs[k] < N;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[3 * k + c] = ok ? v_posed[fl + 3 * k + c] : 0.f;
+      }
+    }
+  };
+  float cur[12], nxt[12];
+  if (pair0 < npairs) load_pair(pair0, cur);
+#pragma unroll 1
+  for (int p = 0; p < P; ++p) {
+    const int pair = pair0 + p;
+    if (pair >= npairs) break;
+    float* s_A = smem + (p & 1) * 2 * J * 12;
+    {
+      const float4* A4 = reinterpret_cast<const float4*>(A);
+      float4* sA4 = reinterpret_cast<float4*>(s_A);
+      for (int i = tid; i < 2 * per; i += 256) {
+        const int fr = i / per;
+        if (2 * pair + fr < N) sA4[i] = A4[(size_t)(2 * pair + fr) * per + (i - fr * per)];
+      }
+    }
+    if (p + 1 < P && pair + 1 < npairs) load_pair(pair + 1, nxt);
+    float tl[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (transl) {
+#pragma unroll
+      for (int fr = 0; fr < 2; ++fr)
+        if (2 * pair + fr < N) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) tl[fr][c] = transl[(size_t)(2 * pair + fr) * 3 + c];
+        }
+    }
+    __syncthreads();      // A of this pair is in LDS (the other buffer may still be read by slower waves of the previous pair)
+    float o[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int fr = frs[k];
+      skin_one(s_A, J, fr, wv[k], id[k], cur[3 * k], cur[3 * k + 1], cur[3 * k + 2], tl[fr][0], tl[fr][1], tl[fr][2], o[3 * k],
+               o[3 * k + 1], o[3 * k + 2]);
+    }
+    const long long fl = ((long long)2 * pair * V + q0) * 3;
+    const bool full = lane_ok && (2 * pair + 1 < N || q0 + 3 < V);
+    if (full) {
+      float* dst = verts + fl;
+      store4<NT>(dst, o[0], o[1], o[2], o[3]);
+      store4<NT>(dst + 4, o[4], o[5], o[6], o[7]);
+      store4<NT>(dst + 8, o[8], o[9], o[10], o[11]);
+    } else if (lane_ok) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (2 * pair + frs[k] < N) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) verts[fl + 3 * k + c] = o[3 * k + c];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) cur[e] = nxt[e];
+  }
+}
+
 static void fill_model(FrameParams& p, const ha_smpl_model* m, int slot) {
   memset(&p, 0, sizeof(p));
   p.Jt = m->Jt; p.Js = m->Js; p.parents = m->parents; p.jdepth = m->jdepth;
@@ -1010,7 +1113,18 @@ extern "C" int ha_lbs_skin(const ha_smpl_model* m, int N, const float* v_posed, 
   const size_t lds = (size_t)(kSkinVerts * 3 + 2 * m->J * 12) * sizeof(float);
   const int variant = g_skin_variant & 3;
   const bool nt = (g_skin_variant & 4) != 0;
-  if (variant == 2) {
+  if (variant == 3 && m->V % 2 == 0) {
+    constexpr int P = 4;
+    const int nwin = ceil_div(m->V / 2, 256);
+    const int npg = ceil_div(ceil_div(N, 2), P);
+    const size_t lds3 = (size_t)(2 * 2 * m->J * 12) * sizeof(float);
+    if (nt)
+      hipLaunchKernelGGL((lbs_skin_pairs_kernel<true, P>), dim3(nwin * npg), dim3(256), lds3, (hipStream_t)stream, v_posed, A, transl,
+                         m->w4, m->idx4, verts, N, m->V, m->J, nwin);
+    else
+      hipLaunchKernelGGL((lbs_skin_pairs_kernel<false, P>), dim3(nwin * npg), dim3(256), lds3, (hipStream_t)stream, v_posed, A, transl,
+                         m->w4, m->idx4, verts, N, m->V, m->J, nwin);
+  } else if (variant == 2 || variant == 3) {
     const size_t lds2 = (size_t)(2 * m->J * 12) * sizeof(float);
     if (nt)
       hipLaunchKernelGGL(lbs_skin_direct_kernel<true>, dim3(blocks), dim3(256), lds2, (hipStream_t)stream, v_posed, A, transl, m->w4,
