@@ -88,30 +88,26 @@ __device__ __forceinline__ float slab_sum(const float* base, int nsplit, int RT,
   return v;
 }
 
-// A wave's fragment of one 64-channel slice for v_mfma_f32_16x16x4_f32: lane l holds, for k-step ks = 0..15, channel
-// cbase + 4 ks + (l>>4) of rows (l&15) [half 0] and 16 + (l&15) [half 1].  In the transposed [C][32] layout that is
-// p[ks*128] and p[ks*128 + 16] with p = slab + (rt*C + cbase)*32 + (l>>4)*32 + (l&15): 64-byte contiguous runs.
+// A wave's fragment of one 64-channel slice for v_mfma_f32_16x16x4_f32, ONE 16-row half: lane l holds, for k-step
+// ks = 0..15, channel cbase + 4 ks + (l>>4) of row 16 rh + (l&15).  In the transposed [C][32] layout that is p[ks*128] with
+// p = slab + (rt*C + cbase)*32 + (l>>4)*32 + 16 rh + (l&15): 64-byte contiguous runs.
 struct Frag {
-  float v[2][16];
+  float v[16];
 };
 
-__device__ __forceinline__ void load_frag16(const float* base, int RT, int C, int rt, int cbase, int lane, Frag& f) {
-  const float* p = base + ((size_t)rt * C + cbase) * 32 + (lane >> 4) * 32 + (lane & 15);
+__device__ __forceinline__ void load_frag16(const float* base, int RT, int C, int rt, int rh, int cbase, int lane, Frag& f) {
+  const float* p = base + ((size_t)rt * C + cbase) * 32 + (lane >> 4) * 32 + rh * 16 + (lane & 15);
   if (cbase + SLICE <= C) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) { f.v[0][ks] = p[ks * 128]; f.v[1][ks] = p[ks * 128 + 16]; }
+    for (int ks = 0; ks < 16; ++ks) f.v[ks] = p[ks * 128];
   } else {        // ragged last slice (339-wide state input, 216 / 96-wide outputs in the adjoint)
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const bool ok = cbase + 4 * ks + (lane >> 4) < C;
-      f.v[0][ks] = ok ? p[ks * 128] : 0.f;
-      f.v[1][ks] = ok ? p[ks * 128 + 16] : 0.f;
-    }
+    for (int ks = 0; ks < 16; ++ks) f.v[ks] = cbase + 4 * ks + (lane >> 4) < C ? p[ks * 128] : 0.f;
   }
 }
 
 // GroupNorm(+ReLU) forward (mode 1) or its adjoint (mode 3) on a fragment.  NG groups (1 or 2) per slice; a group's
-// channels of one row live in 4 lanes (l, l^16, l^32, l^48) x the lane's 16/NG k-steps.
+// channels of one row live in 4 lanes (l, l^16, l^32, l^48) x the lane's 16/NG k-steps.  gamma/beta are LDS arrays.
 template <int NG>
 __device__ __forceinline__ void gn_frag(int mode, const float* gamma, const float* beta, int cbase, int lane, float inv_n,
                                         const Frag& h, Frag& a) {
@@ -119,93 +115,79 @@ __device__ __forceinline__ void gn_frag(int mode, const float* gamma, const floa
   float gam[16], bet[16];
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) { gam[ks] = gamma[cbase + 4 * ks + (lane >> 4)]; bet[ks] = beta[cbase + 4 * ks + (lane >> 4)]; }
+  float mean[NG], rstd[NG];
 #pragma unroll
-  for (int rh = 0; rh < 2; ++rh) {
-    float mean[NG], rstd[NG];
+  for (int g = 0; g < NG; ++g) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s1 += h.v[g * PER + i];
+    s1 += __shfl_xor(s1, 16);
+    s1 += __shfl_xor(s1, 32);
+    const float mu = s1 * inv_n;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float d = h.v[g * PER + i] - mu; s2 = fmaf(d, d, s2); }
+    s2 += __shfl_xor(s2, 16);
+    s2 += __shfl_xor(s2, 32);
+    mean[g] = mu;
+    rstd[g] = rsqrtf(s2 * inv_n + 1e-5f);
+  }
+  if (mode == 1) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int g = ks / PER;
+      a.v[ks] = fmaxf((h.v[ks] - mean[g]) * rstd[g] * gam[ks] + bet[ks], 0.f);
+    }
+  } else {
+    // adjoint: a holds da -> dh = rstd (dxh - mean(dxh) - xh mean(dxh xh)),  dxh = gamma * da * [y > 0]
+    float m1[NG], m2[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { m1[g] = 0.f; m2[g] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int g = ks / PER;
+      const float xh = (h.v[ks] - mean[g]) * rstd[g];
+      const float dxh = (xh * gam[ks] + bet[ks] > 0.f ? a.v[ks] : 0.f) * gam[ks];
+      a.v[ks] = dxh;
+      m1[g] += dxh;
+      m2[g] = fmaf(dxh, xh, m2[g]);
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      float s1 = 0.f;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) s1 += h.v[rh][g * PER + i];
-      s1 += __shfl_xor(s1, 16);
-      s1 += __shfl_xor(s1, 32);
-      const float mu = s1 * inv_n;
-      float s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) { const float d = h.v[rh][g * PER + i] - mu; s2 = fmaf(d, d, s2); }
-      s2 += __shfl_xor(s2, 16);
-      s2 += __shfl_xor(s2, 32);
-      mean[g] = mu;
-      rstd[g] = rsqrtf(s2 * inv_n + 1e-5f);
+      m1[g] += __shfl_xor(m1[g], 16); m1[g] += __shfl_xor(m1[g], 32);
+      m2[g] += __shfl_xor(m2[g], 16); m2[g] += __shfl_xor(m2[g], 32);
+      m1[g] *= inv_n; m2[g] *= inv_n;
     }
-    if (mode == 1) {
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int g = ks / PER;
-        a.v[rh][ks] = fmaxf((h.v[rh][ks] - mean[g]) * rstd[g] * gam[ks] + bet[ks], 0.f);
-      }
-    } else {
-      // adjoint: a holds da -> dh = rstd (dxh - mean(dxh) - xh mean(dxh xh)),  dxh = gamma * da * [y > 0]
-      float m1[NG], m2[NG];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) { m1[g] = 0.f; m2[g] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int g = ks / PER;
-        const float xh = (h.v[rh][ks] - mean[g]) * rstd[g];
-        const float dxh = (xh * gam[ks] + bet[ks] > 0.f ? a.v[rh][ks] : 0.f) * gam[ks];
-        a.v[rh][ks] = dxh;
-        m1[g] += dxh;
-        m2[g] = fmaf(dxh, xh, m2[g]);
-      }
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        m1[g] += __shfl_xor(m1[g], 16); m1[g] += __shfl_xor(m1[g], 32);
-        m2[g] += __shfl_xor(m2[g], 16); m2[g] += __shfl_xor(m2[g], 32);
-        m1[g] *= inv_n; m2[g] *= inv_n;
-      }
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int g = ks / PER;
-        const float xh = (h.v[rh][ks] - mean[g]) * rstd[g];
-        a.v[rh][ks] = rstd[g] * (a.v[rh][ks] - m1[g] - xh * m2[g]);
-      }
+    for (int ks = 0; ks < 16; ++ks) {
+      const int g = ks / PER;
+      const float xh = (h.v[ks] - mean[g]) * rstd[g];
+      a.v[ks] = rstd[g] * (a.v[ks] - m1[g] - xh * m2[g]);
     }
   }
 }
 
-// Layer kernel: block = 4 waves = one 16-column output tile over the FULL K (no partial slabs); wave w owns the
-// 64-channel slices w, w+4, w+8, w+12.  All global loads of the wave's slices are issued before any arithmetic
-// (the layer is latency-bound at 32 rows: one memory round trip, then MFMAs).
+// Layer kernel: block = 4 waves = one 16-column x 16-row output tile over the FULL K (no partial slabs; the two row
+// halves of a 32-row tile go to two blocks so that a 1024-wide layer pair fills the 256 CUs); wave w owns the 64-channel
+// slices w, w+4, w+8, w+12.  All global loads of the wave's slices are issued before any arithmetic: the layer is
+// latency-bound at 32 rows (one memory round trip, then MFMAs); the GroupNorm affine is staged through LDS meanwhile.
 __global__ __launch_bounds__(NWL * 64) void mlp_layer_kernel(LayerLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // NWL * 8 * 64 floats (K reduction)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // NWL*4*64 (K reduction) + 2 * SPW*NWL*SLICE (affine)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int b = blockIdx.x;
   int ti = 0;
   if (L.ntasks > 1 && b >= L.t[0].nblocks) { b -= L.t[0].nblocks; ti = 1; }
   const LayerTask& T = L.t[ti];
-  const int tile = b;
+  const int tile = b >> 1, rh = b & 1;
   const float inv_n = 1.0f / (float)T.group;
-  // GroupNorm affine of the whole input width staged in LDS once per block (keeps 2 x 16 x SPW values per lane out of the
-  // register file, which is full of in-flight activation / weight loads)
-  float* s_gamma = smem + NWL * 8 * 64;
+  float* s_gamma = smem + NWL * 4 * 64;
   float* s_beta = s_gamma + SPW * NWL * SLICE;
-  if (T.mode != 0) {
-    for (int c = threadIdx.x; c < T.nslices * SLICE; c += NWL * 64) {
-      const bool ok = c < T.Csrc && c < T.Ch + T.Csrc;   // gamma/beta have Cin (= consumer input) entries
-      s_gamma[c] = ok ? T.gamma[c] : 0.f;
-      s_beta[c] = ok ? T.beta[c] : 0.f;
-    }
-    __syncthreads();
-  }
 
   for (int rt = 0; rt < L.RT; ++rt) {
-    f32x4 acc[2];
+    f32x4 acc;
 #pragma unroll
-    for (int rh = 0; rh < 2; ++rh)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[rh][i] = 0.f;
-    // ---- issue every load of this wave's (at most two) slices ----
+    for (int i = 0; i < 4; ++i) acc[i] = 0.f;
+    // ---- issue every load of this wave's (at most SPW) slices ----
     Frag a[SPW], h[SPW];
     float w[SPW][16];
 #pragma unroll
@@ -216,9 +198,18 @@ __global__ __launch_bounds__(NWL * 64) void mlp_layer_kernel(LayerLaunch L) {
         const float* wp = T.Wp + ((size_t)tile * T.nslices + slice) * 16 * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) w[q][ks] = wp[ks * 64];
-        load_frag16(T.src, L.RT, T.Csrc, rt, cbase, lane, a[q]);
-        if (T.mode == 3) load_frag16(T.hsrc, L.RT, T.Ch, rt, cbase, lane, h[q]);
+        load_frag16(T.src, L.RT, T.Csrc, rt, rh, cbase, lane, a[q]);
+        if (T.mode == 3) load_frag16(T.hsrc, L.RT, T.Ch, rt, rh, cbase, lane, h[q]);
       }
+    }
+    if (rt == 0 && T.mode != 0) {
+      // GroupNorm affine of the whole input width -> LDS (overlaps the loads above)
+      for (int c = threadIdx.x; c < T.nslices * SLICE; c += NWL * 64) {
+        const bool ok = c < T.Csrc;
+        s_gamma[c] = ok ? T.gamma[c] : 0.f;
+        s_beta[c] = ok ? T.beta[c] : 0.f;
+      }
+      __syncthreads();
     }
     // ---- prologue + MFMA ----
 #pragma unroll
@@ -234,26 +225,20 @@ __global__ __launch_bounds__(NWL * 64) void mlp_layer_kernel(LayerLaunch L) {
           else gn_frag<2>(3, s_gamma, s_beta, cbase, lane, inv_n, h[q], a[q]);
         }
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].v[0][ks], w[q][ks], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].v[1][ks], w[q][ks], acc[1], 0, 0, 0);
-        }
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].v[ks], w[q][ks], acc, 0, 0, 0);
       }
     }
-    // ---- cross-wave K reduction through LDS; waves 0/1 finish row halves 0/1 ----
+    // ---- cross-wave K reduction through LDS; wave 0 finishes ----
 #pragma unroll
-    for (int rh = 0; rh < 2; ++rh)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) smem[((wave * 2 + rh) * 4 + i) * 64 + lane] = acc[rh][i];
+    for (int i = 0; i < 4; ++i) smem[(wave * 4 + i) * 64 + lane] = acc[i];
     __syncthreads();
-    if (wave < 2) {
-      const int rh = wave;
+    if (wave == 0) {
       float o[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float v = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < NWL; ++ww) v += smem[((ww * 2 + rh) * 4 + i) * 64 + lane];
+        for (int ww = 0; ww < NWL; ++ww) v += smem[(ww * 4 + i) * 64 + lane];
         o[i] = v;
       }
       const int n = tile * 16 + (lane & 15);
@@ -1020,7 +1005,7 @@ static void fwd_task(LayerTask& T, const PackedLayer& L, const float* src, const
   T.gamma = L.gamma; T.beta = L.beta; T.group = L.group ? L.group : 64;
   if (L.skip && zterm_step) { T.zterm = zterm_step + (size_t)L.zoff * 32; T.zstride = ztot; }
   T.dst = dst;
-  T.nblocks = L.ntiles_f;
+  T.nblocks = 2 * L.ntiles_f;     // x2: the two 16-row halves
 }
 
 // backward through layer L: A = dh (adjoint of L's raw output), output = adjoint of L's input (main channels, then the
@@ -1037,13 +1022,13 @@ static void bwd_task(LayerTask& T, const PackedLayer& L, const float* dsrc, int 
   else T.group = 64;
   T.hsrc = hsrc; T.nsplit_h = nsplit_h; T.Ch = L.Nout_pad;
   T.dst = dst;
-  T.nblocks = L.ntiles_b;
+  T.nblocks = 2 * L.ntiles_b;
 }
 
 static int launch_layers(LayerLaunch& LL, hipStream_t st) {
   int blocks = 0;
   for (int i = 0; i < LL.ntasks; ++i) blocks += LL.t[i].nblocks;
-  hipLaunchKernelGGL(mlp_layer_kernel, dim3(blocks), dim3(NWL * 64), (NWL * 8 * 64 + 2 * SPW * NWL * SLICE) * sizeof(float), st, LL);
+  hipLaunchKernelGGL(mlp_layer_kernel, dim3(blocks), dim3(NWL * 64), (NWL * 4 * 64 + 2 * SPW * NWL * SLICE) * sizeof(float), st, LL);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

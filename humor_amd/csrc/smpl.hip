@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace ha
 
 namespace ha {
-int g_skin_variant = 2;   // 0: LDS-staged window, 1: + hoisted weight loads, 2: direct 48-byte per-thread path, 3: frame-pair windows; +4: non-temporal
+int g_skin_variant = 2;   // 0: LDS-staged window, 1: + hoisted weight loads, 2: direct 48-byte per-thread path, 3: frame-pair windows; +4: non-temporal; +8/+16: 2/4 vertex groups per thread (variant 2)
 }
 extern "C" int ha_tune_set(const char* key, int value) {
   HA_REQUIRE(key, "ha_tune_set: null key");
@@ -886,48 +886,64 @@ __device__ __forceinline__ void skin_one(const float* s_A, int J, int fr, float4
   oz = fmaf(r1.z, x, fmaf(r1.w, y, fmaf(r2.x, z, r2.w))) + tz;
 }
 
-// Variant 2: no LDS staging of the vertices.  Thread i owns global vertices 4i..4i+3 = 48 contiguous bytes = three 16-byte
-// loads / stores (a wave's three instructions together cover 3072 contiguous bytes); only A goes through LDS.
-template <bool NT>
+// Variant 2: no LDS staging of the vertices.  A block owns a window of 1024*GPT consecutive global vertices (16-byte
+// aligned, at most two frames); thread t owns the four-vertex groups t, t+256, ... (GPT of them) = GPT x three 16-byte
+// loads / stores, all issued up front: the kernel is latency-bound, so bytes in flight per wave are what matters
+// (rocprofv3: ~16 resident waves/CU, LDS bank conflicts 6 % of LDS-active cycles -- profiles/r01_run5_pmc_lbs).
+// Blocks are remapped so that an XCD (block % 8) walks a contiguous range of windows: a frame's A is then fetched
+// into one L2 instead of eight.
+template <bool NT, int GPT>
 __global__ __launch_bounds__(256) void lbs_skin_direct_kernel(const float* __restrict__ v_posed, const float* __restrict__ A,
                                                               const float* __restrict__ transl, const float4* __restrict__ w4,
                                                               const uint32_t* __restrict__ idx4, float* __restrict__ verts,
-                                                              int N, int V, int J) {
+                                                              int N, int V, int J, int nblocks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_A = smem;   // 2 frames x J x 12
   const int tid = threadIdx.x;
+  constexpr int WIN = kSkinVerts * GPT;
+  // XCD-aware remap (bijective for any nblocks): physical block b -> window index
+  const int q8 = nblocks / 8, r8 = nblocks % 8, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+  const int win = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
   const long long total = (long long)N * V;
-  const long long gv0 = (long long)blockIdx.x * kSkinVerts;
+  const long long gv0 = (long long)win * WIN;
   const int n0 = (int)(gv0 / V);
   const long long total3 = total * 3;
-  const long long gvt = gv0 + 4 * tid;          // this thread's first vertex
-  const long long fl = gvt * 3;                 // first float (multiple of 4)
-  // issue every global load up front
-  float f[12];
-  const bool full = fl + 11 < total3;
-  if (full) {
-    const float4* src = reinterpret_cast<const float4*>(v_posed + fl);
-    const float4 a = src[0], b = src[1], c = src[2];
-    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-    f[8] = c.x; f[9] = c.y; f[10] = c.z; f[11] = c.w;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 12; ++e) f[e] = fl + e < total3 ? v_posed[fl + e] : 0.f;
-  }
   const long long frame1_start = (long long)(n0 + 1) * V;
-  float4 wv[4];
-  uint32_t id[4];
-  int frs[4];
+  float f[GPT][12];
+  float4 wv[GPT][4];
+  uint32_t id[GPT][4];
+  int frs[GPT][4];
+  bool full[GPT];
+  // issue every global load up front
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const long long gv = gvt + k;
-    const int fr = gv >= frame1_start ? 1 : 0;
-    int v = (int)(gv - (long long)(n0 + fr) * V);
-    if (gv >= total) v = 0;
-    frs[k] = fr;
-    wv[k] = w4[v];
-    id[k] = idx4[v];
+  for (int g = 0; g < GPT; ++g) {
+    const long long gvt = gv0 + 4 * (tid + 256 * g);
+    const long long fl = gvt * 3;
+    full[g] = fl + 11 < total3;
+    if (full[g]) {
+      const vf4* src = reinterpret_cast<const vf4*>(v_posed + fl);
+      vf4 a, b, c;
+      if (NT) { a = __builtin_nontemporal_load(src); b = __builtin_nontemporal_load(src + 1); c = __builtin_nontemporal_load(src + 2); }
+      else { a = src[0]; b = src[1]; c = src[2]; }
+      f[g][0] = a.x; f[g][1] = a.y; f[g][2] = a.z; f[g][3] = a.w; f[g][4] = b.x; f[g][5] = b.y; f[g][6] = b.z; f[g][7] = b.w;
+      f[g][8] = c.x; f[g][9] = c.y; f[g][10] = c.z; f[g][11] = c.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 12; ++e) f[g][e] = fl + e < total3 ? v_posed[fl + e] : 0.f;
+    }
   }
+#pragma unroll
+  for (int g = 0; g < GPT; ++g)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long gv = gv0 + 4 * (tid + 256 * g) + k;
+      const int fr = gv >= frame1_start ? 1 : 0;
+      int v = (int)(gv - (long long)(n0 + fr) * V);
+      if (gv >= total) v = 0;
+      frs[g][k] = fr;
+      wv[g][k] = w4[v];
+      id[g][k] = idx4[v];
+    }
   float tl[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
   if (transl) {
 #pragma unroll
@@ -947,22 +963,26 @@ __global__ __launch_bounds__(256) void lbs_skin_direct_kernel(const float* __res
     }
   }
   __syncthreads();
-  float o[12];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int fr = frs[k];
-    skin_one(s_A, J, fr, wv[k], id[k], f[3 * k], f[3 * k + 1], f[3 * k + 2], tl[fr][0], tl[fr][1], tl[fr][2], o[3 * k], o[3 * k + 1],
-             o[3 * k + 2]);
-  }
-  if (full) {
-    float* dst = verts + fl;
-    store4<NT>(dst, o[0], o[1], o[2], o[3]);
-    store4<NT>(dst + 4, o[4], o[5], o[6], o[7]);
-    store4<NT>(dst + 8, o[8], o[9], o[10], o[11]);
-  } else {
+  for (int g = 0; g < GPT; ++g) {
+    float o[12];
 #pragma unroll
-    for (int e = 0; e < 12; ++e)
-      if (fl + e < total3) verts[fl + e] = o[e];
+    for (int k = 0; k < 4; ++k) {
+      const int fr = frs[g][k];
+      skin_one(s_A, J, fr, wv[g][k], id[g][k], f[g][3 * k], f[g][3 * k + 1], f[g][3 * k + 2], tl[fr][0], tl[fr][1], tl[fr][2],
+               o[3 * k], o[3 * k + 1], o[3 * k + 2]);
+    }
+    const long long fl = (gv0 + 4 * (tid + 256 * g)) * 3;
+    if (full[g]) {
+      float* dst = verts + fl;
+      store4<NT>(dst, o[0], o[1], o[2], o[3]);
+      store4<NT>(dst + 4, o[4], o[5], o[6], o[7]);
+      store4<NT>(dst + 8, o[8], o[9], o[10], o[11]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 12; ++e)
+        if (fl + e < total3) verts[fl + e] = o[e];
+    }
   }
 }
 
@@ -1126,12 +1146,17 @@ extern "C" int ha_lbs_skin(const ha_smpl_model* m, int N, const float* v_posed, 
                          m->w4, m->idx4, verts, N, m->V, m->J, nwin);
   } else if (variant == 2 || variant == 3) {
     const size_t lds2 = (size_t)(2 * m->J * 12) * sizeof(float);
-    if (nt)
-      hipLaunchKernelGGL(lbs_skin_direct_kernel<true>, dim3(blocks), dim3(256), lds2, (hipStream_t)stream, v_posed, A, transl, m->w4,
-                         m->idx4, verts, N, m->V, m->J);
-    else
-      hipLaunchKernelGGL(lbs_skin_direct_kernel<false>, dim3(blocks), dim3(256), lds2, (hipStream_t)stream, v_posed, A, transl, m->w4,
-                         m->idx4, verts, N, m->V, m->J);
+    const int gpt = (g_skin_variant >> 3) & 3;      // 0: 1 group/thread, 1: 2, 2: 4
+#define HA_SKIN_LAUNCH(NTV, G)                                                                                          \
+    do {                                                                                                                 \
+      const int nb = (int)((total + (long long)kSkinVerts * G - 1) / ((long long)kSkinVerts * G));                       \
+      hipLaunchKernelGGL((lbs_skin_direct_kernel<NTV, G>), dim3(nb), dim3(256), lds2, (hipStream_t)stream, v_posed, A,   \
+                         transl, m->w4, m->idx4, verts, N, m->V, m->J, nb);                                              \
+    } while (0)
+    if (gpt == 2 && m->V >= 4 * kSkinVerts) { if (nt) HA_SKIN_LAUNCH(true, 4); else HA_SKIN_LAUNCH(false, 4); }
+    else if (gpt == 1 && m->V >= 2 * kSkinVerts) { if (nt) HA_SKIN_LAUNCH(true, 2); else HA_SKIN_LAUNCH(false, 2); }
+    else { if (nt) HA_SKIN_LAUNCH(true, 1); else HA_SKIN_LAUNCH(false, 1); }
+#undef HA_SKIN_LAUNCH
   } else {
     hipLaunchKernelGGL(lbs_skin_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, v_posed, A, transl, m->w4, m->idx4,
                        verts, N, m->V, m->J, variant);
