@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace ha
 
 namespace ha {
-int g_skin_variant = 2;   // 0: LDS-staged window, 1: + hoisted weight loads, 2: direct 48-byte per-thread path, 3: frame-pair windows; +4: non-temporal; +8/+16: 2/4 vertex groups per thread (variant 2)
+int g_skin_variant = -1;  // -1 = auto: direct kernel, NT stores when the output fits the 256 MiB Infinity Cache   // 0: LDS-staged window, 1: + hoisted weight loads, 2: direct 48-byte per-thread path, 3: frame-pair windows; +4: non-temporal; +8/+16: 2/4 vertex groups per thread (variant 2)
 }
 extern "C" int ha_tune_set(const char* key, int value) {
   HA_REQUIRE(key, "ha_tune_set: null key");
@@ -890,8 +890,6 @@ __device__ __forceinline__ void skin_one(const float* s_A, int J, int fr, float4
 // aligned, at most two frames); thread t owns the four-vertex groups t, t+256, ... (GPT of them) = GPT x three 16-byte
 // loads / stores, all issued up front: the kernel is latency-bound, so bytes in flight per wave are what matters
 // (rocprofv3: ~16 resident waves/CU, LDS bank conflicts 6 % of LDS-active cycles -- profiles/r01_run5_pmc_lbs).
-// Blocks are remapped so that an XCD (block % 8) walks a contiguous range of windows: a frame's A is then fetched
-// into one L2 instead of eight.
 template <bool NT, int GPT>
 __global__ __launch_bounds__(256) void lbs_skin_direct_kernel(const float* __restrict__ v_posed, const float* __restrict__ A,
                                                               const float* __restrict__ transl, const float4* __restrict__ w4,
@@ -901,9 +899,8 @@ __global__ __launch_bounds__(256) void lbs_skin_direct_kernel(const float* __res
   float* s_A = smem;   // 2 frames x J x 12
   const int tid = threadIdx.x;
   constexpr int WIN = kSkinVerts * GPT;
-  // XCD-aware remap (bijective for any nblocks): physical block b -> window index
-  const int q8 = nblocks / 8, r8 = nblocks % 8, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-  const int win = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+  const int win = blockIdx.x;       // (an XCD-contiguous remap of the windows measured neutral-to-worse)
+  (void)nblocks;
   const long long total = (long long)N * V;
   const long long gv0 = (long long)win * WIN;
   const int n0 = (int)(gv0 / V);
@@ -923,8 +920,7 @@ __global__ __launch_bounds__(256) void lbs_skin_direct_kernel(const float* __res
     if (full[g]) {
       const vf4* src = reinterpret_cast<const vf4*>(v_posed + fl);
       vf4 a, b, c;
-      if (NT) { a = __builtin_nontemporal_load(src); b = __builtin_nontemporal_load(src + 1); c = __builtin_nontemporal_load(src + 2); }
-      else { a = src[0]; b = src[1]; c = src[2]; }
+      a = src[0]; b = src[1]; c = src[2];     // (non-temporal LOADS measured 25-35 % slower; only the stores are NT)
       f[g][0] = a.x; f[g][1] = a.y; f[g][2] = a.z; f[g][3] = a.w; f[g][4] = b.x; f[g][5] = b.y; f[g][6] = b.z; f[g][7] = b.w;
       f[g][8] = c.x; f[g][9] = c.y; f[g][10] = c.z; f[g][11] = c.w;
     } else {
@@ -1131,8 +1127,9 @@ extern "C" int ha_lbs_skin(const ha_smpl_model* m, int N, const float* v_posed, 
   const long long total = (long long)N * m->V;
   const int blocks = (int)((total + kSkinVerts - 1) / kSkinVerts);
   const size_t lds = (size_t)(kSkinVerts * 3 + 2 * m->J * 12) * sizeof(float);
-  const int variant = g_skin_variant & 3;
-  const bool nt = (g_skin_variant & 4) != 0;
+  const int sv = g_skin_variant >= 0 ? g_skin_variant : (total * 12 <= (200ll << 20) ? 6 : 2);
+  const int variant = sv & 3;
+  const bool nt = (sv & 4) != 0;
   if (variant == 3 && m->V % 2 == 0) {
     constexpr int P = 4;
     const int nwin = ceil_div(m->V / 2, 256);
@@ -1146,7 +1143,7 @@ extern "C" int ha_lbs_skin(const ha_smpl_model* m, int N, const float* v_posed, 
                          m->w4, m->idx4, verts, N, m->V, m->J, nwin);
   } else if (variant == 2 || variant == 3) {
     const size_t lds2 = (size_t)(2 * m->J * 12) * sizeof(float);
-    const int gpt = (g_skin_variant >> 3) & 3;      // 0: 1 group/thread, 1: 2, 2: 4
+    const int gpt = (sv >> 3) & 3;      // 0: 1 group/thread, 1: 2, 2: 4
 #define HA_SKIN_LAUNCH(NTV, G)                                                                                          \
     do {                                                                                                                 \
       const int nb = (int)((total + (long long)kSkinVerts * G - 1) / ((long long)kSkinVerts * G));                       \
