@@ -35,6 +35,11 @@ HBM_PEAK_GBS = 8000.0                   # /opt/skills/guides/MI355X_MICROARCH.md
 V, J = 6890, 52
 # algorithmic HBM bytes per frame of the LBS skinning kernel = read v_posed (V*12) + A (J*48), write verts (V*12)
 SKIN_BYTES_PER_FRAME = V * 12 * 2 + J * 48
+# HBM traffic of one ha_lbs_skin launch at N=1920 from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+# tools/skin_once.py; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM', WRITE_SIZE as reported, both x1024):
+# 2 * 97000 KB + 188580 KB.  Offline measurement (counters cannot be read inside bench.py); see profiles/r01_run5_pmc_lbs/.
+PMC_TRAFFIC_BYTES = int((2 * 97000.2 + 188580.7) * 1024)
+PMC_TRAFFIC_SOURCE = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_run5_pmc_lbs (FETCH x2 gfx950 correction)'
 
 
 def parse():
@@ -159,7 +164,8 @@ def skin_roofline(dev, npz):
     nbytes = SKIN_BYTES_PER_FRAME * N
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {'kernel': 'lbs_skin (ha_lbs_skin)', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'avg_launch_us': round(ms * 1e3, 2),
+            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': PMC_TRAFFIC_BYTES, 'traffic_source': PMC_TRAFFIC_SOURCE,
+            'avg_launch_us': round(ms * 1e3, 2),
             'bytes_per_launch': nbytes, 'frames_per_launch': N}
 
 
@@ -233,7 +239,9 @@ def main():
     from humor_amd import synth
     tmp = tempfile.mkdtemp(prefix='humor_amd_bench_')
     npz = synth.write_smplh_npz(os.path.join(tmp, f'model_{rank}.npz'), seed=0)
-    fc = FitClosure(dev, npz, world, rank, None, use_graphs=not args.eager)
+    # hipGraph capture of the closure is used on one GPU only: capturing RCCL collectives cannot be exercised in the
+    # 1-GPU development environment, and a rank-divergent capture failure would dead-lock the job.
+    fc = FitClosure(dev, npz, world, rank, None, use_graphs=(not args.eager) and world == 1)
 
     for _ in range(args.warmup):
         fc.step()
