@@ -45,3 +45,16 @@ def test_rollout_determinism(gpu_lib, dev):
 def test_rotation_kernels(gpu_lib, dev):
     RC.check_rot_random(gpu_lib, dev, n=100000)
     RC.check_rotations_golden(gpu_lib, dev)
+
+
+def test_c5_size_rollout(gpu_lib, dev):
+    """BASELINE config C5 batch (256 sequences = 8 row tiles), 119 steps: finite and equal, sequence by sequence, to the
+    same sequences rolled out in a batch of 32 (row tiles are independent)."""
+    hm, _ = RC.make_model(gpu_lib, dev)
+    g = torch.Generator().manual_seed(2)
+    past = RC.canonical_state(256, g).to(dev)
+    z = (0.5 * torch.randn(256, 119, 48, generator=g)).to(dev)
+    big = RC.world_of(hm.roll_out(past, None, 119, z_seq=z))
+    assert torch.isfinite(big).all()
+    small = RC.world_of(hm.roll_out(past[64:96], None, 119, z_seq=z[64:96]))
+    assert torch.equal(big[64:96], small)

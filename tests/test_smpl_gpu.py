@@ -74,3 +74,20 @@ def test_errors_are_exceptions(gpu_lib, smplh_npz, dev):
     from humor_amd._lib import HumorAmdError
     with pytest.raises(HumorAmdError):
         gpu_lib.call('ha_smpl_forward', None, 0, 1, 22, None, None, None, None, None, None, None, None, 0, None)
+
+
+def test_c5_size_dense_smpl(gpu_lib, smplh_npz, smplh_struct, dev):
+    """BASELINE config C5 size (256 x 120 = 30 720 frames, 2.5 GB of vertices): finite, two kernels agree on a slice,
+    oracle spot check."""
+    from humor_amd.body_model import BodyModel
+    N = 256 * 120
+    inp = {k: v.detach() for k, v in SC.make_inputs(N, 5, dev).items()}
+    o2 = BodyModel(smplh_npz, num_betas=16, use_vtx_selector=True, algo=2)(**inp)
+    assert o2.v.shape == (N, 6890, 3)
+    assert torch.isfinite(o2.v[::997]).all()
+    sel = [0, 12345, N - 1]
+    ref, _ = SC.oracle_forward(smplh_struct, {k: v[sel] for k, v in inp.items()}, True)
+    assert (o2.v[sel].cpu() - ref.vertices).abs().max().item() < 1e-4
+    assert (o2.Jtr[sel].cpu() - ref.joints).abs().max().item() < 1e-4
+    o1 = BodyModel(smplh_npz, num_betas=16, use_vtx_selector=True, algo=1)(**{k: v[-64:] for k, v in inp.items()})
+    assert (o1.v - o2.v[-64:]).abs().max().item() < 1e-4
