@@ -206,28 +206,35 @@ __global__ __launch_bounds__(NW * 64) void mlp_layer_kernel(LayerLaunch L) {
   const bool is_main = slice < T.main_slices;
   const int cbase = is_main ? slice * SLICE : (slice - T.main_slices) * SLICE;
 
+  // The row-tile loop is software-pipelined one deep: the next tile's fragments are in flight while this tile's MFMAs run
+  // (at 256 rows per step the loop otherwise pays a full memory round trip per tile).
+  float a_cur[32], h_cur[32], a_nxt[32], h_nxt[32];
+  auto issue_loads = [&](int rt, float (&a)[32], float (&h)[32]) {
+    if (!is_main) load_frag_n(T.skip, 1, L.RT, T.skip_dim, rt, cbase, lane, a);
+    else {
+      load_frag_n(T.src, T.nsplit_src, L.RT, T.Csrc, rt, cbase, lane, a);
+      if (T.mode == 3) load_frag_n(T.hsrc, T.nsplit_h, L.RT, T.Ch, rt, cbase, lane, h);
+    }
+  };
+  if (active) issue_loads(0, a_cur, h_cur);
+
   for (int rt = 0; rt < L.RT; ++rt) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     if (active) {
-      float a[32];
-      if (!is_main) {
-        load_frag_n(T.skip, 1, L.RT, T.skip_dim, rt, cbase, lane, a);
-      } else {
-        load_frag_n(T.src, T.nsplit_src, L.RT, T.Csrc, rt, cbase, lane, a);
-        if (T.mode != 0) {
-          // GroupNorm over groups of T.group (64 or 32) channels: the lane holds 32 channels of its row (one parity),
-          // the other parity lives in lane^32.
-          float h[32];
-          if (T.mode == 3) load_frag_n(T.hsrc, T.nsplit_h, L.RT, T.Ch, rt, cbase, lane, h);
-          else {
-#pragma unroll
-            for (int kp = 0; kp < 32; ++kp) h[kp] = a[kp];
-          }
-          const float inv_n = 1.0f / (float)T.group;
-          if (T.group == SLICE) gn_apply<1>(T.mode, T.gamma, T.beta, cbase, hi, inv_n, h, a);
-          else gn_apply<2>(T.mode, T.gamma, T.beta, cbase, hi, inv_n, h, a);
+      if (rt + 1 < L.RT) issue_loads(rt + 1, a_nxt, h_nxt);
+      float (&a)[32] = a_cur;
+      if (is_main && T.mode != 0) {
+        // GroupNorm over groups of T.group (64 or 32) channels: the lane holds 32 channels of its row (one parity),
+        // the other parity lives in lane^32.
+        const float inv_n = 1.0f / (float)T.group;
+        if (T.mode == 1) {
+          if (T.group == SLICE) gn_apply<1>(1, T.gamma, T.beta, cbase, hi, inv_n, a_cur, a);
+          else gn_apply<2>(1, T.gamma, T.beta, cbase, hi, inv_n, a_cur, a);
+        } else {
+          if (T.group == SLICE) gn_apply<1>(3, T.gamma, T.beta, cbase, hi, inv_n, h_cur, a);
+          else gn_apply<2>(3, T.gamma, T.beta, cbase, hi, inv_n, h_cur, a);
         }
       }
 #pragma unroll
@@ -257,6 +264,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_layer_kernel(LayerLaunch L) {
       *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
+    if (active && rt + 1 < L.RT) {
+#pragma unroll
+      for (int kp = 0; kp < 32; ++kp) { a_cur[kp] = a_nxt[kp]; h_cur[kp] = h_nxt[kp]; }
+    }
   }
 }
 
