@@ -1,0 +1,79 @@
+"""GPU tier: end-to-end 3-stage fits (MotionOptimizer.run) on synthetic problems with a known ground-truth motion --
+the whole pipeline the reference drives from run_fitting.py, at reduced iteration counts."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fitting_checks as FC
+from humor_amd import results, synth
+from humor_amd.body_model import BodyModel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    return torch.device('cuda:0')
+
+
+def _gt_joints(npz, dev, B, T, seed):
+    root, body, trans = synth.smooth_pose_sequence(B, T, seed=seed, amp=0.2)
+    betas = 0.5 * torch.randn(B, 16, generator=torch.Generator().manual_seed(seed))
+    bm = BodyModel(npz, num_betas=16, use_vtx_selector=False, vertex_subset=[0])
+    N = B * T
+    out = bm(root_orient=root.reshape(N, 3).to(dev), pose_body=body.reshape(N, 63).to(dev), trans=trans.reshape(N, 3).to(dev),
+             betas=betas.unsqueeze(1).expand(B, T, 16).reshape(N, 16).to(dev))
+    gt = dict(trans=trans, root_orient=root, pose_body=body, betas=betas)
+    return out.Jtr[:, :22].reshape(B, T, 22, 3).detach(), gt
+
+
+@pytest.mark.parametrize('use_graphs', [False, True])
+def test_amass_style_fit_reduces_joint_error(gpu_lib, dev, smplh_npz, tmp_path, use_graphs):
+    """fit_amass_joints-shaped problem (config C2): noisy 3D joints of a known motion; the three stages must reduce the
+    joint error substantially and return the reference's result structure; results are written in its npz layout."""
+    B, T = 2, 30
+    joints, gt = _gt_joints(smplh_npz, dev, B, T, seed=7)
+    g = torch.Generator().manual_seed(1)
+    obs = {'joints3d': joints + 0.02 * torch.randn(joints.shape, generator=g).to(dev)}
+    opt = FC.build(gpu_lib, dev, 'amass', B, T, smplh_npz)
+    opt.use_graphs = use_graphs
+    opt.loss_trace = []
+    final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[6, 10, 8], lbfgs_max_iter=20)
+    err0 = (joints - 0.0).norm(dim=-1).mean().item()
+    err2 = (stages['stage2']['joints3d'] - joints).norm(dim=-1).mean().item()
+    err3 = (stages['stage3']['joints3d'] - joints).norm(dim=-1).mean().item()
+    assert err2 < 0.25 * err0, (err0, err2)
+    assert np.isfinite(err3) and err3 < 0.6 * err0, (err0, err3)
+    tr = np.array(opt.loss_trace)
+    for st in range(3):
+        ls = tr[tr[:, 0] == st][:, 1]
+        assert ls[-1] < ls[0]                       # every stage made progress
+    assert final['trans'].shape == (B, T, 3) and final['pose_body'].shape == (B, T, 63)
+    assert final['latent_motion'].shape == (B, T - 1, 48) and final['contacts'].shape == (B, T, 22)
+    assert set(torch.unique(final['contacts']).tolist()) <= {0.0, 1.0}
+    out_dirs = [str(tmp_path / f'seq{b}') for b in range(B)]
+    results.save_optim_result(out_dirs, final, stages, gt_data=gt, observed_data=obs, data_type='AMASS', optim_floor=False)
+    d = np.load(os.path.join(out_dirs[0], 'stage3_results.npz'))
+    assert d['trans'].shape == (T, 3) and d['pose_body'].shape == (T, 63) and d['betas'].shape == (16,) and d['contacts'].shape == (T, 22)
+    assert os.path.exists(os.path.join(out_dirs[1], 'gt_results.npz')) and os.path.exists(os.path.join(out_dirs[1], 'observations.npz'))
+
+
+def test_rgb_style_fit_runs_all_phases(gpu_lib, dev, smplh_npz):
+    """fit_rgb_demo_use_split-shaped problem (config C3/C4 shape): 2D keypoints, floor optimisation, overlapping
+    sub-sequences; exercises the tune-init / frozen-init / refine phases of stage 3 and the floor outputs."""
+    from oracle import closure_cases as CC
+    B, T = 4, 20
+    opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
+    opt.stage3_tune_init_freeze_start, opt.stage3_tune_init_freeze_end = 2, 4
+    opt.use_graphs = True
+    opt.loss_trace = []
+    obs = {k: v.to(dev) for k, v in CC.make_case('rgb', B, T, seed=4)['obs'].items()}
+    obs['seq_interval'] = torch.tensor([[b * (T - 5), b * (T - 5) + T] for b in range(B)])
+    final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[3, 4, 6], lbfgs_max_iter=10)
+    assert final['floor_plane'].shape == (B, 4)
+    assert 'prior_trans' in stages['stage3'] and 'prior_joints3d_rollout' in stages['stage3']
+    assert all(torch.isfinite(v).all() for v in final.values())
+    tr = np.array(opt.loss_trace)
+    assert (tr[:, 0] == 2).sum() > 10 and np.isfinite(tr[:, 1]).all()
