@@ -43,6 +43,7 @@ _SIGS = {
     'ha_humor_net_destroy': (C.c_int, [C.c_void_p]),
     'ha_humor_rollout_workspace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     'ha_humor_rollout_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p]),
+    'ha_humor_rollout_sample': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_humor_rollout_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
 }
 

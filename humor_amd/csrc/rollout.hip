@@ -777,6 +777,30 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
   }
 }
 
+// z_t = mu + eps * sqrt(var) (or mu when eps is null) from the prior output slabs of step t; writes the transposed
+// latent of step t (the decoder's skip operand) and the row-major z / prior outputs (humor_model.py:1029-1047).
+struct SampleParams {
+  int B, S, t, RT;
+  const float* pri_out; int pri_nsplit; int pri_pad;
+  const float* eps;         // [B][S][48] or null
+  float* zT_t;              // [RT][48][32]
+  float* z_out;             // [B][S][48]
+};
+
+__global__ __launch_bounds__(64) void sample_z_kernel(SampleParams p) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int rt = r >> 5, rr = r & 31;
+  if (lane >= ZD) return;
+  float* dst = p.zT_t + ((size_t)rt * ZD + lane) * 32 + rr;
+  if (r >= p.B) { *dst = 0.f; return; }
+  const float mu = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, lane, rr);
+  const float lv = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, ZD + lane, rr);
+  const size_t o = ((size_t)r * p.S + p.t) * ZD + lane;
+  const float z = p.eps ? mu + p.eps[o] * sqrtf(expf(lv)) : mu;
+  *dst = z;
+  p.z_out[o] = z;
+}
+
 // [B][S][48] -> [S][RT][48][32] (zero-padded rows) ; [B][339] -> [RT][339][32]
 __global__ void transpose_in_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int S, int C, int RT) {
   const size_t total = (size_t)S * RT * C * 32;
@@ -1100,6 +1124,69 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
     const PackedLayer& DL = net->dec[net->n_dec - 1];
     g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = DL.nsplit_f; g.dec_pad = DL.Nout_pad;
     const PackedLayer& PL = net->pri[net->n_pri - 1];
+    g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = PL.nsplit_f; g.pri_pad = PL.Nout_pad;
+    g.Gs = sp + L.off_G;
+    g.Gs_next = step_ptr(t + 1) + L.off_G;
+    g.t2j = stash + L.t2j;
+    g.world = world;
+    g.prior_mu = prior_mu; g.prior_var = prior_var;
+    hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(64), S_TOTAL * sizeof(float), st, g);
+    HA_LAUNCH_CHECK();
+  }
+  return HA_OK;
+}
+
+extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, const float* past_in0, const float* eps_seq,
+                                       float* world, float* prior_mu, float* prior_var, float* z_out, float* stash, void* stream) {
+  HA_REQUIRE(net && past_in0 && world && prior_mu && prior_var && z_out && stash, "ha_humor_rollout_sample: null argument");
+  HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_sample: B and S must be >= 1");
+  DeviceGuard guard(net->device);
+  hipStream_t st = (hipStream_t)stream;
+  StashLayout L;
+  make_layout(net, B, S, L);
+  const int RT = L.RT, rows = RT * 32;
+  auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
+  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, step_ptr(0) + L.off_x, B, 1, D_IN, RT);
+  HA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
+  HA_LAUNCH_CHECK();
+  const PackedLayer& DL = net->dec[net->n_dec - 1];
+  const PackedLayer& PL = net->pri[net->n_pri - 1];
+  for (int t = 0; t < S; ++t) {
+    float* sp = step_ptr(t);
+    float* zT = stash + L.zT + (size_t)t * RT * ZD * 32;
+    // the latent of this step depends on the prior of this step: prior network first, then sample, then the decoder
+    for (int l = 0; l < net->n_pri; ++l) {
+      LayerLaunch LL;
+      memset(&LL, 0, sizeof(LL));
+      LL.RT = RT;
+      const float* src = l == 0 ? sp + L.off_x : sp + L.off_pri[l - 1];
+      fwd_task(LL.t[LL.ntasks++], net->pri[l], src, l == 0 ? 1 : net->pri[l - 1].nsplit_f, nullptr, sp + L.off_pri[l]);
+      int rc = launch_layers(LL, st);
+      if (rc != HA_OK) return rc;
+    }
+    SampleParams sp_;
+    memset(&sp_, 0, sizeof(sp_));
+    sp_.B = B; sp_.S = S; sp_.t = t; sp_.RT = RT;
+    sp_.pri_out = sp + L.off_pri[net->n_pri - 1]; sp_.pri_nsplit = PL.nsplit_f; sp_.pri_pad = PL.Nout_pad;
+    sp_.eps = eps_seq; sp_.zT_t = zT; sp_.z_out = z_out;
+    hipLaunchKernelGGL(sample_z_kernel, dim3(rows), dim3(64), 0, st, sp_);
+    HA_LAUNCH_CHECK();
+    for (int l = 0; l < net->n_dec; ++l) {
+      LayerLaunch LL;
+      memset(&LL, 0, sizeof(LL));
+      LL.RT = RT;
+      const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
+      fwd_task(LL.t[LL.ntasks++], net->dec[l], src, l == 0 ? 1 : net->dec[l - 1].nsplit_f, zT, sp + L.off_dec[l]);
+      int rc = launch_layers(LL, st);
+      if (rc != HA_OK) return rc;
+    }
+    GlueParams g;
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.S = S; g.t = t; g.RT = RT;
+    g.xT = sp + L.off_x;
+    g.xT_next = step_ptr(t + 1) + L.off_x;
+    g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = DL.nsplit_f; g.dec_pad = DL.Nout_pad;
     g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = PL.nsplit_f; g.pri_pad = PL.Nout_pad;
     g.Gs = sp + L.off_G;
     g.Gs_next = step_ptr(t + 1) + L.off_G;

@@ -119,3 +119,33 @@ def estimate_angular_velocity(rot_seq, h):
     wy = (w[..., 0, 2] - w[..., 2, 0]) / 2.0
     wz = (-w[..., 0, 1] + w[..., 1, 0]) / 2.0
     return torch.stack([wx, wy, wz], dim=-1)
+
+
+def canonicalize_state(past_in):
+    """[B,339] world-frame state -> the same state in its own heading-aligned frame, plus (R0, t0, t2j) to undo it
+    (HumorModel.roll_out(canonicalize_input=True), humor_model.py:808-832)."""
+    B = past_in.shape[0]
+    R0 = world2aligned_mat(past_in[:, 6:15].reshape(B, 3, 3))
+    zero = torch.zeros(B, 1, dtype=past_in.dtype, device=past_in.device)
+    t0 = torch.cat([-past_in[:, 0:2], zero], dim=1)
+    t2j = torch.cat([-(past_in[:, 207:209] + t0[:, :2]), zero], dim=1)
+    rot = lambda v: torch.einsum('bij,bj->bi', R0, v)
+    joints = torch.einsum('bij,bkj->bki', R0, past_in[:, 207:273].reshape(B, 22, 3) + t0.unsqueeze(1) + t2j.unsqueeze(1)) - t2j.unsqueeze(1)
+    jvel = torch.einsum('bij,bkj->bki', R0, past_in[:, 273:339].reshape(B, 22, 3))
+    local = torch.cat([rot(past_in[:, 0:3] + t0), rot(past_in[:, 3:6]), torch.matmul(R0, past_in[:, 6:15].reshape(B, 3, 3)).reshape(B, 9),
+                       rot(past_in[:, 15:18]), past_in[:, 18:207], joints.reshape(B, 66), jvel.reshape(B, 66)], dim=1)
+    return local, (R0, t0, t2j)
+
+
+def uncanonicalize_world(world, R0, t0, t2j):
+    """Maps canonical-frame roll-out outputs [B,S,348] back into the frame of the original input
+    (uncanonicalize_output=True): the accumulated transform only gains the constant (R0, t0) factor."""
+    B, S = world.shape[0], world.shape[1]
+    Rt = R0.transpose(1, 2)
+    rot = lambda v: torch.einsum('bij,bsj->bsi', Rt, v)
+    joints = (torch.einsum('bij,bskj->bski', Rt, world[:, :, 207:273].reshape(B, S, 22, 3) + t2j.view(B, 1, 1, 3))
+              - t2j.view(B, 1, 1, 3) - t0.view(B, 1, 1, 3))
+    jvel = torch.einsum('bij,bskj->bski', Rt, world[:, :, 273:339].reshape(B, S, 22, 3))
+    Rroot = torch.einsum('bij,bsjk->bsik', Rt, world[:, :, 6:15].reshape(B, S, 3, 3)).reshape(B, S, 9)
+    return torch.cat([rot(world[:, :, 0:3]) - t0.unsqueeze(1), rot(world[:, :, 3:6]), Rroot, rot(world[:, :, 15:18]),
+                      world[:, :, 18:207], joints.reshape(B, S, 66), jvel.reshape(B, S, 66), world[:, :, 339:348]], dim=2)

@@ -160,6 +160,22 @@ class _RolloutFunction(torch.autograd.Function):
         return g_past, g_z, None, None
 
 
+def _rollout_sample(handle, past_in, eps, S):
+    """Sampling roll-out through ha_humor_rollout_sample (no autograd)."""
+    lib = handle.lib
+    past_in = past_in.contiguous().float()
+    B, dev = past_in.shape[0], past_in.device
+    n = C.c_int64()
+    lib.call('ha_humor_rollout_workspace', handle.ptr, B, S, C.byref(n))
+    stash = torch.empty(n.value, dtype=torch.float32, device=dev)
+    new = lambda d: torch.empty(B, S, d, dtype=torch.float32, device=dev)
+    world, pm, pv, z = new(348), new(48), new(48), new(48)
+    eps = None if eps is None else eps.contiguous().float()
+    lib.call('ha_humor_rollout_sample', handle.ptr, B, S, _lib.ptr(past_in), _lib.ptr(eps), _lib.ptr(world), _lib.ptr(pm),
+             _lib.ptr(pv), _lib.ptr(z), _lib.ptr(stash), _lib.stream_ptr(past_in))
+    return world, pm, pv, z
+
+
 class HumorModel(nn.Module):
 
     def __init__(self, in_rot_rep='aa', out_rot_rep='aa', latent_size=48, steps_in=1, conditional_prior=True,
@@ -291,23 +307,42 @@ class HumorModel(nn.Module):
         return self._net_handles[key][1]
 
     def roll_out(self, x_past, init_input_dict, num_steps, use_mean=False, z_seq=None, return_prior=False, gender=None,
-                 betas=None, return_z=False, canonicalize_input=False, uncanonicalize_output=False):
+                 betas=None, return_z=False, canonicalize_input=False, uncanonicalize_output=False, eps_seq=None):
         '''
-        Rolls the model out from the initial state with the given latent sequence (humor_model.py:785-1017).
+        Rolls the model out from the initial state (humor_model.py:785-1017): with the given latent sequence (differentiable,
+        the fitting path) or, with z_seq=None, sampling z_t = mu_t + eps_t * sigma_t from the conditional prior at every step
+        (use_mean: z_t = mu_t; forward only).  eps_seq [B,S,48] is an extension for reproducible sampling (default: randn).
         Returns a dict of world-frame [B, num_steps, D] tensors (rotations as matrices), optionally (prior mean, var).
         '''
         self._check_rollout_config()
-        if canonicalize_input:
-            raise NotImplementedError('canonicalize_input=True: canonicalise with MotionOptimizer / ops first (fitting calls roll_out with the default)')
-        if z_seq is None:
-            raise NotImplementedError('sampling roll-out (z_seq=None) is not on the fitting path; pass z_seq')
-        if x_past is not None:
+        if x_past is not None and not canonicalize_input:
             past_in = x_past.reshape(x_past.size(0), -1)
         else:
             past_in = torch.cat([init_input_dict[k][:, -1, :] for k in self.data_names], dim=1)
-        z_seq = z_seq[:, :num_steps]
+        B = past_in.size(0)
+        uncanon = None
+        if canonicalize_input:
+            # express the initial state in its own heading-aligned frame (humor_model.py:808-832)
+            from .frames import canonicalize_state
+            past_in, uncanon = canonicalize_state(past_in)
         handle = self._net_handle(past_in.device)
-        world, pm, pv = _RolloutFunction.apply(past_in, z_seq, handle, bool(return_prior))
+        z_out = None
+        if z_seq is None:
+            # sampling from the conditional prior (or its mean): forward only
+            if use_mean:
+                eps = None
+            elif eps_seq is not None:
+                eps = eps_seq[:, :num_steps]
+            else:
+                eps = torch.randn(B, num_steps, self.latent_size, device=past_in.device)
+            world, pm, pv, z_out = _rollout_sample(handle, past_in.detach(), eps, num_steps)
+        else:
+            z_seq = z_seq[:, :num_steps]
+            world, pm, pv = _RolloutFunction.apply(past_in, z_seq, handle, bool(return_prior))
+            z_out = z_seq
+        if canonicalize_input and uncanonicalize_output:
+            from .frames import uncanonicalize_world
+            world = uncanonicalize_world(world, *uncanon)
         out, s = {}, 0
         for n, d in zip(self.data_names, self.delta_output_dim_list):
             out[n] = world[:, :, s:s + d]
@@ -315,7 +350,7 @@ class HumorModel(nn.Module):
         if self.pred_contacts:
             out['contacts'] = world[:, :, s:s + 9]
         if return_z:
-            out['z'] = z_seq
+            out['z'] = z_out
         if return_prior:
             return out, (pm, pv)
         return out

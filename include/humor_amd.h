@@ -147,6 +147,12 @@ int ha_humor_rollout_workspace(const ha_humor_net* net, int B, int S, int64_t* s
 int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, const float* past_in0, const float* z_seq,
                              float* world, float* prior_mu, float* prior_var, float* stash, void* stream);
 
+/* Sampling roll-out (HumorModel.roll_out with z_seq=None, humor_model.py:1029-1047; test_humor.py:224): at every step
+ * z_t = prior_mu_t + eps_t * sqrt(prior_var_t) (eps_seq [B,S,48]; NULL = use the prior mean, `use_mean=True`).
+ * Outputs as ha_humor_rollout_forward plus the sampled latents z_out [B,S,48].  Forward only. */
+int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, const float* past_in0, const float* eps_seq,
+                            float* world, float* prior_mu, float* prior_var, float* z_out, float* stash, void* stream);
+
 /* Backward roll-out: given gradients of the outputs, produce gradients of the inputs.
  *   g_world [B,S,348], g_prior_mu / g_prior_var [B,S,48] (NULL = zero)
  * outputs g_past_in0 [B,339], g_z_seq [B,S,48].  `stash` is the forward's, consumed read-only except

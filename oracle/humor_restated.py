@@ -156,24 +156,30 @@ def to_world(state, G, gt, t2j):
     return torch.cat([trans, tvel, R_root, rvel, state[:, 18:207], joints, jvel, state[:, 339:348]], dim=1)
 
 
-def roll_out(sd, past_in0, z_seq, return_prior=True):
-    """past_in0 [B,339] (already canonical), z_seq [B,S,48] -> world states [B,S,348], (pm, pv) [B,S,48] each."""
+def roll_out(sd, past_in0, z_seq, return_prior=True, eps_seq=None, G0=None, gt0=None, t2j=None):
+    """past_in0 [B,339] (already canonical), z_seq [B,S,48] -> world states [B,S,348], (pm, pv) [B,S,48] each.
+    With z_seq=None the latent is sampled per step: z_t = pm_t + eps_seq[:, t] * sqrt(pv_t) (sample_step,
+    humor_model.py:1029-1047; eps_seq=0 reproduces use_mean=True).  (G0, gt0, t2j) seed the accumulated world transform
+    for canonicalize_input + uncanonicalize_output (humor_model.py:852-858)."""
     dec_lin, dec_gn = mlp_params(sd, 'decoder')
     pri_lin, pri_gn = mlp_params(sd, 'prior_net')
-    B, S = z_seq.shape[0], z_seq.shape[1]
+    sampling = z_seq is None
+    B, S = (eps_seq if sampling else z_seq).shape[0], (eps_seq if sampling else z_seq).shape[1]
     dt = past_in0.dtype
-    G = torch.eye(3, dtype=dt).unsqueeze(0).repeat(B, 1, 1)
-    gt = torch.zeros(B, 3, dtype=dt)
+    G = torch.eye(3, dtype=dt).unsqueeze(0).repeat(B, 1, 1) if G0 is None else G0
+    gt = torch.zeros(B, 3, dtype=dt) if gt0 is None else gt0
     zero = torch.zeros(B, 1, dtype=dt)
-    t2j = -torch.cat([past_in0[:, 207:209], zero], dim=1)
+    if t2j is None:
+        t2j = -torch.cat([past_in0[:, 207:209], zero], dim=1)
+    return_prior = return_prior or sampling
     past_in = past_in0
     world, pms, pvs = [], [], []
     for t in range(S):
-        z = z_seq[:, t]
         if return_prior:
             po = mlp_forward(past_in, pri_lin, pri_gn)
             pms.append(po[:, :LATENT])
             pvs.append(torch.exp(po[:, LATENT:]))
+        z = pms[-1] + eps_seq[:, t] * torch.sqrt(pvs[-1]) if sampling else z_seq[:, t]
         raw = mlp_forward(torch.cat([past_in, z], dim=1), dec_lin, dec_gn, skip=z)
         pred = decode_compose(past_in, raw)
         W = world2aligned(pred[:, 6:15].reshape(B, 3, 3))

@@ -154,3 +154,48 @@ def check_rot_random(lib, device, n=4096, seed=0):
     ang = b_ref.detach().norm(dim=1)
     good = (ang > 0.2) & (ang < 2.6)
     assert (gr[good] - gr_ref[good]).abs().max().item() < 1e-3 * max(1.0, gr_ref[good].abs().max().item())
+
+
+def check_sampling_rollout(lib, device, B=2, S=30, seed=0, n_mean=6, n_canon=5):
+    """BASELINE config C1 shape (test_humor_sampling_debug: batch 2, 30 steps, z sampled from the prior each step) and the
+    canonicalize_input / uncanonicalize_output options of HumorModel.roll_out, against the oracle with the same noise."""
+    hm, sd = make_model(lib, device, seed=seed)
+    g = torch.Generator().manual_seed(seed + 11)
+    past = canonical_state(B, g)
+    eps = torch.randn(B, S, 48, generator=g)
+    out, (pm, pv) = hm.roll_out(past.to(device), None, S, z_seq=None, return_prior=True, return_z=True, eps_seq=eps.to(device))
+    w_ref, (pm_r, pv_r) = H.roll_out(sd, past, None, eps_seq=eps)
+    n = min(S, 12)          # compare where the chain is still well conditioned
+    assert (world_of(out)[:, :n].cpu() - w_ref[:, :n]).abs().max().item() < FWD_TOL
+    assert (pm[:, :n].cpu() - pm_r[:, :n]).abs().max().item() < FWD_TOL
+    z_ref = pm_r + eps * torch.sqrt(pv_r)
+    assert (out['z'][:, :n].cpu() - z_ref[:, :n]).abs().max().item() < FWD_TOL
+    assert torch.isfinite(world_of(out)).all()
+    # use_mean
+    out_m = hm.roll_out(past.to(device), None, n_mean, z_seq=None, use_mean=True)
+    w_m, _ = H.roll_out(sd, past, None, eps_seq=torch.zeros(B, n_mean, 48))
+    assert (world_of(out_m).cpu() - w_m).abs().max().item() < FWD_TOL
+    # canonicalize_input (+ uncanonicalize_output): a state rotated/translated in the world
+    from humor_amd import frames
+    ang = torch.tensor([0.7, -1.2])[:B]
+    Rz = L.batch_rodrigues(torch.stack([torch.zeros_like(ang), torch.zeros_like(ang), ang], 1))
+    shift = torch.tensor([[1.5, -0.7, 0.0], [-2.0, 0.3, 0.0]])[:B]
+    rot = lambda v: torch.einsum('bij,bj->bi', Rz, v)
+    j = torch.einsum('bij,bkj->bki', Rz, past[:, 207:273].reshape(B, 22, 3)) + shift.unsqueeze(1)
+    jv = torch.einsum('bij,bkj->bki', Rz, past[:, 273:339].reshape(B, 22, 3))
+    moved = torch.cat([rot(past[:, 0:3]) + shift, rot(past[:, 3:6]), torch.matmul(Rz, past[:, 6:15].reshape(B, 3, 3)).reshape(B, 9),
+                       rot(past[:, 15:18]), past[:, 18:207], j.reshape(B, 66), jv.reshape(B, 66)], 1)
+    z = torch.randn(B, n_canon, 48, generator=g)
+    keys = ['trans', 'trans_vel', 'root_orient', 'root_orient_vel', 'pose_body', 'joints', 'joints_vel']
+    dims = [3, 3, 9, 3, 189, 66, 66]
+    d, o = {}, 0
+    for k, nn in zip(keys, dims):
+        d[k] = moved[:, o:o + nn].unsqueeze(1).to(device)
+        o += nn
+    out_c = hm.roll_out(None, d, n_canon, z_seq=z.to(device), canonicalize_input=True, uncanonicalize_output=True)
+    local, (R0, t0, t2j) = frames.canonicalize_state(moved)
+    w_c, _ = H.roll_out(sd, local, z, G0=R0, gt0=t0, t2j=t2j)
+    assert (world_of(out_c).cpu() - w_c).abs().max().item() < 2e-4
+    out_cc = hm.roll_out(None, d, n_canon, z_seq=z.to(device), canonicalize_input=True)
+    w_cc, _ = H.roll_out(sd, local, z, t2j=t2j)
+    assert (world_of(out_cc).cpu() - w_cc).abs().max().item() < 2e-4

@@ -26,3 +26,8 @@ def test_rollout_refuses_cpu():
         hm.roll_out(torch.zeros(2, 339), None, 2, z_seq=torch.zeros(2, 2, 48))
     with pytest.raises(NotImplementedError):
         HumorModel(in_rot_rep='aa', out_rot_rep='aa').roll_out(torch.zeros(2, 300), None, 2, z_seq=torch.zeros(2, 2, 48))
+
+
+@pytest.mark.slow
+def test_emu_sampling_and_canonicalize(emu_lib):
+    RC.check_sampling_rollout(emu_lib, torch.device('cpu'), B=2, S=2, n_mean=1, n_canon=1)

@@ -58,3 +58,7 @@ def test_c5_size_rollout(gpu_lib, dev):
     assert torch.isfinite(big).all()
     small = RC.world_of(hm.roll_out(past[64:96], None, 119, z_seq=z[64:96]))
     assert torch.equal(big[64:96], small)
+
+
+def test_sampling_and_canonicalize(gpu_lib, dev):
+    RC.check_sampling_rollout(gpu_lib, dev, B=2, S=30)
