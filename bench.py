@@ -36,10 +36,11 @@ V, J = 6890, 52
 # algorithmic HBM bytes per frame of the LBS skinning kernel = read v_posed (V*12) + A (J*48), write verts (V*12)
 SKIN_BYTES_PER_FRAME = V * 12 * 2 + J * 48
 # HBM traffic of one ha_lbs_skin launch at N=1920 from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
-# tools/skin_once.py; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM', WRITE_SIZE as reported, both x1024):
-# 2 * 97000 KB + 188580 KB.  Offline measurement (counters cannot be read inside bench.py); see profiles/r01_run5_pmc_lbs/.
-PMC_TRAFFIC_BYTES = int((2 * 97000.2 + 188580.7) * 1024)
-PMC_TRAFFIC_SOURCE = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_run5_pmc_lbs (FETCH x2 gfx950 correction)'
+# tools/skin_once.py via tools/pmc_lbs.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM', WRITE_SIZE as reported, KiB;
+# both calibrated in the same passes on a device copy of exactly 155,025 KiB): 2 * 88692.8 + 155148.1 KiB.
+# Offline measurement (counters cannot be read inside bench.py); see profiles/r01_run6_pmc_lbs/SUMMARY.txt.
+PMC_TRAFFIC_BYTES = int((2 * 88692.8 + 155148.1) * 1024)
+PMC_TRAFFIC_SOURCE = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_run6_pmc_lbs (FETCH x2 gfx950 correction, copy-calibrated)'
 
 
 def parse():

@@ -7,6 +7,13 @@
 
 #include "../../include/humor_amd.h"
 
+// occupancy hint for a kernel (register budget = 512 / waves); the host SIMT emulator of the test tier has no such notion
+#ifdef HA_SIMT_EMU
+#define HA_WAVES_PER_EU(lo, hi)
+#else
+#define HA_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
+
 namespace ha {
 
 void set_error(const char* fmt, ...);

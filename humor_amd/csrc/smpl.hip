@@ -14,8 +14,8 @@
 //                           scan with parent-side (deterministic) accumulation over a children CSR.
 //   pose_blend_mfma_kernel  dense path: v_posed[N, V*3] = C[N,Kc] x Pd[Kc, V*3] on v_mfma_f32_32x32x2_f32
 //                           (exact fp32), 64 frames x 32 vertices (x,y,z as three column tiles) per wave.
-//   lbs_skin_kernel         dense path: the HBM-streaming skinning kernel, 16-byte coalesced loads/stores of
-//                           the [N,V,3] arrays through an LDS transpose, A of the touched frames in LDS.
+//   lbs_skin_wave_kernel    dense path: the HBM-streaming skinning kernel, lane-contiguous 16-byte loads / non-temporal
+//                           stores of the [N,V,3] arrays through a per-wave LDS transpose, A of the touched frames in LDS.
 #include <stdarg.h>
 #include <string.h>
 
@@ -36,7 +36,9 @@ void set_error(const char* fmt, ...) {
 }  // namespace ha
 
 namespace ha {
-int g_skin_variant = -1;  // -1 = auto: direct kernel, NT stores when the output fits the 256 MiB Infinity Cache   // 0: LDS-staged window, 1: + hoisted weight loads, 2: direct 48-byte per-thread path, 3: frame-pair windows; +4: non-temporal; +8/+16: 2/4 vertex groups per thread (variant 2)
+// ha_tune_set("skin_variant"): -1 = auto; else bits 0-1: waves per block 4 << b; +4: non-temporal stores;
+// +8 / +16: profiling modes of the streaming kernel (LDS-transposed copy only / every lane gathers bone 0)
+int g_skin_variant = -1;
 }
 extern "C" int ha_tune_set(const char* key, int value) {
   HA_REQUIRE(key, "ha_tune_set: null key");
@@ -749,340 +751,152 @@ __global__ __launch_bounds__(256) void pose_blend_mfma_kernel(const float* __res
 
 // ===================================================================================================
 // dense path: streaming linear-blend skinning (HBM-bound)
-// Flat partition of the [N*V] vertex index space: block b owns global vertices [1024 b, 1024 b + 1024), i.e. a
-// 12 KiB, 16-byte aligned window of both arrays that spans at most two frames (V >= 1024).
+// Flat partition of the [N*V] vertex index space: a block of NW waves owns 256*NW consecutive global vertices, i.e. a
+// 16-byte aligned window of both arrays that spans at most two frames (V >= 256*NW).
 // ===================================================================================================
-constexpr int kSkinVerts = 1024;
-
-__global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__ v_posed, const float* __restrict__ A,
-                                                       const float* __restrict__ transl, const float4* __restrict__ w4,
-                                                       const uint32_t* __restrict__ idx4, float* __restrict__ verts,
-                                                       int N, int V, int J, int hoist) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_v = smem;                      // 3072 floats
-  float* s_A = smem + kSkinVerts * 3;     // 2 frames x J x 12 floats
-  const int tid = threadIdx.x;
-  const long long total = (long long)N * V;
-  const long long gv0 = (long long)blockIdx.x * kSkinVerts;
-  const int n0 = (int)(gv0 / V);
-  const long long total3 = total * 3;
-  const long long fbase = gv0 * 3;        // first float of the window (multiple of 4 floats)
-
-  // A of the (at most two) frames this window touches
-  {
-    const int per = J * 3;                // float4s per frame
-    const float4* A4 = reinterpret_cast<const float4*>(A);
-    float4* sA4 = reinterpret_cast<float4*>(s_A);
-    for (int i = tid; i < 2 * per; i += 256) {
-      const int fr = i / per;
-      if (n0 + fr < N) sA4[i] = A4[(size_t)(n0 + fr) * per + (i - fr * per)];
-    }
-  }
-  // coalesced 16-byte loads of the window
-  {
-    const float4* src = reinterpret_cast<const float4*>(v_posed + fbase);
-    float4* dst = reinterpret_cast<float4*>(s_v);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int i = tid + 256 * q;
-      const long long fl = fbase + (long long)i * 4;
-      if (fl + 3 < total3) {
-        dst[i] = src[i];
-      } else {
-        for (int e = 0; e < 4; ++e)
-          if (fl + e < total3) s_v[i * 4 + e] = v_posed[fl + e];
-      }
-    }
-  }
-  const long long frame1_start = (long long)(n0 + 1) * V;
-  float4 hw[4];
-  uint32_t hid[4];
-  if (hoist) {
-#pragma unroll
-    for (int sidx = 0; sidx < 4; ++sidx) {
-      const long long gv = gv0 + tid + 256 * sidx;
-      const int fr = gv >= frame1_start ? 1 : 0;
-      int v = (int)(gv - (long long)(n0 + fr) * V);
-      if (gv >= total) v = 0;
-      hw[sidx] = w4[v];
-      hid[sidx] = idx4[v];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int sidx = 0; sidx < 4; ++sidx) {
-    const int lv = tid + 256 * sidx;
-    const long long gv = gv0 + lv;
-    if (gv < total) {
-      const int fr = gv >= frame1_start ? 1 : 0;
-      const int n = n0 + fr;
-      const int v = (int)(gv - (long long)n * V);
-      const float4 wv = hoist ? hw[sidx] : w4[v];
-      const uint32_t id = hoist ? hid[sidx] : idx4[v];
-      const float x = s_v[lv * 3], y = s_v[lv * 3 + 1], z = s_v[lv * 3 + 2];
-      const float4* Af = reinterpret_cast<const float4*>(s_A + fr * J * 12);
-      const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
-      float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int jq = (id >> (8 * q)) & 0xff;
-        const float4 a0 = Af[jq * 3], a1 = Af[jq * 3 + 1], a2 = Af[jq * 3 + 2];
-        r0.x = fmaf(wq[q], a0.x, r0.x); r0.y = fmaf(wq[q], a0.y, r0.y); r0.z = fmaf(wq[q], a0.z, r0.z); r0.w = fmaf(wq[q], a0.w, r0.w);
-        r1.x = fmaf(wq[q], a1.x, r1.x); r1.y = fmaf(wq[q], a1.y, r1.y); r1.z = fmaf(wq[q], a1.z, r1.z); r1.w = fmaf(wq[q], a1.w, r1.w);
-        r2.x = fmaf(wq[q], a2.x, r2.x); r2.y = fmaf(wq[q], a2.y, r2.y); r2.z = fmaf(wq[q], a2.z, r2.z); r2.w = fmaf(wq[q], a2.w, r2.w);
-      }
-      // T = [R00 R01 R02 R10 | R11 R12 R20 R21 | R22 t0 t1 t2]
-      float tx = 0.f, ty = 0.f, tz = 0.f;
-      if (transl) { tx = transl[(size_t)n * 3]; ty = transl[(size_t)n * 3 + 1]; tz = transl[(size_t)n * 3 + 2]; }
-      const float ox = fmaf(r0.x, x, fmaf(r0.y, y, fmaf(r0.z, z, r2.y))) + tx;
-      const float oy = fmaf(r0.w, x, fmaf(r1.x, y, fmaf(r1.y, z, r2.z))) + ty;
-      const float oz = fmaf(r1.z, x, fmaf(r1.w, y, fmaf(r2.x, z, r2.w))) + tz;
-      s_v[lv * 3] = ox; s_v[lv * 3 + 1] = oy; s_v[lv * 3 + 2] = oz;
-    }
-  }
-  __syncthreads();
-  {
-    float4* dst = reinterpret_cast<float4*>(verts + fbase);
-    const float4* src = reinterpret_cast<const float4*>(s_v);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int i = tid + 256 * q;
-      const long long fl = fbase + (long long)i * 4;
-      if (fl + 3 < total3) {
-        dst[i] = src[i];
-      } else {
-        for (int e = 0; e < 4; ++e)
-          if (fl + e < total3) verts[fl + e] = s_v[i * 4 + e];
-      }
-    }
-  }
-}
-
+constexpr int kSkinMinVerts = 1024;     // smallest block window (4 waves)
 typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
 
-template <bool NT>
-__device__ __forceinline__ void store4(float* dst, float a, float b, float c, float d) {
-  vf4 v = {a, b, c, d};
-  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<vf4*>(dst));
-  else *reinterpret_cast<vf4*>(dst) = v;
-}
-
+// One vertex: T = sum_q w_q A_q (12 floats), out = T [v; 1] + transl.  The blend runs as packed fp32 FMAs (v_pk_fma_f32:
+// two IEEE fmaf per lane per instruction, bit-identical to the scalar chain) -- at 7 TB/s the VALU, not only the memory
+// system, is on the critical path of this kernel (~110 scalar VALU ops per vertex before packing).
 __device__ __forceinline__ void skin_one(const float* s_A, int J, int fr, float4 wv, uint32_t id, float x, float y, float z,
                                          float tx, float ty, float tz, float& ox, float& oy, float& oz) {
-  const float4* Af = reinterpret_cast<const float4*>(s_A + fr * J * 12);
+  const vf4* Af = reinterpret_cast<const vf4*>(s_A + fr * J * 12);
   const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
-  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+  vf2 r[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r[i] = vf2{0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int jq = (id >> (8 * q)) & 0xff;
-    const float4 a0 = Af[jq * 3], a1 = Af[jq * 3 + 1], a2 = Af[jq * 3 + 2];
-    r0.x = fmaf(wq[q], a0.x, r0.x); r0.y = fmaf(wq[q], a0.y, r0.y); r0.z = fmaf(wq[q], a0.z, r0.z); r0.w = fmaf(wq[q], a0.w, r0.w);
-    r1.x = fmaf(wq[q], a1.x, r1.x); r1.y = fmaf(wq[q], a1.y, r1.y); r1.z = fmaf(wq[q], a1.z, r1.z); r1.w = fmaf(wq[q], a1.w, r1.w);
-    r2.x = fmaf(wq[q], a2.x, r2.x); r2.y = fmaf(wq[q], a2.y, r2.y); r2.z = fmaf(wq[q], a2.z, r2.z); r2.w = fmaf(wq[q], a2.w, r2.w);
+    const vf4 a0 = Af[jq * 3], a1 = Af[jq * 3 + 1], a2 = Af[jq * 3 + 2];
+    const vf2 w2 = {wq[q], wq[q]};
+    r[0] = __builtin_elementwise_fma(w2, a0.lo, r[0]);
+    r[1] = __builtin_elementwise_fma(w2, a0.hi, r[1]);
+    r[2] = __builtin_elementwise_fma(w2, a1.lo, r[2]);
+    r[3] = __builtin_elementwise_fma(w2, a1.hi, r[3]);
+    r[4] = __builtin_elementwise_fma(w2, a2.lo, r[4]);
+    r[5] = __builtin_elementwise_fma(w2, a2.hi, r[5]);
   }
-  // T = [R00 R01 R02 R10 | R11 R12 R20 R21 | R22 t0 t1 t2]
-  ox = fmaf(r0.x, x, fmaf(r0.y, y, fmaf(r0.z, z, r2.y))) + tx;
-  oy = fmaf(r0.w, x, fmaf(r1.x, y, fmaf(r1.y, z, r2.z))) + ty;
-  oz = fmaf(r1.z, x, fmaf(r1.w, y, fmaf(r2.x, z, r2.w))) + tz;
+  // T = [R00 R01 | R02 R10 | R11 R12 | R20 R21 | R22 t0 | t1 t2]
+  ox = fmaf(r[0].x, x, fmaf(r[0].y, y, fmaf(r[1].x, z, r[4].y))) + tx;
+  oy = fmaf(r[1].y, x, fmaf(r[2].x, y, fmaf(r[2].y, z, r[5].x))) + ty;
+  oz = fmaf(r[3].x, x, fmaf(r[3].y, y, fmaf(r[4].x, z, r[5].y))) + tz;
 }
 
-// Variant 2: no LDS staging of the vertices.  A block owns a window of 1024*GPT consecutive global vertices (16-byte
-// aligned, at most two frames); thread t owns the four-vertex groups t, t+256, ... (GPT of them) = GPT x three 16-byte
-// loads / stores, all issued up front: the kernel is latency-bound, so bytes in flight per wave are what matters
-// (rocprofv3: ~16 resident waves/CU, LDS bank conflicts 6 % of LDS-active cycles -- profiles/r01_run5_pmc_lbs).
-template <bool NT, int GPT>
-__global__ __launch_bounds__(256) void lbs_skin_direct_kernel(const float* __restrict__ v_posed, const float* __restrict__ A,
-                                                              const float* __restrict__ transl, const float4* __restrict__ w4,
-                                                              const uint32_t* __restrict__ idx4, float* __restrict__ verts,
-                                                              int N, int V, int J, int nblocks) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_A = smem;   // 2 frames x J x 12
-  const int tid = threadIdx.x;
-  constexpr int WIN = kSkinVerts * GPT;
-  const int win = blockIdx.x;       // (an XCD-contiguous remap of the windows measured neutral-to-worse)
-  (void)nblocks;
-  const long long total = (long long)N * V;
-  const long long gv0 = (long long)win * WIN;
+// "Wave-sliced" streaming kernel: every global access is lane-contiguous (each 16-byte wave instruction covers 1 KiB), which is
+// what the HBM/Infinity-Cache path wants (tools/microbench/hbm_stream.hip: 7.0-7.2 TB/s for this geometry with
+// non-temporal stores against 4-5.5 TB/s for per-thread 48-byte runs).  The [vertex][xyz] <-> 16-byte-vector transposition
+// goes through a PRIVATE 3 KiB LDS slice per wave (256 vertices), so the only block barrier is the early one that
+// publishes the <=2 frames' A matrices; the waves of a block then drift apart and overlap their load / skin / store phases.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// INTERIOR: the whole block window lies inside [0, N*V) (every block but the last) -- all guards fold away and the
+// addressing is a block-uniform base pointer plus 32-bit lane offsets (the 64-bit per-lane form costs ~100 VALU ops).
+template <bool NT, int DIAG, int NW, bool INTERIOR>
+__device__ __forceinline__ void skin_wave_body(const float* __restrict__ v_posed, const float* __restrict__ A,
+                                               const float* __restrict__ transl, const float4* __restrict__ w4,
+                                               const uint32_t* __restrict__ idx4, float* __restrict__ verts, int N, int V, int J,
+                                               float* smem) {
+  float* s_A = smem;                                   // 2 frames x J x 12
+  const int tid = threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
+  float* s_v = smem + 2 * J * 12 + wv_id * 768;        // this wave's 256 vertices
+  const long long gv0 = (long long)blockIdx.x * (256 * NW);
   const int n0 = (int)(gv0 / V);
-  const long long total3 = total * 3;
-  const long long frame1_start = (long long)(n0 + 1) * V;
-  float f[GPT][12];
-  float4 wv[GPT][4];
-  uint32_t id[GPT][4];
-  int frs[GPT][4];
-  bool full[GPT];
-  // issue every global load up front
-#pragma unroll
-  for (int g = 0; g < GPT; ++g) {
-    const long long gvt = gv0 + 4 * (tid + 256 * g);
-    const long long fl = gvt * 3;
-    full[g] = fl + 11 < total3;
-    if (full[g]) {
-      const vf4* src = reinterpret_cast<const vf4*>(v_posed + fl);
-      vf4 a, b, c;
-      a = src[0]; b = src[1]; c = src[2];     // (non-temporal LOADS measured 25-35 % slower; only the stores are NT)
-      f[g][0] = a.x; f[g][1] = a.y; f[g][2] = a.z; f[g][3] = a.w; f[g][4] = b.x; f[g][5] = b.y; f[g][6] = b.z; f[g][7] = b.w;
-      f[g][8] = c.x; f[g][9] = c.y; f[g][10] = c.z; f[g][11] = c.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 12; ++e) f[g][e] = fl + e < total3 ? v_posed[fl + e] : 0.f;
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < GPT; ++g)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const long long gv = gv0 + 4 * (tid + 256 * g) + k;
-      const int fr = gv >= frame1_start ? 1 : 0;
-      int v = (int)(gv - (long long)(n0 + fr) * V);
-      if (gv >= total) v = 0;
-      frs[g][k] = fr;
-      wv[g][k] = w4[v];
-      id[g][k] = idx4[v];
-    }
-  float tl[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-  if (transl) {
-#pragma unroll
-    for (int fr = 0; fr < 2; ++fr)
-      if (n0 + fr < N) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) tl[fr][c] = transl[(size_t)(n0 + fr) * 3 + c];
-      }
-  }
-  {
+  const int rel0 = (int)(gv0 - (long long)n0 * V);     // window start within frame n0
+  const long long rem3 = ((long long)N * V - gv0) * 3; // floats from the window start to the end of the arrays
+  const bool two = rel0 + 256 * NW > V && n0 + 1 < N;  // does the window reach into frame n0 + 1?
+  // A first (the barrier below waits for these only), then the streaming loads
+  if (DIAG != 1) {
     const int per = J * 3;
-    const float4* A4 = reinterpret_cast<const float4*>(A);
+    const float4* A4 = reinterpret_cast<const float4*>(A) + (size_t)n0 * per;
     float4* sA4 = reinterpret_cast<float4*>(s_A);
-    for (int i = tid; i < 2 * per; i += 256) {
-      const int fr = i / per;
-      if (n0 + fr < N) sA4[i] = A4[(size_t)(n0 + fr) * per + (i - fr * per)];
-    }
+    const int cnt = two ? 2 * per : per;               // the two frames' A are contiguous in memory
+    for (int i = tid; i < cnt; i += 64 * NW) sA4[i] = A4[i];
   }
-  __syncthreads();
+  const float* src = v_posed + gv0 * 3;                // block-uniform bases (16-byte aligned: 256 * NW * 3 floats per window)
+  float* dst = verts + gv0 * 3;
+  const int f0 = (wv_id * 192 + lane) * 4;             // this lane's first float within the window
+  vf4 q[3];
 #pragma unroll
-  for (int g = 0; g < GPT; ++g) {
-    float o[12];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int fr = frs[g][k];
-      skin_one(s_A, J, fr, wv[g][k], id[g][k], f[g][3 * k], f[g][3 * k + 1], f[g][3 * k + 2], tl[fr][0], tl[fr][1], tl[fr][2],
-               o[3 * k], o[3 * k + 1], o[3 * k + 2]);
-    }
-    const long long fl = (gv0 + 4 * (tid + 256 * g)) * 3;
-    if (full[g]) {
-      float* dst = verts + fl;
-      store4<NT>(dst, o[0], o[1], o[2], o[3]);
-      store4<NT>(dst + 4, o[4], o[5], o[6], o[7]);
-      store4<NT>(dst + 8, o[8], o[9], o[10], o[11]);
+  for (int k = 0; k < 3; ++k) {
+    const int fl = f0 + 256 * k;
+    if (INTERIOR || fl + 3 < rem3) {
+      q[k] = *reinterpret_cast<const vf4*>(src + fl);
     } else {
+      q[k] = vf4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 12; ++e)
-        if (fl + e < total3) verts[fl + e] = o[e];
+      for (int e = 0; e < 4; ++e)
+        if (fl + e < rem3) q[k][e] = src[fl + e];
     }
   }
-}
-
-// Variant 3: frame-PAIR windows.  V is even (6890), so two consecutive frames form a 16-byte aligned unit of V/2 groups of
-// four vertices whose (frame, vertex) pattern is identical in every pair.  A block owns one 256-group window and walks
-// P consecutive pairs with the per-thread skinning weights held in registers (weight/index traffic / P, one barrier per
-// pair), prefetching the next pair's 48 bytes per thread while the current one is skinned.
-template <bool NT, int P>
-__global__ __launch_bounds__(256) void lbs_skin_pairs_kernel(const float* __restrict__ v_posed, const float* __restrict__ A,
-                                                             const float* __restrict__ transl, const float4* __restrict__ w4,
-                                                             const uint32_t* __restrict__ idx4, float* __restrict__ verts,
-                                                             int N, int V, int J, int nwin) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 buffers x 2 frames x J x 12
-  const int tid = threadIdx.x;
-  const int win = blockIdx.x % nwin, pg = blockIdx.x / nwin;
-  const int ngroups = V / 2;                   // groups of 4 vertices per frame pair
-  const int grp = win * 256 + tid;
-  const bool lane_ok = grp < ngroups;
-  const int q0 = 4 * grp;                      // flat vertex offset inside the pair
-  const int per = J * 3;                       // float4s of A per frame
-  // per-thread constants: the four vertices' frame-in-pair, weights and joints
-  float4 wv[4];
+  float4 wgt[4];
   uint32_t id[4];
   int frs[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int q = q0 + k;
-    frs[k] = q >= V ? 1 : 0;
-    const int v = lane_ok ? q - frs[k] * V : 0;
-    wv[k] = w4[v];
-    id[k] = idx4[v];
+    const int rel = rel0 + wv_id * 256 + lane + 64 * k;
+    const int fr = rel >= V ? 1 : 0;
+    int v = rel - (fr ? V : 0);
+    if (!INTERIOR && n0 + fr >= N) v = 0;
+    frs[k] = fr;
+    wgt[k] = w4[v];
+    id[k] = DIAG == 2 ? 0u : idx4[v];
   }
-  const int npairs = (N + 1) / 2;
-  const int pair0 = pg * P;
-  auto load_pair = [&](int pair, float (&f)[12]) {
-    const long long fl = ((long long)2 * pair * V + q0) * 3;
-    const bool full = lane_ok && (2 * pair + 1 < N || q0 + 3 < V);
-    if (full) {
-      const vf4* src = reinterpret_cast<const vf4*>(v_posed + fl);
-      vf4 a, b, c;
-      if (NT) { a = __builtin_nontemporal_load(src); b = __builtin_nontemporal_load(src + 1); c = __builtin_nontemporal_load(src + 2); }
-      else { a = src[0]; b = src[1]; c = src[2]; }
-      f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-      f[8] = c.x; f[9] = c.y; f[10] = c.z; f[11] = c.w;
+  float tl[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  if (transl) {
+#pragma unroll
+    for (int fr = 0; fr < 2; ++fr)
+      if (fr == 0 || two) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tl[fr][c] = transl[(size_t)(n0 + fr) * 3 + c];
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) *reinterpret_cast<vf4*>(s_v + (lane + 64 * k) * 4) = q[k];
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float* pv = s_v + (lane + 64 * k) * 3;
+    const int fr = frs[k];
+    float ox, oy, oz;
+    if (DIAG == 1) { ox = pv[0] + wgt[k].x; oy = pv[1] + wgt[k].y; oz = pv[2] + tl[fr][2]; }
+    else skin_one(s_A, J, fr, wgt[k], id[k], pv[0], pv[1], pv[2], tl[fr][0], tl[fr][1], tl[fr][2], ox, oy, oz);
+    pv[0] = ox; pv[1] = oy; pv[2] = oz;
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int fl = f0 + 256 * k;
+    const vf4 o = *reinterpret_cast<const vf4*>(s_v + (lane + 64 * k) * 4);
+    if (INTERIOR || fl + 3 < rem3) {
+      if (NT) __builtin_nontemporal_store(o, reinterpret_cast<vf4*>(dst + fl));
+      else *reinterpret_cast<vf4*>(dst + fl) = o;
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool ok = lane_ok && 2 * pair + frs[k] < N;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) f[3 * k + c] = ok ? v_posed[fl + 3 * k + c] : 0.f;
-      }
+      for (int e = 0; e < 4; ++e)
+        if (fl + e < rem3) dst[fl + e] = o[e];
     }
-  };
-  float cur[12], nxt[12];
-  if (pair0 < npairs) load_pair(pair0, cur);
-#pragma unroll 1
-  for (int p = 0; p < P; ++p) {
-    const int pair = pair0 + p;
-    if (pair >= npairs) break;
-    float* s_A = smem + (p & 1) * 2 * J * 12;
-    {
-      const float4* A4 = reinterpret_cast<const float4*>(A);
-      float4* sA4 = reinterpret_cast<float4*>(s_A);
-      for (int i = tid; i < 2 * per; i += 256) {
-        const int fr = i / per;
-        if (2 * pair + fr < N) sA4[i] = A4[(size_t)(2 * pair + fr) * per + (i - fr * per)];
-      }
-    }
-    if (p + 1 < P && pair + 1 < npairs) load_pair(pair + 1, nxt);
-    float tl[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    if (transl) {
-#pragma unroll
-      for (int fr = 0; fr < 2; ++fr)
-        if (2 * pair + fr < N) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) tl[fr][c] = transl[(size_t)(2 * pair + fr) * 3 + c];
-        }
-    }
-    __syncthreads();      // A of this pair is in LDS (the other buffer may still be read by slower waves of the previous pair)
-    float o[12];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int fr = frs[k];
-      skin_one(s_A, J, fr, wv[k], id[k], cur[3 * k], cur[3 * k + 1], cur[3 * k + 2], tl[fr][0], tl[fr][1], tl[fr][2], o[3 * k],
-               o[3 * k + 1], o[3 * k + 2]);
-    }
-    const long long fl = ((long long)2 * pair * V + q0) * 3;
-    const bool full = lane_ok && (2 * pair + 1 < N || q0 + 3 < V);
-    if (full) {
-      float* dst = verts + fl;
-      store4<NT>(dst, o[0], o[1], o[2], o[3]);
-      store4<NT>(dst + 4, o[4], o[5], o[6], o[7]);
-      store4<NT>(dst + 8, o[8], o[9], o[10], o[11]);
-    } else if (lane_ok) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (2 * pair + frs[k] < N) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) verts[fl + 3 * k + c] = o[3 * k + c];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 12; ++e) cur[e] = nxt[e];
   }
+}
+
+template <bool NT, int DIAG, int NW>
+__global__ __launch_bounds__(64 * NW) void lbs_skin_wave_kernel(const float* __restrict__ v_posed, const float* __restrict__ A,
+                                                                const float* __restrict__ transl, const float4* __restrict__ w4,
+                                                                const uint32_t* __restrict__ idx4, float* __restrict__ verts,
+                                                                int N, int V, int J) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((long long)(blockIdx.x + 1) * (256 * NW) <= (long long)N * V)
+    skin_wave_body<NT, DIAG, NW, true>(v_posed, A, transl, w4, idx4, verts, N, V, J, smem);
+  else
+    skin_wave_body<NT, DIAG, NW, false>(v_posed, A, transl, w4, idx4, verts, N, V, J, smem);
 }
 
 static void fill_model(FrameParams& p, const ha_smpl_model* m, int slot) {
@@ -1119,45 +933,29 @@ extern "C" int ha_lbs_skin(const ha_smpl_model* m, int N, const float* v_posed, 
                            float* verts, void* stream) {
   HA_REQUIRE(m && v_posed && A && verts, "ha_lbs_skin: null argument");
   HA_REQUIRE(N >= 1, "ha_lbs_skin: N must be >= 1");
-  if (m->nnz > 4 || m->V < kSkinVerts) {
-    set_error("ha_lbs_skin: needs <=4 influences per vertex and V>=%d (model has nnz=%d V=%d)", kSkinVerts, m->nnz, m->V);
+  if (m->nnz > 4 || m->V < kSkinMinVerts) {
+    set_error("ha_lbs_skin: needs <=4 influences per vertex and V>=%d (model has nnz=%d V=%d)", kSkinMinVerts, m->nnz, m->V);
     return HA_ERR_UNSUPPORTED;
   }
   DeviceGuard guard(m->device);
   const long long total = (long long)N * m->V;
-  const int blocks = (int)((total + kSkinVerts - 1) / kSkinVerts);
-  const size_t lds = (size_t)(kSkinVerts * 3 + 2 * m->J * 12) * sizeof(float);
-  const int sv = g_skin_variant >= 0 ? g_skin_variant : (total * 12 <= (200ll << 20) ? 6 : 2);
-  const int variant = sv & 3;
+  // auto: 8 waves per block while the arrays fit the 256 MiB Infinity Cache, 16 beyond (measured +2 % at N=30720);
+  // non-temporal stores always (the output is consumed by another kernel, never re-read by this one)
+  const int sv = g_skin_variant >= 0 ? g_skin_variant : ((total * 12 <= (400ll << 20) ? 1 : 2) | 4);
+  int nw = 4 << (sv & 3);
+  while (nw > 4 && m->V < 256 * nw) nw >>= 1;
   const bool nt = (sv & 4) != 0;
-  if (variant == 3 && m->V % 2 == 0) {
-    constexpr int P = 4;
-    const int nwin = ceil_div(m->V / 2, 256);
-    const int npg = ceil_div(ceil_div(N, 2), P);
-    const size_t lds3 = (size_t)(2 * 2 * m->J * 12) * sizeof(float);
-    if (nt)
-      hipLaunchKernelGGL((lbs_skin_pairs_kernel<true, P>), dim3(nwin * npg), dim3(256), lds3, (hipStream_t)stream, v_posed, A, transl,
-                         m->w4, m->idx4, verts, N, m->V, m->J, nwin);
-    else
-      hipLaunchKernelGGL((lbs_skin_pairs_kernel<false, P>), dim3(nwin * npg), dim3(256), lds3, (hipStream_t)stream, v_posed, A, transl,
-                         m->w4, m->idx4, verts, N, m->V, m->J, nwin);
-  } else if (variant == 2 || variant == 3) {
-    const size_t lds2 = (size_t)(2 * m->J * 12) * sizeof(float);
-    const int gpt = (sv >> 3) & 3;      // 0: 1 group/thread, 1: 2, 2: 4
-#define HA_SKIN_LAUNCH(NTV, G)                                                                                          \
-    do {                                                                                                                 \
-      const int nb = (int)((total + (long long)kSkinVerts * G - 1) / ((long long)kSkinVerts * G));                       \
-      hipLaunchKernelGGL((lbs_skin_direct_kernel<NTV, G>), dim3(nb), dim3(256), lds2, (hipStream_t)stream, v_posed, A,   \
-                         transl, m->w4, m->idx4, verts, N, m->V, m->J, nb);                                              \
-    } while (0)
-    if (gpt == 2 && m->V >= 4 * kSkinVerts) { if (nt) HA_SKIN_LAUNCH(true, 4); else HA_SKIN_LAUNCH(false, 4); }
-    else if (gpt == 1 && m->V >= 2 * kSkinVerts) { if (nt) HA_SKIN_LAUNCH(true, 2); else HA_SKIN_LAUNCH(false, 2); }
-    else { if (nt) HA_SKIN_LAUNCH(true, 1); else HA_SKIN_LAUNCH(false, 1); }
-#undef HA_SKIN_LAUNCH
-  } else {
-    hipLaunchKernelGGL(lbs_skin_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, v_posed, A, transl, m->w4, m->idx4,
-                       verts, N, m->V, m->J, variant);
-  }
+  const int diag = (sv >> 3) & 3;
+  const int nb = (int)((total + 256 * nw - 1) / (256 * nw));
+  const size_t lds = (size_t)(2 * m->J * 12 + 256 * nw * 3) * sizeof(float);
+#define HA_SKIN(NTV, D, NWV) hipLaunchKernelGGL((lbs_skin_wave_kernel<NTV, D, NWV>), dim3(nb), dim3(64 * NWV), lds, (hipStream_t)stream, \
+                                               v_posed, A, transl, m->w4, m->idx4, verts, N, m->V, m->J)
+  if (diag == 1) HA_SKIN(true, 1, 8);
+  else if (diag == 2) HA_SKIN(true, 2, 8);
+  else if (nw == 4) { if (nt) HA_SKIN(true, 0, 4); else HA_SKIN(false, 0, 4); }
+  else if (nw == 8) { if (nt) HA_SKIN(true, 0, 8); else HA_SKIN(false, 0, 8); }
+  else { if (nt) HA_SKIN(true, 0, 16); else HA_SKIN(false, 0, 16); }
+#undef HA_SKIN
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -1169,9 +967,9 @@ extern "C" int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_ac
   if (rc != HA_OK) return rc;
   HA_REQUIRE(pose && betas, "ha_smpl_forward: pose and betas are required");
   HA_REQUIRE(algo >= 0 && algo <= 2, "ha_smpl_forward: unknown algo %d", algo);
-  const bool dense_ok = slot == 0 && m->nnz <= 4 && m->V >= kSkinVerts && ws_vposed && ws_coeff && A_out;
+  const bool dense_ok = slot == 0 && m->nnz <= 4 && m->V >= kSkinMinVerts && ws_vposed && ws_coeff && A_out;
   if (algo == 2 && !dense_ok) {
-    set_error("ha_smpl_forward: algo 2 needs slot 0, <=4 skinning influences, V>=%d and the A/vposed/coeff workspaces", kSkinVerts);
+    set_error("ha_smpl_forward: algo 2 needs slot 0, <=4 skinning influences, V>=%d and the A/vposed/coeff workspaces", kSkinMinVerts);
     return HA_ERR_INVALID_ARG;
   }
   if (algo == 0) algo = (dense_ok && verts) ? 2 : 1;

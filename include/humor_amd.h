@@ -34,7 +34,7 @@ const char* ha_last_error(void);
 int ha_abi_version(void);
 /* Writes the device's gcnArchName (e.g. "gfx950:sramecc+:xnack-") into buf. */
 int ha_device_arch(int device, char* buf, int buflen);
-/* Development knob for kernel variants (A/B measurements); keys: "skin_variant". Process-wide. */
+/* Development knob for kernel launch variants (A/B measurements); keys: "skin_variant" (-1 = auto). Process-wide. */
 int ha_tune_set(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 // Model: one OS thread per work-item of a block (blocks run one after another), std::barrier for
 // __syncthreads, a per-wave exchange buffer + barrier for cross-lane ops.  Wave size 64.
 #pragma once
+#define HA_SIMT_EMU 1
 #include <atomic>
 #include <barrier>
 #include <cmath>
@@ -80,6 +81,9 @@ inline T shfl_any(T v, int src) {
 #define gridDim (simt_emu::t_gridDim)
 
 static inline void __syncthreads() { simt_emu::t_ctx->block_bar->arrive_and_wait(); }
+// wave-scope LDS hand-off: lockstep on hardware, a real per-wave barrier here
+static inline void __builtin_amdgcn_wave_barrier() { simt_emu::wave_sync(); }
+static inline void __builtin_amdgcn_fence(int, const char*) { std::atomic_thread_fence(std::memory_order_seq_cst); }
 template <typename T> static inline T __shfl(T v, int src) { return simt_emu::shfl_any(v, src); }
 template <typename T> static inline T __shfl_xor(T v, int mask) { return simt_emu::shfl_any(v, simt_emu::lane_id() ^ mask); }
 template <typename T> static inline T __shfl_down(T v, int d) { int s = simt_emu::lane_id() + d; return simt_emu::shfl_any(v, s > 63 ? simt_emu::lane_id() : s); }

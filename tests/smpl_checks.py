@@ -80,3 +80,39 @@ def check_golden(lib, npz, device):
     for k, gr in zip(('g_root', 'g_body', 'g_betas', 'g_trans'), grads):
         scale = max(1.0, np.abs(gd[k]).max())
         assert np.abs(gr.cpu().numpy() - gd[k]).max() < GRAD_RTOL * scale, k
+
+
+def check_skin_variants(lib, npz, ds, device, N=3, variants=(5, 4, 6, 0, 1, 2), seed=0):
+    """ha_lbs_skin on its own (the streaming LBS kernel of the roofline): every launch geometry selectable through
+    ha_tune_set('skin_variant') must give the same bits, and those must match the fp64 linear-blend formula
+    verts = (sum_q w_q A_q) [v; 1] + transl  (smplx lbs.py:223-233) to fp32 rounding."""
+    from humor_amd import _lib
+    V, J = ds.v_template.shape[0], ds.weights.shape[1]
+    g = torch.Generator().manual_seed(seed)
+    vp = torch.randn(N * V * 3 + 4, generator=g)
+    A = torch.randn(N, J, 12, generator=g)
+    tr = torch.randn(N, 3, generator=g)
+    W = torch.from_numpy(np.asarray(ds.weights)).double()                      # [V,J]
+    # kernel layout of A: [R00 R01 R02 R10 | R11 R12 R20 R21 | R22 t0 t1 t2]
+    R = A[:, :, :9].reshape(N, J, 3, 3).double()
+    t = A[:, :, 9:12].double()
+    Tr = torch.einsum('vj,njab->nvab', W, R)
+    Tt = torch.einsum('vj,nja->nva', W, t)
+    v = vp[:N * V * 3].reshape(N, V, 3).double()
+    ref = torch.einsum('nvab,nvb->nva', Tr, v) + Tt + tr.double().unsqueeze(1)
+    h = BodyModel(npz, num_betas=16, _lib_override=lib)._handle_for(device)
+    vp_d, A_d, tr_d = vp.to(device), A.to(device), tr.to(device)
+    outs = {}
+    try:
+        for var in variants:
+            lib.call('ha_tune_set', b'skin_variant', var)
+            out = torch.full((N, V, 3), float('nan'), device=device)
+            lib.call('ha_lbs_skin', h.ptr, N, _lib.ptr(vp_d), _lib.ptr(A_d), _lib.ptr(tr_d), _lib.ptr(out), _lib.stream_ptr(out))
+            outs[var] = out.cpu()
+    finally:
+        lib.call('ha_tune_set', b'skin_variant', -1)
+    first = outs[variants[0]]
+    scale = ref.abs().max().item()
+    assert (first.double() - ref).abs().max().item() < 2e-6 * scale
+    for var, o in outs.items():
+        assert torch.equal(o, first), f'skin variant {var} differs from variant {variants[0]}'

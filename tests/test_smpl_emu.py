@@ -37,3 +37,7 @@ def test_no_cpu_fallback(smplh_npz):
     bm = BodyModel(smplh_npz, num_betas=16)
     with pytest.raises((HumorAmdError, RuntimeError)):
         bm(root_orient=torch.zeros(1, 3), pose_body=torch.zeros(1, 63), betas=torch.zeros(1, 16), trans=torch.zeros(1, 3))
+
+
+def test_emu_skin_kernel_variants(emu_lib, smplh_npz, smplh_struct):
+    SC.check_skin_variants(emu_lib, smplh_npz, smplh_struct, torch.device('cpu'), N=2, variants=(5, 4, 2))

@@ -91,3 +91,7 @@ def test_c5_size_dense_smpl(gpu_lib, smplh_npz, smplh_struct, dev):
     assert (o2.Jtr[sel].cpu() - ref.joints).abs().max().item() < 1e-4
     o1 = BodyModel(smplh_npz, num_betas=16, use_vtx_selector=True, algo=1)(**{k: v[-64:] for k, v in inp.items()})
     assert (o1.v - o2.v[-64:]).abs().max().item() < 1e-4
+
+
+def test_skin_kernel_variants(gpu_lib, smplh_npz, smplh_struct, dev):
+    SC.check_skin_variants(gpu_lib, smplh_npz, smplh_struct, dev, N=5)

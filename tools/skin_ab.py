@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""A/B of the LBS skinning kernel variants on the GPU (interleaved rounds in one process).
+"""A/B of the LBS skinning kernel launch variants on the GPU (interleaved rounds in one process).
+skin_variant bits: 0-1 waves/block = 4 << b, +4 non-temporal stores, +8 copy-only profiling mode, +16 uniform-bone mode.
 usage: python tools/skin_ab.py [N ...]"""
 import os
 import sys
@@ -12,6 +13,7 @@ from humor_amd import _lib, synth                      # noqa: E402
 from humor_amd.body_model import BodyModel             # noqa: E402
 
 V, J = 6890, 52
+VARIANTS = [int(v) for v in os.environ.get('SKIN_VARIANTS', '5,4,6,1,13,21').split(',')]
 
 
 def main():
@@ -29,7 +31,7 @@ def main():
         nbytes = N * (V * 24 + J * 48)
         res = {}
         for rnd in range(5):
-            for var in (2, 6, 10, 14, 18, 22):
+            for var in VARIANTS:
                 lib.call('ha_tune_set', b'skin_variant', var)
                 for _ in range(3):
                     lib.call('ha_lbs_skin', h.ptr, N, _lib.ptr(vp), _lib.ptr(A), _lib.ptr(tr), _lib.ptr(out), st)
