@@ -5,12 +5,15 @@
 // (humor/models/humor_model.py:785-1017; prior :407-418, decode :445-498, MLP :1206-1241,
 // apply_world2local_trans :696-772; compute_world2aligned_mat humor/utils/transforms.py:17-42).
 //
-// Data layout: every activation lives transposed in 32-row tiles, X^T[tile][channel][32 rows], so that the A
-// operand of v_mfma_f32_32x32x2_f32 (lane l <-> row l&31, k = l>>5) is a fully coalesced 256-byte read and an
-// output tile's four consecutive rows per lane are one 16-byte store.  Weights are re-packed once into the B
-// operand's lane order.  A wave owns a 64-channel K-slice (= GroupNorm groups, so the statistics are lane-local +
-// one cross-half shuffle); NW waves of a block split K further and reduce through LDS; blocks split K across the
-// chip and the consumer layer's prologue sums those partial slabs (the launch-boundary reduce).
+// Data layout: every activation lives transposed in 32-row tiles with the channels interleaved in quads,
+// X^T[tile][channel/4][32 rows][4], so that the A operand of v_mfma_f32_32x32x2_f32 (lane l <-> row l&31, k = l>>5)
+// is read with eight 16-byte loads per lane and 64-channel slice (the layer is a pure latency chain: a wave can keep
+// only 63 vector-memory instructions in flight, so 4-byte loads -- 32 per slab and operand -- serialised into several
+// memory round trips; in-kernel timestamps: tools/layer_timing.py).  Lane (row, hi) of a slice owns its channels
+// cbase + 32*hi + kp, kp = 0..31; weights are re-packed once into the matching B-operand order.  A wave owns a
+// 64-channel K-slice (one or two GroupNorm groups: statistics are lane-local, plus one cross-half shuffle for 64-channel
+// groups); NW waves of a block split K further and reduce through LDS; blocks split K across the chip and the consumer
+// layer's prologue sums those partial slabs (the launch-boundary reduce).
 #include <string.h>
 
 #include <vector>
@@ -20,16 +23,24 @@
 namespace ha {
 
 constexpr int D_IN = 339, D_RAW = 216, D_STATE = 348, ZD = 48, NJT = 22, NBODY = 21;
-constexpr int NW = 4;            // waves per block in the layer kernel
+constexpr int D_INP = 340;       // D_IN rounded up to a channel quad (the pad channel of a state slab is kept at zero)
 constexpr int SLICE = 64;        // channels per wave K-slice
 constexpr int MAXL = 8;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+// offset of channel c inside one row's view of a quad-interleaved tile: element (c, row) of tile rt of a C-channel slab
+// (C % 4 == 0) is slab[rt * C * 32 + row * 4 + qoff(c)]
+__device__ __forceinline__ size_t qoff(int c) { return (size_t)(c >> 2) * 128 + (c & 3); }
+
+// layer-kernel launch policy picked up by ha_humor_net_create (ha_tune_set "layer_spb" / "layer_nw"; 0 = default)
+int g_layer_spb = 0, g_layer_nw = 0;
 
 struct PackedLayer {
   int Cin = 0, skip = 0, Nout = 0;
-  int nslices_f = 0, main_slices = 0, ntiles_f = 0, nsplit_f = 0, Nout_pad = 0;
-  int nslices_b = 0, ntiles_b = 0, nsplit_b = 0, Nin_pad = 0;
+  int nslices_f = 0, main_slices = 0, ntiles_f = 0, Nout_pad = 0;
+  int nslices_b = 0, ntiles_b = 0, Nin_pad = 0;
   int group = 0;
   float* Wf = nullptr;   // [ntiles_f][nslices_f][32][64]
   float* Wb = nullptr;   // [ntiles_b][nslices_b][32][64]
@@ -58,7 +69,8 @@ struct LayerTask {
   const float* gamma; const float* beta; int group;
   const float* hsrc; int nsplit_h; int Ch;          // mode 3: forward pre-activation slabs of the same channels ([..][Ch][32])
   float* dst;                                       // [nsplit_dst][RT][Nout_pad][32]
-  int nblocks;                                      // ntiles * nsplit_dst
+  int spb, nsplit_dst;                              // K-slices per block, ceil(nslices / spb)
+  int nblocks;                                      // ntiles * nsplit_dst * RT
 };
 
 struct LayerLaunch {
@@ -67,13 +79,13 @@ struct LayerLaunch {
   int RT;
 };
 
-constexpr int MAXSPLIT = 6;   // K-slices / NW never exceeds this for the supported layer widths
+constexpr int MAXSPLIT = 5;   // K-slices / NW never exceeds this for the supported layer widths (K <= 1280)
 
 // sums `nsplit` (<= MAXSPLIT) partial slabs of element (channel c, row) of tile rt.  All loads are unconditional (clamped
 // slab index, zero weight beyond nsplit) so they issue back-to-back instead of one round trip per slab.
 __device__ __forceinline__ float slab_sum(const float* base, int nsplit, int RT, int C, int rt, int c, int row) {
   const size_t stride = (size_t)RT * C * 32;
-  const float* p = base + ((size_t)rt * C + c) * 32 + row;
+  const float* p = base + (size_t)rt * C * 32 + (size_t)row * 4 + qoff(c);
   float t[MAXSPLIT];
 #pragma unroll
   for (int s = 0; s < MAXSPLIT; ++s) t[s] = p[(size_t)(s < nsplit ? s : 0) * stride];
@@ -83,192 +95,206 @@ __device__ __forceinline__ float slab_sum(const float* base, int nsplit, int RT,
   return v;
 }
 
-// A wave's 64-channel x 32-row fragment of a slab stack: element kp of lane l is (channel cbase + 2 kp + (l>>5), row l&31),
-// i.e. p[kp * 64] with p = slab + (rt*C + cbase)*32 + lane.  All NS x 32 loads are issued back-to-back (independent), then
-// summed in split order -- the layer is latency-bound, so the loads must not be serialised by a runtime loop.
+// A wave's 64-channel x 32-row fragment of a slab stack: lane (row, hi) reads channels cbase + 32 hi + kp as eight quads.
+// All NS x 8 16-byte loads are issued back-to-back (independent) and summed in split order.  nq = number of quads that
+// exist (the tail slice of a 339- or 48-channel operand); missing quads read quad 0 and are zeroed.
 template <int NS>
-__device__ __forceinline__ void load_frag(const float* p, size_t stride, float (&a)[32]) {
-  float part[NS][32];
+__device__ __forceinline__ void load_frag(const float* p, size_t stride, int nq, float (&a)[32]) {
+  vf4 part[NS][8];
 #pragma unroll
   for (int s = 0; s < NS; ++s)
 #pragma unroll
-    for (int kp = 0; kp < 32; ++kp) part[s][kp] = p[(size_t)s * stride + kp * 64];
+    for (int j = 0; j < 8; ++j) part[s][j] = *reinterpret_cast<const vf4*>(p + (size_t)s * stride + (size_t)(j < nq ? j : 0) * 128);
 #pragma unroll
-  for (int kp = 0; kp < 32; ++kp) {
-    float v = part[0][kp];
+  for (int j = 0; j < 8; ++j) {
+    vf4 v = part[0][j];
 #pragma unroll
-    for (int s = 1; s < NS; ++s) v += part[s][kp];
-    a[kp] = v;
+    for (int s = 1; s < NS; ++s) v += part[s][j];
+    if (j >= nq) v = vf4{0.f, 0.f, 0.f, 0.f};
+    a[4 * j] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
   }
 }
 
 __device__ __forceinline__ void load_frag_n(const float* base, int nsplit, int RT, int C, int rt, int cbase, int lane, float (&a)[32]) {
   const size_t stride = (size_t)RT * C * 32;
-  if (cbase + SLICE <= C) {
-    const float* p = base + ((size_t)rt * C + cbase) * 32 + lane;
-    switch (nsplit) {
-      case 1: load_frag<1>(p, stride, a); return;
-      case 2: load_frag<2>(p, stride, a); return;
-      case 3: load_frag<3>(p, stride, a); return;
-      case 4: load_frag<4>(p, stride, a); return;
-      case 5: load_frag<5>(p, stride, a); return;
-      default: break;
-    }
-  }
-  const int row = lane & 31, hi = lane >> 5;
-#pragma unroll
-  for (int kp = 0; kp < 32; ++kp) {
-    const int c = cbase + 2 * kp + hi;
-    a[kp] = c < C ? slab_sum(base, nsplit, RT, C, rt, c, row) : 0.f;
+  const int row = lane & 31, c0 = cbase + 32 * (lane >> 5);
+  int nq = (C - c0) >> 2;
+  nq = nq < 0 ? 0 : (nq > 8 ? 8 : nq);
+  const int q0 = nq > 0 ? (c0 >> 2) : 0;
+  const float* p = base + (size_t)rt * C * 32 + (size_t)q0 * 128 + (size_t)row * 4;
+  switch (nsplit) {
+    case 1: load_frag<1>(p, stride, nq, a); return;
+    case 2: load_frag<2>(p, stride, nq, a); return;
+    case 3: load_frag<3>(p, stride, nq, a); return;
+    case 4: load_frag<4>(p, stride, nq, a); return;
+    default: load_frag<MAXSPLIT>(p, stride, nq, a); return;
   }
 }
 
-// per-row GroupNorm statistics of the lane's fragment; NG groups (1 or 2) per 64-channel slice
+// per-row GroupNorm statistics of the lane's 32 channels.  NG = 1: the 64-channel slice is one group (the other half lives
+// in lane^32); NG = 2: each half-slice is its own 32-channel group, entirely lane-local.
 template <int NG>
-__device__ __forceinline__ void gn_stats(const float (&h)[32], float inv_n, float (&mean)[2], float (&rstd)[2]) {
-  constexpr int PER = 32 / NG;
+__device__ __forceinline__ void gn_stats(const float (&h)[32], float inv_n, float& mean, float& rstd) {
+  float s1 = 0.f;
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    float s1 = 0.f;
+  for (int kp = 0; kp < 32; ++kp) s1 += h[kp];
+  if (NG == 1) s1 += __shfl_xor(s1, 32);
+  const float mu = s1 * inv_n;
+  float s2 = 0.f;
 #pragma unroll
-    for (int kp = 0; kp < PER; ++kp) s1 += h[g * PER + kp];
-    s1 += __shfl_xor(s1, 32);
-    const float mu = s1 * inv_n;
-    float s2 = 0.f;
-#pragma unroll
-    for (int kp = 0; kp < PER; ++kp) { const float d = h[g * PER + kp] - mu; s2 = fmaf(d, d, s2); }
-    s2 += __shfl_xor(s2, 32);
-    mean[g] = mu;
-    rstd[g] = rsqrtf(s2 * inv_n + 1e-5f);
-  }
+  for (int kp = 0; kp < 32; ++kp) { const float d = h[kp] - mu; s2 = fmaf(d, d, s2); }
+  if (NG == 1) s2 += __shfl_xor(s2, 32);
+  mean = mu;
+  rstd = rsqrtf(s2 * inv_n + 1e-5f);
 }
 
 template <int NG>
-__device__ __forceinline__ void gn_apply(int mode, const float* gamma, const float* beta, int cbase, int hi, float inv_n,
+__device__ __forceinline__ void gn_apply(int mode, const float (&gam)[32], const float (&bet)[32], float inv_n,
                                          const float (&h)[32], float (&a)[32]) {
-  constexpr int PER = 32 / NG;
-  float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+  float mean, rstd;
   gn_stats<NG>(h, inv_n, mean, rstd);
-  float gam[32], bet[32];
-#pragma unroll
-  for (int kp = 0; kp < 32; ++kp) { gam[kp] = gamma[cbase + 2 * kp + hi]; bet[kp] = beta[cbase + 2 * kp + hi]; }
   if (mode == 1) {
 #pragma unroll
-    for (int kp = 0; kp < 32; ++kp) {
-      const int g = kp / PER;
-      a[kp] = fmaxf((h[kp] - mean[g]) * rstd[g] * gam[kp] + bet[kp], 0.f);
-    }
+    for (int kp = 0; kp < 32; ++kp) a[kp] = fmaxf((h[kp] - mean) * rstd * gam[kp] + bet[kp], 0.f);
   } else {
     // adjoint: a holds da; through ReLU and GroupNorm -> dh
     float dxh[32], xh[32];
-    float m1[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
+    float m1 = 0.f, m2 = 0.f;
 #pragma unroll
     for (int kp = 0; kp < 32; ++kp) {
-      const int g = kp / PER;
-      xh[kp] = (h[kp] - mean[g]) * rstd[g];
+      xh[kp] = (h[kp] - mean) * rstd;
       const float y = xh[kp] * gam[kp] + bet[kp];
       dxh[kp] = (y > 0.f ? a[kp] : 0.f) * gam[kp];
-      m1[g] += dxh[kp];
-      m2[g] = fmaf(dxh[kp], xh[kp], m2[g]);
+      m1 += dxh[kp];
+      m2 = fmaf(dxh[kp], xh[kp], m2);
     }
+    if (NG == 1) { m1 += __shfl_xor(m1, 32); m2 += __shfl_xor(m2, 32); }
+    m1 *= inv_n;
+    m2 *= inv_n;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      m1[g] = (m1[g] + __shfl_xor(m1[g], 32)) * inv_n;
-      m2[g] = (m2[g] + __shfl_xor(m2[g], 32)) * inv_n;
-    }
-#pragma unroll
-    for (int kp = 0; kp < 32; ++kp) {
-      const int g = kp / PER;
-      a[kp] = rstd[g] * (dxh[kp] - m1[g] - xh[kp] * m2[g]);
-    }
+    for (int kp = 0; kp < 32; ++kp) a[kp] = rstd * (dxh[kp] - m1 - xh[kp] * m2);
   }
 }
 
-__global__ __launch_bounds__(NW * 64) void mlp_layer_kernel(LayerLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // NW * 1024 floats
+#ifdef HA_LAYER_TIMING
+// profiling build only (tools/layer_timing.py): phase timestamps of (block 0, wave 0) of the most recent launches
+__device__ unsigned long long g_layer_ts[64][10];
+__device__ unsigned int g_layer_launches;
+#define HA_TS(i, drain)                                                              \
+  do {                                                                               \
+    if (ts_on) {                                                                     \
+      if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       \
+      g_layer_ts[ts_slot][i] = clock64();                                            \
+    }                                                                                \
+  } while (0)
+#else
+#define HA_TS(i, drain)
+#endif
+
+// One block = (task, row tile rt, output tile, K-split ks): its NWT waves walk the block's `spb` consecutive 64-channel
+// K-slices (wave w takes slices w, w + NWT, ...), accumulate in registers, reduce across waves through LDS and write one
+// partial slab.  spb is the per-network policy (ha_tune_set "layer_spb"): few slices per block spread the fp32 MFMA work
+// (256 FLOP/clk/CU) over more CUs but make every consumer block re-read nsplit partial slabs; spb >= nslices is full-K.
+template <int NWT>
+__global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // NWT * 1024 floats
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef HA_LAYER_TIMING
+  const bool ts_on = blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned ts_slot = 0;
+  if (ts_on) {
+    ts_slot = atomicAdd(&g_layer_launches, 1u) & 63;
+    g_layer_ts[ts_slot][8] = wall_clock64();
+    g_layer_ts[ts_slot][9] = ((unsigned long long)L.t[0].nblocks << 32) | (unsigned)(L.ntasks > 1 ? L.t[1].nblocks : 0);
+  }
+  HA_TS(0, false);
+#endif
   int b = blockIdx.x;
   int ti = 0;
   if (L.ntasks > 1 && b >= L.t[0].nblocks) { b -= L.t[0].nblocks; ti = 1; }
   const LayerTask& T = L.t[ti];
-  const int tile = b % T.ntiles, ks = b / T.ntiles;
-  const int slice = ks * NW + wave;
-  const bool active = slice < T.nslices;
+  const int tile = b % T.ntiles;
+  const int b2 = b / T.ntiles;
+  const int ks = b2 % T.nsplit_dst, rt = b2 / T.nsplit_dst;
   const int hi = lane >> 5;
+  const int s_end = (ks + 1) * T.spb < T.nslices ? (ks + 1) * T.spb : T.nslices;
 
-  // B operand: this wave's 64 x 32 weight panel, resident in registers for all row tiles
-  float bw[32];
-  if (active) {
-    const float* wp = T.Wp + ((size_t)tile * T.nslices + slice) * 32 * 64 + lane;
+  f32x16 acc;
 #pragma unroll
-    for (int kp = 0; kp < 32; ++kp) bw[kp] = wp[kp * 64];
-  }
-  const bool is_main = slice < T.main_slices;
-  const int cbase = is_main ? slice * SLICE : (slice - T.main_slices) * SLICE;
-
-  // The row-tile loop is software-pipelined one deep: the next tile's fragments are in flight while this tile's MFMAs run
-  // (at 256 rows per step the loop otherwise pays a full memory round trip per tile).
-  float a_cur[32], h_cur[32], a_nxt[32], h_nxt[32];
-  auto issue_loads = [&](int rt, float (&a)[32], float (&h)[32]) {
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int slice = ks * T.spb + wave; slice < s_end; slice += NWT) {
+    // B operand: this slice's 64 x 32 weight panel
+    float bw[32];
+    {
+      const float* wp = T.Wp + ((size_t)tile * T.nslices + slice) * 32 * 64 + lane * 4;   // [kp / 4][lane][4]
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const vf4 w = *reinterpret_cast<const vf4*>(wp + j * 256);
+        bw[4 * j] = w.x; bw[4 * j + 1] = w.y; bw[4 * j + 2] = w.z; bw[4 * j + 3] = w.w;
+      }
+    }
+    const bool is_main = slice < T.main_slices;
+    const int cbase = is_main ? slice * SLICE : (slice - T.main_slices) * SLICE;
+    // GroupNorm affine of the lane's channels, fetched with the same batch of loads (not behind the activation wait)
+    float gam[32], bet[32];
+    const bool has_gn = is_main && T.mode != 0;
+    if (has_gn) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const vf4 g4 = *reinterpret_cast<const vf4*>(T.gamma + cbase + 32 * hi + 4 * j);
+        const vf4 b4 = *reinterpret_cast<const vf4*>(T.beta + cbase + 32 * hi + 4 * j);
+        gam[4 * j] = g4.x; gam[4 * j + 1] = g4.y; gam[4 * j + 2] = g4.z; gam[4 * j + 3] = g4.w;
+        bet[4 * j] = b4.x; bet[4 * j + 1] = b4.y; bet[4 * j + 2] = b4.z; bet[4 * j + 3] = b4.w;
+      }
+    }
+    float a[32], h[32];
     if (!is_main) load_frag_n(T.skip, 1, L.RT, T.skip_dim, rt, cbase, lane, a);
     else {
       load_frag_n(T.src, T.nsplit_src, L.RT, T.Csrc, rt, cbase, lane, a);
       if (T.mode == 3) load_frag_n(T.hsrc, T.nsplit_h, L.RT, T.Ch, rt, cbase, lane, h);
     }
-  };
-  if (active) issue_loads(0, a_cur, h_cur);
-
-  for (int rt = 0; rt < L.RT; ++rt) {
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    if (active) {
-      if (rt + 1 < L.RT) issue_loads(rt + 1, a_nxt, h_nxt);
-      float (&a)[32] = a_cur;
-      if (is_main && T.mode != 0) {
-        // GroupNorm over groups of T.group (64 or 32) channels: the lane holds 32 channels of its row (one parity),
-        // the other parity lives in lane^32.
-        const float inv_n = 1.0f / (float)T.group;
-        if (T.mode == 1) {
-          if (T.group == SLICE) gn_apply<1>(1, T.gamma, T.beta, cbase, hi, inv_n, a_cur, a);
-          else gn_apply<2>(1, T.gamma, T.beta, cbase, hi, inv_n, a_cur, a);
-        } else {
-          if (T.group == SLICE) gn_apply<1>(3, T.gamma, T.beta, cbase, hi, inv_n, h_cur, a);
-          else gn_apply<2>(3, T.gamma, T.beta, cbase, hi, inv_n, h_cur, a);
-        }
+    HA_TS(1, false);
+    HA_TS(2, true);
+    if (has_gn) {
+      // GroupNorm over groups of T.group (64 or 32) channels: the lane holds one half-slice of its row
+      const float inv_n = 1.0f / (float)T.group;
+      if (T.mode == 1) {
+        if (T.group == SLICE) gn_apply<1>(1, gam, bet, inv_n, a, a);
+        else gn_apply<2>(1, gam, bet, inv_n, a, a);
+      } else {
+        if (T.group == SLICE) gn_apply<1>(3, gam, bet, inv_n, h, a);
+        else gn_apply<2>(3, gam, bet, inv_n, h, a);
       }
-#pragma unroll
-      for (int kp = 0; kp < 32; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], bw[kp], acc, 0, 0, 0);
     }
-    // cross-wave K reduction through LDS, then one 16-byte store per (lane, row quad)
+    HA_TS(3, false);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) smem[(wave * 16 + i) * 64 + lane] = acc[i];
-    __syncthreads();
-    {
-      const int l2 = threadIdx.x & 63, rq = threadIdx.x >> 6;   // NW == 4 row quads of 4 registers
-      float o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) v += smem[(w * 16 + rq * 4 + e) * 64 + l2];
-        o[e] = v;
-      }
-      const int n = tile * 32 + (l2 & 31);
-      if (ks == 0 && T.bias && n < T.Nout) {
-        const float bv = T.bias[n];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] += bv;
-      }
-      float* dst = T.dst + (((size_t)ks * L.RT + rt) * T.Nout_pad + n) * 32 + 8 * rq + 4 * (l2 >> 5);
-      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-    __syncthreads();
-    if (active && rt + 1 < L.RT) {
-#pragma unroll
-      for (int kp = 0; kp < 32; ++kp) { a_cur[kp] = a_nxt[kp]; h_cur[kp] = h_nxt[kp]; }
-    }
+    for (int kp = 0; kp < 32; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], bw[kp], acc, 0, 0, 0);
   }
+  // cross-wave K reduction through LDS, then one 16-byte store per (row, column quad)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) smem[(wave * 16 + i) * 64 + lane] = acc[i];
+  HA_TS(4, true);
+  __syncthreads();
+  HA_TS(5, false);
+  if (threadIdx.x < 256) {
+    // thread <-> (row, quad of output columns): accumulator register i of lane l is row (i&3) + 8 (i>>2) + 4 (l>>5),
+    // column l&31, so a column quad of one row is 16 contiguous bytes of the staged accumulators
+    const int row = threadIdx.x & 31, cq = threadIdx.x >> 5;            // 32 rows x 8 column quads
+    const int reg = (row & 3) + 4 * (row >> 3), half = (row >> 2) & 1;
+    vf4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NWT; ++w) o += *reinterpret_cast<const vf4*>(smem + (w * 16 + reg) * 64 + half * 32 + cq * 4);
+    const int n = tile * 32 + cq * 4;
+    if (ks == 0 && T.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < T.Nout) o[e] += T.bias[n + e];
+    }
+    float* dst = T.dst + ((size_t)ks * L.RT + rt) * T.Nout_pad * 32 + (size_t)(n >> 2) * 128 + row * 4;
+    *reinterpret_cast<vf4*>(dst) = o;
+  }
+  HA_TS(6, true);
+  HA_TS(7, false);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -331,11 +357,11 @@ __device__ __forceinline__ void stage_slabs(float* dst, const float* base, int n
     float t[MAXSPLIT][NC];
 #pragma unroll
     for (int sidx = 0; sidx < MAXSPLIT; ++sidx) {
-      const float* p = base + (size_t)(sidx < nsplit ? sidx : 0) * stride + (size_t)rt * C * 32 + rr;
+      const float* p = base + (size_t)(sidx < nsplit ? sidx : 0) * stride + (size_t)rt * C * 32 + (size_t)rr * 4;
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
-        t[sidx][i] = p[(size_t)(c < nch ? c : 0) * 32];
+        t[sidx][i] = p[qoff(c < nch ? c : 0)];
       }
     }
 #pragma unroll
@@ -389,16 +415,17 @@ __global__ __launch_bounds__(64) void glue_fwd_kernel(GlueParams p) {
   const int r = blockIdx.x, lane = threadIdx.x;
   const int rt = r >> 5, rr = r & 31;
   const bool valid = r < p.B;
-  float* XN = p.xT_next + (size_t)rt * D_IN * 32 + rr;
+  float* XN = p.xT_next + (size_t)rt * D_INP * 32 + (size_t)rr * 4;
   if (!valid) {
-    for (int c = lane; c < D_IN; c += 64) XN[(size_t)c * 32] = 0.f;
+    for (int c = lane; c < D_INP; c += 64) XN[qoff(c)] = 0.f;
     return;
   }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sX = smem + S_X;
   float* sRAW = smem + S_RAW;
-  stage_slabs<6>(sX, p.xT, 1, p.RT, D_IN, D_IN, rt, rr, lane, false);
+  stage_slabs<6>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
   stage_slabs<4>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, lane, false);
+  if (lane == 0) XN[qoff(D_IN)] = 0.f;      // pad channel of the next state slab
   __syncthreads();
   PredState s;
   glue_predict(sX, sRAW, lane, s);
@@ -426,10 +453,10 @@ __global__ __launch_bounds__(64) void glue_fwd_kernel(GlueParams p) {
     for (int c = 0; c < 3; ++c) q[c] = s.pj[c] + wt[c] + t2j[c];
     mat3_vec(W, q, o);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) XN[(size_t)(207 + 3 * j + c) * 32] = o[c] - t2j[c];
+    for (int c = 0; c < 3; ++c) XN[qoff(207 + 3 * j + c)] = o[c] - t2j[c];
     mat3_vec(W, s.jv, o);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) XN[(size_t)(273 + 3 * j + c) * 32] = o[c];
+    for (int c = 0; c < 3; ++c) XN[qoff(273 + 3 * j + c)] = o[c];
     // world: G^T (pj + t2j) - t2j - gt ; G^T jv
 #pragma unroll
     for (int c = 0; c < 3; ++c) q[c] = s.pj[c] + t2j[c];
@@ -442,7 +469,7 @@ __global__ __launch_bounds__(64) void glue_fwd_kernel(GlueParams p) {
     if (j >= 1) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
-        XN[(size_t)(18 + 9 * (j - 1) + i) * 32] = s.pB[i];
+        XN[qoff(18 + 9 * (j - 1) + i)] = s.pB[i];
         WO[18 + 9 * (j - 1) + i] = s.pB[i];
       }
     }
@@ -453,16 +480,16 @@ __global__ __launch_bounds__(64) void glue_fwd_kernel(GlueParams p) {
     for (int c = 0; c < 3; ++c) q[c] = s.ptrans[c] + wt[c];
     mat3_vec(W, q, o);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) XN[(size_t)c * 32] = o[c];
+    for (int c = 0; c < 3; ++c) XN[qoff(c)] = o[c];
     mat3_vec(W, s.ptvel, o);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) XN[(size_t)(3 + c) * 32] = o[c];
+    for (int c = 0; c < 3; ++c) XN[qoff(3 + c)] = o[c];
     mat3_mul(W, s.pR, M);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) XN[(size_t)(6 + i) * 32] = M[i];
+    for (int i = 0; i < 9; ++i) XN[qoff(6 + i)] = M[i];
     mat3_vec(W, s.prvel, o);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) XN[(size_t)(15 + c) * 32] = o[c];
+    for (int c = 0; c < 3; ++c) XN[qoff(15 + c)] = o[c];
     // world
     float wtr[3];
     mat3_tvec(G, s.ptrans, wtr);
@@ -529,12 +556,12 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
   if (last) {
     for (int c = lane; c < D_IN; c += 64) sGXN[c] = 0.f;
   } else {
-    stage_slabs<6>(sGXN, p.gx_dir_in, 1, p.RT, D_IN, D_IN, rt, rr, lane, false);
+    stage_slabs<6>(sGXN, p.gx_dir_in, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
     stage_slabs<6>(sGXN, p.gxp_pri, p.gxp_pri_nsplit, p.RT, p.gxp_pri_pad, D_IN, rt, rr, lane, true);
     stage_slabs<6>(sGXN, p.gxp_dec, p.gxp_dec_nsplit, p.RT, p.gxp_dec_pad, D_IN, rt, rr, lane, true);
   }
   if (!final_collect) {
-    stage_slabs<6>(sX, p.xT, 1, p.RT, D_IN, D_IN, rt, rr, lane, false);
+    stage_slabs<6>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
     stage_slabs<4>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, lane, false);
     const float* GWp = p.g_world ? p.g_world + ((size_t)r * p.S + p.t) * D_STATE : nullptr;
     for (int c = lane; c < D_STATE; c += 64) sGW[c] = GWp ? GWp[c] : 0.f;
@@ -592,8 +619,8 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
 #pragma unroll
   for (int i = 0; i < 9; ++i) { gW[i] = 0.f; gG[i] = 0.f; }
 
-  float* GD = p.g_dec_out + (size_t)rt * p.dec_pad * 32 + rr;      // adjoint of decoder raw output, channel stride 32
-  float* GX = p.gx_dir_out + (size_t)rt * D_IN * 32 + rr;
+  float* GD = p.g_dec_out + (size_t)rt * p.dec_pad * 32 + (size_t)rr * 4;   // adjoint of the decoder raw output (quad layout)
+  float* GX = p.gx_dir_out + (size_t)rt * D_INP * 32 + (size_t)rr * 4;
 
   if (lane < NJT) {
     const int j = lane;
@@ -629,10 +656,10 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
     // residual composition: pj = raw + x
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      GD[(size_t)(75 + 3 * j + c) * 32] = gpj[c];
-      GX[(size_t)(207 + 3 * j + c) * 32] = gpj[c];
-      GD[(size_t)(141 + 3 * j + c) * 32] = gjv[c];
-      GX[(size_t)(273 + 3 * j + c) * 32] = gjv[c];
+      GD[qoff(75 + 3 * j + c)] = gpj[c];
+      GX[qoff(207 + 3 * j + c)] = gpj[c];
+      GD[qoff(141 + 3 * j + c)] = gjv[c];
+      GX[qoff(273 + 3 * j + c)] = gjv[c];
     }
     if (j >= 1) {
       // body rotation: pB = dB * Bin goes unchanged to both outputs
@@ -644,9 +671,9 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
       mat3_tmul(s.dB, gpB, gBin);      // gBin = dB^T * gpB
       rodrigues_bwd(s.raw_aa_b, gdB, gaa);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) GD[(size_t)(12 + 3 * bidx + c) * 32] = gaa[c];
+      for (int c = 0; c < 3; ++c) GD[qoff(12 + 3 * bidx + c)] = gaa[c];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) GX[(size_t)(18 + 9 * bidx + i) * 32] = gBin[i];
+      for (int i = 0; i < 9; ++i) GX[qoff(18 + 9 * bidx + i)] = gBin[i];
     }
   }
   // root pieces (lane 0) contribute to the shared adjoints before the reduction
@@ -747,13 +774,13 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
     rodrigues_bwd(s.raw_aa_r, gdR, gaa);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      GD[(size_t)c * 32] = gptrans[c];        GX[(size_t)c * 32] = gptrans[c];
-      GD[(size_t)(3 + c) * 32] = gptvel[c];   GX[(size_t)(3 + c) * 32] = gptvel[c];
-      GD[(size_t)(6 + c) * 32] = gaa[c];
-      GD[(size_t)(9 + c) * 32] = gprvel[c];   GX[(size_t)(15 + c) * 32] = gprvel[c];
+      GD[qoff(c)] = gptrans[c];        GX[qoff(c)] = gptrans[c];
+      GD[qoff(3 + c)] = gptvel[c];   GX[qoff(3 + c)] = gptvel[c];
+      GD[qoff(6 + c)] = gaa[c];
+      GD[qoff(9 + c)] = gprvel[c];   GX[qoff(15 + c)] = gprvel[c];
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) GX[(size_t)(6 + i) * 32] = gRin[i];
+    for (int i = 0; i < 9; ++i) GX[qoff(6 + i)] = gRin[i];
     // carry to step t-1
 #pragma unroll
     for (int i = 0; i < 9; ++i) carry[i] = gG[i];
@@ -761,19 +788,19 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
     for (int c = 0; c < 3; ++c) { carry[9 + c] = ggt[c]; carry[12 + c] = g_t2j_acc[c] + gt2[c]; }
   }
   // contacts pass straight through; padded decoder channels get zero
-  if (lane >= 32 && lane < 32 + 9) GD[(size_t)(207 + lane - 32) * 32] = gw(339 + lane - 32);
-  for (int c = D_RAW + lane; c < p.dec_pad; c += 64) GD[(size_t)c * 32] = 0.f;
+  if (lane >= 32 && lane < 32 + 9) GD[qoff(207 + lane - 32)] = gw(339 + lane - 32);
+  for (int c = D_RAW + lane; c < p.dec_pad; c += 64) GD[qoff(c)] = 0.f;
   // prior output adjoint: (g_mu, g_var * var)
   if (p.g_pri_out) {
-    float* GP = p.g_pri_out + (size_t)rt * p.pri_pad * 32 + rr;
+    float* GP = p.g_pri_out + (size_t)rt * p.pri_pad * 32 + (size_t)rr * 4;
     if (lane < ZD) {
       const size_t o = ((size_t)r * p.S + p.t) * ZD + lane;
-      GP[(size_t)lane * 32] = p.g_prior_mu ? p.g_prior_mu[o] : 0.f;
+      GP[qoff(lane)] = p.g_prior_mu ? p.g_prior_mu[o] : 0.f;
       // var = exp(logvar): d/dlogvar = g_var * var (recomputed from the stashed prior output slabs)
       const float var = expf(slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, ZD + lane, rr));
-      GP[(size_t)(ZD + lane) * 32] = p.g_prior_var ? p.g_prior_var[o] * var : 0.f;
+      GP[qoff(ZD + lane)] = p.g_prior_var ? p.g_prior_var[o] * var : 0.f;
     }
-    for (int c = 2 * ZD + lane; c < p.pri_pad; c += 64) GP[(size_t)c * 32] = 0.f;
+    for (int c = 2 * ZD + lane; c < p.pri_pad; c += 64) GP[qoff(c)] = 0.f;
   }
 }
 
@@ -791,7 +818,7 @@ __global__ __launch_bounds__(64) void sample_z_kernel(SampleParams p) {
   const int r = blockIdx.x, lane = threadIdx.x;
   const int rt = r >> 5, rr = r & 31;
   if (lane >= ZD) return;
-  float* dst = p.zT_t + ((size_t)rt * ZD + lane) * 32 + rr;
+  float* dst = p.zT_t + (size_t)rt * ZD * 32 + (size_t)rr * 4 + qoff(lane);
   if (r >= p.B) { *dst = 0.f; return; }
   const float mu = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, lane, rr);
   const float lv = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, ZD + lane, rr);
@@ -801,18 +828,18 @@ __global__ __launch_bounds__(64) void sample_z_kernel(SampleParams p) {
   p.z_out[o] = z;
 }
 
-// [B][S][48] -> [S][RT][48][32] (zero-padded rows) ; [B][339] -> [RT][339][32]
-__global__ void transpose_in_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int S, int C, int RT) {
-  const size_t total = (size_t)S * RT * C * 32;
+// [B][S][C] -> [S][RT][Cp/4][32][4] (quad-interleaved tiles, zero-padded rows and channels); Cp = C rounded up to 4
+__global__ void transpose_in_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int S, int C, int Cp, int RT) {
+  const size_t total = (size_t)S * RT * Cp * 32;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int rr = (int)(i & 31);
-    const size_t q = i >> 5;
-    const int c = (int)(q % C);
-    const size_t q2 = q / C;
+    const int e = (int)(i & 3), rr = (int)((i >> 2) & 31);
+    const size_t q = i >> 7;
+    const int c = (int)(q % (Cp >> 2)) * 4 + e;
+    const size_t q2 = q / (Cp >> 2);
     const int rt = (int)(q2 % RT);
     const int s = (int)(q2 / RT);
     const int r = rt * 32 + rr;
-    dst[i] = r < B ? src[((size_t)r * S + s) * C + c] : 0.f;
+    dst[i] = (r < B && c < C) ? src[((size_t)r * S + s) * C + c] : 0.f;
   }
 }
 
@@ -891,26 +918,27 @@ static int pack_layer(PackedLayer& L, const float* W, const float* bias, const f
   L.nslices_f = L.main_slices + ceil_div(skip, SLICE);
   L.ntiles_f = ceil_div(Nout, 32);
   L.Nout_pad = L.ntiles_f * 32;
-  L.nsplit_f = ceil_div(L.nslices_f, NW);
+
   L.nslices_b = ceil_div(Nout, SLICE);
   L.ntiles_b = ceil_div(Cin + skip, 32);
   L.Nin_pad = L.ntiles_b * 32;
-  L.nsplit_b = ceil_div(L.nslices_b, NW);
+
   L.group = has_gn ? Cin / 16 : 0;
-  HA_REQUIRE(L.nsplit_f <= MAXSPLIT && L.nsplit_b <= MAXSPLIT, "layer %dx%d needs more than %d K-splits", Nout, Cin + skip, MAXSPLIT);
+  HA_REQUIRE(ceil_div(L.nslices_f, 4) <= MAXSPLIT && ceil_div(L.nslices_b, 4) <= MAXSPLIT, "layer %dx%d needs more than %d K-splits", Nout,
+             Cin + skip, MAXSPLIT);
   const int Kin = Cin + skip;
-  // forward pack: lane l of (tile, slice, kp) <-> W[n = tile*32 + (l&31)][k], k = channel of the slice
+  // forward pack [tile][slice][kp/4][lane][kp%4]: lane l of (tile, slice, kp) <-> W[n = tile*32 + (l&31)][k]
   std::vector<float> wf((size_t)L.ntiles_f * L.nslices_f * 32 * 64, 0.f);
   for (int tile = 0; tile < L.ntiles_f; ++tile)
     for (int sl = 0; sl < L.nslices_f; ++sl)
       for (int kp = 0; kp < 32; ++kp)
         for (int l = 0; l < 64; ++l) {
           const int n = tile * 32 + (l & 31);
-          const int cc = 2 * kp + (l >> 5);
+          const int cc = 32 * (l >> 5) + kp;        // lane (n, hi) owns channels 32 hi + kp of its slice
           int k;
           if (sl < L.main_slices) { const int c = sl * SLICE + cc; k = c < Cin ? c : -1; }
           else { const int c = (sl - L.main_slices) * SLICE + cc; k = c < skip ? Cin + c : -1; }
-          if (n < Nout && k >= 0) wf[(((size_t)tile * L.nslices_f + sl) * 32 + kp) * 64 + l] = W[(size_t)n * Kin + k];
+          if (n < Nout && k >= 0) wf[(((size_t)tile * L.nslices_f + sl) * 8 + (kp >> 2)) * 256 + l * 4 + (kp & 3)] = W[(size_t)n * Kin + k];
         }
   // backward pack: A = dh [rows, Nout channels], output columns = input channels (main then skip)
   std::vector<float> wb((size_t)L.ntiles_b * L.nslices_b * 32 * 64, 0.f);
@@ -919,8 +947,8 @@ static int pack_layer(PackedLayer& L, const float* W, const float* bias, const f
       for (int kp = 0; kp < 32; ++kp)
         for (int l = 0; l < 64; ++l) {
           const int n = tile * 32 + (l & 31);                 // input channel
-          const int k = sl * SLICE + 2 * kp + (l >> 5);       // output channel
-          if (n < Kin && k < Nout) wb[(((size_t)tile * L.nslices_b + sl) * 32 + kp) * 64 + l] = W[(size_t)k * Kin + n];
+          const int k = sl * SLICE + 32 * (l >> 5) + kp;      // output channel
+          if (n < Kin && k < Nout) wb[(((size_t)tile * L.nslices_b + sl) * 8 + (kp >> 2)) * 256 + l * 4 + (kp & 3)] = W[(size_t)k * Kin + n];
         }
   int rc;
   if ((rc = upload_vec(&L.Wf, wf)) != HA_OK) return rc;
@@ -955,6 +983,9 @@ static int pack_mlp(PackedLayer* out, const ha_mlp_desc* d, const char* name) {
 // Offsets (in floats) into the caller-owned stash.
 struct StashLayout {
   int RT = 0;
+  // launch policy of the layer kernel for this batch size: K-slices per block and the resulting partial-slab counts
+  int spb = 4, nw = 4;
+  int nsf_pri[MAXL], nsf_dec[MAXL], nsb_pri[MAXL], nsb_dec[MAXL];
   size_t zT = 0, t2j = 0, per_step = 0, steps = 0;
   size_t off_x = 0, off_G = 0;
   size_t off_pri[MAXL], off_dec[MAXL];
@@ -967,6 +998,13 @@ struct StashLayout {
 static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   L.RT = ceil_div(B, 32);
   const size_t RT = L.RT;
+  // few row tiles: split K over many CUs (the layer is a latency chain and fp32 MFMA is 256 FLOP/clk/CU); many row tiles:
+  // full-K blocks (no partial slabs to re-read, the row tiles fill the chip).  Measured: tools/rollout_ab.py.
+  L.spb = g_layer_spb > 0 ? g_layer_spb : (L.RT >= 4 ? 32 : 4);
+  if (L.spb < 4) L.spb = 4;      // MAXSPLIT partial slabs at most (checked against the layer widths at pack time)
+  L.nw = 4;
+  for (int i = 0; i < net->n_pri; ++i) { L.nsf_pri[i] = ceil_div(net->pri[i].nslices_f, L.spb); L.nsb_pri[i] = ceil_div(net->pri[i].nslices_b, L.spb); }
+  for (int i = 0; i < net->n_dec; ++i) { L.nsf_dec[i] = ceil_div(net->dec[i].nslices_f, L.spb); L.nsb_dec[i] = ceil_div(net->dec[i].nslices_b, L.spb); }
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
   L.zT = take((size_t)S * RT * ZD * 32);
@@ -974,39 +1012,41 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   // per-step region
   size_t p = 0;
   auto ptake = [&](size_t n) { size_t r = p; p += (n + 63) / 64 * 64; return r; };
-  L.off_x = ptake(RT * D_IN * 32);
+  L.off_x = ptake(RT * D_INP * 32);
   L.off_G = ptake(RT * 32 * 12);
-  for (int i = 0; i < net->n_pri; ++i) L.off_pri[i] = ptake((size_t)net->pri[i].nsplit_f * RT * net->pri[i].Nout_pad * 32);
-  for (int i = 0; i < net->n_dec; ++i) L.off_dec[i] = ptake((size_t)net->dec[i].nsplit_f * RT * net->dec[i].Nout_pad * 32);
+  for (int i = 0; i < net->n_pri; ++i) L.off_pri[i] = ptake((size_t)L.nsf_pri[i] * RT * net->pri[i].Nout_pad * 32);
+  for (int i = 0; i < net->n_dec; ++i) L.off_dec[i] = ptake((size_t)L.nsf_dec[i] * RT * net->dec[i].Nout_pad * 32);
   L.per_step = p;
   L.steps = take(p * (size_t)(S + 1));
-  L.gx_dir[0] = take(RT * D_IN * 32);
-  L.gx_dir[1] = take(RT * D_IN * 32);
+  L.gx_dir[0] = take(RT * D_INP * 32);
+  L.gx_dir[1] = take(RT * D_INP * 32);
   L.carry = take(RT * 32 * 16);
   L.g_dec_out = take(RT * net->dec[net->n_dec - 1].Nout_pad * 32);
   L.g_pri_out = take(RT * net->pri[net->n_pri - 1].Nout_pad * 32);
-  for (int i = 0; i < net->n_pri; ++i) L.bwd_pri[i] = take((size_t)net->pri[i].nsplit_b * RT * net->pri[i].Nin_pad * 32);
-  for (int i = 0; i < net->n_dec; ++i) L.bwd_dec[i] = take((size_t)net->dec[i].nsplit_b * RT * net->dec[i].Nin_pad * 32);
+  for (int i = 0; i < net->n_pri; ++i) L.bwd_pri[i] = take((size_t)L.nsb_pri[i] * RT * net->pri[i].Nin_pad * 32);
+  for (int i = 0; i < net->n_dec; ++i) L.bwd_dec[i] = take((size_t)L.nsb_dec[i] * RT * net->dec[i].Nin_pad * 32);
   L.total = o;
 }
 
-static void fwd_task(LayerTask& T, const PackedLayer& L, const float* src, int nsplit_src, const float* skip, float* dst) {
+static void fwd_task(LayerTask& T, const PackedLayer& L, const float* src, int nsplit_src, const float* skip, float* dst, int spb,
+                     int nsplit_dst) {
   memset(&T, 0, sizeof(T));
   T.Wp = L.Wf; T.bias = L.bias;
   T.ntiles = L.ntiles_f; T.nslices = L.nslices_f; T.main_slices = L.main_slices; T.Nout = L.Nout; T.Nout_pad = L.Nout_pad;
-  T.src = src; T.nsplit_src = nsplit_src; T.Csrc = L.Cin;
+  T.src = src; T.nsplit_src = nsplit_src; T.Csrc = (L.Cin + 3) & ~3;   // slab width (D_INP for the state input)
   T.skip = skip; T.skip_dim = L.skip;
   T.mode = L.group ? 1 : 0;
   T.gamma = L.gamma; T.beta = L.beta; T.group = L.group ? L.group : 64;
   T.dst = dst;
-  T.nblocks = L.ntiles_f * L.nsplit_f;
+  T.spb = spb; T.nsplit_dst = nsplit_dst;
+  T.nblocks = L.ntiles_f * nsplit_dst;          // x RT in launch_layers
 }
 
 // backward through layer L: A = dh (adjoint of L's raw output), output = adjoint of L's input activation slabs.
 // `Lnext_gn` describes the GroupNorm that follows L (i.e. the consumer layer's gamma/beta/group) when dh has to be
 // derived from the consumer's input-gradient slabs (mode 3); null when dh is given directly (mode 0).
 static void bwd_task(LayerTask& T, const PackedLayer& L, const float* dsrc, int nsplit_d, int dC, const PackedLayer* Lnext_gn,
-                     const float* hsrc, int nsplit_h, float* dst) {
+                     const float* hsrc, int nsplit_h, float* dst, int spb, int nsplit_dst) {
   memset(&T, 0, sizeof(T));
   T.Wp = L.Wb; T.bias = nullptr;
   T.ntiles = L.ntiles_b; T.nslices = L.nslices_b; T.main_slices = L.nslices_b; T.Nout = L.Cin + L.skip; T.Nout_pad = L.Nin_pad;
@@ -1016,13 +1056,15 @@ static void bwd_task(LayerTask& T, const PackedLayer& L, const float* dsrc, int 
   else T.group = 64;
   T.hsrc = hsrc; T.nsplit_h = nsplit_h; T.Ch = L.Nout_pad;
   T.dst = dst;
-  T.nblocks = L.ntiles_b * L.nsplit_b;
+  T.spb = spb; T.nsplit_dst = nsplit_dst;
+  T.nblocks = L.ntiles_b * nsplit_dst;
 }
 
-static int launch_layers(LayerLaunch& LL, hipStream_t st) {
+static int launch_layers(LayerLaunch& LL, int nw, hipStream_t st) {
   int blocks = 0;
-  for (int i = 0; i < LL.ntasks; ++i) blocks += LL.t[i].nblocks;
-  hipLaunchKernelGGL(mlp_layer_kernel, dim3(blocks), dim3(NW * 64), NW * 1024 * sizeof(float), st, LL);
+  for (int i = 0; i < LL.ntasks; ++i) { LL.t[i].nblocks *= LL.RT; blocks += LL.t[i].nblocks; }
+  (void)nw;   // 8-wave blocks need a register diet first (256-VGPR cap at 2 waves/SIMD -> scratch spills, measured 4x slower)
+  hipLaunchKernelGGL(mlp_layer_kernel<4>, dim3(blocks), dim3(256), 4 * 1024 * sizeof(float), st, LL);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -1065,6 +1107,15 @@ extern "C" int ha_humor_net_destroy(ha_humor_net* net) {
   return HA_OK;
 }
 
+#ifdef HA_LAYER_TIMING
+extern "C" int ha_debug_layer_timing(unsigned long long* out /* [64][10] */, unsigned int* launches) {
+  HA_CHECK_HIP(hipDeviceSynchronize());
+  HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_layer_ts), sizeof(unsigned long long) * 640));
+  HA_CHECK_HIP(hipMemcpyFromSymbol(launches, HIP_SYMBOL(ha::g_layer_launches), sizeof(unsigned int)));
+  return HA_OK;
+}
+#endif
+
 extern "C" int ha_humor_rollout_workspace(const ha_humor_net* net, int B, int S, int64_t* stash_floats) {
   HA_REQUIRE(net && stash_floats, "ha_humor_rollout_workspace: null argument");
   HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_workspace: B and S must be >= 1");
@@ -1086,9 +1137,9 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
   const int RT = L.RT, rows = RT * 32;
   auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
 
-  hipLaunchKernelGGL(transpose_in_kernel, dim3(256), dim3(256), 0, st, z_seq, stash + L.zT, B, S, ZD, RT);
+  hipLaunchKernelGGL(transpose_in_kernel, dim3(256), dim3(256), 0, st, z_seq, stash + L.zT, B, S, ZD, ZD, RT);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, step_ptr(0) + L.off_x, B, 1, D_IN, RT);
+  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, step_ptr(0) + L.off_x, B, 1, D_IN, D_INP, RT);
   HA_LAUNCH_CHECK();
   hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
   HA_LAUNCH_CHECK();
@@ -1105,15 +1156,15 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
       if (l < net->n_dec) {
         const PackedLayer& P = net->dec[l];
         const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
-        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : net->dec[l - 1].nsplit_f, zT, sp + L.off_dec[l]);
+        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
       }
       if (with_prior && l < net->n_pri) {
         const PackedLayer& P = net->pri[l];
         const float* src = l == 0 ? sp + L.off_x : sp + L.off_pri[l - 1];
-        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : net->pri[l - 1].nsplit_f, nullptr, sp + L.off_pri[l]);
+        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_pri[l - 1], nullptr, sp + L.off_pri[l], L.spb, L.nsf_pri[l]);
       }
       if (LL.ntasks == 0) continue;
-      int rc = launch_layers(LL, st);
+      int rc = launch_layers(LL, L.nw, st);
       if (rc != HA_OK) return rc;
     }
     GlueParams g;
@@ -1122,9 +1173,9 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
     g.xT = sp + L.off_x;
     g.xT_next = step_ptr(t + 1) + L.off_x;
     const PackedLayer& DL = net->dec[net->n_dec - 1];
-    g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = DL.nsplit_f; g.dec_pad = DL.Nout_pad;
+    g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = L.nsf_dec[net->n_dec - 1]; g.dec_pad = DL.Nout_pad;
     const PackedLayer& PL = net->pri[net->n_pri - 1];
-    g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = PL.nsplit_f; g.pri_pad = PL.Nout_pad;
+    g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = L.nsf_pri[net->n_pri - 1]; g.pri_pad = PL.Nout_pad;
     g.Gs = sp + L.off_G;
     g.Gs_next = step_ptr(t + 1) + L.off_G;
     g.t2j = stash + L.t2j;
@@ -1146,7 +1197,7 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
   make_layout(net, B, S, L);
   const int RT = L.RT, rows = RT * 32;
   auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
-  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, step_ptr(0) + L.off_x, B, 1, D_IN, RT);
+  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, step_ptr(0) + L.off_x, B, 1, D_IN, D_INP, RT);
   HA_LAUNCH_CHECK();
   hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
   HA_LAUNCH_CHECK();
@@ -1161,14 +1212,14 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
       memset(&LL, 0, sizeof(LL));
       LL.RT = RT;
       const float* src = l == 0 ? sp + L.off_x : sp + L.off_pri[l - 1];
-      fwd_task(LL.t[LL.ntasks++], net->pri[l], src, l == 0 ? 1 : net->pri[l - 1].nsplit_f, nullptr, sp + L.off_pri[l]);
-      int rc = launch_layers(LL, st);
+      fwd_task(LL.t[LL.ntasks++], net->pri[l], src, l == 0 ? 1 : L.nsf_pri[l - 1], nullptr, sp + L.off_pri[l], L.spb, L.nsf_pri[l]);
+      int rc = launch_layers(LL, L.nw, st);
       if (rc != HA_OK) return rc;
     }
     SampleParams sp_;
     memset(&sp_, 0, sizeof(sp_));
     sp_.B = B; sp_.S = S; sp_.t = t; sp_.RT = RT;
-    sp_.pri_out = sp + L.off_pri[net->n_pri - 1]; sp_.pri_nsplit = PL.nsplit_f; sp_.pri_pad = PL.Nout_pad;
+    sp_.pri_out = sp + L.off_pri[net->n_pri - 1]; sp_.pri_nsplit = L.nsf_pri[net->n_pri - 1]; sp_.pri_pad = PL.Nout_pad;
     sp_.eps = eps_seq; sp_.zT_t = zT; sp_.z_out = z_out;
     hipLaunchKernelGGL(sample_z_kernel, dim3(rows), dim3(64), 0, st, sp_);
     HA_LAUNCH_CHECK();
@@ -1177,8 +1228,8 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
       memset(&LL, 0, sizeof(LL));
       LL.RT = RT;
       const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
-      fwd_task(LL.t[LL.ntasks++], net->dec[l], src, l == 0 ? 1 : net->dec[l - 1].nsplit_f, zT, sp + L.off_dec[l]);
-      int rc = launch_layers(LL, st);
+      fwd_task(LL.t[LL.ntasks++], net->dec[l], src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
+      int rc = launch_layers(LL, L.nw, st);
       if (rc != HA_OK) return rc;
     }
     GlueParams g;
@@ -1186,8 +1237,8 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
     g.B = B; g.S = S; g.t = t; g.RT = RT;
     g.xT = sp + L.off_x;
     g.xT_next = step_ptr(t + 1) + L.off_x;
-    g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = DL.nsplit_f; g.dec_pad = DL.Nout_pad;
-    g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = PL.nsplit_f; g.pri_pad = PL.Nout_pad;
+    g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = L.nsf_dec[net->n_dec - 1]; g.dec_pad = DL.Nout_pad;
+    g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = L.nsf_pri[net->n_pri - 1]; g.pri_pad = PL.Nout_pad;
     g.Gs = sp + L.off_G;
     g.Gs_next = step_ptr(t + 1) + L.off_G;
     g.t2j = stash + L.t2j;
@@ -1225,18 +1276,18 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
     // step t+1 products (consumed when t < S-1)
     g.gx_dir_in = stash + L.gx_dir[(t + 1) & 1];
     g.gx_dir_out = stash + L.gx_dir[t & 1];
-    g.gxp_dec = stash + L.bwd_dec[0]; g.gxp_dec_nsplit = net->dec[0].nsplit_b; g.gxp_dec_pad = net->dec[0].Nin_pad;
-    if (with_prior) { g.gxp_pri = stash + L.bwd_pri[0]; g.gxp_pri_nsplit = net->pri[0].nsplit_b; g.gxp_pri_pad = net->pri[0].Nin_pad; }
+    g.gxp_dec = stash + L.bwd_dec[0]; g.gxp_dec_nsplit = L.nsb_dec[0]; g.gxp_dec_pad = net->dec[0].Nin_pad;
+    if (with_prior) { g.gxp_pri = stash + L.bwd_pri[0]; g.gxp_pri_nsplit = L.nsb_pri[0]; g.gxp_pri_pad = net->pri[0].Nin_pad; }
     g.dz_n = net->n_dec;
     for (int i = 0; i < net->n_dec; ++i) {
-      g.dz_src[i] = stash + L.bwd_dec[i]; g.dz_nsplit[i] = net->dec[i].nsplit_b; g.dz_pad[i] = net->dec[i].Nin_pad;
+      g.dz_src[i] = stash + L.bwd_dec[i]; g.dz_nsplit[i] = L.nsb_dec[i]; g.dz_pad[i] = net->dec[i].Nin_pad;
       g.dz_off[i] = net->dec[i].Cin;
     }
     if (t >= 0) {
       float* sp = step_ptr(t);
       g.xT = sp + L.off_x;
-      g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = DL.nsplit_f; g.dec_pad = DL.Nout_pad;
-      g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = PL.nsplit_f; g.pri_pad = PL.Nout_pad;
+      g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = L.nsf_dec[net->n_dec - 1]; g.dec_pad = DL.Nout_pad;
+      g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = L.nsf_pri[net->n_pri - 1]; g.pri_pad = PL.Nout_pad;
       g.Gs = sp + L.off_G;
       g.g_world = g_world;
       g.g_prior_mu = g_prior_mu; g.g_prior_var = g_prior_var;
@@ -1260,21 +1311,21 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
       if (l < net->n_dec) {
         const PackedLayer& P = net->dec[l];
         if (l == net->n_dec - 1)
-          bwd_task(LL.t[LL.ntasks++], P, stash + L.g_dec_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_dec[l]);
+          bwd_task(LL.t[LL.ntasks++], P, stash + L.g_dec_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
         else
-          bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_dec[l + 1], net->dec[l + 1].nsplit_b, net->dec[l + 1].Nin_pad, &net->dec[l + 1],
-                   sp + L.off_dec[l], P.nsplit_f, stash + L.bwd_dec[l]);
+          bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_dec[l + 1], L.nsb_dec[l + 1], net->dec[l + 1].Nin_pad, &net->dec[l + 1],
+                   sp + L.off_dec[l], L.nsf_dec[l], stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
       }
       if (with_prior && l < net->n_pri) {
         const PackedLayer& P = net->pri[l];
         if (l == net->n_pri - 1)
-          bwd_task(LL.t[LL.ntasks++], P, stash + L.g_pri_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_pri[l]);
+          bwd_task(LL.t[LL.ntasks++], P, stash + L.g_pri_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_pri[l], L.spb, L.nsb_pri[l]);
         else
-          bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_pri[l + 1], net->pri[l + 1].nsplit_b, net->pri[l + 1].Nin_pad, &net->pri[l + 1],
-                   sp + L.off_pri[l], P.nsplit_f, stash + L.bwd_pri[l]);
+          bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_pri[l + 1], L.nsb_pri[l + 1], net->pri[l + 1].Nin_pad, &net->pri[l + 1],
+                   sp + L.off_pri[l], L.nsf_pri[l], stash + L.bwd_pri[l], L.spb, L.nsb_pri[l]);
       }
       if (LL.ntasks == 0) continue;
-      int rc = launch_layers(LL, st);
+      int rc = launch_layers(LL, L.nw, st);
       if (rc != HA_OK) return rc;
     }
   }

@@ -27,9 +27,11 @@ def test_rollout_golden(gpu_lib, dev):
 
 def test_rollout_full_length(gpu_lib, dev):
     """BASELINE size (32 sequences x 59 steps): conditioning-aware parity (see check_rollout_conditioned) plus the
-    gradient check on a 16-step chain (the adjoint is amplified like the forward error, hence the looser bound)."""
+    gradient check on an 8-step chain judged against an fp64 oracle.  (The adjoint is amplified like the forward error:
+    at 12-16 steps two fp32 implementations already differ by 1-10 % of a gradient whose scale itself varies over three
+    decades between seeds -- tools/grad_accuracy.py tabulates GPU fp32 vs CPU fp32 vs fp64 by chain length.)"""
     RC.check_rollout_conditioned(gpu_lib, dev, B=32, S=59, seed=3)
-    RC.check_rollout(gpu_lib, dev, B=32, S=16, seed=4, fwd_tol=1e-3, grad_rtol=1e-2)
+    RC.check_rollout(gpu_lib, dev, B=32, S=8, seed=4, fwd_tol=1e-3, grad_rtol=1e-2, cond_aware=True)
 
 
 def test_rollout_determinism(gpu_lib, dev):
@@ -48,16 +50,19 @@ def test_rotation_kernels(gpu_lib, dev):
 
 
 def test_c5_size_rollout(gpu_lib, dev):
-    """BASELINE config C5 batch (256 sequences = 8 row tiles), 119 steps: finite and equal, sequence by sequence, to the
-    same sequences rolled out in a batch of 32 (row tiles are independent)."""
+    """BASELINE config C5 batch (256 sequences = 8 row tiles), 119 steps: finite and bit-equal, sequence by sequence, to the
+    same sequences rolled out in a batch of 128 (row tiles are independent; same full-K launch policy), and equal within
+    fp32 rounding over the first steps to a batch of 32 (split-K policy: another summation order)."""
     hm, _ = RC.make_model(gpu_lib, dev)
     g = torch.Generator().manual_seed(2)
     past = RC.canonical_state(256, g).to(dev)
     z = (0.5 * torch.randn(256, 119, 48, generator=g)).to(dev)
     big = RC.world_of(hm.roll_out(past, None, 119, z_seq=z))
     assert torch.isfinite(big).all()
-    small = RC.world_of(hm.roll_out(past[64:96], None, 119, z_seq=z[64:96]))
-    assert torch.equal(big[64:96], small)
+    mid = RC.world_of(hm.roll_out(past[64:192], None, 119, z_seq=z[64:192]))
+    assert torch.equal(big[64:192], mid)
+    small = RC.world_of(hm.roll_out(past[64:96], None, 8, z_seq=z[64:96, :8]))
+    assert (big[64:96, :8] - small).abs().max().item() < 1e-4
 
 
 def test_sampling_and_canonicalize(gpu_lib, dev):
