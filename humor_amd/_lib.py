@@ -102,7 +102,8 @@ def get_lib():
     """The product library (gfx950 build).  Raises if it has not been built."""
     global _lib
     if _lib is None:
-        _lib = Lib(DEFAULT_LIB)
+        # HUMOR_AMD_LIB: another gfx950 build of the same sources (A/B measurements of kernel variants); never a fallback
+        _lib = Lib(os.environ.get('HUMOR_AMD_LIB', DEFAULT_LIB))
     return _lib
 
 

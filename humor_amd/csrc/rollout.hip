@@ -346,33 +346,39 @@ struct PredState {
 // round trips per lane.)
 constexpr int S_X = 0, S_RAW = 352, S_GXN = 576, S_GW = 928, S_TOTAL = 1280;
 
-template <int NC>   // NC = ceil(channels / 64)
+template <int NQ>   // NQ = ceil(channel quads / 64): lane l stages quads l, l + 64, ... (16-byte loads)
 __device__ __forceinline__ void stage_slabs(float* dst, const float* base, int nsplit, int RT, int C, int nch, int rt, int rr,
                                             int lane, bool accumulate) {
-  float v[NC];
+  vf4 t[MAXSPLIT][NQ];
 #pragma unroll
-  for (int i = 0; i < NC; ++i) v[i] = 0.f;
+  for (int sidx = 0; sidx < MAXSPLIT; ++sidx)
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) t[sidx][i] = vf4{0.f, 0.f, 0.f, 0.f};
   if (base) {
     const size_t stride = (size_t)RT * C * 32;
-    float t[MAXSPLIT][NC];
-#pragma unroll
-    for (int sidx = 0; sidx < MAXSPLIT; ++sidx) {
-      const float* p = base + (size_t)(sidx < nsplit ? sidx : 0) * stride + (size_t)rt * C * 32 + (size_t)rr * 4;
-#pragma unroll
-      for (int i = 0; i < NC; ++i) {
-        const int c = lane + 64 * i;
-        t[sidx][i] = p[qoff(c < nch ? c : 0)];
-      }
-    }
+    const float* p0 = base + (size_t)rt * C * 32 + (size_t)rr * 4;
+    // only the slabs that exist are read (nsplit is launch-uniform); every load is issued before the first use
 #pragma unroll
     for (int sidx = 0; sidx < MAXSPLIT; ++sidx)
+      if (sidx < nsplit) {
 #pragma unroll
-      for (int i = 0; i < NC; ++i) v[i] += sidx < nsplit ? t[sidx][i] : 0.f;
+        for (int i = 0; i < NQ; ++i) {
+          const int q = lane + 64 * i;
+          if (4 * q < nch) t[sidx][i] = *reinterpret_cast<const vf4*>(p0 + (size_t)sidx * stride + (size_t)q * 128);
+        }
+      }
   }
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nch) dst[c] = accumulate ? dst[c] + v[i] : v[i];
+  for (int i = 0; i < NQ; ++i) {
+    vf4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sidx = 0; sidx < MAXSPLIT; ++sidx) v += t[sidx][i];
+    const int q = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * q + e;
+      if (c < nch) dst[c] = accumulate ? dst[c] + v[e] : v[e];
+    }
   }
 }
 
@@ -423,8 +429,8 @@ __global__ __launch_bounds__(64) void glue_fwd_kernel(GlueParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sX = smem + S_X;
   float* sRAW = smem + S_RAW;
-  stage_slabs<6>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
-  stage_slabs<4>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, lane, false);
+  stage_slabs<2>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
+  stage_slabs<1>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, lane, false);
   if (lane == 0) XN[qoff(D_IN)] = 0.f;      // pad channel of the next state slab
   __syncthreads();
   PredState s;
@@ -556,13 +562,13 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
   if (last) {
     for (int c = lane; c < D_IN; c += 64) sGXN[c] = 0.f;
   } else {
-    stage_slabs<6>(sGXN, p.gx_dir_in, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
-    stage_slabs<6>(sGXN, p.gxp_pri, p.gxp_pri_nsplit, p.RT, p.gxp_pri_pad, D_IN, rt, rr, lane, true);
-    stage_slabs<6>(sGXN, p.gxp_dec, p.gxp_dec_nsplit, p.RT, p.gxp_dec_pad, D_IN, rt, rr, lane, true);
+    stage_slabs<2>(sGXN, p.gx_dir_in, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
+    stage_slabs<2>(sGXN, p.gxp_pri, p.gxp_pri_nsplit, p.RT, p.gxp_pri_pad, D_IN, rt, rr, lane, true);
+    stage_slabs<2>(sGXN, p.gxp_dec, p.gxp_dec_nsplit, p.RT, p.gxp_dec_pad, D_IN, rt, rr, lane, true);
   }
   if (!final_collect) {
-    stage_slabs<6>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
-    stage_slabs<4>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, lane, false);
+    stage_slabs<2>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
+    stage_slabs<1>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, lane, false);
     const float* GWp = p.g_world ? p.g_world + ((size_t)r * p.S + p.t) * D_STATE : nullptr;
     for (int c = lane; c < D_STATE; c += 64) sGW[c] = GWp ? GWp[c] : 0.f;
   }
