@@ -345,8 +345,9 @@ struct PredState {
 // per-joint math reads LDS.  (The kernels are pure latency: a runtime slab loop per element would serialise ~100 L2/HBM
 // round trips per lane.)
 constexpr int S_X = 0, S_RAW = 352, S_GXN = 576, S_GW = 928, S_TOTAL = 1280;
+constexpr int S_SH = 1280, S_RED = 1296, S_TOTAL_BWD = 1328;   // + W(9) ptr(3) of the root | the joint wave's sums (27)
 
-template <int NQ>   // NQ = ceil(channel quads / 64): lane l stages quads l, l + 64, ... (16-byte loads)
+template <int NQ, int NT = 64>   // NQ = ceil(channel quads / NT): thread l stages quads l, l + NT, ... (16-byte loads)
 __device__ __forceinline__ void stage_slabs(float* dst, const float* base, int nsplit, int RT, int C, int nch, int rt, int rr,
                                             int lane, bool accumulate) {
   vf4 t[MAXSPLIT][NQ];
@@ -363,7 +364,7 @@ __device__ __forceinline__ void stage_slabs(float* dst, const float* base, int n
       if (sidx < nsplit) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-          const int q = lane + 64 * i;
+          const int q = lane + NT * i;
           if (4 * q < nch) t[sidx][i] = *reinterpret_cast<const vf4*>(p0 + (size_t)sidx * stride + (size_t)q * 128);
         }
       }
@@ -373,7 +374,7 @@ __device__ __forceinline__ void stage_slabs(float* dst, const float* base, int n
     vf4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sidx = 0; sidx < MAXSPLIT; ++sidx) v += t[sidx][i];
-    const int q = lane + 64 * i;
+    const int q = lane + NT * i;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = 4 * q + e;
@@ -382,76 +383,109 @@ __device__ __forceinline__ void stage_slabs(float* dst, const float* base, int n
   }
 }
 
-__device__ __forceinline__ void glue_predict(const float* sX, const float* sRAW, int lane, PredState& s) {
-  auto X = [&](int c) { return sX[c]; };
-  auto RAW = [&](int c) { return sRAW[c]; };
-  const int j = lane;
-  if (j < NJT) {
+__device__ __forceinline__ void predict_joints(const float* sX, const float* sRAW, int j, PredState& s) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      s.pj[c] = RAW(75 + 3 * j + c) + X(207 + 3 * j + c);
-      s.jv[c] = RAW(141 + 3 * j + c) + X(273 + 3 * j + c);
-    }
-  }
-  if (j >= 1 && j < NJT) {
-    const int bidx = j - 1;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) s.raw_aa_b[c] = RAW(12 + 3 * bidx + c);
-    rodrigues(s.raw_aa_b, s.dB);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) s.Bin[i] = X(18 + 9 * bidx + i);
-    mat3_mul(s.dB, s.Bin, s.pB);
-  }
-  if (j == 0) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      s.ptrans[c] = RAW(c) + X(c);
-      s.ptvel[c] = RAW(3 + c) + X(3 + c);
-      s.raw_aa_r[c] = RAW(6 + c);
-      s.prvel[c] = RAW(9 + c) + X(15 + c);
-    }
-    rodrigues(s.raw_aa_r, s.dR);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) s.Rin[i] = X(6 + i);
-    mat3_mul(s.dR, s.Rin, s.pR);
+  for (int c = 0; c < 3; ++c) {
+    s.pj[c] = sRAW[75 + 3 * j + c] + sX[207 + 3 * j + c];
+    s.jv[c] = sRAW[141 + 3 * j + c] + sX[273 + 3 * j + c];
   }
 }
+__device__ __forceinline__ void predict_body(const float* sX, const float* sRAW, int bidx, PredState& s) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s.raw_aa_b[c] = sRAW[12 + 3 * bidx + c];
+  rodrigues(s.raw_aa_b, s.dB);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s.Bin[i] = sX[18 + 9 * bidx + i];
+  mat3_mul(s.dB, s.Bin, s.pB);
+}
+__device__ __forceinline__ void predict_root(const float* sX, const float* sRAW, PredState& s) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    s.ptrans[c] = sRAW[c] + sX[c];
+    s.ptvel[c] = sRAW[3 + c] + sX[3 + c];
+    s.raw_aa_r[c] = sRAW[6 + c];
+    s.prvel[c] = sRAW[9 + c] + sX[15 + c];
+  }
+  rodrigues(s.raw_aa_r, s.dR);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s.Rin[i] = sX[6 + i];
+  mat3_mul(s.dR, s.Rin, s.pR);
+}
 
-__global__ __launch_bounds__(64) void glue_fwd_kernel(GlueParams p) {
-  const int r = blockIdx.x, lane = threadIdx.x;
+// Forward glue of step t.  Three waves per sequence (the same split as glue_bwd_kernel): wave 0 the root (lane 0), wave 1
+// the joints, wave 2 the body rotations, contact logits and the prior outputs.
+__global__ __launch_bounds__(192) void glue_fwd_kernel(GlueParams p) {
+  const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rt = r >> 5, rr = r & 31;
   const bool valid = r < p.B;
   float* XN = p.xT_next + (size_t)rt * D_INP * 32 + (size_t)rr * 4;
   if (!valid) {
-    for (int c = lane; c < D_INP; c += 64) XN[qoff(c)] = 0.f;
+    for (int c = tid; c < D_INP; c += 192) XN[qoff(c)] = 0.f;
     return;
   }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sX = smem + S_X;
   float* sRAW = smem + S_RAW;
-  stage_slabs<2>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
-  stage_slabs<1>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, lane, false);
-  if (lane == 0) XN[qoff(D_IN)] = 0.f;      // pad channel of the next state slab
-  __syncthreads();
-  PredState s;
-  glue_predict(sX, sRAW, lane, s);
-  // heading alignment from the predicted root orientation (lane 0), broadcast
-  W2A wa;
-  if (lane == 0) w2a_fwd(s.pR, wa);
-  float W[9], ptr[3];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) W[i] = __shfl(wa.W[i], 0);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) ptr[c] = __shfl(s.ptrans[c], 0);
+  float* sSH = smem + S_SH;
+  stage_slabs<1, 192>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, tid, false);
+  stage_slabs<1, 192>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, tid, false);
+  if (tid == 0) XN[qoff(D_IN)] = 0.f;      // pad channel of the next state slab
   float G[9], gt[3], t2j[3];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) G[i] = p.Gs[(size_t)r * 12 + i];
+  for (int i = 0; i < 9; ++i) G[i] = 0.f;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { gt[c] = p.Gs[(size_t)r * 12 + 9 + c]; t2j[c] = p.t2j[(size_t)r * 3 + c]; }
-  const float wt[3] = {-ptr[0], -ptr[1], 0.f};
+  for (int c = 0; c < 3; ++c) { gt[c] = 0.f; t2j[c] = 0.f; }
+  if (wave < 2) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) G[i] = p.Gs[(size_t)r * 12 + i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gt[c] = p.Gs[(size_t)r * 12 + 9 + c]; t2j[c] = p.t2j[(size_t)r * 3 + c]; }
+  }
+  __syncthreads();
   float* WO = p.world + ((size_t)r * p.S + p.t) * D_STATE;
+  PredState s;
+  if (wave == 0) {
+    // heading alignment from the predicted root orientation
+    if (lane == 0) {
+      predict_root(sX, sRAW, s);
+      W2A wa;
+      w2a_fwd(s.pR, wa);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sSH[i] = wa.W[i];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sSH[9 + c] = s.ptrans[c];
+    }
+  } else if (wave == 1) {
+    if (lane < NJT) predict_joints(sX, sRAW, lane, s);
+  } else {
+    if (lane >= 1 && lane < NJT) {
+      predict_body(sX, sRAW, lane - 1, s);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        XN[qoff(18 + 9 * (lane - 1) + i)] = s.pB[i];
+        WO[18 + 9 * (lane - 1) + i] = s.pB[i];
+      }
+    }
+    if (lane >= 32 && lane < 32 + 9) {
+      const int c = lane - 32;
+      WO[339 + c] = sRAW[207 + c];
+    }
+    if (p.prior_mu && lane < ZD) {
+      const float mu = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, lane, rr);
+      const float lv = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, ZD + lane, rr);
+      p.prior_mu[((size_t)r * p.S + p.t) * ZD + lane] = mu;
+      p.prior_var[((size_t)r * p.S + p.t) * ZD + lane] = expf(lv);
+    }
+  }
+  __syncthreads();
+  float W[9], ptr[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) W[i] = sSH[i];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ptr[c] = sSH[9 + c];
+  const float wt[3] = {-ptr[0], -ptr[1], 0.f};
 
-  if (lane < NJT) {
+  if (wave == 1 && lane < NJT) {
     const int j = lane;
     float q[3], o[3];
     // next input: W (pj + wt + t2j) - t2j ; W jv
@@ -472,15 +506,8 @@ __global__ __launch_bounds__(64) void glue_fwd_kernel(GlueParams p) {
     mat3_tvec(G, s.jv, o);
 #pragma unroll
     for (int c = 0; c < 3; ++c) WO[273 + 3 * j + c] = o[c];
-    if (j >= 1) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        XN[qoff(18 + 9 * (j - 1) + i)] = s.pB[i];
-        WO[18 + 9 * (j - 1) + i] = s.pB[i];
-      }
-    }
   }
-  if (lane == 0) {
+  if (wave == 0 && lane == 0) {
     float q[3], o[3], M[9];
 #pragma unroll
     for (int c = 0; c < 3; ++c) q[c] = s.ptrans[c] + wt[c];
@@ -518,16 +545,6 @@ __global__ __launch_bounds__(64) void glue_fwd_kernel(GlueParams p) {
     p.Gs_next[(size_t)r * 12 + 10] = -wtr[1];
     p.Gs_next[(size_t)r * 12 + 11] = 0.f;
   }
-  if (lane >= 32 && lane < 32 + 9) {
-    const int c = lane - 32;
-    WO[339 + c] = sRAW[207 + c];
-  }
-  if (p.prior_mu && lane < ZD) {
-    const float mu = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, lane, rr);
-    const float lv = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, ZD + lane, rr);
-    p.prior_mu[((size_t)r * p.S + p.t) * ZD + lane] = mu;
-    p.prior_var[((size_t)r * p.S + p.t) * ZD + lane] = expf(lv);
-  }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -546,8 +563,13 @@ __device__ __forceinline__ void outer_acc(float M[9], const float a[3], const fl
 
 // Backward of step t.  Also collects dL/dz of step t+1 (its decoder backward has completed) and, when
 // p.t == -1 ("final collect"), only assembles dL/dpast_in0 and dL/dz_0.
-__global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
-  const int r = blockIdx.x, lane = threadIdx.x;
+// One block of four waves per sequence: the kernel is a single dependent chain of ~6000 instructions when one wave does
+// everything, so the independent pieces run side by side -- wave 0 the root (lane 0), wave 1 the 22 joints, wave 2 the 21
+// body rotations, wave 3 the latent / prior / contact adjoints -- and meet at two barriers (W from the root's forward
+// recomputation; the joint wave's reduced shared adjoints back to the root).
+
+__global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
+  const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rt = r >> 5, rr = r & 31;
   if (r >= p.B) return;
   const bool last = p.t == p.S - 1;      // no step t+1 behind this one
@@ -558,32 +580,53 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
   float* sRAW = smem + S_RAW;
   float* sGXN = smem + S_GXN;
   float* sGW = smem + S_GW;
-  // ---- total adjoint of x_{t+1}: direct part + layer-0 input-gradient slabs of step t+1 -------------
+  float* sSH = smem + S_SH;
+  float* sRED = smem + S_RED;
+  // ---- total adjoint of x_{t+1}: direct part + layer-0 input-gradient slabs of step t+1 (all 256 threads stage) -------
   if (last) {
-    for (int c = lane; c < D_IN; c += 64) sGXN[c] = 0.f;
+    for (int c = tid; c < D_IN; c += 256) sGXN[c] = 0.f;
   } else {
-    stage_slabs<2>(sGXN, p.gx_dir_in, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
-    stage_slabs<2>(sGXN, p.gxp_pri, p.gxp_pri_nsplit, p.RT, p.gxp_pri_pad, D_IN, rt, rr, lane, true);
-    stage_slabs<2>(sGXN, p.gxp_dec, p.gxp_dec_nsplit, p.RT, p.gxp_dec_pad, D_IN, rt, rr, lane, true);
+    stage_slabs<1, 256>(sGXN, p.gx_dir_in, 1, p.RT, D_INP, D_IN, rt, rr, tid, false);
+    stage_slabs<1, 256>(sGXN, p.gxp_pri, p.gxp_pri_nsplit, p.RT, p.gxp_pri_pad, D_IN, rt, rr, tid, true);
+    stage_slabs<1, 256>(sGXN, p.gxp_dec, p.gxp_dec_nsplit, p.RT, p.gxp_dec_pad, D_IN, rt, rr, tid, true);
   }
   if (!final_collect) {
-    stage_slabs<2>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, lane, false);
-    stage_slabs<1>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, lane, false);
+    stage_slabs<1, 256>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, tid, false);
+    stage_slabs<1, 256>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, tid, false);
     const float* GWp = p.g_world ? p.g_world + ((size_t)r * p.S + p.t) * D_STATE : nullptr;
-    for (int c = lane; c < D_STATE; c += 64) sGW[c] = GWp ? GWp[c] : 0.f;
+    for (int c = tid; c < D_STATE; c += 256) sGW[c] = GWp ? GWp[c] : 0.f;
+  }
+  // per-sequence state: issued before the barrier so that it overlaps the staging round trip
+  float* carry = p.carry + (size_t)r * 16;
+  float G[9], gt[3], t2j[3], gGn[9], ggtn[3], g_t2j_acc[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { G[i] = 0.f; gGn[i] = 0.f; }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { gt[c] = 0.f; t2j[c] = 0.f; ggtn[c] = 0.f; g_t2j_acc[c] = 0.f; }
+  if (!final_collect && wave < 2) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) G[i] = p.Gs[(size_t)r * 12 + i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gt[c] = p.Gs[(size_t)r * 12 + 9 + c]; t2j[c] = p.t2j[(size_t)r * 3 + c]; }
+    if (!last && wave == 0) {
+      // incoming carried adjoints of (G', gt') = state after this step
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gGn[i] = carry[i];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { ggtn[c] = carry[9 + c]; g_t2j_acc[c] = carry[12 + c]; }
+    }
   }
   __syncthreads();
   auto GXN = [&](int c) -> float { return sGXN[c]; };
-  // ---- dz of step t+1 ---------------------------------------------------------------------------------
-  if (!last && p.g_z && lane < ZD) {
-    float v = 0.f;
-    for (int i = 0; i < p.dz_n; ++i) v += slab_sum(p.dz_src[i], p.dz_nsplit[i], p.RT, p.dz_pad[i], rt, p.dz_off[i] + lane, rr);
-    p.g_z[((size_t)r * p.S + (p.t + 1)) * ZD + lane] = v;
-  }
-  float* carry = p.carry + (size_t)r * 16;
+  auto gw = [&](int c) { return sGW[c]; };
   if (final_collect) {
-    // dL/dpast_in0 = adjoint of x_0 ; t2j = -(x0[207], x0[208], 0)
-    for (int c = lane; c < D_IN; c += 64) {
+    // dz of step 0 ; dL/dpast_in0 = adjoint of x_0 ; t2j = -(x0[207], x0[208], 0)
+    if (p.g_z && tid < ZD) {
+      float v = 0.f;
+      for (int i = 0; i < p.dz_n; ++i) v += slab_sum(p.dz_src[i], p.dz_nsplit[i], p.RT, p.dz_pad[i], rt, p.dz_off[i] + tid, rr);
+      p.g_z[((size_t)r * p.S + (p.t + 1)) * ZD + tid] = v;
+    }
+    for (int c = tid; c < D_IN; c += 256) {
       float v = GXN(c);
       if (c == 207) v -= carry[12];
       if (c == 208) v -= carry[13];
@@ -592,44 +635,79 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
     return;
   }
 
+  float* GD = p.g_dec_out + (size_t)rt * p.dec_pad * 32 + (size_t)rr * 4;   // adjoint of the decoder raw output (quad layout)
+  float* GX = p.gx_dir_out + (size_t)rt * D_INP * 32 + (size_t)rr * 4;
   PredState s;
-  glue_predict(sX, sRAW, lane, s);
   W2A wa;
-  if (lane == 0) w2a_fwd(s.pR, wa);
-  float W[9], ptr[3];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) W[i] = __shfl(wa.W[i], 0);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) ptr[c] = __shfl(s.ptrans[c], 0);
-  float G[9], gt[3], t2j[3];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) G[i] = p.Gs[(size_t)r * 12 + i];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { gt[c] = p.Gs[(size_t)r * 12 + 9 + c]; t2j[c] = p.t2j[(size_t)r * 3 + c]; }
-  const float wt[3] = {-ptr[0], -ptr[1], 0.f};
-
-  // incoming carried adjoints of (G', gt') = state after this step
-  float gGn[9], ggtn[3];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) gGn[i] = last ? 0.f : carry[i];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) ggtn[c] = last ? 0.f : carry[9 + c];
-  float g_t2j_acc[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) g_t2j_acc[c] = last ? 0.f : carry[12 + c];
-
-  auto gw = [&](int c) { return sGW[c]; };
-
-  // lane-local partial sums of the wave-shared adjoints
+  // lane-local partial sums of the adjoints shared by the whole sequence (W, G, gt, wt, t2j)
   float gW[9], gG[9], ggt[3] = {0.f, 0.f, 0.f}, gwt[3] = {0.f, 0.f, 0.f}, gt2[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 9; ++i) { gW[i] = 0.f; gG[i] = 0.f; }
 
-  float* GD = p.g_dec_out + (size_t)rt * p.dec_pad * 32 + (size_t)rr * 4;   // adjoint of the decoder raw output (quad layout)
-  float* GX = p.gx_dir_out + (size_t)rt * D_INP * 32 + (size_t)rr * 4;
+  // ---- phase 1 (before W is known) ---------------------------------------------------------------------
+  if (wave == 0) {
+    if (lane == 0) {
+      predict_root(sX, sRAW, s);
+      w2a_fwd(s.pR, wa);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sSH[i] = wa.W[i];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sSH[9 + c] = s.ptrans[c];
+    }
+  } else if (wave == 1) {
+    if (lane < NJT) predict_joints(sX, sRAW, lane, s);
+  } else if (wave == 2) {
+    // body rotation: pB = dB * Bin goes unchanged to both outputs (no dependence on W or G)
+    if (lane >= 1 && lane < NJT) {
+      const int bidx = lane - 1;
+      predict_body(sX, sRAW, bidx, s);
+      float gpB[9], gdB[9], gBin[9], gaa[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gpB[i] = gw(18 + 9 * bidx + i) + GXN(18 + 9 * bidx + i);
+      mat3_mult(gpB, s.Bin, gdB);      // gdB = gpB * Bin^T
+      mat3_tmul(s.dB, gpB, gBin);      // gBin = dB^T * gpB
+      rodrigues_bwd(s.raw_aa_b, gdB, gaa);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) GD[qoff(12 + 3 * bidx + c)] = gaa[c];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) GX[qoff(18 + 9 * bidx + i)] = gBin[i];
+    }
+  } else {
+    // dz of step t+1, contacts, padded decoder channels, prior output adjoint
+    if (!last && p.g_z && lane < ZD) {
+      float v = 0.f;
+      for (int i = 0; i < p.dz_n; ++i) v += slab_sum(p.dz_src[i], p.dz_nsplit[i], p.RT, p.dz_pad[i], rt, p.dz_off[i] + lane, rr);
+      p.g_z[((size_t)r * p.S + (p.t + 1)) * ZD + lane] = v;
+    }
+    if (lane >= 32 && lane < 32 + 9) GD[qoff(207 + lane - 32)] = gw(339 + lane - 32);
+    for (int c = D_RAW + lane; c < p.dec_pad; c += 64) GD[qoff(c)] = 0.f;
+    if (p.g_pri_out) {
+      float* GP = p.g_pri_out + (size_t)rt * p.pri_pad * 32 + (size_t)rr * 4;
+      if (lane < ZD) {
+        const size_t o = ((size_t)r * p.S + p.t) * ZD + lane;
+        GP[qoff(lane)] = p.g_prior_mu ? p.g_prior_mu[o] : 0.f;
+        // var = exp(logvar): d/dlogvar = g_var * var (recomputed from the stashed prior output slabs)
+        const float var = expf(slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, ZD + lane, rr));
+        GP[qoff(ZD + lane)] = p.g_prior_var ? p.g_prior_var[o] * var : 0.f;
+      }
+      for (int c = 2 * ZD + lane; c < p.pri_pad; c += 64) GP[qoff(c)] = 0.f;
+    }
+  }
+  __syncthreads();
+  float W[9], ptr[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) W[i] = sSH[i];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ptr[c] = sSH[9 + c];
+  const float wt[3] = {-ptr[0], -ptr[1], 0.f};
 
-  if (lane < NJT) {
-    const int j = lane;
+  // ---- phase 2: joints (wave 1) next to the root (wave 0, lane 0) ----------------------------------------
+  float gptrans[3] = {0.f, 0.f, 0.f}, gptvel[3] = {0.f, 0.f, 0.f}, gprvel[3] = {0.f, 0.f, 0.f}, gpR[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) gpR[i] = 0.f;
+  if (wave == 1) {
+    if (lane < NJT) {
+      const int j = lane;
     float g[3], q[3], o[3], gpj[3] = {0.f, 0.f, 0.f}, gjv[3] = {0.f, 0.f, 0.f};
     // world joints: wj = G^T (pj + t2j) - t2j - gt
 #pragma unroll
@@ -667,26 +745,19 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
       GD[qoff(141 + 3 * j + c)] = gjv[c];
       GX[qoff(273 + 3 * j + c)] = gjv[c];
     }
-    if (j >= 1) {
-      // body rotation: pB = dB * Bin goes unchanged to both outputs
-      const int bidx = j - 1;
-      float gpB[9], gdB[9], gBin[9], gaa[3];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) gpB[i] = gw(18 + 9 * bidx + i) + GXN(18 + 9 * bidx + i);
-      mat3_mult(gpB, s.Bin, gdB);      // gdB = gpB * Bin^T
-      mat3_tmul(s.dB, gpB, gBin);      // gBin = dB^T * gpB
-      rodrigues_bwd(s.raw_aa_b, gdB, gaa);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) GD[qoff(12 + 3 * bidx + c)] = gaa[c];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) GX[qoff(18 + 9 * bidx + i)] = gBin[i];
     }
-  }
-  // root pieces (lane 0) contribute to the shared adjoints before the reduction
-  float gptrans[3] = {0.f, 0.f, 0.f}, gptvel[3] = {0.f, 0.f, 0.f}, gprvel[3] = {0.f, 0.f, 0.f}, gpR[9];
+    // reduce the joint lanes' partial sums and hand them to the root
 #pragma unroll
-  for (int i = 0; i < 9; ++i) gpR[i] = 0.f;
-  if (lane == 0) {
+    for (int i = 0; i < 9; ++i) { gW[i] = wave_sum(gW[i]); gG[i] = wave_sum(gG[i]); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { ggt[c] = wave_sum(ggt[c]); gwt[c] = wave_sum(gwt[c]); gt2[c] = wave_sum(gt2[c]); }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { sRED[i] = gW[i]; sRED[9 + i] = gG[i]; }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { sRED[18 + c] = ggt[c]; sRED[21 + c] = gwt[c]; sRED[24 + c] = gt2[c]; }
+    }
+  } else if (wave == 0 && lane == 0) {
     float g[3], o[3], q[3];
     // carried: gt' = (-wtrans.x, -wtrans.y, 0)
     float gwtr[3] = {gw(0) - ggtn[0], gw(1) - ggtn[1], gw(2)};
@@ -758,13 +829,14 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
     for (int c = 0; c < 3; ++c) gprvel[c] += o[c];
     outer_acc(gW, g, s.prvel);
   }
-  // wave reduction of the shared adjoints
-#pragma unroll
-  for (int i = 0; i < 9; ++i) { gW[i] = wave_sum(gW[i]); gG[i] = wave_sum(gG[i]); }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { ggt[c] = wave_sum(ggt[c]); gwt[c] = wave_sum(gwt[c]); gt2[c] = wave_sum(gt2[c]); }
+  __syncthreads();
 
-  if (lane == 0) {
+  // ---- phase 3: the root finishes (heading alignment and root rotation adjoints, carried state) -------------
+  if (wave == 0 && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { gW[i] += sRED[i]; gG[i] += sRED[9 + i]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { ggt[c] += sRED[18 + c]; gwt[c] += sRED[21 + c]; gt2[c] += sRED[24 + c]; }
     // wt = (-ptrans.x, -ptrans.y, 0)
     gptrans[0] -= gwt[0];
     gptrans[1] -= gwt[1];
@@ -792,21 +864,6 @@ __global__ __launch_bounds__(64) void glue_bwd_kernel(GlueParams p) {
     for (int i = 0; i < 9; ++i) carry[i] = gG[i];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { carry[9 + c] = ggt[c]; carry[12 + c] = g_t2j_acc[c] + gt2[c]; }
-  }
-  // contacts pass straight through; padded decoder channels get zero
-  if (lane >= 32 && lane < 32 + 9) GD[qoff(207 + lane - 32)] = gw(339 + lane - 32);
-  for (int c = D_RAW + lane; c < p.dec_pad; c += 64) GD[qoff(c)] = 0.f;
-  // prior output adjoint: (g_mu, g_var * var)
-  if (p.g_pri_out) {
-    float* GP = p.g_pri_out + (size_t)rt * p.pri_pad * 32 + (size_t)rr * 4;
-    if (lane < ZD) {
-      const size_t o = ((size_t)r * p.S + p.t) * ZD + lane;
-      GP[qoff(lane)] = p.g_prior_mu ? p.g_prior_mu[o] : 0.f;
-      // var = exp(logvar): d/dlogvar = g_var * var (recomputed from the stashed prior output slabs)
-      const float var = expf(slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, ZD + lane, rr));
-      GP[qoff(ZD + lane)] = p.g_prior_var ? p.g_prior_var[o] * var : 0.f;
-    }
-    for (int c = 2 * ZD + lane; c < p.pri_pad; c += 64) GP[qoff(c)] = 0.f;
   }
 }
 
@@ -1159,15 +1216,17 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
       LayerLaunch LL;
       memset(&LL, 0, sizeof(LL));
       LL.RT = RT;
-      if (l < net->n_dec) {
-        const PackedLayer& P = net->dec[l];
-        const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
-        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
-      }
+      // prior first: the decoder's last K-split holds only the 48-channel latent slice, and those light blocks should be
+      // the ones that share a CU when a launch has more than 256 blocks
       if (with_prior && l < net->n_pri) {
         const PackedLayer& P = net->pri[l];
         const float* src = l == 0 ? sp + L.off_x : sp + L.off_pri[l - 1];
         fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_pri[l - 1], nullptr, sp + L.off_pri[l], L.spb, L.nsf_pri[l]);
+      }
+      if (l < net->n_dec) {
+        const PackedLayer& P = net->dec[l];
+        const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
+        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
       }
       if (LL.ntasks == 0) continue;
       int rc = launch_layers(LL, L.nw, st);
@@ -1187,7 +1246,7 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
     g.t2j = stash + L.t2j;
     g.world = world;
     g.prior_mu = prior_mu; g.prior_var = prior_var;
-    hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(64), S_TOTAL * sizeof(float), st, g);
+    hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(192), S_TOTAL_BWD * sizeof(float), st, g);
     HA_LAUNCH_CHECK();
   }
   return HA_OK;
@@ -1250,7 +1309,7 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
     g.t2j = stash + L.t2j;
     g.world = world;
     g.prior_mu = prior_mu; g.prior_var = prior_var;
-    hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(64), S_TOTAL * sizeof(float), st, g);
+    hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(192), S_TOTAL_BWD * sizeof(float), st, g);
     HA_LAUNCH_CHECK();
   }
   return HA_OK;
@@ -1305,7 +1364,7 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
   for (int t = S - 1; t >= 0; --t) {
     GlueParams g;
     fill_glue(g, t);
-    hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(64), S_TOTAL * sizeof(float), st, g);
+    hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(256), S_TOTAL_BWD * sizeof(float), st, g);
     HA_LAUNCH_CHECK();
     (void)0;
     float* sp = step_ptr(t);
@@ -1337,7 +1396,7 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
   }
   GlueParams g;
   fill_glue(g, -1);
-  hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(64), S_TOTAL * sizeof(float), st, g);
+  hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(256), S_TOTAL_BWD * sizeof(float), st, g);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
