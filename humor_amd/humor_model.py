@@ -343,12 +343,13 @@ class HumorModel(nn.Module):
         if canonicalize_input and uncanonicalize_output:
             from .frames import uncanonicalize_world
             world = uncanonicalize_world(world, *uncanon)
-        out, s = {}, 0
-        for n, d in zip(self.data_names, self.delta_output_dim_list):
-            out[n] = world[:, :, s:s + d]
-            s += d
+        # one split (views forward, a single cat backward) instead of one slice + zero-fill + add per output
+        dims = list(self.delta_output_dim_list)
+        rest = world.size(2) - sum(dims)
+        parts = torch.split(world, dims + ([rest] if rest > 0 else []), dim=2)
+        out = dict(zip(self.data_names, parts))
         if self.pred_contacts:
-            out['contacts'] = world[:, :, s:s + 9]
+            out['contacts'] = parts[len(self.data_names)]
         if return_z:
             out['z'] = z_out
         if return_prior:
