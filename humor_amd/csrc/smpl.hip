@@ -75,6 +75,7 @@ static int upload(T** dst, const std::vector<T>& src) {
 
 static void free_set(VertexSet& s) {
   if (s.Pd_v) (void)hipFree(s.Pd_v);
+  if (s.Pd_k) (void)hipFree(s.Pd_k);
   if (s.w) (void)hipFree(s.w);
   if (s.idx) (void)hipFree(s.idx);
   if (s.ids) (void)hipFree(s.ids);
@@ -89,6 +90,8 @@ static int build_set(ha_smpl_model* m, int slot, const int32_t* ids, int n) {
   s.npad = s.nchunks * kChunk;
   const int K = m->Kfull, V = m->V, nnz = m->nnz;
   std::vector<float> pd((size_t)s.nchunks * K * 3 * kChunk, 0.0f);
+  const int Kp = ceil_div(K, 64) * 64;
+  std::vector<float> pdk((size_t)s.nchunks * 3 * kChunk * Kp, 0.0f);   // coefficient-major copy for the adjoint
   std::vector<float> w((size_t)s.nchunks * nnz * kChunk, 0.0f);
   std::vector<int32_t> ix((size_t)s.nchunks * nnz * kChunk, 0);
   for (int i = 0; i < n; ++i) {
@@ -96,7 +99,11 @@ static int build_set(ha_smpl_model* m, int slot, const int32_t* ids, int n) {
     const int ch = i / kChunk, ln = i % kChunk;
     for (int k = 0; k < K; ++k)
       for (int c = 0; c < 3; ++c)
-        pd[(((size_t)ch * K + k) * 3 + c) * kChunk + ln] = m->h_Pd[((size_t)k * V + v) * 3 + c];
+      {
+        const float val = m->h_Pd[((size_t)k * V + v) * 3 + c];
+        pd[(((size_t)ch * K + k) * 3 + c) * kChunk + ln] = val;
+        pdk[((size_t)ch * 3 * kChunk + c * kChunk + ln) * Kp + k] = val;
+      }
     for (int q = 0; q < nnz; ++q) {
       w[((size_t)ch * nnz + q) * kChunk + ln] = m->h_w[(size_t)v * nnz + q];
       ix[((size_t)ch * nnz + q) * kChunk + ln] = m->h_idx[(size_t)v * nnz + q];
@@ -104,6 +111,7 @@ static int build_set(ha_smpl_model* m, int slot, const int32_t* ids, int n) {
   }
   int rc;
   if ((rc = upload(&s.Pd_v, pd)) != HA_OK) return rc;
+  if ((rc = upload(&s.Pd_k, pdk)) != HA_OK) return rc;
   if ((rc = upload(&s.w, w)) != HA_OK) return rc;
   if ((rc = upload(&s.idx, ix)) != HA_OK) return rc;
   if (ids) {
@@ -286,7 +294,7 @@ struct FrameParams {
   const int32_t* child_start; const int32_t* child_idx;
   int J, NB, Kfull, Kfull_pad, kf4, depth;   // kf4: Kfull_pad rounded to 4 floats (LDS stride)
   // vertex set
-  const float* Pd_v; const float* w; const int32_t* idx;
+  const float* Pd_v; const float* Pd_k; int Kp; const float* w; const int32_t* idx;
   int nverts, nchunks, nnz;
   // problem
   int N, n_active, Kc;
@@ -551,24 +559,30 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
         }
       }
       __syncthreads();
-      // dL/dcoeff[k] += sum_{v,c} gvp[c][v] * Pd[k][c][v]   (lane = k, each lane streams its own 768-B row)
-#pragma unroll
-      for (int m = 0; m < kMaxKM; ++m) {
-        const int k = lane + 64 * m;
-        if (k < p.Kc) {
-          const float4* row = reinterpret_cast<const float4*>(p.Pd_v + ((size_t)chunk * p.Kfull + k) * 192);
-          const float4* gq = reinterpret_cast<const float4*>(gvp);
-          float acc = 0.f;
-#pragma unroll 4
-          for (int i = 0; i < 48; ++i) {
-            const float4 a = row[i];
-            const float4 b = gq[i];
-            acc = fmaf(a.x, b.x, acc);
-            acc = fmaf(a.y, b.y, acc);
-            acc = fmaf(a.z, b.z, acc);
-            acc = fmaf(a.w, b.w, acc);
+      // dL/dcoeff[k] += sum_{v,c} gvp[c][v] * Pd[k][c][v]   (lane = k; the coefficient-major copy makes every load a
+      // coalesced 256-byte row segment -- each lane streaming its own 768-byte row of Pd_v cost 64 cache lines per load)
+      // (register m = 4 r + e of lane l holds coefficient k = 256 r + 4 l + e: one 16-byte load per row and range)
+      {
+        const float* base = p.Pd_k + (size_t)chunk * 192 * p.Kp + 4 * lane;
+        if (p.Kc <= 256) {
+#pragma unroll 8
+          for (int i = 0; i < 192; ++i) {
+            const float gi = gvp[i];
+            const float4 a = *reinterpret_cast<const float4*>(base + (size_t)i * p.Kp);
+            gco_reg[0] = fmaf(a.x, gi, gco_reg[0]); gco_reg[1] = fmaf(a.y, gi, gco_reg[1]);
+            gco_reg[2] = fmaf(a.z, gi, gco_reg[2]); gco_reg[3] = fmaf(a.w, gi, gco_reg[3]);
           }
-          gco_reg[m] += acc;
+        } else {
+#pragma unroll 4
+          for (int i = 0; i < 192; ++i) {
+            const float gi = gvp[i];
+            const float4 a = *reinterpret_cast<const float4*>(base + (size_t)i * p.Kp);
+            const float4 b = *reinterpret_cast<const float4*>(base + (size_t)i * p.Kp + 256);
+            gco_reg[0] = fmaf(a.x, gi, gco_reg[0]); gco_reg[1] = fmaf(a.y, gi, gco_reg[1]);
+            gco_reg[2] = fmaf(a.z, gi, gco_reg[2]); gco_reg[3] = fmaf(a.w, gi, gco_reg[3]);
+            gco_reg[4] = fmaf(b.x, gi, gco_reg[4]); gco_reg[5] = fmaf(b.y, gi, gco_reg[5]);
+            gco_reg[6] = fmaf(b.z, gi, gco_reg[6]); gco_reg[7] = fmaf(b.w, gi, gco_reg[7]);
+          }
         }
       }
       __syncthreads();
@@ -576,7 +590,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
   }
 #pragma unroll
   for (int m = 0; m < kMaxKM; ++m) {
-    const int k = lane + 64 * m;
+    const int k = 256 * (m >> 2) + 4 * lane + (m & 3);
     if (k < p.Kfull_pad) gco[k] = (k < p.Kc) ? gco_reg[m] : 0.f;
   }
   __syncthreads();
@@ -908,7 +922,7 @@ static void fill_model(FrameParams& p, const ha_smpl_model* m, int slot) {
   p.child_start = m->child_start; p.child_idx = m->child_idx;
   p.J = m->J; p.NB = m->NB; p.Kfull = m->Kfull; p.Kfull_pad = m->Kfull_pad; p.kf4 = (m->Kfull_pad + 3) & ~3; p.depth = m->depth;
   const VertexSet& s = m->sets[slot];
-  p.Pd_v = s.Pd_v; p.w = s.w; p.idx = s.idx;
+  p.Pd_v = s.Pd_v; p.Pd_k = s.Pd_k; p.Kp = ceil_div(m->Kfull, 64) * 64; p.w = s.w; p.idx = s.idx;
   p.nverts = s.n; p.nchunks = s.nchunks; p.nnz = m->nnz;
 }
 

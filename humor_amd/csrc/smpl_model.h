@@ -19,6 +19,8 @@ struct VertexSet {
   int nchunks = 0;
   // wave-per-frame layout: [nchunks][Kfull][3][64]
   float* Pd_v = nullptr;
+  // coefficient-major copy for the adjoint: [nchunks][3*64][Kp], Kp = Kfull rounded up to 64
+  float* Pd_k = nullptr;
   // skinning weights / joint indices, general form: [nchunks][nnz][64]
   float* w = nullptr;
   int32_t* idx = nullptr;
