@@ -74,7 +74,7 @@ struct LayerTask {
 };
 
 struct LayerLaunch {
-  LayerTask t[2];
+  LayerTask t[3];
   int ntasks;
   int RT;
 };
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
 #endif
   int b = blockIdx.x;
   int ti = 0;
-  if (L.ntasks > 1 && b >= L.t[0].nblocks) { b -= L.t[0].nblocks; ti = 1; }
+  while (ti + 1 < L.ntasks && b >= L.t[ti].nblocks) { b -= L.t[ti].nblocks; ++ti; }
   const LayerTask& T = L.t[ti];
   const int tile = b % T.ntiles;
   const int b2 = b / T.ntiles;
@@ -891,6 +891,38 @@ __global__ __launch_bounds__(64) void sample_z_kernel(SampleParams p) {
   p.z_out[o] = z;
 }
 
+// Prior outputs of every step, off the recurrence: mu / var = exp(logvar) from the stashed prior output slabs (forward), and
+// the adjoint of those slabs (g_mu, g_var * var, zero padding) for the backward pass.  One block per (sequence, step).
+struct PriorIOParams {
+  int B, S, RT;
+  const float* pri_out0; size_t step_stride; int pri_nsplit; int pri_pad;   // slabs of step t at pri_out0 + t * step_stride
+  float* prior_mu; float* prior_var;                 // forward: [B][S][48]
+  const float* g_prior_mu; const float* g_prior_var; // backward inputs (either may be null)
+  float* g_pri_all;                                  // backward: [S][RT][pri_pad][32]
+};
+
+__global__ __launch_bounds__(64) void prior_io_kernel(PriorIOParams p) {
+  const int r = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+  const int rt = r >> 5, rr = r & 31;
+  const float* po = p.pri_out0 + (size_t)t * p.step_stride;
+  float mu = 0.f, var = 0.f;
+  if (r < p.B && lane < ZD) {
+    mu = slab_sum(po, p.pri_nsplit, p.RT, p.pri_pad, rt, lane, rr);
+    var = expf(slab_sum(po, p.pri_nsplit, p.RT, p.pri_pad, rt, ZD + lane, rr));
+  }
+  const size_t o = ((size_t)r * p.S + t) * ZD + lane;
+  if (p.prior_mu && r < p.B && lane < ZD) { p.prior_mu[o] = mu; p.prior_var[o] = var; }
+  if (p.g_pri_all) {
+    float* GP = p.g_pri_all + ((size_t)t * p.RT + rt) * p.pri_pad * 32 + (size_t)rr * 4;
+    if (lane < ZD) {
+      const bool live = r < p.B;
+      GP[qoff(lane)] = (live && p.g_prior_mu) ? p.g_prior_mu[o] : 0.f;
+      GP[qoff(ZD + lane)] = (live && p.g_prior_var) ? p.g_prior_var[o] * var : 0.f;
+    }
+    for (int c = 2 * ZD + lane; c < p.pri_pad; c += 64) GP[qoff(c)] = 0.f;
+  }
+}
+
 // [B][S][C] -> [S][RT][Cp/4][32][4] (quad-interleaved tiles, zero-padded rows and channels); Cp = C rounded up to 4
 __global__ void transpose_in_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int S, int C, int Cp, int RT) {
   const size_t total = (size_t)S * RT * Cp * 32;
@@ -1085,7 +1117,7 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   L.gx_dir[1] = take(RT * D_INP * 32);
   L.carry = take(RT * 32 * 16);
   L.g_dec_out = take(RT * net->dec[net->n_dec - 1].Nout_pad * 32);
-  L.g_pri_out = take(RT * net->pri[net->n_pri - 1].Nout_pad * 32);
+  L.g_pri_out = take((size_t)S * RT * net->pri[net->n_pri - 1].Nout_pad * 32);   // prior-output adjoints of all steps
   for (int i = 0; i < net->n_pri; ++i) L.bwd_pri[i] = take((size_t)L.nsb_pri[i] * RT * net->pri[i].Nin_pad * 32);
   for (int i = 0; i < net->n_dec; ++i) L.bwd_dec[i] = take((size_t)L.nsb_dec[i] * RT * net->dec[i].Nin_pad * 32);
   L.total = o;
@@ -1142,6 +1174,7 @@ extern "C" int ha_humor_net_create(ha_humor_net** out, int device, const ha_mlp_
              "ha_humor_net_create: decoder must map [339+48] -> 216 with a 48-d latent skip (got in=%d skip=%d)", decoder->in_dim, decoder->skip_dim);
   HA_REQUIRE(prior->in_dim == D_IN && prior->skip_dim == 0 && prior->out_dims[prior->n_linear - 1] == 2 * ZD,
              "ha_humor_net_create: prior must map 339 -> 96");
+  HA_REQUIRE(prior->n_linear <= 2 * decoder->n_linear, "ha_humor_net_create: the prior may be at most twice as deep as the decoder");
   DeviceGuard guard(device);
   HA_REQUIRE(guard.ok, "ha_humor_net_create: cannot select device %d", device);
   ha_humor_net* net = new ha_humor_net();
@@ -1208,27 +1241,30 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
   HA_LAUNCH_CHECK();
 
   const bool with_prior = prior_mu != nullptr;
-  const int nl = net->n_dec > net->n_pri ? net->n_dec : net->n_pri;
+  const int nd = net->n_dec, np = net->n_pri;
+  // The prior is off the recurrence (only its outputs are wanted), so its layers beyond the decoder's depth are deferred:
+  // layer nd + l of step t-1 rides in the level-l launch of step t instead of costing a launch of its own per step.
+  auto pri_task = [&](LayerLaunch& LL, int l, int t) {
+    float* sp = step_ptr(t);
+    const float* src = l == 0 ? sp + L.off_x : sp + L.off_pri[l - 1];
+    fwd_task(LL.t[LL.ntasks++], net->pri[l], src, l == 0 ? 1 : L.nsf_pri[l - 1], nullptr, sp + L.off_pri[l], L.spb, L.nsf_pri[l]);
+  };
   for (int t = 0; t < S; ++t) {
     float* sp = step_ptr(t);
     const float* zT = stash + L.zT + (size_t)t * RT * ZD * 32;
-    for (int l = 0; l < nl; ++l) {
+    for (int l = 0; l < nd; ++l) {
       LayerLaunch LL;
       memset(&LL, 0, sizeof(LL));
       LL.RT = RT;
       // prior first: the decoder's last K-split holds only the 48-channel latent slice, and those light blocks should be
       // the ones that share a CU when a launch has more than 256 blocks
-      if (with_prior && l < net->n_pri) {
-        const PackedLayer& P = net->pri[l];
-        const float* src = l == 0 ? sp + L.off_x : sp + L.off_pri[l - 1];
-        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_pri[l - 1], nullptr, sp + L.off_pri[l], L.spb, L.nsf_pri[l]);
-      }
-      if (l < net->n_dec) {
+      if (with_prior && l < np) pri_task(LL, l, t);
+      if (with_prior && t > 0 && nd + l < np) pri_task(LL, nd + l, t - 1);
+      {
         const PackedLayer& P = net->dec[l];
         const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
         fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
       }
-      if (LL.ntasks == 0) continue;
       int rc = launch_layers(LL, L.nw, st);
       if (rc != HA_OK) return rc;
     }
@@ -1239,14 +1275,29 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
     g.xT_next = step_ptr(t + 1) + L.off_x;
     const PackedLayer& DL = net->dec[net->n_dec - 1];
     g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = L.nsf_dec[net->n_dec - 1]; g.dec_pad = DL.Nout_pad;
-    const PackedLayer& PL = net->pri[net->n_pri - 1];
-    g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = L.nsf_pri[net->n_pri - 1]; g.pri_pad = PL.Nout_pad;
     g.Gs = sp + L.off_G;
     g.Gs_next = step_ptr(t + 1) + L.off_G;
     g.t2j = stash + L.t2j;
     g.world = world;
-    g.prior_mu = prior_mu; g.prior_var = prior_var;
     hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(192), S_TOTAL_BWD * sizeof(float), st, g);
+    HA_LAUNCH_CHECK();
+  }
+  if (with_prior) {
+    for (int l = nd; l < np; ++l) {      // the deferred layers of the last step
+      LayerLaunch LL;
+      memset(&LL, 0, sizeof(LL));
+      LL.RT = RT;
+      pri_task(LL, l, S - 1);
+      int rc = launch_layers(LL, L.nw, st);
+      if (rc != HA_OK) return rc;
+    }
+    PriorIOParams q;
+    memset(&q, 0, sizeof(q));
+    q.B = B; q.S = S; q.RT = RT;
+    q.pri_out0 = step_ptr(0) + L.off_pri[np - 1]; q.step_stride = L.per_step; q.pri_nsplit = L.nsf_pri[np - 1];
+    q.pri_pad = net->pri[np - 1].Nout_pad;
+    q.prior_mu = prior_mu; q.prior_var = prior_var;
+    hipLaunchKernelGGL(prior_io_kernel, dim3(rows, S), dim3(64), 0, st, q);
     HA_LAUNCH_CHECK();
   }
   return HA_OK;
@@ -1357,39 +1408,64 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
       g.g_world = g_world;
       g.g_prior_mu = g_prior_mu; g.g_prior_var = g_prior_var;
       g.g_dec_out = stash + L.g_dec_out;
-      g.g_pri_out = with_prior ? stash + L.g_pri_out : nullptr;
+      g.g_pri_out = nullptr;      // prior-output adjoints of all steps come from prior_io_kernel
     }
   };
 
+  const int nd = net->n_dec, np = net->n_pri;
+  // adjoint of the prior layer l of step t (its top layer reads the prior-output adjoints prepared for all steps)
+  auto pri_bwd_task = [&](LayerLaunch& LL, int l, int t) {
+    float* sp = step_ptr(t);
+    const PackedLayer& P = net->pri[l];
+    if (l == np - 1)
+      bwd_task(LL.t[LL.ntasks++], P, stash + L.g_pri_out + (size_t)t * RT * P.Nout_pad * 32, 1, P.Nout_pad, nullptr, nullptr, 0,
+               stash + L.bwd_pri[l], L.spb, L.nsb_pri[l]);
+    else
+      bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_pri[l + 1], L.nsb_pri[l + 1], net->pri[l + 1].Nin_pad, &net->pri[l + 1],
+               sp + L.off_pri[l], L.nsf_pri[l], stash + L.bwd_pri[l], L.spb, L.nsb_pri[l]);
+  };
+  if (with_prior) {
+    PriorIOParams q;
+    memset(&q, 0, sizeof(q));
+    q.B = B; q.S = S; q.RT = RT;
+    q.pri_out0 = step_ptr(0) + L.off_pri[np - 1]; q.step_stride = L.per_step; q.pri_nsplit = L.nsf_pri[np - 1];
+    q.pri_pad = PL.Nout_pad;
+    q.g_prior_mu = g_prior_mu; q.g_prior_var = g_prior_var;
+    q.g_pri_all = stash + L.g_pri_out;
+    hipLaunchKernelGGL(prior_io_kernel, dim3(rows, S), dim3(64), 0, st, q);
+    HA_LAUNCH_CHECK();
+    // the prior layers above the decoder's depth run one step ahead of the chain (they do not depend on it); for the last
+    // step there is no launch to ride in
+    for (int l = np - 1; l >= nd; --l) {
+      LayerLaunch LL;
+      memset(&LL, 0, sizeof(LL));
+      LL.RT = RT;
+      pri_bwd_task(LL, l, S - 1);
+      int rc = launch_layers(LL, L.nw, st);
+      if (rc != HA_OK) return rc;
+    }
+  }
   for (int t = S - 1; t >= 0; --t) {
     GlueParams g;
     fill_glue(g, t);
     hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(256), S_TOTAL_BWD * sizeof(float), st, g);
     HA_LAUNCH_CHECK();
-    (void)0;
     float* sp = step_ptr(t);
-    const int nl = net->n_dec > net->n_pri ? net->n_dec : net->n_pri;
-    for (int l = nl - 1; l >= 0; --l) {
+    for (int l = nd - 1; l >= 0; --l) {
       LayerLaunch LL;
       memset(&LL, 0, sizeof(LL));
       LL.RT = RT;
-      if (l < net->n_dec) {
+      {
         const PackedLayer& P = net->dec[l];
-        if (l == net->n_dec - 1)
+        if (l == nd - 1)
           bwd_task(LL.t[LL.ntasks++], P, stash + L.g_dec_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
         else
           bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_dec[l + 1], L.nsb_dec[l + 1], net->dec[l + 1].Nin_pad, &net->dec[l + 1],
                    sp + L.off_dec[l], L.nsf_dec[l], stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
       }
-      if (with_prior && l < net->n_pri) {
-        const PackedLayer& P = net->pri[l];
-        if (l == net->n_pri - 1)
-          bwd_task(LL.t[LL.ntasks++], P, stash + L.g_pri_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_pri[l], L.spb, L.nsb_pri[l]);
-        else
-          bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_pri[l + 1], L.nsb_pri[l + 1], net->pri[l + 1].Nin_pad, &net->pri[l + 1],
-                   sp + L.off_pri[l], L.nsf_pri[l], stash + L.bwd_pri[l], L.spb, L.nsb_pri[l]);
-      }
-      if (LL.ntasks == 0) continue;
+      if (with_prior && l < np) pri_bwd_task(LL, l, t);
+      // step t-1's prior layers nd .. np-1, in descending order, in the last np - nd launches of this step
+      if (with_prior && t > 0 && nd + l < np) pri_bwd_task(LL, nd + l, t - 1);
       int rc = launch_layers(LL, L.nw, st);
       if (rc != HA_OK) return rc;
     }
