@@ -50,6 +50,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not capture the closure into a hipGraph')
+    ap.add_argument('--graph', dest='auto', action='store_false', help='always replay the captured hipGraph (default: time graph replay against eager evaluation once and keep the faster)')
     return ap.parse_args()
 
 
@@ -129,6 +130,18 @@ class FitClosure:
 
     def step(self):
         return self.closure()
+
+
+def closure_mode(args, fc):
+    o = fc.opt
+    if args.eager or not o.use_graphs or getattr(o, 'graph_failures', 0):
+        return 'eager'
+    picked = getattr(o, 'closure_mode', None)
+    if picked is not None:
+        tg, te = o.closure_mode_times_ms
+        return ('%s (picked by a one-off timing: hipGraph replay %.2f ms vs eager %.2f ms per closure)'
+                % ('hipGraph replay' if picked == 'graph' else 'eager launches', tg, te))
+    return 'hipGraph replay (objective + backward + all-reduce captured once)'
 
 
 def time_events(fn, iters, warm=2):
@@ -242,7 +255,7 @@ def main():
     npz = synth.write_smplh_npz(os.path.join(tmp, f'model_{rank}.npz'), seed=0)
     # hipGraph capture of the closure is used on one GPU only: capturing RCCL collectives cannot be exercised in the
     # 1-GPU development environment, and a rank-divergent capture failure would dead-lock the job.
-    fc = FitClosure(dev, npz, world, rank, None, use_graphs=(not args.eager) and world == 1)
+    fc = FitClosure(dev, npz, world, rank, None, use_graphs=('auto' if args.auto else True) if ((not args.eager) and world == 1) else False)
 
     for _ in range(args.warmup):
         fc.step()
@@ -275,7 +288,7 @@ def main():
                                    f'{B_SEQ * world} sub-sequences), joints2d + floor + overlap-consistency, SMPL+H 6890 verts / 52 joints / '
                                    '16 betas, HuMoR 48-d latent, 59-step roll-out; step = one stage-3 closure (fwd+bwd)',
                        'global_batch': B_SEQ * world, 'seq_len': T_SEQ, 'parallelism': f'dp{world} (sub-sequence sharding, replicated L-BFGS)'},
-            'closure_mode': 'eager' if (args.eager or not fc.opt.use_graphs or getattr(fc.opt, 'graph_failures', 0)) else 'hipGraph replay (objective + backward + all-reduce captured once)',
+            'closure_mode': closure_mode(args, fc),
             'lbfgs_outer_iters_per_sec_est': round(args.steps * world / dt / 25.0, 3),
             'smpl_verts_per_sec': round(B_SEQ * T_SEQ * V / (ms_dense * 1e-3), 1),
             'smpl_dense_fwd_ms': round(ms_dense, 4),

@@ -13,6 +13,7 @@ Multi-GPU: pass ``shard=humor_amd.distributed.Shard(B, group)`` -- replicated L-
 of sub-sequences, one packed all-reduce per closure (humor_amd/distributed.py).
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -48,7 +49,8 @@ class MotionOptimizer():
         self.im_dim = im_dim
         self.shard = shard
         self.verbose = verbose
-        self.use_graphs = use_graphs and torch.device(device).type == 'cuda'   # whole-closure hipGraph capture
+        # whole-closure hipGraph capture: False | True (always replay) | 'auto' (time replay against eager once, keep the faster)
+        self.use_graphs = use_graphs if torch.device(device).type == 'cuda' else False
         self.closure_evals = 0
         self.loss_trace = None      # set to a list to record (stage, loss) of every closure evaluation (host sync per eval)
         if motion_prior is None:
@@ -191,6 +193,30 @@ class MotionOptimizer():
                     self.closure_evals, self.loss_trace = evals, trace
                     state['grads'] = [p.grad for p in params]
                     state['graph'] = g
+                    if self.use_graphs == 'auto':
+                        # replay costs ~1.5 us of graph-node overhead per kernel, eager costs host time the roll-out's long
+                        # launches partly hide: measure both once and keep the faster (values are identical)
+                        def timed(fn, n=10):
+                            fn()
+                            fn()
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            for _ in range(n):
+                                fn()
+                            torch.cuda.synchronize()
+                            return (time.perf_counter() - t0) / n
+                        evals, trace = self.closure_evals, self.loss_trace
+                        self.loss_trace = None
+                        t_eager = timed(eager)
+                        for p, gbuf in zip(params, state['grads']):
+                            p.grad = gbuf
+                        t_graph = timed(g.replay)
+                        self.closure_evals, self.loss_trace = evals, trace
+                        self.closure_mode = 'graph' if t_graph <= t_eager else 'eager'
+                        self.closure_mode_times_ms = (1e3 * t_graph, 1e3 * t_eager)
+                        if self.closure_mode == 'eager':
+                            state['failed'] = True      # "do not replay": evaluate eagerly from now on
+                            return eager()
                 except Exception as e:          # capture is an optimisation: fall back to eager evaluation
                     print('humor_amd: hipGraph capture of the closure failed (%s: %s); running eagerly' % (type(e).__name__, str(e)[:600]))
                     state['failed'] = True
