@@ -96,7 +96,7 @@ def check_rollout(lib, device, B, S, seed=0, with_prior=True, weight_scale=1.0, 
 def check_rollout_conditioned(lib, device, B=32, S=59, seed=3):
     """Full BASELINE length (59 steps).  With random-init weights the autoregressive chain amplifies rounding error by
     ~1e4 (measured: the reference-style fp32 CPU evaluation drifts 6e-2 from an fp64 evaluation of the same chain at
-    step 58, tools/rollout_diag.py), so a fixed 1e-4 bound against the fp32 oracle is meaningless there.  Criterion:
+    step 58, tests/diagnostics/rollout_diag.py), so a fixed 1e-4 bound against the fp32 oracle is meaningless there.  Criterion:
     at every step the HIP result must be as close to the fp64 evaluation as the fp32 oracle is (factor 4 + a 1e-5
     relative floor), and within 1e-4 absolute over the first steps where the chain is still well conditioned."""
     hm, sd = make_model(lib, device, seed=seed)

@@ -1,4 +1,5 @@
-"""Second half of __graft_entry__.smoke(): one tiny HuMoR roll-out (forward + backward) on the GPU against the oracle."""
+"""Second half of __graft_entry__.smoke(): one tiny HuMoR roll-out (forward + backward) on the GPU against the oracle.
+(Test infrastructure: lives under tests/ because it imports oracle/.)"""
 import torch
 
 

@@ -29,7 +29,7 @@ def test_rollout_full_length(gpu_lib, dev):
     """BASELINE size (32 sequences x 59 steps): conditioning-aware parity (see check_rollout_conditioned) plus the
     gradient check on an 8-step chain judged against an fp64 oracle.  (The adjoint is amplified like the forward error:
     at 12-16 steps two fp32 implementations already differ by 1-10 % of a gradient whose scale itself varies over three
-    decades between seeds -- tools/grad_accuracy.py tabulates GPU fp32 vs CPU fp32 vs fp64 by chain length.)"""
+    decades between seeds -- tests/diagnostics/grad_accuracy.py tabulates GPU fp32 vs CPU fp32 vs fp64 by chain length.)"""
     RC.check_rollout_conditioned(gpu_lib, dev, B=32, S=59, seed=3)
     RC.check_rollout(gpu_lib, dev, B=32, S=8, seed=4, fwd_tol=1e-3, grad_rtol=1e-2, cond_aware=True)
 
