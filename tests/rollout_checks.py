@@ -221,3 +221,33 @@ def check_sampling_rollout(lib, device, B=2, S=30, seed=0, n_mean=6, n_canon=5):
     out_cc = hm.roll_out(None, d, n_canon, z_seq=z.to(device), canonicalize_input=True)
     w_cc, _ = H.roll_out(sd, local, z, t2j=t2j)
     assert (world_of(out_cc).cpu() - w_cc).abs().max().item() < 2e-4
+
+
+def check_sampling_golden(lib, device):
+    """Reference-generated vectors (oracle/make_golden_sampling.py) for BASELINE config C1's sampling roll-out, the prior-mean
+    roll-out and the two canonicalize_input forms.  Sampling compounds rounding through the drawn latents, so the 30-step
+    chain is compared over its first 10 steps at the stated 1e-4 and checked finite/bounded beyond."""
+    gd = golden('rollout_sampling.npz')
+    hm, _ = make_model(lib, device, seed=int(gd['weight_seed']))
+    past = torch.from_numpy(gd['past']).to(device)
+    eps = torch.from_numpy(gd['eps']).to(device)
+    S = eps.shape[1]
+    out = hm.roll_out(past, None, S, z_seq=None, return_z=True, eps_seq=eps)
+    w = world_of(out).cpu().numpy()
+    n = 10
+    assert np.abs(w[:, :n] - gd['world_sampled'][:, :n]).max() < FWD_TOL
+    assert np.abs(out['z'].cpu().numpy()[:, :n] - gd['z_sampled'][:, :n]).max() < FWD_TOL
+    assert np.isfinite(w).all() and np.abs(w - gd['world_sampled']).max() < 0.5
+    out_m = hm.roll_out(past, None, gd['world_mean'].shape[1], z_seq=None, use_mean=True)
+    assert np.abs(world_of(out_m).cpu().numpy() - gd['world_mean']).max() < FWD_TOL
+    moved = torch.from_numpy(gd['moved'])
+    keys = ['trans', 'trans_vel', 'root_orient', 'root_orient_vel', 'pose_body', 'joints', 'joints_vel']
+    dims = [3, 3, 9, 3, 189, 66, 66]
+    d, o = {}, 0
+    for k, nn in zip(keys, dims):
+        d[k] = moved[:, o:o + nn].unsqueeze(1).to(device)
+        o += nn
+    z = torch.from_numpy(gd['z_canon']).to(device)
+    for unc, key in ((True, 'world_canon_uncanon'), (False, 'world_canon')):
+        oc = hm.roll_out(None, d, z.shape[1], z_seq=z, canonicalize_input=True, uncanonicalize_output=unc)
+        assert np.abs(world_of(oc).cpu().numpy() - gd[key]).max() < 2e-4

@@ -115,6 +115,26 @@ def test_golden_rotations_match_oracle():
     assert np.abs(back.numpy() - gd['aa_back']).max() == 0.0
 
 
+def test_golden_sampling_matches_oracle():
+    """The restatement's sampling / canonicalising forms against the reference-generated vectors (no reference needed)."""
+    from humor_amd import frames
+    gd = golden('rollout_sampling.npz')
+    sd = synth.humor_state_dict(seed=int(gd['weight_seed']))
+    past, eps = torch.from_numpy(gd['past']), torch.from_numpy(gd['eps'])
+    w, (pm, pv) = H.roll_out(sd, past, None, eps_seq=eps)
+    assert np.abs(w.numpy() - gd['world_sampled']).max() < 1e-5
+    assert np.abs((pm + eps * torch.sqrt(pv)).numpy() - gd['z_sampled']).max() < 1e-5
+    n = gd['world_mean'].shape[1]
+    wm, _ = H.roll_out(sd, past, None, eps_seq=torch.zeros(past.shape[0], n, 48))
+    assert np.abs(wm.numpy() - gd['world_mean']).max() < 1e-5
+    moved, z = torch.from_numpy(gd['moved']), torch.from_numpy(gd['z_canon'])
+    local, (R0, t0, t2j) = frames.canonicalize_state(moved)
+    wu, _ = H.roll_out(sd, local, z, G0=R0, gt0=t0, t2j=t2j)
+    wc, _ = H.roll_out(sd, local, z, t2j=t2j)
+    assert np.abs(wu.numpy() - gd['world_canon_uncanon']).max() < 1e-5
+    assert np.abs(wc.numpy() - gd['world_canon']).max() < 1e-5
+
+
 @needs_ref
 def test_reference_rollout_live():
     """The restatement against the unmodified reference HumorModel.roll_out, forward and gradients."""
@@ -145,6 +165,67 @@ def test_reference_rollout_live():
     g2 = torch.autograd.grad((world * gw).sum() + pm2.sum(), [past0, z])
     for a, b in zip(g1, g2):
         assert (a - b).abs().max() < 1e-3 * max(1.0, a.abs().max().item())
+
+
+@needs_ref
+def test_reference_sampling_and_canonicalize_live():
+    """BASELINE config C1's path (test_humor sampling: z drawn from the conditional prior at every step) and the
+    canonicalize_input / uncanonicalize_output options, restatement vs the unmodified reference (same noise)."""
+    from humor_amd import frames
+    from oracle import lbs_restated as L
+    from oracle.make_golden import canonical_state
+    R = ref_loader.load()
+    sd = synth.humor_state_dict(seed=0)
+    hm = R.humor_model.HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48,
+                                  model_data_config='smpl+joints+contacts', steps_in=1)
+    hm.load_state_dict(sd)
+    hm.eval()
+    g = torch.Generator().manual_seed(3)
+    B, S = 2, 8
+    past = canonical_state(B, g)
+    eps = torch.randn(B, S, 48, generator=g)
+    names = ['trans', 'trans_vel', 'root_orient', 'root_orient_vel', 'pose_body', 'joints', 'joints_vel']
+    dims = [3, 3, 9, 3, 189, 66, 66]
+
+    def as_dict(p):
+        d, o = {}, 0
+        for k, n in zip(names, dims):
+            d[k] = p[:, o:o + n].unsqueeze(1)
+            o += n
+        return d
+
+    # sampling with the reference's torch.randn_like replaced by our noise sequence
+    it = iter([eps[:, t] for t in range(S)])
+    orig = torch.randn_like
+    torch.randn_like = lambda x: next(it)
+    try:
+        with torch.no_grad():
+            pred = hm.roll_out(None, as_dict(past), S)
+    finally:
+        torch.randn_like = orig
+    ref_w = torch.cat([pred[k] for k in names + ['contacts']], 2)
+    w, _ = H.roll_out(sd, past, None, eps_seq=eps)
+    assert (w - ref_w).abs().max() < 1e-5
+    # a state moved rigidly in the world, canonicalised by the model
+    ang = torch.tensor([0.7, -1.2])
+    Rz = L.batch_rodrigues(torch.stack([torch.zeros(2), torch.zeros(2), ang], 1))
+    shift = torch.tensor([[1.5, -0.7, 0.0], [-2.0, 0.3, 0.0]])
+    rot = lambda v: torch.einsum('bij,bj->bi', Rz, v)
+    j = torch.einsum('bij,bkj->bki', Rz, past[:, 207:273].reshape(B, 22, 3)) + shift.unsqueeze(1)
+    jv = torch.einsum('bij,bkj->bki', Rz, past[:, 273:339].reshape(B, 22, 3))
+    moved = torch.cat([rot(past[:, 0:3]) + shift, rot(past[:, 3:6]), torch.matmul(Rz, past[:, 6:15].reshape(B, 3, 3)).reshape(B, 9),
+                       rot(past[:, 15:18]), past[:, 18:207], j.reshape(B, 66), jv.reshape(B, 66)], 1)
+    z = torch.randn(B, 5, 48, generator=g)
+    local, (R0, t0, t2j) = frames.canonicalize_state(moved)
+    for unc in (True, False):
+        with torch.no_grad():
+            pred = hm.roll_out(None, as_dict(moved.clone()), 5, z_seq=z, canonicalize_input=True, uncanonicalize_output=unc)
+        ref_w = torch.cat([pred[k] for k in names + ['contacts']], 2)
+        w, _ = H.roll_out(sd, local, z, G0=R0 if unc else None, gt0=t0 if unc else None, t2j=t2j)
+        assert (w - ref_w).abs().max() < 1e-5
+        if unc:
+            wc, _ = H.roll_out(sd, local, z, t2j=t2j)
+            assert (frames.uncanonicalize_world(wc, R0, t0, t2j) - w).abs().max() < 1e-5
 
 
 @needs_ref

@@ -67,3 +67,7 @@ def test_c5_size_rollout(gpu_lib, dev):
 
 def test_sampling_and_canonicalize(gpu_lib, dev):
     RC.check_sampling_rollout(gpu_lib, dev, B=2, S=30)
+
+
+def test_sampling_golden_vectors(gpu_lib, dev):
+    RC.check_sampling_golden(gpu_lib, dev)
