@@ -214,16 +214,19 @@ extern "C" int ha_smpl_model_create(ha_smpl_model** out, int device, int V, int 
   if ((rc = upload(&m->child_idx, cidx)) != HA_OK) return fail(rc);
   if ((rc = build_set(m, 0, nullptr, V)) != HA_OK) return fail(rc);
 
-  // MFMA B-operand layout: [Vpad/32][Kfull_pad/2][3][64], lane l <-> (k = 2*kp + (l>>5), vertex = vt*32 + (l&31))
+  // MFMA B-operand layout [Vpad/32][KQ][3][64][4]: lane l <-> (vertex = vt*32 + (l&31), k = 2*kp + (l>>5)); the 12 floats a lane
+  // needs for four consecutive k-pairs ((kp % 4) * 3 + component) are three 16-byte loads, each contiguous across the wave
   {
-    const int nvt = m->Vpad / 32, KP = m->Kfull_pad / 2;
-    std::vector<float> pm((size_t)nvt * KP * 3 * 64, 0.0f);
+    const int nvt = m->Vpad / 32, KQ = ceil_div(m->Kfull_pad / 2, 4);
+    std::vector<float> pm((size_t)nvt * KQ * 3 * 64 * 4, 0.0f);
     for (int vt = 0; vt < nvt; ++vt)
-      for (int kp = 0; kp < KP; ++kp)
+      for (int kp = 0; kp < KQ * 4; ++kp)
         for (int c = 0; c < 3; ++c)
           for (int l = 0; l < 64; ++l) {
             const int k = 2 * kp + (l >> 5), v = vt * 32 + (l & 31);
-            if (k < K && v < V) pm[(((size_t)vt * KP + kp) * 3 + c) * 64 + l] = m->h_Pd[((size_t)k * V + v) * 3 + c];
+            const int e = (kp & 3) * 3 + c;           // position among the lane's 12 floats of this k-pair quad
+            if (k < K && v < V)
+              pm[((((size_t)vt * KQ + (kp >> 2)) * 3 + (e >> 2)) * 64 + l) * 4 + (e & 3)] = m->h_Pd[((size_t)k * V + v) * 3 + c];
           }
     if ((rc = upload(&m->Pd_m, pm)) != HA_OK) return fail(rc);
   }
@@ -346,7 +349,7 @@ __device__ __forceinline__ void joint_forward(const FrameParams& p, int f, int l
   for (int i = lane; i < p.NB; i += 64) coeff[i] = p.betas[(size_t)f * p.NB + i];
   if (lane == 0) {
     coeff[p.NB] = 1.0f;
-    if (p.Kc & 1) coeff[p.Kc] = 0.0f;   // pad entry read by the MFMA path's last k-pair
+    for (int k = p.Kc; k < ((p.Kc + 7) & ~7) && k < p.kf4; ++k) coeff[k] = 0.0f;   // pad entries read by the MFMA path's last k-pair quad
   }
   if (isj && j >= 1 && j < p.n_active) {
 #pragma unroll
@@ -464,8 +467,16 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_fwd_kernel(FrameParams p) 
   }
   __syncthreads();
   if (p.coeffT && valid) {
-    const int kc_pad = p.Kc + (p.Kc & 1);
-    for (int k = lane; k < kc_pad; k += 64) p.coeffT[(size_t)k * p.Npad + f] = coeff[k];
+    // coefficient matrix for the MFMA blend, [k/4][frame][4]: a lane's operands for two k-pairs are one 16-byte load
+    const int nq = (p.Kc + 7) >> 3 << 1;               // quads, rounded to whole k-pair quads (8 coefficients)
+    for (int q = lane; q < nq; q += 64) {
+      float4 v;
+      v.x = 4 * q < p.kf4 ? coeff[4 * q] : 0.f;
+      v.y = 4 * q + 1 < p.kf4 ? coeff[4 * q + 1] : 0.f;
+      v.z = 4 * q + 2 < p.kf4 ? coeff[4 * q + 2] : 0.f;
+      v.w = 4 * q + 3 < p.kf4 ? coeff[4 * q + 3] : 0.f;
+      *reinterpret_cast<float4*>(p.coeffT + ((size_t)q * p.Npad + f) * 4) = v;
+    }
   }
   if (p.verts) {
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
@@ -717,7 +728,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // grid: 1-D, block = 4 waves = 4 vertex tiles (32 vertices each) x 64 frames.
 // Blocks that share a vertex-tile group (the B panel, ~300 KB) are mapped to the same XCD (b % 8).
-__global__ __launch_bounds__(256) void pose_blend_mfma_kernel(const float* __restrict__ coeffT, int Npad, int KP, int KPfull,
+// Operands arrive as 16-byte loads: per four k-pairs a lane issues 4 loads of coefficients (frames l&31 and 32 + l&31, two
+// coefficient quads) and 3 loads of the blend matrix, against 24 MFMAs.
+__global__ __launch_bounds__(256) void pose_blend_mfma_kernel(const float* __restrict__ coeffQ, int Npad, int KQ, int KQfull,
                                                               const float* __restrict__ Pd_m, float* __restrict__ v_posed,
                                                               int N, int V, int n_vt, int n_ft) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -727,8 +740,9 @@ __global__ __launch_bounds__(256) void pose_blend_mfma_kernel(const float* __res
   const int vt = vtg * 4 + wave;
   if (vt >= n_vt) return;
   const int f0 = ft * 64;
-  const float* a_ptr = coeffT + (size_t)(lane >> 5) * Npad + f0 + (lane & 31);
-  const float* b_ptr = Pd_m + (size_t)vt * KPfull * 192 + lane;
+  const bool hi = lane >= 32;
+  const float4* a_ptr = reinterpret_cast<const float4*>(coeffQ) + f0 + (lane & 31);
+  const float4* b_ptr = reinterpret_cast<const float4*>(Pd_m) + (size_t)vt * KQfull * 192 + lane;
   f32x16 acc[2][3];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
@@ -737,18 +751,23 @@ __global__ __launch_bounds__(256) void pose_blend_mfma_kernel(const float* __res
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
 #pragma unroll 2
-  for (int kp = 0; kp < KP; ++kp) {
-    const float a0 = a_ptr[(size_t)2 * kp * Npad];
-    const float a1 = a_ptr[(size_t)2 * kp * Npad + 32];
-    const float b0 = b_ptr[(size_t)kp * 192];
-    const float b1 = b_ptr[(size_t)kp * 192 + 64];
-    const float b2 = b_ptr[(size_t)kp * 192 + 128];
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
+  for (int kq = 0; kq < KQ; ++kq) {
+    // coefficient quads 2 kq and 2 kq + 1 = k-pairs 4 kq .. 4 kq + 3
+    const float4 a0q0 = a_ptr[(size_t)(2 * kq) * Npad], a1q0 = a_ptr[(size_t)(2 * kq) * Npad + 32];
+    const float4 a0q1 = a_ptr[(size_t)(2 * kq + 1) * Npad], a1q1 = a_ptr[(size_t)(2 * kq + 1) * Npad + 32];
+    const float4 b0 = b_ptr[(size_t)kq * 192], b1 = b_ptr[(size_t)kq * 192 + 64], b2 = b_ptr[(size_t)kq * 192 + 128];
+    const float a0[4] = {hi ? a0q0.y : a0q0.x, hi ? a0q0.w : a0q0.z, hi ? a0q1.y : a0q1.x, hi ? a0q1.w : a0q1.z};
+    const float a1[4] = {hi ? a1q0.y : a1q0.x, hi ? a1q0.w : a1q0.z, hi ? a1q1.y : a1q1.x, hi ? a1q1.w : a1q1.z};
+    const float bb[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[3 * j], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[3 * j + 1], acc[0][1], 0, 0, 0);
+      acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[3 * j + 2], acc[0][2], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bb[3 * j], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bb[3 * j + 1], acc[1][1], 0, 0, 0);
+      acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bb[3 * j + 2], acc[1][2], 0, 0, 0);
+    }
   }
   const int v = vt * 32 + (lane & 31);
   if (v >= V) return;
@@ -942,7 +961,7 @@ extern "C" int ha_smpl_workspace(const ha_smpl_model* m, int N, int n_active, in
   const int Kc = m->NB + 1 + (n_active - 1) * 9;
   const int64_t Npad = (int64_t)ceil_div(N, 64) * 64;
   if (vposed) *vposed = (int64_t)N * m->V * 3 + 4;   // +4: the streaming kernel's last 16-byte vector
-  if (coeff) *coeff = (int64_t)(Kc + (Kc & 1)) * Npad;
+  if (coeff) *coeff = (int64_t)((Kc + 7) / 8 * 8) * Npad;   // [k/4][frame][4], whole k-pair quads
   return HA_OK;
 }
 
@@ -1018,8 +1037,8 @@ extern "C" int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_ac
     const int n_vt = m->Vpad / 32, n_ft = p.Npad / 64;
     const int n_vtg = ceil_div(n_vt, 4);
     const int n_vtg8 = ceil_div(n_vtg, 8) * 8;
-    const int KP = (p.Kc + 1) / 2;
-    hipLaunchKernelGGL(pose_blend_mfma_kernel, dim3(n_vtg8 * n_ft), dim3(256), 0, st, ws_coeff, p.Npad, KP, m->Kfull_pad / 2,
+    const int KQ = (p.Kc + 7) / 8;      // quads of k-pairs
+    hipLaunchKernelGGL(pose_blend_mfma_kernel, dim3(n_vtg8 * n_ft), dim3(256), 0, st, ws_coeff, p.Npad, KQ, ceil_div(m->Kfull_pad / 2, 4),
                        m->Pd_m, ws_vposed, N, m->V, n_vt, n_ft);
     HA_LAUNCH_CHECK();
   }

@@ -45,7 +45,7 @@ struct ha_smpl_model {
   int32_t* child_start = nullptr;  // [J+1] CSR of children (deterministic parent-side accumulation in backward)
   int32_t* child_idx = nullptr;    // [J]
   // dense (slot 0) extras
-  float* Pd_m = nullptr;      // MFMA B-operand layout [Vpad/32][Kfull_pad/2][3][64]
+  float* Pd_m = nullptr;      // MFMA B-operand layout [Vpad/32][KQ][3][64][4] (KQ = k-pair quads)
   float4* w4 = nullptr;       // [V] (nnz <= 4 fast path)
   uint32_t* idx4 = nullptr;   // [V] 4 x uint8 joint ids
   ha::VertexSet sets[ha::kMaxSubsets];
