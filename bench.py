@@ -294,7 +294,7 @@ def main():
             'smpl_dense_fwd_ms': round(ms_dense, 4),
             'roofline': skin_roofline(dev, npz),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 of the 1-GPU run only
             res['cpu_baseline'] = cpu_baseline(npz)
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -12,7 +12,7 @@ def dev():
     return torch.device('cuda:0')
 
 
-@pytest.mark.parametrize('B,S', [(1, 1), (2, 3), (4, 10), (32, 12), (33, 5), (70, 3)])
+@pytest.mark.parametrize('B,S', [(1, 1), (2, 3), (4, 10), (32, 12), (33, 5), (70, 3), (130, 2)])   # 130 rows: full-K launch policy
 def test_rollout_forward_backward(gpu_lib, dev, B, S):
     RC.check_rollout(gpu_lib, dev, B=B, S=S, seed=B)
 
