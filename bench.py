@@ -50,6 +50,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not capture the closure into a hipGraph')
+    ap.add_argument('--no-c5', action='store_true', help='skip the BASELINE C5-size (256x120) kernel rooflines appended at N=1')
     ap.add_argument('--graph', dest='auto', action='store_false', help='always replay the captured hipGraph (default: time graph replay against eager evaluation once and keep the faster)')
     return ap.parse_args()
 
@@ -294,6 +295,13 @@ def main():
             'smpl_dense_fwd_ms': round(ms_dense, 4),
             'roofline': skin_roofline(dev, npz),
         }
+        if world == 1 and not args.no_c5:
+            # BASELINE config C5 (batch 256 x 120 frames): LBS GB/s, pose-blend and decoder/prior MLP fp32-MFMA utilisation
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import bench_c5
+            del fc
+            torch.cuda.empty_cache()
+            res['c5_rooflines'] = bench_c5.measure(256, 120, dev)
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 of the 1-GPU run only
             res['cpu_baseline'] = cpu_baseline(npz)
         print(json.dumps(res), flush=True)

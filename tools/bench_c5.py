@@ -31,10 +31,9 @@ def ev(fn, iters=5, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
-def main():
-    B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 120)
+def measure(B=256, T=120, dev=None):
     N = B * T
-    dev = torch.device('cuda:0')
+    dev = dev if dev is not None else torch.device('cuda:0')
     lib = _lib.get_lib()
     npz = synth.write_smplh_npz(os.path.join(tempfile.mkdtemp(), 'm.npz'))
     bm = BodyModel(npz, num_betas=NB, use_vtx_selector=True)
@@ -90,7 +89,12 @@ def main():
     mlp_flops = 11.55e6 * B * (T - 1)                  # 11.55 MFLOP per row-step (prior + decoder)
     res['rollout'] = {'fwd_ms': round(ms_f, 2), 'fwd_bwd_ms': round(ms_fb, 2), 'steps_per_sec_fwd': round(B * (T - 1) / (ms_f * 1e-3), 1),
                       'mlp_TFLOPs_fwd': round(mlp_flops / ms_f / 1e9, 2), 'frac_fp32_mfma_fwd': round(mlp_flops / ms_f / 1e9 / MFMA_F32_PEAK, 4)}
-    print(json.dumps(res))
+    return res
+
+
+def main():
+    B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 120)
+    print(json.dumps(measure(B, T)))
 
 
 if __name__ == '__main__':
