@@ -244,12 +244,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     dist = None
-    dev = torch.device(f'cuda:{local}')
+    # validation aid for 1-GPU boxes: HUMOR_AMD_BENCH_BACKEND=gloo HUMOR_AMD_BENCH_ONE_GPU=1 runs all ranks on cuda:0 with host-
+    # staged collectives (exercises the sharded code path; the numbers mean nothing).  Default: one GPU per rank over RCCL.
+    backend = os.environ.get('HUMOR_AMD_BENCH_BACKEND', 'nccl')
+    dev = torch.device('cuda:0' if os.environ.get('HUMOR_AMD_BENCH_ONE_GPU') == '1' else f'cuda:{local}')
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from humor_amd import synth
     tmp = tempfile.mkdtemp(prefix='humor_amd_bench_')

@@ -32,6 +32,18 @@ class Shard:
         return x[self.b0:self.b1]
 
 
+def _all_gather(out, x, group):
+    """dist.all_gather; the gloo backend (CPU tests, and two test ranks sharing one GPU) cannot gather device tensors, so
+    those go through host memory.  RCCL ('nccl') gathers device tensors directly."""
+    if x.is_cuda and dist.get_backend(group) == 'gloo':
+        host = [torch.empty(x.shape, dtype=x.dtype) for _ in out]
+        dist.all_gather(host, x.cpu(), group=group)
+        for o, h in zip(out, host):
+            o.copy_(h)
+    else:
+        dist.all_gather(out, x, group=group)
+
+
 class _AllGatherGrad(torch.autograd.Function):
     """x [L] -> [world, L]; backward all-reduces the gathered gradient and returns this rank's row."""
 
@@ -40,7 +52,7 @@ class _AllGatherGrad(torch.autograd.Function):
         ctx.group = group
         world = dist.get_world_size(group)
         out = [torch.empty_like(x) for _ in range(world)]
-        dist.all_gather(out, x.contiguous(), group=group)
+        _all_gather(out, x.contiguous(), group)
         return torch.stack(out, dim=0)
 
     @staticmethod

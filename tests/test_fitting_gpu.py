@@ -1,9 +1,13 @@
 """GPU tier: the fitting objectives (stage 1/2/3 closures) and short MotionOptimizer runs against fixtures produced by
 the reference MotionOptimizer."""
+import os
+import sys
+
 import pytest
 import torch
 
 import fitting_checks as FC
+from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -55,3 +59,50 @@ def test_graphed_closure_equals_eager(gpu_lib, dev, smplh_npz):
         assert abs(l0 - l1) <= 1e-5 * abs(l0)
         for a, b in zip(g0, g1):
             assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())
+
+
+def _sharded_gpu_worker(rank, world, port, npz, out):
+    """Two ranks on the ONE GPU of the test box (gloo: device tensors are staged through the host), sharded stage-3 closure."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle import closure_cases as CC
+    from humor_amd import _lib
+    from humor_amd.distributed import Shard, allreduce_loss_and_grads
+    dev = torch.device('cuda:0')
+    lib = _lib.get_lib()
+    B, T = 6, 10
+    case = CC.make_case('rgb', B, T, seed=2)
+    opt = FC.build(lib, dev, 'rgb', B, T, npz, shard=Shard(B))
+    res = FC.eval_stage(opt, case, 2, dev)
+    keys = [k for k in res if k != 'loss']
+    params = [torch.zeros_like(res[k]).requires_grad_(True) for k in keys]
+    for p, k in zip(params, keys):
+        p.grad = res[k].clone()
+    loss = allreduce_loss_and_grads(res['loss'], params)
+    if rank == 0:
+        torch.save({'loss': loss.item(), **{k: p.grad.cpu() for k, p in zip(keys, params)}}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_stage3_closure_on_gpu(gpu_lib, dev, smplh_npz, tmp_path):
+    """The multi-GPU closure path (bench.py --gpus N, MotionOptimizer(shard=...)) for stage 3 with the real kernels: two
+    ranks, three sub-sequences each, loss and every gradient equal the single-process closure."""
+    import torch.multiprocessing as mp
+    from oracle import closure_cases as CC
+    out = str(tmp_path / 'sharded3.pt')
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_sharded_gpu_worker, args=(2, port, smplh_npz, out), nprocs=2, join=True)
+    sharded = torch.load(out)
+    B, T = 6, 10
+    case = CC.make_case('rgb', B, T, seed=2)
+    opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
+    res = FC.eval_stage(opt, case, 2, dev)
+    assert abs(res['loss'].item() - sharded['loss']) <= 1e-5 * abs(res['loss'].item())
+    for k, v in res.items():
+        if k != 'loss':
+            v = v.detach().cpu()
+            assert (v - sharded[k]).abs().max().item() <= 2e-4 * max(1.0, v.abs().max().item()), k
