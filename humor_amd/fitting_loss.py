@@ -167,7 +167,8 @@ class FittingLoss(nn.Module):
         iv = seq_interval
         prev_tail = halo.get('prev_tail') if halo is not None else None
         nb = verts3d.size(0) + (1 if prev_tail is not None else 0)
-        ovs = [int(iv[b - 1, 1]) - int(iv[b, 0]) for b in range(1, nb)]
+        vals = iv.tolist()      # one host read of the (CPU) interval table instead of two scalar reads per pair
+        ovs = [int(vals[b - 1][1]) - int(vals[b][0]) for b in range(1, nb)]
         pos = verts3d.new_zeros(())
         vel = verts3d.new_zeros(())
         if not ovs:
