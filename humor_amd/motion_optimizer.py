@@ -49,8 +49,9 @@ class MotionOptimizer():
         self.im_dim = im_dim
         self.shard = shard
         self.verbose = verbose
-        # whole-closure hipGraph capture: False | True (always replay) | 'auto' (time replay against eager once, keep the faster)
-        self.use_graphs = use_graphs if torch.device(device).type == 'cuda' else False
+        # whole-closure hipGraph capture (replay costs ~1.5 us of node hand-off per kernel, eager costs host time that the
+        # roll-out's long launches partly hide: which one wins depends on the host -- bench.py times both)
+        self.use_graphs = bool(use_graphs) and torch.device(device).type == 'cuda'
         self.closure_evals = 0
         self.loss_trace = None      # set to a list to record (stage, loss) of every closure evaluation (host sync per eval)
         if motion_prior is None:
@@ -193,30 +194,6 @@ class MotionOptimizer():
                     self.closure_evals, self.loss_trace = evals, trace
                     state['grads'] = [p.grad for p in params]
                     state['graph'] = g
-                    if self.use_graphs == 'auto':
-                        # replay costs ~1.5 us of graph-node overhead per kernel, eager costs host time the roll-out's long
-                        # launches partly hide: measure both once and keep the faster (values are identical)
-                        def timed(fn, n=10):
-                            fn()
-                            fn()
-                            torch.cuda.synchronize()
-                            t0 = time.perf_counter()
-                            for _ in range(n):
-                                fn()
-                            torch.cuda.synchronize()
-                            return (time.perf_counter() - t0) / n
-                        evals, trace = self.closure_evals, self.loss_trace
-                        self.loss_trace = None
-                        t_eager = timed(eager)
-                        for p, gbuf in zip(params, state['grads']):
-                            p.grad = gbuf
-                        t_graph = timed(g.replay)
-                        self.closure_evals, self.loss_trace = evals, trace
-                        self.closure_mode = 'graph' if t_graph <= t_eager else 'eager'
-                        self.closure_mode_times_ms = (1e3 * t_graph, 1e3 * t_eager)
-                        if self.closure_mode == 'eager':
-                            state['failed'] = True      # "do not replay": evaluate eagerly from now on
-                            return eager()
                 except Exception as e:          # capture is an optimisation: fall back to eager evaluation
                     print('humor_amd: hipGraph capture of the closure failed (%s: %s); running eagerly' % (type(e).__name__, str(e)[:600]))
                     state['failed'] = True
@@ -526,16 +503,19 @@ class MotionOptimizer():
         root_orient, trans = data_dict['root_orient'], data_dict['trans']
         B, T, _ = root_orient.size()
         Rm = ops.batch_rodrigues(root_orient.reshape(-1, 3), _lib_override=lib).reshape(B, T, 3, 3)
+        # 3x3 products as broadcast multiply + sum: a batched rocBLAS call costs ~50 us of host time and a 10-20 us kernel for
+        # a few hundred tiny matrices (and two more of each in the backward pass)
         Rt = R.unsqueeze(1)
-        new_R = torch.matmul(Rt.transpose(3, 2), Rm) if inverse else torch.matmul(Rt, Rm)
+        Rl = Rt.transpose(3, 2) if inverse else Rt
+        new_R = (Rl.unsqueeze(-1) * Rm.unsqueeze(-3)).sum(-2)
         out['root_orient'] = ops.rotation_matrix_to_angle_axis(new_R.reshape(-1, 3, 3), _lib_override=lib).reshape(B, T, 3)
         # key_frame_idx is the first frame on the fitting path (motion_optimizer.py:109: init_fidx = zeros)
         assert not np.any(np.asarray(key_frame_idx)), 'non-zero key frames are not supported'
         if inverse:
             off = trans[:, 0:1]
-            tr = torch.matmul(Rt.transpose(3, 2), (trans - off).unsqueeze(-1))[..., 0] - t.unsqueeze(1)
+            tr = (Rl * (trans - off).unsqueeze(-2)).sum(-1) - t.unsqueeze(1)
         else:
-            tr = torch.matmul(Rt, (trans + t.unsqueeze(1)).unsqueeze(-1))[..., 0]
+            tr = (Rl * (trans + t.unsqueeze(1)).unsqueeze(-2)).sum(-1)
             smpl, _ = self.smpl_results(tr, out['root_orient'], body_pose, betas)
             cur_h = smpl['joints3d'][:, 0, 0, 2:3]
             dh = root_height - cur_h
