@@ -135,14 +135,20 @@ __device__ __forceinline__ void load_frag_n(const float* base, int nsplit, int R
 // in lane^32); NG = 2: each half-slice is its own 32-channel group, entirely lane-local.
 template <int NG>
 __device__ __forceinline__ void gn_stats(const float (&h)[32], float inv_n, float& mean, float& rstd) {
-  float s1 = 0.f;
+  // four interleaved partial sums: a single 32-long dependent add chain is ~32 x the VALU latency on the launch's critical path
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
 #pragma unroll
-  for (int kp = 0; kp < 32; ++kp) s1 += h[kp];
+  for (int kp = 0; kp < 32; kp += 4) { p0 += h[kp]; p1 += h[kp + 1]; p2 += h[kp + 2]; p3 += h[kp + 3]; }
+  float s1 = (p0 + p1) + (p2 + p3);
   if (NG == 1) s1 += __shfl_xor(s1, 32);
   const float mu = s1 * inv_n;
-  float s2 = 0.f;
+  p0 = p1 = p2 = p3 = 0.f;
 #pragma unroll
-  for (int kp = 0; kp < 32; ++kp) { const float d = h[kp] - mu; s2 = fmaf(d, d, s2); }
+  for (int kp = 0; kp < 32; kp += 4) {
+    const float d0 = h[kp] - mu, d1 = h[kp + 1] - mu, d2 = h[kp + 2] - mu, d3 = h[kp + 3] - mu;
+    p0 = fmaf(d0, d0, p0); p1 = fmaf(d1, d1, p1); p2 = fmaf(d2, d2, p2); p3 = fmaf(d3, d3, p3);
+  }
+  float s2 = (p0 + p1) + (p2 + p3);
   if (NG == 1) s2 += __shfl_xor(s2, 32);
   mean = mu;
   rstd = rsqrtf(s2 * inv_n + 1e-5f);
@@ -159,15 +165,16 @@ __device__ __forceinline__ void gn_apply(int mode, const float (&gam)[32], const
   } else {
     // adjoint: a holds da; through ReLU and GroupNorm -> dh
     float dxh[32], xh[32];
-    float m1 = 0.f, m2 = 0.f;
+    float m1p[4] = {0.f, 0.f, 0.f, 0.f}, m2p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kp = 0; kp < 32; ++kp) {
       xh[kp] = (h[kp] - mean) * rstd;
       const float y = xh[kp] * gam[kp] + bet[kp];
       dxh[kp] = (y > 0.f ? a[kp] : 0.f) * gam[kp];
-      m1 += dxh[kp];
-      m2 = fmaf(dxh[kp], xh[kp], m2);
+      m1p[kp & 3] += dxh[kp];
+      m2p[kp & 3] = fmaf(dxh[kp], xh[kp], m2p[kp & 3]);
     }
+    float m1 = (m1p[0] + m1p[1]) + (m1p[2] + m1p[3]), m2 = (m2p[0] + m2p[1]) + (m2p[2] + m2p[3]);
     if (NG == 1) { m1 += __shfl_xor(m1, 32); m2 += __shfl_xor(m2, 32); }
     m1 *= inv_n;
     m2 *= inv_n;
