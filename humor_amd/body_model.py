@@ -213,6 +213,7 @@ class BodyModel(nn.Module):
         self._algo = algo
         self._handles = {}
         self._sel_cache = {}
+        self._zero_cache = {}
         self._selector = list(SMPLH_SELECTOR_VERTS) if use_vtx_selector else []
         self._subset = None if vertex_subset is None else [int(i) for i in vertex_subset]
         faces = torch.from_numpy(np.asarray(np.load(bm_path, encoding='latin1', allow_pickle=True)['f']).astype(np.int64))
@@ -256,8 +257,15 @@ class BodyModel(nn.Module):
         rest = h.J * 3 - 3 - nbody - nhand       # SMPL's two hand joints live in body_pose (69 values)
         if pose_hand is None:
             n_active = 1 + nbody // 3
-            full_pose = torch.cat([root_orient, pose_body, zeros(nhand + rest)], dim=1)
-            pose_hand_out = zeros(nhand) if has_hands else None
+            # constant zero padding (hands at rest), cached per (N, device): this runs several times per fitting closure
+            key = (N, nhand + rest, str(ref.device))
+            pad = self._zero_cache.get(key)
+            if pad is None:
+                if len(self._zero_cache) > 16:
+                    self._zero_cache.clear()
+                pad = self._zero_cache[key] = zeros(nhand + rest)
+            full_pose = torch.cat([root_orient, pose_body, pad], dim=1)
+            pose_hand_out = pad[:, :nhand] if has_hands else None
         else:
             n_active = h.J
             full_pose = torch.cat([root_orient, pose_body, pose_hand] + ([zeros(rest)] if rest else []), dim=1)

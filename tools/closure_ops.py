@@ -56,6 +56,9 @@ def main():
     for n in names:
         wrap(o, n)
     wrap(o.fitting_loss, 'motion_fit')
+    for n in ['joints2d_loss', 'overlap_verts_loss', 'joints3d_smooth_loss', 'motion_prior_loss', 'init_motion_prior_loss',
+              'bone_length_loss', 'contact_vel_loss', 'contact_height_loss', 'floor_reg_loss', 'joints3d_loss']:
+        wrap(o.fitting_loss, n)
     with Counter() as total:
         loss, _ = o._stage3_objective(fc.obs_local, None, fc.prior_params, False, 15, 1.0, fc.og_w, True, 'neutral')
     print('forward dispatches total:', sum(total.counts.values()))
@@ -67,7 +70,7 @@ def main():
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CPU]) as prof:
         fc.step()
-    print(prof.key_averages().table(sort_by='self_cpu_time_total', row_limit=22, max_name_column_width=50))
+    print(prof.key_averages().table(sort_by='self_cpu_time_total', row_limit=8, max_name_column_width=50))
 
 
 if __name__ == '__main__':
