@@ -35,7 +35,7 @@ typedef float vf4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ size_t qoff(int c) { return (size_t)(c >> 2) * 128 + (c & 3); }
 
 // layer-kernel launch policy picked up by ha_humor_net_create (ha_tune_set "layer_spb" / "layer_nw"; 0 = default)
-int g_layer_spb = 0, g_layer_nw = 0;
+int g_layer_spb = 0, g_layer_nw = 0, g_layer_finish = 1;
 
 struct PackedLayer {
   int Cin = 0, skip = 0, Nout = 0;
@@ -115,6 +115,7 @@ __device__ __forceinline__ void load_frag(const float* p, size_t stride, int nq,
   }
 }
 
+template <bool SINGLE = false>
 __device__ __forceinline__ void load_frag_n(const float* base, int nsplit, int RT, int C, int rt, int cbase, int lane, float (&a)[32]) {
   const size_t stride = (size_t)RT * C * 32;
   const int row = lane & 31, c0 = cbase + 32 * (lane >> 5);
@@ -122,6 +123,7 @@ __device__ __forceinline__ void load_frag_n(const float* base, int nsplit, int R
   nq = nq < 0 ? 0 : (nq > 8 ? 8 : nq);
   const int q0 = nq > 0 ? (c0 >> 2) : 0;
   const float* p = base + (size_t)rt * C * 32 + (size_t)q0 * 128 + (size_t)row * 4;
+  if (SINGLE) { load_frag<1>(p, stride, nq, a); return; }
   switch (nsplit) {
     case 1: load_frag<1>(p, stride, nq, a); return;
     case 2: load_frag<2>(p, stride, nq, a); return;
@@ -202,7 +204,9 @@ __device__ unsigned int g_layer_launches;
 // K-slices (wave w takes slices w, w + NWT, ...), accumulate in registers, reduce across waves through LDS and write one
 // partial slab.  spb is the per-network policy (ha_tune_set "layer_spb"): few slices per block spread the fp32 MFMA work
 // (256 FLOP/clk/CU) over more CUs but make every consumer block re-read nsplit partial slabs; spb >= nslices is full-K.
-template <int NWT>
+// LEAN: every task is a plain GEMM on finished single slabs (behind gn_finish_kernel): no GroupNorm state and no partial-slab
+// staging -- 56 VGPRs instead of 338, a quarter of the operand bytes per block.
+template <int NWT, bool LEAN>
 __global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // NWT * 1024 floats
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
     const int cbase = is_main ? slice * SLICE : (slice - T.main_slices) * SLICE;
     // GroupNorm affine of the lane's channels, fetched with the same batch of loads (not behind the activation wait)
     float gam[32], bet[32];
-    const bool has_gn = is_main && T.mode != 0;
+    const bool has_gn = !LEAN && is_main && T.mode != 0;
     if (has_gn) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -255,10 +259,10 @@ __global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
       }
     }
     float a[32], h[32];
-    if (!is_main) load_frag_n(T.skip, 1, L.RT, T.skip_dim, rt, cbase, lane, a);
+    if (!is_main) load_frag_n<true>(T.skip, 1, L.RT, T.skip_dim, rt, cbase, lane, a);
     else {
-      load_frag_n(T.src, T.nsplit_src, L.RT, T.Csrc, rt, cbase, lane, a);
-      if (T.mode == 3) load_frag_n(T.hsrc, T.nsplit_h, L.RT, T.Ch, rt, cbase, lane, h);
+      load_frag_n<LEAN>(T.src, T.nsplit_src, L.RT, T.Csrc, rt, cbase, lane, a);
+      if (!LEAN && T.mode == 3) load_frag_n(T.hsrc, T.nsplit_h, L.RT, T.Ch, rt, cbase, lane, h);
     }
     HA_TS(1, false);
     HA_TS(2, true);
@@ -302,6 +306,50 @@ __global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
   }
   HA_TS(6, true);
   HA_TS(7, false);
+}
+
+// Two or more row tiles: the split-K partial slabs are summed and the GroupNorm(+ReLU) prologue -- or its adjoint -- is
+// applied ONCE per activation by this kernel into a finished slab, and the layer kernel then runs as a plain GEMM on it
+// (mode 0, one slab per operand).  Inside the layer kernel that work is repeated by each of the 32 output-tile blocks (every
+// block re-reads up to five partial slabs; 3-4 k cycles of GroupNorm per slice against 2.3 k cycles of MFMA), which held
+// the 256-row launches at ~25 us; at 32 rows the extra launch costs more than it saves.
+// One wave per (task, row tile, 64-channel slice).
+struct FinishLaunch {
+  LayerTask t[3];
+  float* dst[3];
+  int nblk[3];          // blocks of each task = RT * main_slices
+  int ntasks, RT;
+};
+
+__global__ __launch_bounds__(64) void gn_finish_kernel(FinishLaunch F) {
+  int b = blockIdx.x, ti = 0;
+  while (ti + 1 < F.ntasks && b >= F.nblk[ti]) { b -= F.nblk[ti]; ++ti; }
+  const LayerTask& T = F.t[ti];
+  const int lane = threadIdx.x, hi = lane >> 5;
+  const int slice = b % T.main_slices, rt = b / T.main_slices;
+  const int cbase = slice * SLICE;
+  float gam[32], bet[32], a[32], h[32];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const vf4 g4 = *reinterpret_cast<const vf4*>(T.gamma + cbase + 32 * hi + 4 * j);
+    const vf4 b4 = *reinterpret_cast<const vf4*>(T.beta + cbase + 32 * hi + 4 * j);
+    gam[4 * j] = g4.x; gam[4 * j + 1] = g4.y; gam[4 * j + 2] = g4.z; gam[4 * j + 3] = g4.w;
+    bet[4 * j] = b4.x; bet[4 * j + 1] = b4.y; bet[4 * j + 2] = b4.z; bet[4 * j + 3] = b4.w;
+  }
+  load_frag_n(T.src, T.nsplit_src, F.RT, T.Csrc, rt, cbase, lane, a);
+  if (T.mode == 3) load_frag_n(T.hsrc, T.nsplit_h, F.RT, T.Ch, rt, cbase, lane, h);
+  const float inv_n = 1.0f / (float)T.group;
+  if (T.mode == 1) {
+    if (T.group == SLICE) gn_apply<1>(1, gam, bet, inv_n, a, a);
+    else gn_apply<2>(1, gam, bet, inv_n, a, a);
+  } else {
+    if (T.group == SLICE) gn_apply<1>(3, gam, bet, inv_n, h, a);
+    else gn_apply<2>(3, gam, bet, inv_n, h, a);
+  }
+  // finished slab: same quad layout, width = the channels this task consumes (main_slices * 64)
+  float* d = F.dst[ti] + (size_t)rt * (T.main_slices * SLICE) * 32 + (size_t)((cbase + 32 * hi) >> 2) * 128 + (size_t)(lane & 31) * 4;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<vf4*>(d + j * 128) = vf4{a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]};
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1094,15 +1142,19 @@ struct StashLayout {
   // backward scratch
   size_t gx_dir[2], carry = 0, g_dec_out = 0, g_pri_out = 0;
   size_t bwd_pri[MAXL], bwd_dec[MAXL];
+  size_t fin[3] = {0, 0, 0};   // finished-activation scratch of the up to three tasks of a launch (full-K policy only)
+  bool finish = false;
   size_t total = 0;
 };
 
 static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   L.RT = ceil_div(B, 32);
   const size_t RT = L.RT;
-  // few row tiles: split K over many CUs (the layer is a latency chain and fp32 MFMA is 256 FLOP/clk/CU); many row tiles:
-  // full-K blocks (no partial slabs to re-read, the row tiles fill the chip).  Measured: tools/rollout_ab.py.
-  L.spb = g_layer_spb > 0 ? g_layer_spb : (L.RT >= 4 ? 32 : 4);
+  // K is split over blocks of 4 slices (the fp32 MFMA rate is 256 FLOP/clk/CU: the work has to be spread over the chip).  At
+  // one row tile the consumer's prologue sums the partial slabs and applies GroupNorm itself (one launch per level, the
+  // launch is a latency chain); from two row tiles on a finishing pass does that once per activation (gn_finish_kernel) and
+  // the layer kernel runs as a lean GEMM.  Measured with tools/rollout_ab.py (fwd+bwd ms, in-kernel vs finishing pass):
+  // 32 rows 5.7 / 6.4, 64 rows 7.9 / 7.2, 96 rows 10.2 / 7.7, 128 rows 10.6 / 8.3, 256 rows x 119 steps 29.6 / 21.2.
   if (L.spb < 4) L.spb = 4;      // MAXSPLIT partial slabs at most (checked against the layer widths at pack time)
   L.nw = 4;
   for (int i = 0; i < net->n_pri; ++i) { L.nsf_pri[i] = ceil_div(net->pri[i].nslices_f, L.spb); L.nsb_pri[i] = ceil_div(net->pri[i].nslices_b, L.spb); }
@@ -1127,6 +1179,10 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   L.g_pri_out = take((size_t)S * RT * net->pri[net->n_pri - 1].Nout_pad * 32);   // prior-output adjoints of all steps
   for (int i = 0; i < net->n_pri; ++i) L.bwd_pri[i] = take((size_t)L.nsb_pri[i] * RT * net->pri[i].Nin_pad * 32);
   for (int i = 0; i < net->n_dec; ++i) L.bwd_dec[i] = take((size_t)L.nsb_dec[i] * RT * net->dec[i].Nin_pad * 32);
+  // GroupNorm prologues once per activation in gn_finish_kernel (see there and the policy note above)
+  L.finish = (L.RT >= 2 && g_layer_finish != 0) || g_layer_finish == 2;     // 0: never, 2: always (A/B runs)
+  if (L.finish)
+    for (int i = 0; i < 3; ++i) L.fin[i] = take(RT * 1280 * 32);     // widest operand: K <= 1280 (checked at pack time)
   L.total = o;
 }
 
@@ -1162,11 +1218,37 @@ static void bwd_task(LayerTask& T, const PackedLayer& L, const float* dsrc, int 
   T.nblocks = L.ntiles_b * nsplit_dst;
 }
 
-static int launch_layers(LayerLaunch& LL, int nw, hipStream_t st) {
+static int launch_layers(LayerLaunch& LL, const StashLayout& L, float* stash, hipStream_t st) {
+  if (L.finish) {
+    FinishLaunch F;
+    memset(&F, 0, sizeof(F));
+    F.RT = LL.RT;
+    int fb = 0;
+    for (int i = 0; i < LL.ntasks; ++i) {
+      LayerTask& T = LL.t[i];
+      if (T.mode == 0) continue;
+      const int k = F.ntasks++;
+      F.t[k] = T;
+      F.dst[k] = stash + L.fin[i];
+      F.nblk[k] = LL.RT * T.main_slices;
+      fb += F.nblk[k];
+      // the layer kernel now consumes the finished slab as a raw operand
+      T.src = F.dst[k]; T.nsplit_src = 1; T.Csrc = T.main_slices * SLICE; T.mode = 0;
+      T.hsrc = nullptr; T.nsplit_h = 0;
+    }
+    if (fb) {
+      hipLaunchKernelGGL(gn_finish_kernel, dim3(fb), dim3(64), 0, st, F);
+      HA_LAUNCH_CHECK();
+    }
+  }
+  const int nw = L.nw;
   int blocks = 0;
   for (int i = 0; i < LL.ntasks; ++i) { LL.t[i].nblocks *= LL.RT; blocks += LL.t[i].nblocks; }
   (void)nw;   // 8-wave blocks need a register diet first (256-VGPR cap at 2 waves/SIMD -> scratch spills, measured 4x slower)
-  hipLaunchKernelGGL(mlp_layer_kernel<4>, dim3(blocks), dim3(256), 4 * 1024 * sizeof(float), st, LL);
+  bool lean = L.finish;
+  for (int i = 0; i < LL.ntasks; ++i) lean = lean && LL.t[i].mode == 0 && LL.t[i].nsplit_src <= 1;
+  if (lean) hipLaunchKernelGGL((mlp_layer_kernel<4, true>), dim3(blocks), dim3(256), 4 * 1024 * sizeof(float), st, LL);
+  else hipLaunchKernelGGL((mlp_layer_kernel<4, false>), dim3(blocks), dim3(256), 4 * 1024 * sizeof(float), st, LL);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -1272,7 +1354,7 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
         const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
         fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
       }
-      int rc = launch_layers(LL, L.nw, st);
+      int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
     }
     GlueParams g;
@@ -1295,7 +1377,7 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
       memset(&LL, 0, sizeof(LL));
       LL.RT = RT;
       pri_task(LL, l, S - 1);
-      int rc = launch_layers(LL, L.nw, st);
+      int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
     }
     PriorIOParams q;
@@ -1336,7 +1418,7 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
       LL.RT = RT;
       const float* src = l == 0 ? sp + L.off_x : sp + L.off_pri[l - 1];
       fwd_task(LL.t[LL.ntasks++], net->pri[l], src, l == 0 ? 1 : L.nsf_pri[l - 1], nullptr, sp + L.off_pri[l], L.spb, L.nsf_pri[l]);
-      int rc = launch_layers(LL, L.nw, st);
+      int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
     }
     SampleParams sp_;
@@ -1352,7 +1434,7 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
       LL.RT = RT;
       const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
       fwd_task(LL.t[LL.ntasks++], net->dec[l], src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
-      int rc = launch_layers(LL, L.nw, st);
+      int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
     }
     GlueParams g;
@@ -1448,7 +1530,7 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
       memset(&LL, 0, sizeof(LL));
       LL.RT = RT;
       pri_bwd_task(LL, l, S - 1);
-      int rc = launch_layers(LL, L.nw, st);
+      int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
     }
   }
@@ -1473,7 +1555,7 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
       if (with_prior && l < np) pri_bwd_task(LL, l, t);
       // step t-1's prior layers nd .. np-1, in descending order, in the last np - nd launches of this step
       if (with_prior && t > 0 && nd + l < np) pri_bwd_task(LL, nd + l, t - 1);
-      int rc = launch_layers(LL, L.nw, st);
+      int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
     }
   }

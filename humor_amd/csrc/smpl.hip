@@ -39,13 +39,14 @@ namespace ha {
 // ha_tune_set("skin_variant"): -1 = auto; else bits 0-1: waves per block 4 << b; +4: non-temporal stores;
 // +8 / +16: profiling modes of the streaming kernel (LDS-transposed copy only / every lane gathers bone 0)
 int g_skin_variant = -1;
-extern int g_layer_spb, g_layer_nw;   // rollout.hip
+extern int g_layer_spb, g_layer_nw, g_layer_finish;   // rollout.hip
 }
 extern "C" int ha_tune_set(const char* key, int value) {
   HA_REQUIRE(key, "ha_tune_set: null key");
   if (strcmp(key, "skin_variant") == 0) { ha::g_skin_variant = value; return HA_OK; }
   if (strcmp(key, "layer_spb") == 0) { ha::g_layer_spb = value; return HA_OK; }
   if (strcmp(key, "layer_nw") == 0) { ha::g_layer_nw = value; return HA_OK; }
+  if (strcmp(key, "layer_finish") == 0) { ha::g_layer_finish = value; return HA_OK; }
   ha::set_error("ha_tune_set: unknown key '%s'", key);
   return HA_ERR_INVALID_ARG;
 }

@@ -18,6 +18,16 @@ def test_emu_rollout_two_steps(emu_lib):
     RC.check_rollout(emu_lib, CPU, B=2, S=2)
 
 
+@pytest.mark.slow
+def test_emu_rollout_finishing_pass(emu_lib):
+    # the launch policy of two or more row tiles (gn_finish_kernel + lean GEMM layer kernel), forced at 2 rows
+    emu_lib.call('ha_tune_set', b'layer_finish', 2)
+    try:
+        RC.check_rollout(emu_lib, CPU, B=2, S=2)
+    finally:
+        emu_lib.call('ha_tune_set', b'layer_finish', 1)
+
+
 def test_rollout_refuses_cpu():
     from humor_amd._lib import HumorAmdError
     from humor_amd.humor_model import HumorModel

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A/B of the roll-out layer-kernel launch policy (slices per block, waves per block): event-timed forward and
-forward+backward of HumorModel.roll_out.  usage: rollout_ab.py B S "spb,nw" ["spb,nw" ...]"""
+forward+backward of HumorModel.roll_out.  usage: rollout_ab.py B S "spb,finish" ["spb,finish" ...]   (spb 0 = default; finish 0 off / 1 auto / 2 forced)"""
 import os
 import sys
 
@@ -34,7 +34,7 @@ def main():
     ref = None
     for spb, nw in cfgs:
         lib.call('ha_tune_set', b'layer_spb', spb)
-        lib.call('ha_tune_set', b'layer_nw', nw)
+        lib.call('ha_tune_set', b'layer_finish', nw if nw in (0, 1, 2) else 1)   # second number: 0 off, 1 auto, 2 forced
         hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', model_data_config='smpl+joints+contacts')
         hm.load_state_dict(sd)
         hm = hm.to(dev).eval()
