@@ -313,7 +313,6 @@ __global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
 // (mode 0, one slab per operand).  Inside the layer kernel that work is repeated by each of the 32 output-tile blocks (every
 // block re-reads up to five partial slabs; 3-4 k cycles of GroupNorm per slice against 2.3 k cycles of MFMA), which held
 // the 256-row launches at ~25 us; at 32 rows the extra launch costs more than it saves.
-// One wave per (task, row tile, 64-channel slice).
 struct FinishLaunch {
   LayerTask t[3];
   float* dst[3];
@@ -321,35 +320,82 @@ struct FinishLaunch {
   int ntasks, RT;
 };
 
-__global__ __launch_bounds__(64) void gn_finish_kernel(FinishLaunch F) {
+// 256 threads per (task, row tile, 64-channel slice): thread <-> (row = t & 31, channel octet = t >> 5), i.e. two 16-byte loads
+// per slab and thread, so the whole fragment is one short batch of loads instead of a 60-100-load chain in one wave; the
+// per-row GroupNorm sums cross the waves through LDS (two-pass statistics, as in the layer kernel's prologue).
+__global__ __launch_bounds__(256) void gn_finish_kernel(FinishLaunch F) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [pass 4][row 32][octet 8]
+  float (*s_red)[32][8] = reinterpret_cast<float (*)[32][8]>(smem);
   int b = blockIdx.x, ti = 0;
   while (ti + 1 < F.ntasks && b >= F.nblk[ti]) { b -= F.nblk[ti]; ++ti; }
   const LayerTask& T = F.t[ti];
-  const int lane = threadIdx.x, hi = lane >> 5;
+  const int row = threadIdx.x & 31, oct = threadIdx.x >> 5;
   const int slice = b % T.main_slices, rt = b / T.main_slices;
-  const int cbase = slice * SLICE;
-  float gam[32], bet[32], a[32], h[32];
+  const int c0 = slice * SLICE + oct * 8;            // this thread's 8 channels
+  const vf4 g0 = *reinterpret_cast<const vf4*>(T.gamma + c0), g1 = *reinterpret_cast<const vf4*>(T.gamma + c0 + 4);
+  const vf4 e0 = *reinterpret_cast<const vf4*>(T.beta + c0), e1 = *reinterpret_cast<const vf4*>(T.beta + c0 + 4);
+  // sums `ns` partial slabs of the 8 channels (all loads first, summed in split order)
+  auto load8 = [&](const float* base, int ns, int C, float (&v)[8]) {
+    const size_t stride = (size_t)F.RT * C * 32;
+    const float* p = base + (size_t)rt * C * 32 + (size_t)(c0 >> 2) * 128 + (size_t)row * 4;
+    vf4 t0[MAXSPLIT], t1[MAXSPLIT];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const vf4 g4 = *reinterpret_cast<const vf4*>(T.gamma + cbase + 32 * hi + 4 * j);
-    const vf4 b4 = *reinterpret_cast<const vf4*>(T.beta + cbase + 32 * hi + 4 * j);
-    gam[4 * j] = g4.x; gam[4 * j + 1] = g4.y; gam[4 * j + 2] = g4.z; gam[4 * j + 3] = g4.w;
-    bet[4 * j] = b4.x; bet[4 * j + 1] = b4.y; bet[4 * j + 2] = b4.z; bet[4 * j + 3] = b4.w;
-  }
-  load_frag_n(T.src, T.nsplit_src, F.RT, T.Csrc, rt, cbase, lane, a);
-  if (T.mode == 3) load_frag_n(T.hsrc, T.nsplit_h, F.RT, T.Ch, rt, cbase, lane, h);
+    for (int k = 0; k < MAXSPLIT; ++k) {
+      t0[k] = vf4{0.f, 0.f, 0.f, 0.f};
+      t1[k] = t0[k];
+      if (k < ns) { t0[k] = *reinterpret_cast<const vf4*>(p + k * stride); t1[k] = *reinterpret_cast<const vf4*>(p + k * stride + 128); }
+    }
+    vf4 a0 = t0[0], a1 = t1[0];
+#pragma unroll
+    for (int k = 1; k < MAXSPLIT; ++k) { a0 += t0[k]; a1 += t1[k]; }
+    v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+  };
+  float x[8], da[8];
+  if (T.mode == 1) load8(T.src, T.nsplit_src, T.Csrc, x);
+  else { load8(T.src, T.nsplit_src, T.Csrc, da); load8(T.hsrc, T.nsplit_h, T.Ch, x); }
+  const float gam[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float bet[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+  // a group is 64 channels (all 8 octets of the row) or 32 (octets 0-3 / 4-7)
+  const int per = T.group == SLICE ? 8 : 4, o0 = T.group == SLICE ? 0 : (oct & 4);
   const float inv_n = 1.0f / (float)T.group;
+  auto row_sum = [&](int pass, float v) {
+    s_red[pass][row][oct] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int k = 0; k < per; ++k) t += s_red[pass][row][o0 + k];
+    return t;
+  };
+  float p1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p1 += x[i];
+  const float mu = row_sum(0, p1) * inv_n;
+  float p2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const float d = x[i] - mu; p2 = fmaf(d, d, p2); }
+  const float rstd = rsqrtf(row_sum(1, p2) * inv_n + 1e-5f);
+  float out[8];
   if (T.mode == 1) {
-    if (T.group == SLICE) gn_apply<1>(1, gam, bet, inv_n, a, a);
-    else gn_apply<2>(1, gam, bet, inv_n, a, a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = fmaxf((x[i] - mu) * rstd * gam[i] + bet[i], 0.f);
   } else {
-    if (T.group == SLICE) gn_apply<1>(3, gam, bet, inv_n, h, a);
-    else gn_apply<2>(3, gam, bet, inv_n, h, a);
+    float xh[8], dxh[8], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      xh[i] = (x[i] - mu) * rstd;
+      const float y = xh[i] * gam[i] + bet[i];
+      dxh[i] = (y > 0.f ? da[i] : 0.f) * gam[i];
+      m1 += dxh[i];
+      m2 = fmaf(dxh[i], xh[i], m2);
+    }
+    m1 = row_sum(2, m1) * inv_n;
+    m2 = row_sum(3, m2) * inv_n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = rstd * (dxh[i] - m1 - xh[i] * m2);
   }
   // finished slab: same quad layout, width = the channels this task consumes (main_slices * 64)
-  float* d = F.dst[ti] + (size_t)rt * (T.main_slices * SLICE) * 32 + (size_t)((cbase + 32 * hi) >> 2) * 128 + (size_t)(lane & 31) * 4;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) *reinterpret_cast<vf4*>(d + j * 128) = vf4{a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]};
+  float* d = F.dst[ti] + (size_t)rt * (T.main_slices * SLICE) * 32 + (size_t)(c0 >> 2) * 128 + (size_t)row * 4;
+  *reinterpret_cast<vf4*>(d) = vf4{out[0], out[1], out[2], out[3]};
+  *reinterpret_cast<vf4*>(d + 128) = vf4{out[4], out[5], out[6], out[7]};
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1237,7 +1283,7 @@ static int launch_layers(LayerLaunch& LL, const StashLayout& L, float* stash, hi
       T.hsrc = nullptr; T.nsplit_h = 0;
     }
     if (fb) {
-      hipLaunchKernelGGL(gn_finish_kernel, dim3(fb), dim3(64), 0, st, F);
+      hipLaunchKernelGGL(gn_finish_kernel, dim3(fb), dim3(256), 4 * 32 * 8 * sizeof(float), st, F);
       HA_LAUNCH_CHECK();
     }
   }
