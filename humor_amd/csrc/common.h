@@ -14,6 +14,13 @@
 #define HA_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #endif
 
+// scheduling fence: no instruction is moved across it by the compiler's scheduler (software pipelining by hand)
+#ifdef HA_SIMT_EMU
+#define HA_SCHED_FENCE()
+#else
+#define HA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace ha {
 
 void set_error(const char* fmt, ...);

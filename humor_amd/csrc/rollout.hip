@@ -36,6 +36,7 @@ __device__ __forceinline__ size_t qoff(int c) { return (size_t)(c >> 2) * 128 + 
 
 // layer-kernel launch policy picked up by ha_humor_net_create (ha_tune_set "layer_spb" / "layer_nw"; 0 = default)
 int g_layer_spb = 0, g_layer_nw = 0, g_layer_finish = 1;
+int g_gemm_rm = 0;    // row tiles per wave of the batched prior GEMM (ha_tune_set "gemm_rm"; 0 = by size)
 
 struct PackedLayer {
   int Cin = 0, skip = 0, Nout = 0;
@@ -66,15 +67,17 @@ struct LayerTask {
   const float* src; int nsplit_src; int Csrc;       // A operand main part: partial slabs [nsplit][RT][Csrc][32]
   const float* skip; int skip_dim;                  // raw tail part [RT][skip_dim][32]
   int mode;                                         // 0 raw, 1 GN+ReLU (fwd), 3 GN+ReLU adjoint (bwd)
-  const float* gamma; const float* beta; int group;
+  const float* gamma; const float* beta; int group; float inv_group;
   const float* hsrc; int nsplit_h; int Ch;          // mode 3: forward pre-activation slabs of the same channels ([..][Ch][32])
   float* dst;                                       // [nsplit_dst][RT][Nout_pad][32]
   int spb, nsplit_dst;                              // K-slices per block, ceil(nslices / spb)
   int nblocks;                                      // ntiles * nsplit_dst * RT
 };
 
+// One launch = one (layer, direction).  (A single task: the kernel's start-up is a chain of dependent scalar loads, and
+// indexing an array of tasks by a block-dependent index cost ~15 of them -- 1.3 us per launch on a 4-7 us launch.)
 struct LayerLaunch {
-  LayerTask t[3];
+  LayerTask t[1];
   int ntasks;
   int RT;
 };
@@ -211,22 +214,18 @@ __global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // NWT * 1024 floats
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef HA_LAYER_TIMING
-  const bool ts_on = blockIdx.x == 0 && threadIdx.x == 0;
+  const bool ts_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
   unsigned ts_slot = 0;
   if (ts_on) {
     ts_slot = atomicAdd(&g_layer_launches, 1u) & 63;
     g_layer_ts[ts_slot][8] = wall_clock64();
-    g_layer_ts[ts_slot][9] = ((unsigned long long)L.t[0].nblocks << 32) | (unsigned)(L.ntasks > 1 ? L.t[1].nblocks : 0);
+    g_layer_ts[ts_slot][9] = ((unsigned long long)L.t[0].nblocks << 32);
   }
   HA_TS(0, false);
 #endif
-  int b = blockIdx.x;
-  int ti = 0;
-  while (ti + 1 < L.ntasks && b >= L.t[ti].nblocks) { b -= L.t[ti].nblocks; ++ti; }
-  const LayerTask& T = L.t[ti];
-  const int tile = b % T.ntiles;
-  const int b2 = b / T.ntiles;
-  const int ks = b2 % T.nsplit_dst, rt = b2 / T.nsplit_dst;
+  // grid = (output tile, K-split, row tile): no integer divisions on the start-up path
+  const LayerTask& T = L.t[0];
+  const int tile = blockIdx.x, ks = blockIdx.y, rt = blockIdx.z;
   const int hi = lane >> 5;
   const int s_end = (ks + 1) * T.spb < T.nslices ? (ks + 1) * T.spb : T.nslices;
 
@@ -268,7 +267,7 @@ __global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
     HA_TS(2, true);
     if (has_gn) {
       // GroupNorm over groups of T.group (64 or 32) channels: the lane holds one half-slice of its row
-      const float inv_n = 1.0f / (float)T.group;
+      const float inv_n = T.inv_group;
       if (T.mode == 1) {
         if (T.group == SLICE) gn_apply<1>(1, gam, bet, inv_n, a, a);
         else gn_apply<2>(1, gam, bet, inv_n, a, a);
@@ -314,9 +313,9 @@ __global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
 // block re-reads up to five partial slabs; 3-4 k cycles of GroupNorm per slice against 2.3 k cycles of MFMA), which held
 // the 256-row launches at ~25 us; at 32 rows the extra launch costs more than it saves.
 struct FinishLaunch {
-  LayerTask t[3];
-  float* dst[3];
-  int nblk[3];          // blocks of each task = RT * main_slices
+  LayerTask t[1];
+  float* dst[1];
+  int nblk[1];          // blocks of the task = RT * main_slices
   int ntasks, RT;
 };
 
@@ -326,9 +325,8 @@ struct FinishLaunch {
 __global__ __launch_bounds__(256) void gn_finish_kernel(FinishLaunch F) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [pass 4][row 32][octet 8]
   float (*s_red)[32][8] = reinterpret_cast<float (*)[32][8]>(smem);
-  int b = blockIdx.x, ti = 0;
-  while (ti + 1 < F.ntasks && b >= F.nblk[ti]) { b -= F.nblk[ti]; ++ti; }
-  const LayerTask& T = F.t[ti];
+  const int b = blockIdx.x, ti = 0;
+  const LayerTask& T = F.t[0];
   const int row = threadIdx.x & 31, oct = threadIdx.x >> 5;
   const int slice = b % T.main_slices, rt = b / T.main_slices;
   const int c0 = slice * SLICE + oct * 8;            // this thread's 8 channels
@@ -396,6 +394,189 @@ __global__ __launch_bounds__(256) void gn_finish_kernel(FinishLaunch F) {
   float* d = F.dst[ti] + (size_t)rt * (T.main_slices * SLICE) * 32 + (size_t)(c0 >> 2) * 128 + (size_t)row * 4;
   *reinterpret_cast<vf4*>(d) = vf4{out[0], out[1], out[2], out[3]};
   *reinterpret_cast<vf4*>(d + 128) = vf4{out[4], out[5], out[6], out[7]};
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Batched layer GEMM of the PRIOR network.  The prior is off the recurrence in both directions: its input x_t is known once the
+// decoder chain has produced the states, and its output adjoints (g_mu, g_var) are given up front.  So instead of riding in
+// the per-step launches at M = B rows, each of its layers runs ONCE over all S * RT row tiles (M = 32 S RT rows; 1888 at
+// 32 x 59, 30464 at 256 x 119) as an MFMA-shaped GEMM, forward (humor_model.py:407-418 evaluated for all steps at once) and
+// adjoint.  A wave owns RM x 2 output tiles of 32 x 32 (RM row tiles x one 64-column pair = one 64-channel or two 32-channel
+// GroupNorm groups) and walks the whole K: no split-K partial slabs, no finishing pass -- the GroupNorm(+ReLU) of the
+// produced activation (forward) or its adjoint (backward) is applied in the epilogue, where each row's group is complete
+// inside the wave (lane-local sums plus one lane^32 shuffle, as in the layer kernel's prologue).  The four waves of a block
+// take four adjacent column pairs of the same rows (the A operand is shared through the CU's L1); operands of the next
+// K-slice are fetched into a second register set while the MFMAs of the current one issue.  Blocks are dealt to the XCDs in
+// column-block-major order so that one XCD's L2 holds one 256-column weight panel (<= 1 MB) plus its rows.
+struct GemmTask {
+  const float* Wp; const float* bias;     // packed weights [ntiles][nslices][8][64][4]; bias or null
+  int ntiles, nslices, Nout;              // 32-column output tiles, 64-channel K slices, valid output columns
+  const float* src; int Csrc;             // A operand: finished slab [row tiles][Csrc][32]
+  int nrt;                                // row tiles
+  int epi;                                // 0 raw -> dst_h | 1 raw -> dst_h, ReLU(GroupNorm(.)) -> dst_a | 3 GroupNorm-ReLU adjoint (with hsrc) -> dst_a
+  const float* gamma; const float* beta; int group;
+  const float* hsrc; int Ch;              // epi 3: forward pre-activations of the same channels [row tiles][Ch][32]
+  float* dst_h; float* dst_a; int Cdst;   // output slabs [row tiles][Cdst][32]
+  int nrg, nwork, per_xcd;                // row groups of RM tiles, work items = column blocks x row groups, items per XCD
+};
+
+constexpr int GEMM_LDS_WAVE = 2 * 8 * 132;    // floats of epilogue staging per wave: [column tile][quad][32 rows x 4 + pad]
+
+template <int RM>
+__global__ __launch_bounds__(256) void prior_gemm_kernel(GemmTask T) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = (int)(blockIdx.x & 7) * T.per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= T.per_xcd || w >= T.nwork) return;
+  const int cb = w / T.nrg, rg = w % T.nrg;
+  const int ct0 = (cb * 4 + wave) * 2;
+  if (ct0 >= T.ntiles) return;
+  const int ct1 = ct0 + 1 < T.ntiles ? ct0 + 1 : ct0;      // an odd last tile: the second accumulator is computed and dropped
+  int rt[RM];
+#pragma unroll
+  for (int m = 0; m < RM; ++m) rt[m] = rg * RM + m < T.nrt ? rg * RM + m : T.nrt - 1;
+
+  f32x16 acc[RM][2];
+#pragma unroll
+  for (int m = 0; m < RM; ++m)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][c][i] = 0.f;
+
+  const float* wp0 = T.Wp + (size_t)ct0 * T.nslices * 2048 + lane * 4;
+  const float* wp1 = T.Wp + (size_t)ct1 * T.nslices * 2048 + lane * 4;
+  auto load_b = [&](int slice, float (&b0)[32], float (&b1)[32]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const vf4 u = *reinterpret_cast<const vf4*>(wp0 + (size_t)slice * 2048 + j * 256);
+      const vf4 v = *reinterpret_cast<const vf4*>(wp1 + (size_t)slice * 2048 + j * 256);
+      b0[4 * j] = u.x; b0[4 * j + 1] = u.y; b0[4 * j + 2] = u.z; b0[4 * j + 3] = u.w;
+      b1[4 * j] = v.x; b1[4 * j + 1] = v.y; b1[4 * j + 2] = v.z; b1[4 * j + 3] = v.w;
+    }
+  };
+  // full 64-channel slices: unconditional 16-byte loads (nothing depends on the loaded values before the MFMAs read them)
+  auto load_a = [&](int slice, float (&a)[RM][32]) {
+#pragma unroll
+    for (int m = 0; m < RM; ++m)
+      load_frag<1>(T.src + (size_t)rt[m] * T.Csrc * 32 + (size_t)(slice * 16 + 8 * (lane >> 5)) * 128 + (size_t)(lane & 31) * 4, 0, 8, a[m]);
+  };
+  auto mma = [&](const float (&a)[RM][32], const float (&b0)[32], const float (&b1)[32]) {
+#pragma unroll
+    for (int kp = 0; kp < 32; ++kp)
+#pragma unroll
+      for (int m = 0; m < RM; ++m) {
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][kp], b0[kp], acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][kp], b1[kp], acc[m][1], 0, 0, 0);
+      }
+  };
+  const int nfull = T.Csrc / SLICE < T.nslices ? T.Csrc / SLICE : T.nslices;      // slices whose 64 channels all exist in the slab
+  if (nfull > 0) {
+    float aA[RM][32], bA0[32], bA1[32], aB[RM][32], bB0[32], bB1[32];
+    load_b(0, bA0, bA1);
+    load_a(0, aA);
+    // HA_SCHED_FENCE keeps the compiler from sinking the next slice's loads down to their first use (which serialises every
+    // memory round trip behind the MFMAs instead of hiding it under them)
+    for (int slice = 0; slice < nfull; slice += 2) {
+      const int s1 = slice + 1 < nfull ? slice + 1 : slice;
+      load_b(s1, bB0, bB1);
+      load_a(s1, aB);
+      HA_SCHED_FENCE();
+      mma(aA, bA0, bA1);
+      HA_SCHED_FENCE();
+      if (slice + 1 < nfull) {
+        const int s2 = slice + 2 < nfull ? slice + 2 : slice + 1;
+        load_b(s2, bA0, bA1);
+        load_a(s2, aA);
+        HA_SCHED_FENCE();
+        mma(aB, bB0, bB1);
+        HA_SCHED_FENCE();
+      }
+    }
+  }
+  if (nfull < T.nslices) {
+    // ragged K tail (339 = 5 x 64 + 19 state channels, 96 = 64 + 32 prior outputs): quads beyond the slab width read as zero
+    float a[RM][32], b0[32], b1[32];
+    load_b(nfull, b0, b1);
+#pragma unroll
+    for (int m = 0; m < RM; ++m) load_frag_n<true>(T.src, 1, 0, T.Csrc, rt[m], nfull * SLICE, lane, a[m]);
+    mma(a, b0, b1);
+  }
+
+  // ---- epilogue: accumulators -> (row, 32 channels of one column tile) per lane through the wave's LDS slice -----------------
+  float* sl = smem + wave * GEMM_LDS_WAVE;
+  const int row = lane & 31, hh = lane >> 5;
+  const int ct = hh ? ct0 + 1 : ct0;                  // this lane's column tile
+  const bool ct_ok = ct < T.ntiles;
+  float gam[32], bet[32];
+  if (T.epi != 0 && ct_ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const vf4 g4 = *reinterpret_cast<const vf4*>(T.gamma + ct * 32 + 4 * j);
+      const vf4 b4 = *reinterpret_cast<const vf4*>(T.beta + ct * 32 + 4 * j);
+      gam[4 * j] = g4.x; gam[4 * j + 1] = g4.y; gam[4 * j + 2] = g4.z; gam[4 * j + 3] = g4.w;
+      bet[4 * j] = b4.x; bet[4 * j + 1] = b4.y; bet[4 * j + 2] = b4.z; bet[4 * j + 3] = b4.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { gam[k] = 1.f; bet[k] = 0.f; }
+  }
+#pragma unroll
+  for (int m = 0; m < RM; ++m) {
+    // accumulator register i of lane l: row (i&3) + 8 (i>>2) + 4 (l>>5), column l&31
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = (i & 3) + 8 * (i >> 2) + 4 * hh, col = lane & 31;
+        sl[(c * 8 + (col >> 2)) * 132 + r * 4 + (col & 3)] = acc[m][c][i];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const vf4 q = *reinterpret_cast<const vf4*>(sl + (hh * 8 + j) * 132 + row * 4);
+      v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                  // the slice is rewritten by the next row tile
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool live = ct_ok && rg * RM + m < T.nrt;
+    if (T.bias && ct_ok) {       // the packed bias is zero-padded to whole 32-column tiles
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const vf4 b4 = *reinterpret_cast<const vf4*>(T.bias + ct * 32 + 4 * j);
+        v[4 * j] += b4.x; v[4 * j + 1] += b4.y; v[4 * j + 2] += b4.z; v[4 * j + 3] += b4.w;
+      }
+    }
+    const size_t o = (size_t)rt[m] * T.Cdst * 32 + (size_t)(ct * 8) * 128 + (size_t)row * 4;
+    auto store32 = [&](float* base, const float (&x)[32]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<vf4*>(base + o + (size_t)j * 128) = vf4{x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]};
+    };
+    if (T.epi != 3 && live) store32(T.dst_h, v);
+    if (T.epi == 1) {
+      const float inv_n = 1.0f / (float)T.group;
+      if (T.group == SLICE) gn_apply<1>(1, gam, bet, inv_n, v, v);       // (all lanes: the cross-half shuffle is wave-wide)
+      else gn_apply<2>(1, gam, bet, inv_n, v, v);
+      if (live) store32(T.dst_a, v);
+    } else if (T.epi == 3) {
+      float h[32];
+      const float* hp = T.hsrc + (size_t)rt[m] * T.Ch * 32 + (size_t)((ct_ok ? ct : ct0) * 8) * 128 + (size_t)row * 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const vf4 q = *reinterpret_cast<const vf4*>(hp + (size_t)j * 128);
+        h[4 * j] = q.x; h[4 * j + 1] = q.y; h[4 * j + 2] = q.z; h[4 * j + 3] = q.w;
+      }
+      const float inv_n = 1.0f / (float)T.group;
+      if (T.group == SLICE) gn_apply<1>(3, gam, bet, inv_n, h, v);
+      else gn_apply<2>(3, gam, bet, inv_n, h, v);
+      if (live) store32(T.dst_a, v);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1149,7 +1330,8 @@ static int pack_layer(PackedLayer& L, const float* W, const float* bias, const f
   int rc;
   if ((rc = upload_vec(&L.Wf, wf)) != HA_OK) return rc;
   if ((rc = upload_vec(&L.Wb, wb)) != HA_OK) return rc;
-  std::vector<float> bv(bias, bias + Nout);
+  std::vector<float> bv(L.Nout_pad, 0.f);      // zero-padded to whole output tiles (vector loads in the GEMM epilogue)
+  for (int i = 0; i < Nout; ++i) bv[i] = bias[i];
   if ((rc = upload_vec(&L.bias, bv)) != HA_OK) return rc;
   if (has_gn) {
     std::vector<float> gv(gamma, gamma + Cin), bev(beta, beta + Cin);
@@ -1181,14 +1363,20 @@ struct StashLayout {
   int RT = 0;
   // launch policy of the layer kernel for this batch size: K-slices per block and the resulting partial-slab counts
   int spb = 4, nw = 4;
-  int nsf_pri[MAXL], nsf_dec[MAXL], nsb_pri[MAXL], nsb_dec[MAXL];
+  int nsf_pri[MAXL], nsf_dec[MAXL], nsb_dec[MAXL];
   size_t zT = 0, t2j = 0, per_step = 0, steps = 0;
-  size_t off_x = 0, off_G = 0;
-  size_t off_pri[MAXL], off_dec[MAXL];
+  size_t xT = 0;                  // input states of all steps, contiguous: [(S+1)][RT][D_INP][32] (the batched prior's A operand)
+  size_t off_G = 0;
+  size_t off_dec[MAXL];
+  // batched prior network: pre-activations of every layer for all steps, [S*RT][Nout_pad][32] each (kept for the adjoint)
+  size_t pri_h[MAXL];
+  size_t pri_act[2];              // finished activations / adjoints of consecutive layers (ping-pong), [S*RT][1024][32]
+  size_t gx_pri = 0;              // dL/dx_t through the prior for all steps, [S*RT][Nin_pad(0)][32]
+  size_t smp_pri[MAXL];           // sampling roll-out only: the per-step prior's partial slabs (one step's worth, reused)
   // backward scratch
   size_t gx_dir[2], carry = 0, g_dec_out = 0, g_pri_out = 0;
-  size_t bwd_pri[MAXL], bwd_dec[MAXL];
-  size_t fin[3] = {0, 0, 0};   // finished-activation scratch of the up to three tasks of a launch (full-K policy only)
+  size_t bwd_dec[MAXL];
+  size_t fin[1] = {0};         // finished-activation scratch of a launch's task (finishing-pass policy only)
   bool finish = false;
   size_t total = 0;
 };
@@ -1201,34 +1389,42 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   // launch is a latency chain); from two row tiles on a finishing pass does that once per activation (gn_finish_kernel) and
   // the layer kernel runs as a lean GEMM.  Measured with tools/rollout_ab.py (fwd+bwd ms, in-kernel vs finishing pass):
   // 32 rows 5.7 / 6.4, 64 rows 7.9 / 7.2, 96 rows 10.2 / 7.7, 128 rows 10.6 / 8.3, 256 rows x 119 steps 29.6 / 21.2.
-  if (L.spb < 4) L.spb = 4;      // MAXSPLIT partial slabs at most (checked against the layer widths at pack time)
+  L.spb = g_layer_spb >= 4 ? g_layer_spb : 4;      // MAXSPLIT partial slabs at most (checked against the layer widths at pack time)
   L.nw = 4;
-  for (int i = 0; i < net->n_pri; ++i) { L.nsf_pri[i] = ceil_div(net->pri[i].nslices_f, L.spb); L.nsb_pri[i] = ceil_div(net->pri[i].nslices_b, L.spb); }
+  for (int i = 0; i < net->n_pri; ++i) L.nsf_pri[i] = ceil_div(net->pri[i].nslices_f, L.spb);
   for (int i = 0; i < net->n_dec; ++i) { L.nsf_dec[i] = ceil_div(net->dec[i].nslices_f, L.spb); L.nsb_dec[i] = ceil_div(net->dec[i].nslices_b, L.spb); }
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
   L.zT = take((size_t)S * RT * ZD * 32);
   L.t2j = take(RT * 32 * 3);
-  // per-step region
+  L.xT = take((size_t)(S + 1) * RT * D_INP * 32);
+  // per-step region: accumulated world transform and the decoder's partial slabs
   size_t p = 0;
   auto ptake = [&](size_t n) { size_t r = p; p += (n + 63) / 64 * 64; return r; };
-  L.off_x = ptake(RT * D_INP * 32);
   L.off_G = ptake(RT * 32 * 12);
-  for (int i = 0; i < net->n_pri; ++i) L.off_pri[i] = ptake((size_t)L.nsf_pri[i] * RT * net->pri[i].Nout_pad * 32);
   for (int i = 0; i < net->n_dec; ++i) L.off_dec[i] = ptake((size_t)L.nsf_dec[i] * RT * net->dec[i].Nout_pad * 32);
   L.per_step = p;
   L.steps = take(p * (size_t)(S + 1));
+  size_t widest = 0;
+  for (int i = 0; i < net->n_pri; ++i) {
+    L.pri_h[i] = take((size_t)S * RT * net->pri[i].Nout_pad * 32);
+    if ((size_t)net->pri[i].Nout_pad > widest) widest = net->pri[i].Nout_pad;
+    if ((size_t)net->pri[i].Nin_pad > widest) widest = net->pri[i].Nin_pad;
+    L.smp_pri[i] = take((size_t)L.nsf_pri[i] * RT * net->pri[i].Nout_pad * 32);
+  }
+  L.pri_act[0] = take((size_t)S * RT * widest * 32);
+  L.pri_act[1] = take((size_t)S * RT * widest * 32);
+  L.gx_pri = take((size_t)S * RT * net->pri[0].Nin_pad * 32);
   L.gx_dir[0] = take(RT * D_INP * 32);
   L.gx_dir[1] = take(RT * D_INP * 32);
   L.carry = take(RT * 32 * 16);
   L.g_dec_out = take(RT * net->dec[net->n_dec - 1].Nout_pad * 32);
   L.g_pri_out = take((size_t)S * RT * net->pri[net->n_pri - 1].Nout_pad * 32);   // prior-output adjoints of all steps
-  for (int i = 0; i < net->n_pri; ++i) L.bwd_pri[i] = take((size_t)L.nsb_pri[i] * RT * net->pri[i].Nin_pad * 32);
   for (int i = 0; i < net->n_dec; ++i) L.bwd_dec[i] = take((size_t)L.nsb_dec[i] * RT * net->dec[i].Nin_pad * 32);
   // GroupNorm prologues once per activation in gn_finish_kernel (see there and the policy note above)
   L.finish = (L.RT >= 2 && g_layer_finish != 0) || g_layer_finish == 2;     // 0: never, 2: always (A/B runs)
   if (L.finish)
-    for (int i = 0; i < 3; ++i) L.fin[i] = take(RT * 1280 * 32);     // widest operand: K <= 1280 (checked at pack time)
+    L.fin[0] = take(RT * 1280 * 32);     // widest operand: K <= 1280 (checked at pack time)
   L.total = o;
 }
 
@@ -1241,6 +1437,7 @@ static void fwd_task(LayerTask& T, const PackedLayer& L, const float* src, int n
   T.skip = skip; T.skip_dim = L.skip;
   T.mode = L.group ? 1 : 0;
   T.gamma = L.gamma; T.beta = L.beta; T.group = L.group ? L.group : 64;
+  T.inv_group = 1.0f / (float)T.group;
   T.dst = dst;
   T.spb = spb; T.nsplit_dst = nsplit_dst;
   T.nblocks = L.ntiles_f * nsplit_dst;          // x RT in launch_layers
@@ -1258,6 +1455,7 @@ static void bwd_task(LayerTask& T, const PackedLayer& L, const float* dsrc, int 
   T.mode = Lnext_gn ? 3 : 0;
   if (Lnext_gn) { T.gamma = Lnext_gn->gamma; T.beta = Lnext_gn->beta; T.group = Lnext_gn->group; }
   else T.group = 64;
+  T.inv_group = 1.0f / (float)T.group;
   T.hsrc = hsrc; T.nsplit_h = nsplit_h; T.Ch = L.Nout_pad;
   T.dst = dst;
   T.spb = spb; T.nsplit_dst = nsplit_dst;
@@ -1287,15 +1485,82 @@ static int launch_layers(LayerLaunch& LL, const StashLayout& L, float* stash, hi
       HA_LAUNCH_CHECK();
     }
   }
-  const int nw = L.nw;
-  int blocks = 0;
-  for (int i = 0; i < LL.ntasks; ++i) { LL.t[i].nblocks *= LL.RT; blocks += LL.t[i].nblocks; }
-  (void)nw;   // 8-wave blocks need a register diet first (256-VGPR cap at 2 waves/SIMD -> scratch spills, measured 4x slower)
-  bool lean = L.finish;
-  for (int i = 0; i < LL.ntasks; ++i) lean = lean && LL.t[i].mode == 0 && LL.t[i].nsplit_src <= 1;
-  if (lean) hipLaunchKernelGGL((mlp_layer_kernel<4, true>), dim3(blocks), dim3(256), 4 * 1024 * sizeof(float), st, LL);
-  else hipLaunchKernelGGL((mlp_layer_kernel<4, false>), dim3(blocks), dim3(256), 4 * 1024 * sizeof(float), st, LL);
+  LayerTask& T0 = LL.t[0];
+  const dim3 grid(T0.ntiles, T0.nsplit_dst, LL.RT);
+  T0.nblocks *= LL.RT;
+  // (8-wave blocks need a register diet first: 256-VGPR cap at 2 waves/SIMD -> scratch spills, measured 4x slower)
+  const bool lean = L.finish && T0.mode == 0 && T0.nsplit_src <= 1;
+  if (lean) hipLaunchKernelGGL((mlp_layer_kernel<4, true>), grid, dim3(256), 4 * 1024 * sizeof(float), st, LL);
+  else hipLaunchKernelGGL((mlp_layer_kernel<4, false>), grid, dim3(256), 4 * 1024 * sizeof(float), st, LL);
   HA_LAUNCH_CHECK();
+  return HA_OK;
+}
+
+
+// one batched prior layer (forward l >= 0 / adjoint) over nrt = S * RT row tiles
+static int launch_prior_gemm(GemmTask& T, hipStream_t st) {
+  HA_REQUIRE(T.epi == 0 || (T.ntiles % 2 == 0 && (T.group == 32 || T.group == 64)), "prior GEMM: GroupNorm epilogue needs whole 64-column pairs");
+  // RM = 2 (64 x 64 per wave) once there are enough row tiles to keep every SIMD busy with the larger tile
+  const int ncb = ceil_div(T.ntiles, 8);
+  const int rm = g_gemm_rm == 1 || g_gemm_rm == 2 ? g_gemm_rm : ((T.nrt / 2) * ncb >= 2 * 256 ? 2 : 1);
+  T.nrg = ceil_div(T.nrt, rm);
+  T.nwork = ncb * T.nrg;
+  T.per_xcd = ceil_div(T.nwork, 8);
+  const dim3 grid(T.per_xcd * 8), block(256);
+  const size_t lds = 4 * GEMM_LDS_WAVE * sizeof(float);
+  if (rm == 2) hipLaunchKernelGGL(prior_gemm_kernel<2>, grid, block, lds, st, T);
+  else hipLaunchKernelGGL(prior_gemm_kernel<1>, grid, block, lds, st, T);
+  HA_LAUNCH_CHECK();
+  return HA_OK;
+}
+
+// forward of the whole prior network for all S steps (inputs: the state slabs x_0 .. x_{S-1})
+static int prior_forward_batched(const ha_humor_net* net, const StashLayout& L, float* stash, int S, hipStream_t st) {
+  const int np = net->n_pri;
+  for (int l = 0; l < np; ++l) {
+    const PackedLayer& P = net->pri[l];
+    GemmTask T;
+    memset(&T, 0, sizeof(T));
+    T.Wp = P.Wf; T.bias = P.bias;
+    T.ntiles = P.ntiles_f; T.nslices = P.nslices_f; T.Nout = P.Nout;
+    T.src = l == 0 ? stash + L.xT : stash + L.pri_act[(l - 1) & 1];
+    T.Csrc = l == 0 ? D_INP : net->pri[l - 1].Nout_pad;
+    T.nrt = S * L.RT;
+    T.dst_h = stash + L.pri_h[l]; T.Cdst = P.Nout_pad;
+    if (l + 1 < np) {
+      const PackedLayer& N = net->pri[l + 1];       // the GroupNorm between l and l+1 is stored with its consumer
+      T.epi = 1; T.gamma = N.gamma; T.beta = N.beta; T.group = N.group;
+      T.dst_a = stash + L.pri_act[l & 1];
+    }
+    int rc = launch_prior_gemm(T, st);
+    if (rc != HA_OK) return rc;
+  }
+  return HA_OK;
+}
+
+// adjoint of the whole prior network for all steps: g_pri_out [S*RT][pad][32] -> gx_pri [S*RT][Nin_pad(0)][32]
+static int prior_backward_batched(const ha_humor_net* net, const StashLayout& L, float* stash, int S, hipStream_t st) {
+  const int np = net->n_pri;
+  for (int l = np - 1; l >= 0; --l) {
+    const PackedLayer& P = net->pri[l];
+    GemmTask T;
+    memset(&T, 0, sizeof(T));
+    T.Wp = P.Wb; T.bias = nullptr;
+    T.ntiles = P.ntiles_b; T.nslices = P.nslices_b; T.Nout = P.Cin + P.skip;
+    T.src = l == np - 1 ? stash + L.g_pri_out : stash + L.pri_act[(l + 1) & 1];
+    T.Csrc = P.Nout_pad;
+    T.nrt = S * L.RT;
+    T.Cdst = P.Nin_pad;
+    if (l > 0) {
+      T.epi = 3; T.gamma = P.gamma; T.beta = P.beta; T.group = P.group;
+      T.hsrc = stash + L.pri_h[l - 1]; T.Ch = net->pri[l - 1].Nout_pad;
+      T.dst_a = stash + L.pri_act[l & 1];
+    } else {
+      T.epi = 0; T.dst_h = stash + L.gx_pri;
+    }
+    int rc = launch_prior_gemm(T, st);
+    if (rc != HA_OK) return rc;
+  }
   return HA_OK;
 }
 
@@ -1367,23 +1632,18 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
   make_layout(net, B, S, L);
   const int RT = L.RT, rows = RT * 32;
   auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
+  auto x_ptr = [&](int t) { return stash + L.xT + (size_t)t * RT * D_INP * 32; };
 
   hipLaunchKernelGGL(transpose_in_kernel, dim3(256), dim3(256), 0, st, z_seq, stash + L.zT, B, S, ZD, ZD, RT);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, step_ptr(0) + L.off_x, B, 1, D_IN, D_INP, RT);
+  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, x_ptr(0), B, 1, D_IN, D_INP, RT);
   HA_LAUNCH_CHECK();
   hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
   HA_LAUNCH_CHECK();
 
   const bool with_prior = prior_mu != nullptr;
   const int nd = net->n_dec, np = net->n_pri;
-  // The prior is off the recurrence (only its outputs are wanted), so its layers beyond the decoder's depth are deferred:
-  // layer nd + l of step t-1 rides in the level-l launch of step t instead of costing a launch of its own per step.
-  auto pri_task = [&](LayerLaunch& LL, int l, int t) {
-    float* sp = step_ptr(t);
-    const float* src = l == 0 ? sp + L.off_x : sp + L.off_pri[l - 1];
-    fwd_task(LL.t[LL.ntasks++], net->pri[l], src, l == 0 ? 1 : L.nsf_pri[l - 1], nullptr, sp + L.off_pri[l], L.spb, L.nsf_pri[l]);
-  };
+  // the recurrence: decoder layers + glue per step (the prior only consumes the states: it runs afterwards for all steps at once)
   for (int t = 0; t < S; ++t) {
     float* sp = step_ptr(t);
     const float* zT = stash + L.zT + (size_t)t * RT * ZD * 32;
@@ -1391,23 +1651,17 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
       LayerLaunch LL;
       memset(&LL, 0, sizeof(LL));
       LL.RT = RT;
-      // prior first: the decoder's last K-split holds only the 48-channel latent slice, and those light blocks should be
-      // the ones that share a CU when a launch has more than 256 blocks
-      if (with_prior && l < np) pri_task(LL, l, t);
-      if (with_prior && t > 0 && nd + l < np) pri_task(LL, nd + l, t - 1);
-      {
-        const PackedLayer& P = net->dec[l];
-        const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
-        fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
-      }
+      const PackedLayer& P = net->dec[l];
+      const float* src = l == 0 ? x_ptr(t) : sp + L.off_dec[l - 1];
+      fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
       int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
     }
     GlueParams g;
     memset(&g, 0, sizeof(g));
     g.B = B; g.S = S; g.t = t; g.RT = RT;
-    g.xT = sp + L.off_x;
-    g.xT_next = step_ptr(t + 1) + L.off_x;
+    g.xT = x_ptr(t);
+    g.xT_next = x_ptr(t + 1);
     const PackedLayer& DL = net->dec[net->n_dec - 1];
     g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = L.nsf_dec[net->n_dec - 1]; g.dec_pad = DL.Nout_pad;
     g.Gs = sp + L.off_G;
@@ -1418,19 +1672,13 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
     HA_LAUNCH_CHECK();
   }
   if (with_prior) {
-    for (int l = nd; l < np; ++l) {      // the deferred layers of the last step
-      LayerLaunch LL;
-      memset(&LL, 0, sizeof(LL));
-      LL.RT = RT;
-      pri_task(LL, l, S - 1);
-      int rc = launch_layers(LL, L, stash, st);
-      if (rc != HA_OK) return rc;
-    }
+    int rc = prior_forward_batched(net, L, stash, S, st);
+    if (rc != HA_OK) return rc;
     PriorIOParams q;
     memset(&q, 0, sizeof(q));
     q.B = B; q.S = S; q.RT = RT;
-    q.pri_out0 = step_ptr(0) + L.off_pri[np - 1]; q.step_stride = L.per_step; q.pri_nsplit = L.nsf_pri[np - 1];
     q.pri_pad = net->pri[np - 1].Nout_pad;
+    q.pri_out0 = stash + L.pri_h[np - 1]; q.step_stride = (size_t)RT * q.pri_pad * 32; q.pri_nsplit = 1;
     q.prior_mu = prior_mu; q.prior_var = prior_var;
     hipLaunchKernelGGL(prior_io_kernel, dim3(rows, S), dim3(64), 0, st, q);
     HA_LAUNCH_CHECK();
@@ -1448,7 +1696,8 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
   make_layout(net, B, S, L);
   const int RT = L.RT, rows = RT * 32;
   auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
-  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, step_ptr(0) + L.off_x, B, 1, D_IN, D_INP, RT);
+  auto x_ptr = [&](int t) { return stash + L.xT + (size_t)t * RT * D_INP * 32; };
+  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, x_ptr(0), B, 1, D_IN, D_INP, RT);
   HA_LAUNCH_CHECK();
   hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
   HA_LAUNCH_CHECK();
@@ -1457,20 +1706,21 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
   for (int t = 0; t < S; ++t) {
     float* sp = step_ptr(t);
     float* zT = stash + L.zT + (size_t)t * RT * ZD * 32;
-    // the latent of this step depends on the prior of this step: prior network first, then sample, then the decoder
+    // the latent of this step depends on the prior of this step: prior network first (on the recurrence here), then sample,
+    // then the decoder
     for (int l = 0; l < net->n_pri; ++l) {
       LayerLaunch LL;
       memset(&LL, 0, sizeof(LL));
       LL.RT = RT;
-      const float* src = l == 0 ? sp + L.off_x : sp + L.off_pri[l - 1];
-      fwd_task(LL.t[LL.ntasks++], net->pri[l], src, l == 0 ? 1 : L.nsf_pri[l - 1], nullptr, sp + L.off_pri[l], L.spb, L.nsf_pri[l]);
+      const float* src = l == 0 ? x_ptr(t) : stash + L.smp_pri[l - 1];
+      fwd_task(LL.t[LL.ntasks++], net->pri[l], src, l == 0 ? 1 : L.nsf_pri[l - 1], nullptr, stash + L.smp_pri[l], L.spb, L.nsf_pri[l]);
       int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
     }
     SampleParams sp_;
     memset(&sp_, 0, sizeof(sp_));
     sp_.B = B; sp_.S = S; sp_.t = t; sp_.RT = RT;
-    sp_.pri_out = sp + L.off_pri[net->n_pri - 1]; sp_.pri_nsplit = L.nsf_pri[net->n_pri - 1]; sp_.pri_pad = PL.Nout_pad;
+    sp_.pri_out = stash + L.smp_pri[net->n_pri - 1]; sp_.pri_nsplit = L.nsf_pri[net->n_pri - 1]; sp_.pri_pad = PL.Nout_pad;
     sp_.eps = eps_seq; sp_.zT_t = zT; sp_.z_out = z_out;
     hipLaunchKernelGGL(sample_z_kernel, dim3(rows), dim3(64), 0, st, sp_);
     HA_LAUNCH_CHECK();
@@ -1478,7 +1728,7 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
       LayerLaunch LL;
       memset(&LL, 0, sizeof(LL));
       LL.RT = RT;
-      const float* src = l == 0 ? sp + L.off_x : sp + L.off_dec[l - 1];
+      const float* src = l == 0 ? x_ptr(t) : sp + L.off_dec[l - 1];
       fwd_task(LL.t[LL.ntasks++], net->dec[l], src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
       int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
@@ -1486,10 +1736,10 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
     GlueParams g;
     memset(&g, 0, sizeof(g));
     g.B = B; g.S = S; g.t = t; g.RT = RT;
-    g.xT = sp + L.off_x;
-    g.xT_next = step_ptr(t + 1) + L.off_x;
+    g.xT = x_ptr(t);
+    g.xT_next = x_ptr(t + 1);
     g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = L.nsf_dec[net->n_dec - 1]; g.dec_pad = DL.Nout_pad;
-    g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = L.nsf_pri[net->n_pri - 1]; g.pri_pad = PL.Nout_pad;
+    g.pri_out = stash + L.smp_pri[net->n_pri - 1]; g.pri_nsplit = L.nsf_pri[net->n_pri - 1]; g.pri_pad = PL.Nout_pad;
     g.Gs = sp + L.off_G;
     g.Gs_next = step_ptr(t + 1) + L.off_G;
     g.t2j = stash + L.t2j;
@@ -1513,9 +1763,26 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
   make_layout(net, B, S, L);
   const int RT = L.RT, rows = RT * 32;
   auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
+  auto x_ptr = [&](int t) { return stash + L.xT + (size_t)t * RT * D_INP * 32; };
   const bool with_prior = g_prior_mu != nullptr || g_prior_var != nullptr;
   const PackedLayer& DL = net->dec[net->n_dec - 1];
-  const PackedLayer& PL = net->pri[net->n_pri - 1];
+  const int nd = net->n_dec, np = net->n_pri;
+  const int gxp_pad = net->pri[0].Nin_pad;
+
+  // the prior's contribution to dL/dx_t for every step, before the reverse scan (it does not depend on the scan)
+  if (with_prior) {
+    PriorIOParams q;
+    memset(&q, 0, sizeof(q));
+    q.B = B; q.S = S; q.RT = RT;
+    q.pri_pad = net->pri[np - 1].Nout_pad;
+    q.pri_out0 = stash + L.pri_h[np - 1]; q.step_stride = (size_t)RT * q.pri_pad * 32; q.pri_nsplit = 1;
+    q.g_prior_mu = g_prior_mu; q.g_prior_var = g_prior_var;
+    q.g_pri_all = stash + L.g_pri_out;
+    hipLaunchKernelGGL(prior_io_kernel, dim3(rows, S), dim3(64), 0, st, q);
+    HA_LAUNCH_CHECK();
+    int rc = prior_backward_batched(net, L, stash, S, st);
+    if (rc != HA_OK) return rc;
+  }
 
   auto fill_glue = [&](GlueParams& g, int t) {
     memset(&g, 0, sizeof(g));
@@ -1528,7 +1795,9 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
     g.gx_dir_in = stash + L.gx_dir[(t + 1) & 1];
     g.gx_dir_out = stash + L.gx_dir[t & 1];
     g.gxp_dec = stash + L.bwd_dec[0]; g.gxp_dec_nsplit = L.nsb_dec[0]; g.gxp_dec_pad = net->dec[0].Nin_pad;
-    if (with_prior) { g.gxp_pri = stash + L.bwd_pri[0]; g.gxp_pri_nsplit = L.nsb_pri[0]; g.gxp_pri_pad = net->pri[0].Nin_pad; }
+    if (with_prior && t + 1 < S) {
+      g.gxp_pri = stash + L.gx_pri + (size_t)(t + 1) * RT * gxp_pad * 32; g.gxp_pri_nsplit = 1; g.gxp_pri_pad = gxp_pad;
+    }
     g.dz_n = net->n_dec;
     for (int i = 0; i < net->n_dec; ++i) {
       g.dz_src[i] = stash + L.bwd_dec[i]; g.dz_nsplit[i] = L.nsb_dec[i]; g.dz_pad[i] = net->dec[i].Nin_pad;
@@ -1536,50 +1805,15 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
     }
     if (t >= 0) {
       float* sp = step_ptr(t);
-      g.xT = sp + L.off_x;
+      g.xT = x_ptr(t);
       g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = L.nsf_dec[net->n_dec - 1]; g.dec_pad = DL.Nout_pad;
-      g.pri_out = sp + L.off_pri[net->n_pri - 1]; g.pri_nsplit = L.nsf_pri[net->n_pri - 1]; g.pri_pad = PL.Nout_pad;
       g.Gs = sp + L.off_G;
       g.g_world = g_world;
-      g.g_prior_mu = g_prior_mu; g.g_prior_var = g_prior_var;
       g.g_dec_out = stash + L.g_dec_out;
       g.g_pri_out = nullptr;      // prior-output adjoints of all steps come from prior_io_kernel
     }
   };
 
-  const int nd = net->n_dec, np = net->n_pri;
-  // adjoint of the prior layer l of step t (its top layer reads the prior-output adjoints prepared for all steps)
-  auto pri_bwd_task = [&](LayerLaunch& LL, int l, int t) {
-    float* sp = step_ptr(t);
-    const PackedLayer& P = net->pri[l];
-    if (l == np - 1)
-      bwd_task(LL.t[LL.ntasks++], P, stash + L.g_pri_out + (size_t)t * RT * P.Nout_pad * 32, 1, P.Nout_pad, nullptr, nullptr, 0,
-               stash + L.bwd_pri[l], L.spb, L.nsb_pri[l]);
-    else
-      bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_pri[l + 1], L.nsb_pri[l + 1], net->pri[l + 1].Nin_pad, &net->pri[l + 1],
-               sp + L.off_pri[l], L.nsf_pri[l], stash + L.bwd_pri[l], L.spb, L.nsb_pri[l]);
-  };
-  if (with_prior) {
-    PriorIOParams q;
-    memset(&q, 0, sizeof(q));
-    q.B = B; q.S = S; q.RT = RT;
-    q.pri_out0 = step_ptr(0) + L.off_pri[np - 1]; q.step_stride = L.per_step; q.pri_nsplit = L.nsf_pri[np - 1];
-    q.pri_pad = PL.Nout_pad;
-    q.g_prior_mu = g_prior_mu; q.g_prior_var = g_prior_var;
-    q.g_pri_all = stash + L.g_pri_out;
-    hipLaunchKernelGGL(prior_io_kernel, dim3(rows, S), dim3(64), 0, st, q);
-    HA_LAUNCH_CHECK();
-    // the prior layers above the decoder's depth run one step ahead of the chain (they do not depend on it); for the last
-    // step there is no launch to ride in
-    for (int l = np - 1; l >= nd; --l) {
-      LayerLaunch LL;
-      memset(&LL, 0, sizeof(LL));
-      LL.RT = RT;
-      pri_bwd_task(LL, l, S - 1);
-      int rc = launch_layers(LL, L, stash, st);
-      if (rc != HA_OK) return rc;
-    }
-  }
   for (int t = S - 1; t >= 0; --t) {
     GlueParams g;
     fill_glue(g, t);
@@ -1590,17 +1824,12 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
       LayerLaunch LL;
       memset(&LL, 0, sizeof(LL));
       LL.RT = RT;
-      {
-        const PackedLayer& P = net->dec[l];
-        if (l == nd - 1)
-          bwd_task(LL.t[LL.ntasks++], P, stash + L.g_dec_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
-        else
-          bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_dec[l + 1], L.nsb_dec[l + 1], net->dec[l + 1].Nin_pad, &net->dec[l + 1],
-                   sp + L.off_dec[l], L.nsf_dec[l], stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
-      }
-      if (with_prior && l < np) pri_bwd_task(LL, l, t);
-      // step t-1's prior layers nd .. np-1, in descending order, in the last np - nd launches of this step
-      if (with_prior && t > 0 && nd + l < np) pri_bwd_task(LL, nd + l, t - 1);
+      const PackedLayer& P = net->dec[l];
+      if (l == nd - 1)
+        bwd_task(LL.t[LL.ntasks++], P, stash + L.g_dec_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
+      else
+        bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_dec[l + 1], L.nsb_dec[l + 1], net->dec[l + 1].Nin_pad, &net->dec[l + 1],
+                 sp + L.off_dec[l], L.nsf_dec[l], stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
       int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
     }

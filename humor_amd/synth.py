@@ -146,10 +146,16 @@ def _mlp_keys(prefix, sizes, skip=0):
 
 
 def humor_state_dict(seed=0, weight_scale=1.0, latent=HUMOR_LATENT, in_dim=HUMOR_IN_DIM, out_dim=HUMOR_OUT_DIM,
-                     randomize_gn=True):
+                     randomize_gn=True, out_scale=1.0, yaw_rate=None):
     """Random weights in the reference checkpoint's key layout.  Linear layers use PyTorch's default
     kaiming-uniform bound 1/sqrt(fan_in); GroupNorm affine is perturbed around (1, 0) when
-    ``randomize_gn`` so the affine path is exercised by parity tests."""
+    ``randomize_gn`` so the affine path is exercised by parity tests.
+
+    ``weight_scale`` scales every Linear weight, ``out_scale`` additionally scales the decoder's output layer (weight and
+    bias), ``yaw_rate`` overrides the bias of the root-orientation delta about z (a steady turn, rad / step).  With the
+    defaults the autoregressive chain is chaotic (it amplifies fp32 rounding ~1e4x over 59 steps, so no two fp32
+    implementations agree at length); ``contractive_state_dict`` picks values for which the chain behaves like a trained
+    model at 30 fps -- small per-frame deltas, bounded state -- and fp32 stays within ~1e-5 of fp64 over 119 steps."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     specs = (_mlp_keys('encoder', [2 * in_dim, 1024, 1024, 1024, 1024, 2 * latent]) +
@@ -170,7 +176,28 @@ def humor_state_dict(seed=0, weight_scale=1.0, latent=HUMOR_LATENT, in_dim=HUMOR
                 sd[key] = (torch.rand(shape, generator=g) * 2 - 1) * bound
             else:
                 sd[key] = 0.05 * torch.randn(shape, generator=g) if randomize_gn else torch.zeros(shape)
+    if out_scale != 1.0:
+        last = max(int(k.split('.')[2]) for k in sd if k.startswith('decoder.net.'))
+        sd[f'decoder.net.{last}.weight'] = sd[f'decoder.net.{last}.weight'] * out_scale
+        sd[f'decoder.net.{last}.bias'] = sd[f'decoder.net.{last}.bias'] * out_scale
+    if yaw_rate is not None:
+        last = max(int(k.split('.')[2]) for k in sd if k.startswith('decoder.net.'))
+        sd[f'decoder.net.{last}.bias'][8] = yaw_rate        # decoder output layout: trans 0:3 | trans_vel 3:6 | root aa 6:9 | ...
     return sd
+
+
+CONTRACTIVE = dict(weight_scale=0.5, out_scale=0.05, yaw_rate=0.1)
+
+
+def contractive_state_dict(seed=0):
+    """Well-conditioned synthetic HuMoR weights for parity tests at the BASELINE sequence lengths (59 / 89 / 119 steps).
+    Two things make a random-init roll-out ill-conditioned, and neither is a property of the path: (i) O(1) decoder deltas
+    per step let the state run away chaotically -> the output layer is scaled down (per-frame deltas of a 30 fps model);
+    (ii) with tiny deltas the per-step heading change sits at the singularity of the reference's heading alignment,
+    acos(x / (|xy| + 1e-6)) at x -> 1 (humor/utils/transforms.py:17-31), where fp32 resolves 1 - x to ~6 % -> a steady turn
+    of 0.1 rad / step keeps it away.  Measured fp32-vs-fp64 drift of the reference roll-out with these weights
+    (oracle/make_golden_long.py prints it): < 5e-6 in the states and prior outputs over 119 steps."""
+    return humor_state_dict(seed=seed, **CONTRACTIVE)
 
 
 # --------------------------------------------------------------------------------------------------

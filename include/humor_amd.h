@@ -34,7 +34,7 @@ const char* ha_last_error(void);
 int ha_abi_version(void);
 /* Writes the device's gcnArchName (e.g. "gfx950:sramecc+:xnack-") into buf. */
 int ha_device_arch(int device, char* buf, int buflen);
-/* Development knobs for kernel launch variants (A/B measurements), process-wide: "skin_variant" (-1 = auto), "layer_spb" (K-slices per block of the roll-out layer kernel, 0 = default), "layer_finish" (0 never / 1 auto / 2 always use the GroupNorm finishing pass). */
+/* Development knobs for kernel launch variants (A/B measurements), process-wide: "skin_variant" (-1 = auto), "layer_spb" (K-slices per block of the roll-out layer kernel, 0 = default), "layer_finish" (0 never / 1 auto / 2 always use the GroupNorm finishing pass), "gemm_rm" (row tiles per wave of the batched prior GEMM: 0 by size / 1 / 2). */
 int ha_tune_set(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------

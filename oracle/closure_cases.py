@@ -35,8 +35,26 @@ def camera_matrix(B):
     return K
 
 
-def make_case(kind, B, T, seed=0):
-    """Observations + a random evaluation point (values of every optimisation variable) for `kind`."""
+# BASELINE-length cases: C2 fit_amass_joints (B=2, T=60), C3 fit_rgb_demo_no_split (one ~90-frame clip, no
+# sub-sequence split), a C4 slice (fit_rgb_demo_use_split: 60-frame sub-sequences overlapping by 10; 8 of the 32)
+LONG_CASES = {
+    'c2': dict(kind='amass', B=2, T=60, ov=None),
+    'c3': dict(kind='rgb', B=1, T=90, ov=None),
+    'c4': dict(kind='rgb', B=8, T=60, ov=10),
+}
+
+
+def det_weights(shape, phase=0.0):
+    """Deterministic pseudo-random cotangents cos(0.37 i + 1.3 sin(0.011 i) + phase): recomputed by the tests instead of being
+    stored in the fixtures (the same to ~1 ulp on every machine; they only weight the outputs in a scalar test loss)."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.float64)
+    return torch.from_numpy(np.cos(0.37 * i + 1.3 * np.sin(0.011 * i) + phase).astype(np.float32).reshape(shape))
+
+
+def make_case(kind, B, T, seed=0, ov=3):
+    """Observations + a random evaluation point (values of every optimisation variable) for `kind`.
+    ov: frames shared by consecutive sub-sequences ('rgb' only; None = a single unsplit clip, no seq_interval)."""
     g = torch.Generator().manual_seed(seed)
     r = lambda *s, sc=1.0: sc * torch.randn(*s, generator=g)
     case = {'kind': kind, 'B': B, 'T': T}
@@ -58,8 +76,8 @@ def make_case(kind, B, T, seed=0):
         conf[:, :, 5] = 0.0
         obs['joints2d'] = torch.cat([xy, conf], 3)
         obs['floor_plane'] = torch.tensor([[0.0, -1.0, 0.0, -0.5]]).expand(B, 4).clone()
-        ov = 3
-        obs['seq_interval'] = torch.tensor([[b * (T - ov), b * (T - ov) + T] for b in range(B)])
+        if ov is not None:
+            obs['seq_interval'] = torch.tensor([[b * (T - ov), b * (T - ov) + T] for b in range(B)])
         var['floor_plane'] = torch.tensor([[0.02, 0.5, 0.03]]) + r(B, 3, sc=0.02)
     case['obs'], case['var'] = obs, var
     return case

@@ -19,12 +19,12 @@ from oracle import ref_loader                     # noqa: E402
 OUT = os.path.join(ROOT, 'tests', 'golden')
 
 
-def build_reference(R, kind, B, T, npz):
+def build_reference(R, kind, B, T, npz, state_dict=None):
     dev = torch.device('cpu')
     rgb = kind == 'rgb'
     bm = R.body_model.BodyModel(npz, num_betas=16, batch_size=B * T, use_vtx_selector=rgb).to(dev)
     hm = R.humor_model.HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
-    hm.load_state_dict(synth.humor_state_dict(seed=0))
+    hm.load_state_dict(synth.humor_state_dict(seed=0) if state_dict is None else state_dict)
     hm.eval()
     vp = synth.SynthVPoser(seed=0)
     w, mu, cov = synth.make_gmm(seed=0)

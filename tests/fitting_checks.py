@@ -11,12 +11,12 @@ from humor_amd.motion_optimizer import MotionOptimizer
 from oracle import closure_cases as CC
 
 
-def build(lib, device, kind, B, T, npz, shard=None):
+def build(lib, device, kind, B, T, npz, shard=None, state_dict=None):
     rgb = kind == 'rgb'
     bm = BodyModel(npz, num_betas=16, batch_size=B * T, use_vtx_selector=rgb, _lib_override=lib)
     hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1,
                     _lib_override=lib)
-    hm.load_state_dict(synth.humor_state_dict(seed=0))
+    hm.load_state_dict(synth.humor_state_dict(seed=0) if state_dict is None else state_dict)
     hm = hm.to(device).eval()
     for p in hm.parameters():
         p.requires_grad_(False)
@@ -82,17 +82,52 @@ def check_objectives(lib, device, npz, kind, loss_rtol=2e-4, grad_rtol=2e-3):
             assert err <= grad_rtol * scale, (kind, stage, k, err, scale)
 
 
-def check_short_run(lib, device, npz, kind):
+def check_objectives_long(lib, device, npz, name, loss_rtol=1e-4, grad_rtol=1e-3):
+    """Stage-1/2/3 objectives of the reference MotionOptimizer at the BASELINE sizes (closure_{c2,c3,c4}.npz: C2 2x60 joints3d,
+    C3 1x90 joints2d+floor, C4 slice 8x60 with overlap 10), well-conditioned synthetic prior: loss within 1e-4 relative,
+    every gradient within 1e-3 of its largest entry, per sequence (kink-flagged sequences: see rollout_checks.assert_grad)."""
+    from rollout_checks import assert_grad
+    gd = golden(f'closure_{name}.npz')
+    kind, B, T, ov = str(gd['kind']), int(gd['B']), int(gd['T']), int(gd['ov'])
+    case = CC.make_case(kind, B, T, seed=int(gd['seed']), ov=None if ov < 0 else ov)
+    opt = build(lib, device, kind, B, T, npz, state_dict=synth.contractive_state_dict(int(gd['weight_seed'])))
+    report = {}
+    for stage in range(3):
+        res = eval_stage(opt, case, stage, device)
+        ref_loss = float(gd[f's{stage}_loss'])
+        rel = abs(res['loss'].item() - ref_loss) / abs(ref_loss)
+        assert rel <= loss_rtol, (name, stage, res['loss'].item(), ref_loss)
+        report[f's{stage}_loss'] = rel
+        for k, v in res.items():
+            if k == 'loss':
+                continue
+            ref, stable = gd[f's{stage}_{k}'], gd[f's{stage}_{k}_stable']
+            got = v.detach().cpu().numpy()
+            if stage == 2 and k in ('g_trans', 'g_root_orient', 'g_latent_pose'):
+                ref = ref[:, :1]       # the reference differentiates w.r.t. the full-length tensor; only frame 0 is used
+            report[f's{stage}_{k}'] = assert_grad(f'{name} stage {stage} {k}', got, ref, stable, rtol=grad_rtol)
+    return report
+
+
+def check_short_run(lib, device, npz, kind, long_name=None):
     """The reference's run() for a few L-BFGS iterations vs ours on the same problem.
     L-BFGS with strong-Wolfe line search is a chaotic map of its inputs: stages 1-2 (SMPL only) track the reference
     closure-for-closure; in stage 3 the first evaluations agree to ~1e-5 and the trajectories then separate (measured:
     6e-6 relative at the first stage-3 closure, tests/golden/closure_*.npz `run_trace`).  So: every stage-1/2 closure
     and the first stage-3 closures must match tightly, stage-2 results must match, and stage 3 must make the same kind
     of progress as the reference."""
-    gd = golden(f'closure_{kind}.npz')
+    gd = golden(f'closure_{long_name or kind}.npz')
     B, T = int(gd['B']), int(gd['T'])
-    opt = build(lib, device, kind, B, T, npz)
-    obs = {k: v.clone().to(device) for k, v in CC.make_case(kind, B, T, seed=2)['obs'].items()}
+    if long_name is None:
+        opt = build(lib, device, kind, B, T, npz)
+        obs = CC.make_case(kind, B, T, seed=2)['obs']
+    else:
+        ov = int(gd['ov'])
+        opt = build(lib, device, kind, B, T, npz, state_dict=synth.contractive_state_dict(int(gd['weight_seed'])))
+        obs = CC.make_case(kind, B, T, seed=2, ov=None if ov < 0 else ov)['obs']
+        if 'run_obs_joints3d' in gd.files:
+            obs['joints3d'] = torch.from_numpy(gd['run_obs_joints3d'])
+    obs = {k: v.clone().to(device) for k, v in obs.items()}
     opt.loss_trace = []
     final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[int(x) for x in gd['run_num_iter']], lbfgs_max_iter=5)
     ref_trace = gd['run_trace']
@@ -100,13 +135,23 @@ def check_short_run(lib, device, npz, kind):
     n12 = int((ref_trace[:, 0] < 2).sum())
     assert (ours[:n12, 0] == ref_trace[:n12, 0]).all()
     rel = np.abs(ours[:n12, 1] - ref_trace[:n12, 1]) / np.abs(ref_trace[:n12, 1])
-    assert rel.max() < 1e-4, rel.max()
     s3_ours, s3_ref = ours[ours[:, 0] == 2][:, 1], ref_trace[ref_trace[:, 0] == 2][:, 1]
     rel3 = np.abs(s3_ours[:3] - s3_ref[:3]) / np.abs(s3_ref[:3])
+    d2 = np.abs(stages['stage2']['joints3d'].cpu().numpy() - gd['run_stage2_joints3d']).max()
+    print('short run', long_name or kind, 'stage-1/2 closure losses rel dev', np.array2string(rel, precision=1), 'stage-3 first evals', rel3, 'stage-2 joints', d2)
+    if long_name is None:
+        assert rel.max() < 1e-4, rel.max()
+        assert d2 < 1e-3, d2
+    else:
+        # 60-frame problems: the strong-Wolfe line search amplifies rounding within a few evaluations (the trajectory is a
+        # chaotic map of its inputs); the first evaluations of every stage are the closure-level check, the rest must stay on
+        # the reference's path to within a per cent
+        first = np.concatenate([rel[:2], rel[ours[:n12, 0] == 1][:2]])
+        assert first.max() < 1e-4, first
+        assert rel.max() < 2e-2, rel.max()
+        assert d2 < 2e-2, d2
     assert rel3.max() < 2e-4, rel3
     assert s3_ours[-1] < s3_ours[0] and abs(np.log(s3_ours.min() / s3_ref.min())) < 0.7
-    d2 = np.abs(stages['stage2']['joints3d'].cpu().numpy() - gd['run_stage2_joints3d']).max()
-    assert d2 < 1e-3, d2
     assert set(final.keys()) >= {'trans', 'root_orient', 'pose_body', 'betas', 'latent_pose', 'latent_motion'}
     assert final['latent_motion'].shape == (B, T - 1, 48) and final['trans'].shape == (B, T, 3)
     assert all(torch.isfinite(v).all() for v in final.values())

@@ -23,8 +23,8 @@ def canonical_state(B, gen):
     return torch.cat([trans, 0.3 * r(B, 3), R_root, 0.3 * r(B, 3), R_body, joints, 0.3 * r(B, 66)], 1)
 
 
-def make_model(lib, device, seed=0, weight_scale=1.0):
-    sd = synth.humor_state_dict(seed=seed, weight_scale=weight_scale)
+def make_model(lib, device, seed=0, weight_scale=1.0, contractive=False):
+    sd = synth.contractive_state_dict(seed) if contractive else synth.humor_state_dict(seed=seed, weight_scale=weight_scale)
     hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1,
                     _lib_override=lib)
     hm.load_state_dict(sd)
@@ -114,6 +114,53 @@ def check_rollout_conditioned(lib, device, B=32, S=59, seed=3):
     bound = 4.0 * running + 1e-5 * scale
     assert (e_gpu <= bound).all(), (e_gpu / bound).max().item()
     assert torch.isfinite(world).all() and torch.isfinite(pv).all()
+
+
+def per_seq_rel(a, b):
+    """max |a-b| per sequence (leading index), relative to max(1, max|b|) of the whole tensor."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).reshape(a.shape[0], -1).max(axis=1) / max(1.0, np.abs(b).max())
+
+
+KINK_RTOL = 5e-2     # sequences whose REFERENCE gradient is flagged unstable under fp32-level changes (ReLU kink crossing)
+
+
+def assert_grad(name, got, ref, stable, rtol=GRAD_RTOL):
+    """Flat relative bar on every sequence the fixture marks stable; the flagged ones (the reference's own gradient moves by
+    more than 2e-4 under an fp64 re-evaluation / 1-ulp input perturbations, oracle/make_golden_long.py) get the kink bar."""
+    e = per_seq_rel(got, ref)
+    stable = np.asarray(stable, dtype=bool)
+    assert (e[stable] <= rtol).all(), (name, e.tolist(), stable.tolist())
+    assert (e <= KINK_RTOL).all(), (name, e.tolist())
+    return float(e[stable].max()) if stable.any() else 0.0
+
+
+def check_rollout_long(lib, device, name):
+    """Reference HumorModel.roll_out at a BASELINE length ('c4': 59 steps, 'c3': 89, 'c5': 119) with the well-conditioned
+    synthetic weights: EVERY step's state and prior output within the flat 1e-4, gradients within 1e-3 (relative)."""
+    from oracle import closure_cases as CC
+    gd = golden('rollout_long.npz')
+    pre = f'ro_{name}_'
+    hm, _ = make_model(lib, device, seed=int(gd['weight_seed']), contractive=True)
+    past = torch.tensor(gd[pre + 'past0']).to(device).requires_grad_(True)
+    z = torch.tensor(gd[pre + 'z']).to(device).requires_grad_(True)
+    S = z.shape[1]
+    out, (pm, pv) = hm.roll_out(past, None, S, z_seq=z, return_prior=True)
+    world = world_of(out)
+    e_w = np.abs(world.detach().cpu().numpy() - gd[pre + 'world']).max(axis=(0, 2))       # per step
+    e_m = np.abs(pm.detach().cpu().numpy() - gd[pre + 'prior_mu']).max(axis=(0, 2))
+    e_v = np.abs(pv.detach().cpu().numpy() - gd[pre + 'prior_var']).max(axis=(0, 2))
+    assert e_w.max() < FWD_TOL and e_m.max() < FWD_TOL and e_v.max() < FWD_TOL, (name, e_w.max(), e_m.max(), e_v.max())
+    gw, gm, gv = (CC.det_weights(t.shape, ph).to(device) for t, ph in ((world, 0.1), (pm, 0.2), (pv, 0.3)))
+    g0, gz = torch.autograd.grad((world * gw).sum() + (pm * gm).sum() + (pv * gv).sum(), [past, z])
+    stable = gd[pre + 'stable']
+    eg0 = assert_grad('g_past0', g0.cpu().numpy(), gd[pre + 'g_past0'], stable)
+    egz = assert_grad('g_z', gz.cpu().numpy(), gd[pre + 'g_z'], stable)
+    lab = torch.sigmoid(world[:, :, 339:348].detach().cpu()) > 0.5
+    logits_ref = torch.tensor(gd[pre + 'world'][:, :, 339:348])
+    far = logits_ref.abs() > 1e-4
+    assert (lab[far] == (torch.sigmoid(logits_ref) > 0.5)[far]).all()
+    return dict(world=float(e_w.max()), prior_mu=float(e_m.max()), prior_var=float(e_v.max()), g_past0=eg0, g_z=egz)
 
 
 def check_rollout_golden(lib, device):

@@ -27,6 +27,17 @@ def test_short_run_matches_reference(gpu_lib, dev, smplh_npz, kind):
     FC.check_short_run(gpu_lib, dev, smplh_npz, kind)
 
 
+@pytest.mark.parametrize('name', ['c2', 'c3', 'c4'])
+def test_stage_objectives_at_baseline_sizes(gpu_lib, dev, smplh_npz, name):
+    """C2 (2x60, joints3d), C3 (1x90, joints2d + floor) and a C4 slice (8x60, overlap 10) against the reference MotionOptimizer."""
+    print(name, FC.check_objectives_long(gpu_lib, dev, smplh_npz, name))
+
+
+@pytest.mark.parametrize('name,kind', [('c2', 'amass'), ('c4', 'rgb')])
+def test_short_run_at_baseline_sizes(gpu_lib, dev, smplh_npz, name, kind):
+    FC.check_short_run(gpu_lib, dev, smplh_npz, kind, long_name=name)
+
+
 def test_graphed_closure_equals_eager(gpu_lib, dev, smplh_npz):
     """hipGraph replay of the stage-3 closure returns the eager loss and gradients bit-for-bit, call after call."""
     from oracle import closure_cases as CC

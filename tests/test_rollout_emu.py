@@ -28,6 +28,16 @@ def test_emu_rollout_finishing_pass(emu_lib):
         emu_lib.call('ha_tune_set', b'layer_finish', 1)
 
 
+@pytest.mark.slow
+def test_emu_prior_gemm_two_row_tiles_per_wave(emu_lib):
+    # the batched prior GEMM's large-batch geometry (64 x 64 per wave), forced at 2 rows x 3 steps (odd number of row tiles)
+    emu_lib.call('ha_tune_set', b'gemm_rm', 2)
+    try:
+        RC.check_rollout(emu_lib, CPU, B=2, S=3)
+    finally:
+        emu_lib.call('ha_tune_set', b'gemm_rm', 0)
+
+
 def test_rollout_refuses_cpu():
     from humor_amd._lib import HumorAmdError
     from humor_amd.humor_model import HumorModel

@@ -25,6 +25,13 @@ def test_rollout_golden(gpu_lib, dev):
     RC.check_rollout_golden(gpu_lib, dev)
 
 
+@pytest.mark.parametrize('name', ['c4', 'c3', 'c5'])
+def test_rollout_baseline_lengths_flat_tolerance(gpu_lib, dev, name):
+    """59 / 89 / 119 steps against the reference's own outputs (tests/golden/rollout_long.npz): flat 1e-4 on every step's
+    state and prior output, 1e-3 relative on the gradients -- no conditioning allowance (well-conditioned synthetic prior)."""
+    print(name, RC.check_rollout_long(gpu_lib, dev, name))
+
+
 def test_rollout_full_length(gpu_lib, dev):
     """BASELINE size (32 sequences x 59 steps): conditioning-aware parity (see check_rollout_conditioned) plus the
     gradient check on an 8-step chain judged against an fp64 oracle.  (The adjoint is amplified like the forward error:
