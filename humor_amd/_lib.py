@@ -22,6 +22,27 @@ class MlpDesc(C.Structure):
                 ('w', C.c_void_p * 8), ('b', C.c_void_p * 8), ('gn_gamma', C.c_void_p * 8), ('gn_beta', C.c_void_p * 8)]
 
 
+FIT_NTERMS = 17
+
+
+class FitArgs(C.Structure):
+    """ha_fit_args (include/humor_amd.h)."""
+    _fields_ = [('B', C.c_int), ('T', C.c_int),
+                ('cam_jtr', C.c_void_p), ('nj', C.c_int), ('cam_verts', C.c_void_p), ('nv', C.c_int),
+                ('pri_joints', C.c_void_p), ('pri_nj', C.c_int), ('ro_joints', C.c_void_p), ('contacts_conf', C.c_void_p),
+                ('latent_pose', C.c_void_p), ('dlp', C.c_int), ('betas', C.c_void_p), ('nb', C.c_int),
+                ('latent_motion', C.c_void_p), ('prior_mu', C.c_void_p), ('prior_var', C.c_void_p), ('S', C.c_int), ('dz', C.c_int),
+                ('floor', C.c_void_p), ('prev_tail', C.c_void_p), ('prev_betas', C.c_void_p), ('prev_floor', C.c_void_p),
+                ('obs_j2d', C.c_void_p), ('smpl2op', C.c_void_p), ('op_mask', C.c_void_p), ('cam_f', C.c_void_p), ('cam_c', C.c_void_p),
+                ('sigma', C.c_float), ('obs_j3d', C.c_void_p), ('obs_v3d', C.c_void_p), ('obs_floor', C.c_void_p), ('overlap', C.c_void_p),
+                ('w', C.c_float * FIT_NTERMS), ('nsteps', C.c_float),
+                ('terms', C.c_void_p), ('loss', C.c_void_p),
+                ('g_cam_jtr', C.c_void_p), ('g_cam_verts', C.c_void_p), ('g_pri_joints', C.c_void_p), ('g_ro_joints', C.c_void_p),
+                ('g_contacts_conf', C.c_void_p), ('g_latent_pose', C.c_void_p), ('g_betas', C.c_void_p), ('g_latent_motion', C.c_void_p),
+                ('g_prior_mu', C.c_void_p), ('g_prior_var', C.c_void_p), ('g_floor', C.c_void_p),
+                ('g_prev_tail', C.c_void_p), ('g_prev_betas', C.c_void_p), ('g_prev_floor', C.c_void_p), ('partial', C.c_void_p)]
+
+
 _SIGS = {
     'ha_last_error': (C.c_char_p, []),
     'ha_abi_version': (C.c_int, []),
@@ -45,6 +66,7 @@ _SIGS = {
     'ha_humor_rollout_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p]),
     'ha_humor_rollout_sample': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_humor_rollout_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
+    'ha_fit_loss': (C.c_int, [C.POINTER(FitArgs), C.c_void_p]),
 }
 
 

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fit_kernels as FK
 from .tables import OP_NUM_JOINTS, SMPL_PARENTS
 
 CONTACT_HEIGHT_THRESH = 0.08   # fitting_loss.py:18
@@ -37,8 +38,9 @@ def perspective_projection(points, focal_length, camera_center):
 
 
 def _masked_sq(obs, pred):
-    """0.5 * sum over visible entries of (obs - pred)^2; entries whose observation is +-inf are invisible."""
-    vis = torch.isfinite(obs)
+    """0.5 * sum over visible entries of (obs - pred)^2; entries whose observation is +-inf are invisible (a NaN
+    observation poisons the loss, as in the reference's get_visible_mask = ~isinf, fitting_loss.py:311-315)."""
+    vis = torch.logical_not(torch.isinf(obs))
     diff = torch.where(vis, obs - pred, torch.zeros_like(pred))
     return 0.5 * torch.sum(diff * diff)
 
@@ -69,8 +71,14 @@ class FittingLoss(nn.Module):
     '''
 
     def __init__(self, loss_weights, init_motion_prior=None, smpl2op_map=None, ignore_op_joints=None, cam_f=None,
-                 cam_cent=None, robust_loss='none', robust_tuning_const=4.6851, joints2d_sigma=100, use_chamfer=False):
+                 cam_cent=None, robust_loss='none', robust_tuning_const=4.6851, joints2d_sigma=100, use_chamfer=False,
+                 fused=True, _lib_override=None):
         super(FittingLoss, self).__init__()
+        # fused=True: every term except the init-state GMM is evaluated (value + gradient) by ONE kernel launch
+        # (humor_amd/csrc/fitloss.hip, fit_kernels.FusedFit) whenever the predictions live on the GPU; the term-by-term
+        # PyTorch evaluation below remains for the cases the kernel does not cover (cross-batch `prev_batch_overlap_res`).
+        self.fused = fused
+        self._lib = _lib_override
         self.all_stage_loss_weights = loss_weights
         self.cur_stage_idx = 0
         self.loss_weights = self.all_stage_loss_weights[self.cur_stage_idx]
@@ -104,6 +112,162 @@ class FittingLoss(nn.Module):
             self._dev_cache[key] = torch.as_tensor(list(values), dtype=torch.long, device=device)
         return self._dev_cache[key]
 
+    # ------------------------------------------------------------------------------------------------
+    # fused evaluation (one kernel for all terms and their gradients)
+    # ------------------------------------------------------------------------------------------------
+    def _fusable(self, observed_data, ref):
+        if not self.fused or 'prev_batch_overlap_res' in observed_data or 'points3d' in observed_data:
+            return False
+        if ref.is_cuda:
+            return True
+        return self._lib is not None and self._lib.emulator
+
+    def _const(self, key, make):
+        if key not in self._dev_cache:
+            self._dev_cache[key] = make()
+        return self._dev_cache[key]
+
+    def _fused_fit(self, kind, observed_data, pred_data, cam_pred_data, nsteps, cond_prior=None, init_motion_scale=1.0, halo=None):
+        """kind: 'root' | 'smpl' | 'motion' -- the same presence / weight conditions as root_fit / smpl_fit / motion_fit."""
+        from . import _lib
+        W = self.loss_weights
+        cam = cam_pred_data
+        lib = self._lib if self._lib is not None else _lib.get_lib()
+        w = [0.0] * FK.NT
+        spec = {}
+        t = dict.fromkeys([n for n, _ in FK.DIFF_INPUTS])
+        has = lambda d, k: k in d and d[k] is not None
+        # camera-frame joints: the full Jtr tensor when smpl_results provides it, else joints3d (+ extra)
+        jtr = cam.get('jtr')
+        if jtr is None and 'joints3d' in cam:
+            jtr = torch.cat([cam['joints3d'], cam['joints3d_extra']], dim=2) if 'joints3d_extra' in cam else cam['joints3d']
+        dev = (jtr if jtr is not None else cam['verts3d']).device
+        B, T = (jtr if jtr is not None else cam['verts3d']).shape[:2]
+        spec.update(B=B, T=T, nsteps=nsteps)
+        c = lambda x: x if x.is_contiguous() else x.contiguous()
+        if jtr is not None:
+            t['cam_jtr'] = c(jtr)
+            spec['nj'] = jtr.shape[2]
+            if 'joints3d' in observed_data and W['joints3d'] > 0.0:
+                w[FK.J3D] = W['joints3d']
+                spec['obs_j3d'] = c(observed_data['joints3d'])
+            if 'joints2d' in observed_data and 'joints3d_extra' in cam and W['joints2d'] > 0.0:
+                if not self.can_reproj:
+                    raise RuntimeError('Must provide camera intrinsics and SMPL to OpenPose joint map to use re-projection loss!')
+                w[FK.J2D] = W['joints2d']
+                spec['obs_j2d'] = c(observed_data['joints2d'])
+                spec['smpl2op'] = self._const(('smpl2op32', str(dev)), lambda: self.smpl2op_map.to(device=dev, dtype=torch.int32).contiguous())
+
+                def mk_mask():
+                    m = torch.ones(OP_NUM_JOINTS, device=dev, dtype=torch.float32)
+                    if self.ignore_op_joints is not None:
+                        m[list(self.ignore_op_joints)] = 0.0
+                    return m
+                spec['op_mask'] = self._const(('op_mask', str(dev)), mk_mask)
+                spec['cam_f'] = self._const(('cam_f', str(dev), B), lambda: self.cam_f.reshape(-1, 2).expand(B, 2).contiguous().float())
+                spec['cam_c'] = self._const(('cam_c', str(dev), B), lambda: self.cam_cent.reshape(-1, 2).expand(B, 2).contiguous().float())
+                spec['sigma'] = self.joints2d_sigma
+            if kind != 'root' and W['joints3d_smooth'] > 0.0:
+                w[FK.SMOOTH] = W['joints3d_smooth']
+        if 'verts3d' in cam:
+            t['cam_verts'] = c(cam['verts3d'])
+            spec['nv'] = cam['verts3d'].shape[2]
+            if 'verts3d' in observed_data and W['verts3d'] > 0.0:
+                w[FK.V3D] = W['verts3d']
+                spec['obs_v3d'] = c(observed_data['verts3d'])
+        ovw = W['rgb_overlap_consist'] if 'seq_interval' in observed_data else 0.0
+        if ovw > 0.0:
+            vals = observed_data['seq_interval'].tolist()
+            prev_tail = halo.get('prev_tail') if halo is not None else None
+            ovs = [min(T, int(vals[b - 1][1]) - int(vals[b][0])) for b in range(1, len(vals))]
+            ovs = ([] if prev_tail is not None else [0]) + ovs
+            if len(ovs) != B:
+                raise ValueError('seq_interval does not match the number of (local) sub-sequences')
+            spec['overlap'] = self._const(('overlap', str(dev), tuple(ovs)), lambda: torch.tensor(ovs, dtype=torch.int32, device=dev))
+            if 'verts3d' in cam:
+                w[FK.OV_VPOS] = w[FK.OV_VVEL] = ovw
+                if prev_tail is not None:
+                    t['prev_tail'] = c(prev_tail)
+        if kind != 'root':
+            if 'latent_pose' in cam and W['pose_prior'] > 0.0:
+                w[FK.POSE_PRIOR] = W['pose_prior']
+                t['latent_pose'] = c(cam['latent_pose'])
+                spec['dlp'] = cam['latent_pose'].shape[-1]
+            if 'betas' in cam:
+                use_b = False
+                if W['shape_prior'] > 0.0:
+                    w[FK.SHAPE_PRIOR] = W['shape_prior']
+                    use_b = True
+                if ovw > 0.0:
+                    w[FK.OV_BETAS] = ovw
+                    use_b = True
+                    if halo is not None and halo.get('prev_betas') is not None:
+                        t['prev_betas'] = c(halo['prev_betas'])
+                if use_b:
+                    t['betas'] = c(cam['betas'])
+                    spec['nb'] = cam['betas'].shape[-1]
+        extra = None
+        stats_extra = {}
+        if kind == 'motion':
+            pred = pred_data
+            if 'latent_motion' in pred and W['motion_prior'] > 0.0:
+                w[FK.MOTION_PRIOR] = W['motion_prior']
+                lm = pred['latent_motion']
+                t['latent_motion'] = c(lm)
+                spec['S'], spec['dz'] = lm.shape[1], lm.shape[2]
+                if cond_prior is not None:
+                    t['prior_mu'], t['prior_var'] = c(cond_prior[0]), c(cond_prior[1])
+            if all(k in pred for k in ('joints3d', 'joints_vel', 'trans_vel', 'root_orient_vel')) and W['init_motion_prior'] > 0.0:
+                cur = self.init_motion_prior_loss(pred['joints3d'][:, 0:1], pred['joints_vel'], pred['trans_vel'], pred['root_orient_vel'])
+                extra = W['init_motion_prior'] * init_motion_scale * cur
+                stats_extra['init_motion_prior'] = cur
+            pj = pred.get('jtr')
+            if pj is None and 'joints3d' in pred:
+                pj = pred['joints3d']
+            want_pj = False
+            if 'joints3d_rollout' in pred:
+                ro = pred['joints3d_rollout']
+                use_ro = False
+                if pj is not None and W['joint_consistency'] > 0.0:
+                    w[FK.JOINT_CONSIST] = W['joint_consistency']
+                    use_ro = want_pj = True
+                if W['bone_length'] > 0.0:
+                    w[FK.BONE_LEN] = W['bone_length']
+                    use_ro = True
+                if 'joints3d' in observed_data and W['joints3d_rollout'] > 0.0:
+                    w[FK.J3D_RO] = W['joints3d_rollout']
+                    spec['obs_j3d'] = c(observed_data['joints3d'])
+                    use_ro = True
+                if use_ro:
+                    t['ro_joints'] = c(ro)
+            if 'contacts_conf' in pred and pj is not None and (W['contact_vel'] > 0.0 or W['contact_height'] > 0.0):
+                w[FK.CONTACT_VEL], w[FK.CONTACT_H] = W['contact_vel'], W['contact_height']
+                t['contacts_conf'] = c(pred['contacts_conf'])
+                want_pj = True
+            if want_pj:
+                t['pri_joints'] = c(pj)
+                spec['pri_nj'] = pj.shape[2]
+            if 'floor_plane' in cam:
+                use_f = False
+                if 'floor_plane' in observed_data and W['floor_reg'] > 0.0:
+                    w[FK.FLOOR_REG] = W['floor_reg']
+                    spec['obs_floor'] = c(observed_data['floor_plane'])
+                    use_f = True
+                if ovw > 0.0:
+                    w[FK.OV_FLOOR] = ovw
+                    use_f = True
+                    if halo is not None and halo.get('prev_floor') is not None:
+                        t['prev_floor'] = c(halo['prev_floor'])
+                if use_f:
+                    t['floor'] = c(cam['floor_plane'])
+        spec['w'] = w
+        loss, terms = FK.FusedFit.apply(lib, spec, *[t[n] for n, _ in FK.DIFF_INPUTS])
+        stats = {FK.TERM_NAMES[k]: terms[k] for k in range(FK.NT) if w[k] != 0.0}
+        stats.update(stats_extra)
+        if extra is not None:
+            loss = loss + extra
+        return loss, stats
+
     def set_stage(self, idx):
         ''' Sets the current stage index. Determines which loss weights are used '''
         self.cur_stage_idx = idx
@@ -120,6 +284,9 @@ class FittingLoss(nn.Module):
         For fitting just global root trans/orientation. Only data terms, no priors (fitting_loss.py:94-181).
         '''
         W = self.loss_weights
+        ref = pred_data.get('joints3d', pred_data.get('verts3d'))
+        if ref is not None and self._fusable(observed_data, ref):
+            return self._fused_fit('root', observed_data, pred_data, pred_data, 1, halo=halo)
         stats = dict()
         loss = 0.0
         if 'joints3d' in observed_data and 'joints3d' in pred_data and W['joints3d'] > 0.0:
@@ -197,7 +364,14 @@ class FittingLoss(nn.Module):
         For fitting full shape and pose of SMPL (fitting_loss.py:183-224).  nsteps scales single-step terms.
         '''
         W = self.loss_weights
-        loss, stats = self.root_fit(observed_data, pred_data, halo=halo)
+        ref = pred_data.get('joints3d', pred_data.get('verts3d'))
+        if ref is not None and self._fusable(observed_data, ref):
+            return self._fused_fit('smpl', observed_data, pred_data, pred_data, nsteps, halo=halo)
+        fused, self.fused = self.fused, False          # term-by-term path: root_fit must not take the fused branch on its own
+        try:
+            loss, stats = self.root_fit(observed_data, pred_data, halo=halo)
+        finally:
+            self.fused = fused
         if 'latent_pose' in pred_data and W['pose_prior'] > 0.0:
             cur = torch.sum(pred_data['latent_pose'] ** 2)
             loss = loss + W['pose_prior'] * cur
@@ -229,7 +403,15 @@ class FittingLoss(nn.Module):
         pred_data lives in the prior (canonical) frame, cam_pred_data in the camera frame.
         '''
         W = self.loss_weights
-        loss, stats = self.smpl_fit(observed_data, cam_pred_data, nsteps, halo=halo)
+        ref = cam_pred_data.get('joints3d', cam_pred_data.get('verts3d'))
+        if ref is not None and self._fusable(observed_data, ref):
+            return self._fused_fit('motion', observed_data, pred_data, cam_pred_data, nsteps, cond_prior=cond_prior,
+                                   init_motion_scale=init_motion_scale, halo=halo)
+        fused, self.fused = self.fused, False
+        try:
+            loss, stats = self.smpl_fit(observed_data, cam_pred_data, nsteps, halo=halo)
+        finally:
+            self.fused = fused
         if 'latent_motion' in pred_data and W['motion_prior'] > 0.0:
             cur = self.motion_prior_loss(pred_data['latent_motion'], cond_prior=cond_prior)
             loss = loss + W['motion_prior'] * cur

@@ -35,7 +35,7 @@ class MotionOptimizer():
                  motion_prior=None, init_motion_prior=None, optim_floor=False, camera_matrix=None, robust_loss_type='none',
                  robust_tuning_const=4.6851, joint2d_sigma=100, stage3_tune_init_state=True, stage3_tune_init_num_frames=15,
                  stage3_tune_init_freeze_start=30, stage3_tune_init_freeze_end=50, stage3_contact_refine_only=False,
-                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs=False):
+                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs=False, fused_loss=True):
         B, T = batch_size, seq_len
         self.device = device
         self.batch_size, self.seq_len = B, T
@@ -104,7 +104,7 @@ class MotionOptimizer():
             cam_f, cam_c = shard.sl(cam_f), shard.sl(cam_c)
         self.fitting_loss = FittingLoss(loss_weights, self.init_motion_prior, self.smpl2op_map, OP_IGNORE_JOINTS, cam_f, cam_c,
                                         robust_loss_type, robust_tuning_const, joints2d_sigma=joint2d_sigma,
-                                        use_chamfer=use_chamfer).to(device)
+                                        use_chamfer=use_chamfer, fused=fused_loss, _lib_override=self.fit_bm._lib).to(device)
 
     # ------------------------------------------------------------------------------------------------
     # small helpers
@@ -453,16 +453,23 @@ class MotionOptimizer():
         local_prior_params = [L(p) for p in prior_opt_params]
         rr, cam_rr = self.rollout_latent_motion(trans, root_orient, cur_body_pose, betas, local_prior_params, latent_motion,
                                                 return_prior=self.cond_prior, fit_gender=fit_gender, cam2prior=cam2prior)
-        cur_latent_pose = self.pose2latent(rr['pose_body'])
+        # the reference encodes the rolled-out poses with VPoser on every evaluation (motion_optimizer.py:571) but only the pose
+        # prior reads the result, and no stage-3 configuration weights it: skipped when its weight is zero (same loss value)
+        pose_prior_on = self.fitting_loss.loss_weights['pose_prior'] > 0.0
+        cur_latent_pose = self.pose2latent(rr['pose_body']) if pose_prior_on else None
         pred, _ = self.smpl_results(rr['trans'], rr['root_orient'], rr['pose_body'], betas)
-        pred.update(latent_pose=cur_latent_pose, betas=betas, latent_motion=latent_motion, joints_vel=local_prior_params[1],
+        pred.update(betas=betas, latent_motion=latent_motion, joints_vel=local_prior_params[1],
                     trans_vel=local_prior_params[0], root_orient_vel=local_prior_params[2], joints3d_rollout=rr['joints'])
+        if pose_prior_on:
+            pred['latent_pose'] = cur_latent_pose
         if 'contacts' in rr:
             pred['contacts'], pred['contacts_conf'] = rr['contacts'], rr['contacts_conf']
         cam_pred = pred
         if self.optim_floor:
             cam_pred, _ = self.smpl_results(cam_rr['trans'], cam_rr['root_orient'], rr['pose_body'], betas)
-            cam_pred.update(latent_pose=cur_latent_pose, betas=betas, floor_plane=floor)
+            cam_pred.update(betas=betas, floor_plane=floor)
+            if pose_prior_on:
+                cam_pred['latent_pose'] = cur_latent_pose
         nsteps, obs = self.seq_len, obs_local
         if tune_phase:
             nsteps, obs = n_init, obs_init
@@ -639,5 +646,5 @@ class MotionOptimizer():
         joints = body.Jtr.reshape(B, T, -1, 3)
         nj = len(SMPL_JOINTS)
         pred = {'joints3d': joints[:, :, :nj], 'joints3d_extra': joints[:, :, nj:], 'verts3d': body.v.reshape(B, T, -1, 3),
-                'faces': body.f}
+                'faces': body.f, 'jtr': joints}          # 'jtr': the undivided joint tensor (what the fused loss kernel reads)
         return pred, body

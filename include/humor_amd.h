@@ -161,6 +161,73 @@ int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float
                               const float* g_world, const float* g_prior_mu, const float* g_prior_var,
                               float* stash, float* g_past_in0, float* g_z_seq, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fitting objective: the data / regularisation terms of FittingLoss.root_fit / smpl_fit / motion_fit
+ * (humor/fitting/fitting_loss.py:94-309; term definitions :317-484, 504-516; gmof fitting_utils.py:250-258;
+ * perspective_projection fitting_utils.py:647-676 with identity extrinsics) and their gradients, in one pass.
+ * Not covered (stay with the caller): the init-state GMM term (:416-429), points3d / chamfer, the cross-batch
+ * `prev_batch_overlap_res` terms, irregular (per-pair different) overlaps are covered through `overlap[b]`.
+ * ---------------------------------------------------------------------------------------------- */
+#define HA_FIT_J2D 0            /* joints2d_loss: conf^2 * gmof(projected - observed), OpenPose BODY_25 */
+#define HA_FIT_J3D 1            /* joints3d_loss on the camera-frame SMPL joints (inf = invisible) */
+#define HA_FIT_V3D 2            /* verts3d_loss on the key vertices */
+#define HA_FIT_J3D_RO 3         /* joints3d_loss on the roll-out joints ('joints3d_rollout') */
+#define HA_FIT_POSE_PRIOR 4     /* sum latent_pose^2 */
+#define HA_FIT_SHAPE_PRIOR 5    /* sum betas^2 (x nsteps in the loss) */
+#define HA_FIT_SMOOTH 6         /* joints3d_smooth_loss */
+#define HA_FIT_MOTION_PRIOR 7   /* -sum log N(z; prior_mu, prior_var), or sum z^2 without a conditional prior */
+#define HA_FIT_JOINT_CONSIST 8  /* 0.5 sum (SMPL joints - roll-out joints)^2 */
+#define HA_FIT_BONE_LEN 9       /* bone_length_loss on the roll-out joints (SMPL_PARENTS, body_model/utils.py:9) */
+#define HA_FIT_CONTACT_VEL 10
+#define HA_FIT_CONTACT_H 11     /* contact_height_loss, threshold 0.08 */
+#define HA_FIT_FLOOR_REG 12     /* floor_reg_loss (x nsteps in the loss) */
+#define HA_FIT_OV_VPOS 13       /* overlap consistency of consecutive sub-sequences: key-vertex positions ... */
+#define HA_FIT_OV_VVEL 14       /* ... their frame differences ... */
+#define HA_FIT_OV_BETAS 15      /* ... betas ... */
+#define HA_FIT_OV_FLOOR 16      /* ... floor plane (fitting_loss.py:135-157, 211-215, 296-300) */
+#define HA_FIT_NTERMS 17
+
+/* All pointers are DEVICE pointers to contiguous fp32 (int32 for tables); NULL = absent.  B sub-sequences x T frames. */
+typedef struct ha_fit_args {
+  int B, T;
+  /* predictions */
+  const float* cam_jtr; int nj;        /* [B,T,nj,3] camera-frame SMPL joints (+ selected vertices), nj in [22,128] */
+  const float* cam_verts; int nv;      /* [B,T,nv,3] camera-frame key vertices */
+  const float* pri_joints; int pri_nj; /* [B,T,pri_nj,3] prior-frame SMPL joints (the first 22 are read; pri_nj >= 22) */
+  const float* ro_joints;              /* [B,T,22,3] roll-out joints */
+  const float* contacts_conf;          /* [B,T,22] */
+  const float* latent_pose; int dlp;   /* [B,T,dlp] */
+  const float* betas; int nb;          /* [B,nb] */
+  const float* latent_motion; const float* prior_mu; const float* prior_var; int S; int dz;   /* [B,S,dz], S <= T */
+  const float* floor;                  /* [B,3] */
+  /* halo of the multi-GPU sharding: the sequence before local sequence 0 lives on the previous rank */
+  const float* prev_tail;              /* [T,nv,3] its predicted key vertices */
+  const float* prev_betas;             /* [nb] */
+  const float* prev_floor;             /* [3] */
+  /* observations and tables */
+  const float* obs_j2d;                /* [B,T,25,3] (x, y, confidence) */
+  const int32_t* smpl2op;              /* [25] index into the nj joints (smpl_to_openpose, body_model/utils.py:53-56) */
+  const float* op_mask;                /* [25] 0 for OP_IGNORE_JOINTS (fitting_utils.py:679), else 1 */
+  const float* cam_f; const float* cam_c;   /* [B,2] focal lengths, principal point */
+  float sigma;                         /* joints2d_sigma */
+  const float* obs_j3d;                /* [B,T,22,3], +-inf = invisible */
+  const float* obs_v3d;                /* [B,T,nv,3] */
+  const float* obs_floor;              /* [B,4] (a,b,c,d) */
+  const int32_t* overlap;              /* [B] frames sequence b shares with its predecessor (0 = none); NULL = no overlap terms */
+  /* weights of the current stage, indexed by HA_FIT_* (0 = term off) */
+  float w[HA_FIT_NTERMS];
+  float nsteps;
+  /* outputs: unweighted term values, the weighted loss, and d(loss)/d(input) for every input given (fully written) */
+  float* terms;                        /* [HA_FIT_NTERMS] */
+  float* loss;                         /* [1] */
+  float* g_cam_jtr; float* g_cam_verts; float* g_pri_joints; float* g_ro_joints; float* g_contacts_conf;
+  float* g_latent_pose; float* g_betas; float* g_latent_motion; float* g_prior_mu; float* g_prior_var; float* g_floor;
+  float* g_prev_tail; float* g_prev_betas; float* g_prev_floor;
+  float* partial;                      /* workspace [B*T, HA_FIT_NTERMS] */
+} ha_fit_args;
+
+int ha_fit_loss(const ha_fit_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

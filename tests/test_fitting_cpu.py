@@ -133,3 +133,11 @@ def test_sharded_closure_equals_single_process(emu_lib, smplh_npz, tmp_path):
         for k, v in res.items():
             if k != 'loss':
                 assert (v - sharded[stage][k]).abs().max().item() <= 1e-4 * max(1.0, v.abs().max().item()), (stage, k)
+
+
+def test_emu_fused_fit_loss_equals_term_by_term(emu_lib):
+    """ha_fit_loss (one kernel: all terms + gradients) on the SIMT-emulator build against the term-by-term PyTorch FittingLoss that
+    test_fitting_loss_matches_reference pins to the reference: root / smpl / motion objectives, with and without the halo."""
+    import fitloss_checks as FL
+    worst = FL.check_fused_vs_terms(emu_lib, CPU, B=3, T=5)
+    print('fused fit loss: worst relative gradient difference', worst)

@@ -117,3 +117,11 @@ def test_sharded_stage3_closure_on_gpu(gpu_lib, dev, smplh_npz, tmp_path):
         if k != 'loss':
             v = v.detach().cpu()
             assert (v - sharded[k]).abs().max().item() <= 2e-4 * max(1.0, v.abs().max().item()), k
+
+
+def test_fused_fit_loss_equals_term_by_term(gpu_lib, dev):
+    """ha_fit_loss against the term-by-term PyTorch evaluation (itself pinned bit-for-bit to the reference FittingLoss in the CPU
+    tier): loss, every term, every gradient; C4-like sizes, with and without the multi-GPU halo."""
+    import fitloss_checks as FL
+    for B, T, seed in ((3, 7, 0), (8, 60, 1), (1, 90, 2)):
+        print('fused fit loss', B, T, 'worst rel grad diff', FL.check_fused_vs_terms(gpu_lib, dev, B=B, T=T, seed=seed))
