@@ -15,7 +15,11 @@ decode/encode, 5 SMPL evaluations, HuMoR roll-out (59 steps, prior + decoder) wi
 deterministic unit of "fitting-iter/sec" (an L-BFGS outer iteration is ~25 of these).  Inputs are resident in HBM.
 `value` = closure evaluations per second x (global batch / 32), i.e. aggregate 32x60-batch closure evaluations per second.
 Also reported: `smpl_verts_per_sec` (dense 6890-vertex SMPL forward, N=1920), the `roofline` of the streaming LBS kernel
-(HIP events on the launch stream) and `cpu_baseline` (oracle restatement of the reference closure on the host cores).
+(HIP events on the launch stream), `lbfgs` (REAL torch.optim.LBFGS outer iterations of every stage / stage-3 phase through
+MotionOptimizer.run: outer iterations/s, closure evaluations per outer iteration, and the whole-fit time they imply for the
+reference's 30/80/70 schedule), `strong` (N>1: the same 32-sequence job sharded over the N GPUs, next to the weak-scaling
+headline), `rccl` (collective timings; at N=1 a world-size-1 RCCL group exercises the sharded code path on the one GPU) and
+`cpu_baseline` (oracle restatement of the reference closure on the host cores, best of a thread-count sweep).
 """
 import argparse
 import json
@@ -52,6 +56,10 @@ def parse():
     ap.add_argument('--eager', action='store_true', help='do not capture the closure into a hipGraph')
     ap.add_argument('--no-c5', action='store_true', help='skip the BASELINE C5-size (256x120) kernel rooflines appended at N=1')
     ap.add_argument('--graph', dest='auto', action='store_false', help='always replay the captured hipGraph (default at N=1: time graph replay against eager launches once and keep the faster)')
+    ap.add_argument('--scaling', choices=['weak', 'strong', 'both'], default='both',
+                    help='N>1: weak = 32 sub-sequences per GPU (the headline value), strong = 32 in total; both = time both')
+    ap.add_argument('--no-lbfgs', action='store_true', help='skip the staged L-BFGS outer-iteration measurement (N=1)')
+    ap.add_argument('--no-rccl-check', action='store_true', help='skip the world-size-1 RCCL self-check (N=1)')
     return ap.parse_args()
 
 
@@ -83,39 +91,43 @@ def make_problem(B, T, seed, device):
 
 
 def loss_weights():
-    from oracle.closure_cases import RGB_WEIGHTS       # the per-stage weights of configs/fit_rgb_demo_use_split.cfg (data only)
+    from humor_amd.configs import RGB_WEIGHTS          # the per-stage weights of configs/fit_rgb_demo_use_split.cfg
     return RGB_WEIGHTS
 
 
 def camera_matrix(B, device):
-    from oracle.closure_cases import camera_matrix as cm
+    from humor_amd.configs import camera_matrix as cm
     return cm(B).to(device)
+
+
+def build_optimizer(dev, npz, B, shard=None, use_graphs=False):
+    from humor_amd import synth
+    from humor_amd.body_model import BodyModel
+    from humor_amd.humor_model import HumorModel
+    from humor_amd.motion_optimizer import MotionOptimizer
+    bm = BodyModel(npz, num_betas=16, batch_size=B * T_SEQ, use_vtx_selector=True)
+    hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
+    hm.load_state_dict(synth.humor_state_dict(seed=0))
+    hm = hm.to(dev).eval()
+    for p in hm.parameters():
+        p.requires_grad_(False)
+    w, mu, cov = synth.make_gmm(seed=0)
+    return MotionOptimizer(dev, bm, 16, B, T_SEQ, ['joints2d'], loss_weights(), synth.SynthVPoser(seed=0).to(dev), hm,
+                           {'gmm': (w.to(dev), mu.to(dev), cov.to(dev))}, optim_floor=True, camera_matrix=camera_matrix(B, dev),
+                           robust_loss_type='bisquare', joint2d_sigma=100, shard=shard, use_graphs=use_graphs)
 
 
 class FitClosure:
     """Stage-3 closure of humor_amd.MotionOptimizer on this rank's share of the problem."""
 
-    def __init__(self, dev, npz, world, rank, group, use_graphs=True):
-        from humor_amd import synth
-        from humor_amd.body_model import BodyModel
-        from humor_amd.humor_model import HumorModel
-        from humor_amd.motion_optimizer import MotionOptimizer
-        B = B_SEQ * world
+    def __init__(self, dev, npz, world, rank, group, use_graphs=True, B_total=None):
+        B = B_SEQ * world if B_total is None else B_total
         shard = None
-        if world > 1:
+        if group is not None or world > 1:
             from humor_amd.distributed import Shard
             shard = Shard(B, group)
         obs, init = make_problem(B, T_SEQ, seed=100, device=dev)      # same problem on every rank (replicated variables)
-        bm = BodyModel(npz, num_betas=16, batch_size=B * T_SEQ, use_vtx_selector=True)
-        hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
-        hm.load_state_dict(synth.humor_state_dict(seed=0))
-        hm = hm.to(dev).eval()
-        for p in hm.parameters():
-            p.requires_grad_(False)
-        w, mu, cov = synth.make_gmm(seed=0)
-        self.opt = MotionOptimizer(dev, bm, 16, B, T_SEQ, ['joints2d'], loss_weights(), synth.SynthVPoser(seed=0).to(dev), hm,
-                                   {'gmm': (w.to(dev), mu.to(dev), cov.to(dev))}, optim_floor=True, camera_matrix=camera_matrix(B, dev),
-                                   robust_loss_type='bisquare', joint2d_sigma=100, shard=shard, use_graphs=use_graphs)
+        self.opt = build_optimizer(dev, npz, B, shard=shard, use_graphs=use_graphs)
         o = self.opt
         o.trans, o.root_orient, o.latent_pose, o.betas = init['trans'], init['root_orient'], init['latent_pose'], init['betas']
         o.fitting_loss.set_stage(2)
@@ -192,14 +204,84 @@ def dense_smpl_ms(dev, npz):
         return time_events(lambda: bm(**args), iters=10, warm=2)
 
 
+def lbfgs_profile(dev, npz, k=5):
+    """REAL outer iterations: MotionOptimizer.run on the C4 problem with k torch.optim.LBFGS.step calls (max_iter 20, strong-Wolfe)
+    per stage and per stage-3 phase (tune-init on the first 15 frames / frozen-init / refine); wall time per phase from
+    MotionOptimizer.stage_profile (a device synchronise at every phase boundary)."""
+    from humor_amd.configs import NUM_ITER_RGB, STAGE3_TUNE_INIT_FREEZE
+    opt = build_optimizer(dev, npz, B_SEQ)
+    opt.stage3_tune_init_freeze_start, opt.stage3_tune_init_freeze_end = k, 2 * k
+    opt.stage_profile = {}
+    obs, _ = make_problem(B_SEQ, T_SEQ, seed=100, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    opt.run(obs, data_fps=30, lr=1.0, num_iter=[k, k, 3 * k], lbfgs_max_iter=20)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    prof = {n: v for n, v in opt.stage_profile.items() if not n.startswith('_')}
+    out = {'k_outer_iters_per_phase': k, 'lbfgs_max_iter': 20, 'measured_run_seconds': round(total, 3), 'phases': {}}
+    f0, f1 = STAGE3_TUNE_INIT_FREEZE
+    sched = {'stage1': NUM_ITER_RGB[0], 'stage2': NUM_ITER_RGB[1], 'stage3_tune_init': f0, 'stage3_frozen_init': f1 - f0,
+             'stage3_refine': NUM_ITER_RGB[2] - f1}
+    whole = 0.0
+    for name, n_full in sched.items():
+        p = prof.get(name)
+        if not p or not p['outer_iters']:
+            continue
+        rate = p['outer_iters'] / p['seconds']
+        out['phases'][name] = {'outer_iters_per_sec': round(rate, 3), 'closure_evals_per_outer_iter': round(p['closure_evals'] / p['outer_iters'], 2),
+                               'closure_evals_per_sec': round(p['closure_evals'] / p['seconds'], 2), 'ms_per_closure_eval': round(1e3 * p['seconds'] / max(1, p['closure_evals']), 3)}
+        whole += n_full / rate
+    s3 = [prof[n] for n in ('stage3_tune_init', 'stage3_frozen_init', 'stage3_refine') if n in prof]
+    if s3:
+        out['stage3_outer_iters_per_sec'] = round(sum(p['outer_iters'] for p in s3) / sum(p['seconds'] for p in s3), 3)
+    out['whole_fit_seconds_for_30_80_70_schedule'] = round(whole, 2)
+    out['whole_fit_outer_iters_per_sec'] = round(sum(sched.values()) / whole, 3) if whole > 0 else None
+    return out
+
+
+def rccl_selfcheck(dev, npz):
+    """World-size-1 RCCL process group on the one GPU: init_process_group('nccl'), the sharded closure path (differentiable halo
+    all-gather + packed gradient all-reduce) evaluated through it, and the two collectives timed with HIP events.  Catches
+    import / ABI / device_id errors of the N>1 path that a 1-GPU box can discover."""
+    import torch.distributed as dist
+    out = {'backend': 'nccl (RCCL)', 'world_size': 1}
+    try:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(29400 + os.getpid() % 500))
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        fc = FitClosure(dev, npz, 1, 0, dist.group.WORLD, use_graphs=False)
+        l0 = float(fc.step())
+        ref = FitClosure(dev, npz, 1, 0, None, use_graphs=False)
+        l1 = float(ref.step())
+        out['sharded_closure_loss_rel_diff_vs_unsharded'] = abs(l0 - l1) / abs(l1)
+        n = sum(p.numel() for p in fc.params) + 1
+        packed = torch.zeros(n, device=dev)
+        out['allreduce_packed_floats'] = n
+        out['allreduce_us'] = round(1e3 * time_events(lambda: dist.all_reduce(packed), iters=50, warm=5), 2)
+        halo = torch.zeros(T_SEQ * 43 * 3 + 16 + 3, device=dev)
+        bufs = [torch.empty_like(halo)]
+        out['allgather_halo_floats'] = halo.numel()
+        out['allgather_us'] = round(1e3 * time_events(lambda: dist.all_gather(bufs, halo), iters=50, warm=5), 2)
+        out['ok'] = out['sharded_closure_loss_rel_diff_vs_unsharded'] < 1e-5
+        del fc, ref
+    except Exception as e:                                   # report, never take the benchmark down
+        out['ok'] = False
+        out['error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(npz):
     """oracle/closure_restated.py (restatement of the reference closure: dense smplx-style SMPL on the expanded B*T batch,
-    Python roll-out loop) on the host cores, at the FULL C4 size (32 x 60), forward + backward; 1 warm-up + timed reps."""
+    Python roll-out loop) on the host cores, at the FULL C4 size (32 x 60), forward + backward.  The thread count is swept once
+    ({32, 64, 128, all visible}: one timed evaluation each after a warm-up) and the best one is timed for the reported value."""
     from humor_amd import synth
     from oracle.closure_restated import RestatedFit
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
-    ncores = max(1, min(avail, 32))
-    torch.set_num_threads(ncores)
     data = np.load(npz)
 
     class DS:
@@ -222,16 +304,27 @@ def cpu_baseline(npz):
     def step():
         loss = fit.objective(var, obs)
         torch.autograd.grad(loss, list(var.values()), allow_unused=True)
-    step()
+    sweep = {}
+    for n in sorted({min(avail, c) for c in (32, 64, 128, avail)}):
+        torch.set_num_threads(n)
+        if not sweep:
+            step()                 # warm-up (allocator, first-touch)
+        t0 = time.time()
+        step()
+        sweep[n] = time.time() - t0
+    ncores = min(sweep, key=sweep.get)
+    torch.set_num_threads(ncores)
     reps, t0 = 0, time.time()
-    while reps < 2 or (time.time() - t0 < 15.0 and reps < 20):
+    while reps < 2 or (time.time() - t0 < 12.0 and reps < 20):
         step()
         reps += 1
     dt = (time.time() - t0) / reps
     return {'value': round(1.0 / dt, 4), 'unit': 'closure-evals/s', 'cores': ncores, 'kind': 'port',
-            'sample': f'full C4 batch 32x60, {reps} timed stage-3 closure evaluations (fwd+bwd) after 1 warm-up, {dt * 1e3:.0f} ms each; '
+            'thread_sweep_seconds_per_eval': {str(k): round(v, 3) for k, v in sweep.items()},
+            'sample': f'full C4 batch 32x60, {reps} timed stage-3 closure evaluations (fwd+bwd), {dt * 1e3:.0f} ms each, at the best thread count '
+                      f'of a one-evaluation sweep over {sorted(sweep)} threads ({avail} cores visible); '
                       f'oracle/closure_restated.py = reference closure restated (5 dense 6890-vertex SMPL calls on the expanded B*T batch, '
-                      f'59-step Python roll-out loop, VPoser, all loss terms), torch CPU with {ncores} threads ({avail} cores visible)'}
+                      f'59-step Python roll-out loop, VPoser, all loss terms), torch CPU'}
 
 
 def main():
@@ -292,24 +385,50 @@ def main():
     if not (world == 1 and not args.eager and args.auto and not use_graphs):
         fc = FitClosure(dev, npz, world, rank, None, use_graphs=use_graphs)
     fc.mode_note = mode_note
-    for _ in range(args.warmup):
-        fc.step()
-    torch.cuda.synchronize()
+
+    def timed(f):
+        """W untimed + exactly K timed closure evaluations, bracketed by barrier + synchronise; MAX over ranks (seconds)."""
+        for _ in range(args.warmup):
+            f.step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            f.step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([d], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = t.item()
+        return d
+    dt = timed(fc)
+    strong = None
+    if world > 1 and args.scaling in ('strong', 'both') and B_SEQ >= world:
+        # strong scaling: the SAME 32-sequence job (north_star: "batch=32 sub-seqs sharded over 8 GPUs" = 4 per GPU at N=8)
+        del fc
+        torch.cuda.empty_cache()
+        fc = FitClosure(dev, npz, world, rank, None, use_graphs=False, B_total=B_SEQ)
+        fc.mode_note = None
+        dts = timed(fc)
+        strong = {'scaling': 'strong', 'global_batch': B_SEQ, 'sequences_per_gpu': [B_SEQ // world + (1 if r < B_SEQ % world else 0) for r in range(world)],
+                  'value': round(args.steps / dts, 3), 'unit': 'closure-evals/s of the one 32x60 job', 'ms_per_step': round(dts / args.steps * 1e3, 4)}
+    coll = None
     if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fc.step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        n = sum(p.numel() for p in fc.params) + 1
+        packed = torch.zeros(n, device=dev)
+        halo = torch.zeros(T_SEQ * 43 * 3 + 16 + 3, device=dev)
+        bufs = [torch.empty_like(halo) for _ in range(world)]
+        coll = {'backend': backend, 'allreduce_packed_floats': n,
+                'allreduce_us': round(1e3 * time_events(lambda: dist.all_reduce(packed), iters=50, warm=5), 2),
+                'allgather_halo_floats': halo.numel(),
+                'allgather_us': round(1e3 * time_events(lambda: dist.all_gather(bufs, halo), iters=50, warm=5), 2),
+                'collectives_per_closure': '1 differentiable halo all-gather (+ its all-reduce in backward) + 1 packed [gradient | loss] all-reduce'}
 
     if rank == 0:
         ms_dense = dense_smpl_ms(dev, npz)
@@ -324,16 +443,26 @@ def main():
                                    '16 betas, HuMoR 48-d latent, 59-step roll-out; step = one stage-3 closure (fwd+bwd)',
                        'global_batch': B_SEQ * world, 'seq_len': T_SEQ, 'parallelism': f'dp{world} (sub-sequence sharding, replicated L-BFGS)'},
             'closure_mode': closure_mode(args, fc),
-            'lbfgs_outer_iters_per_sec_est': round(args.steps * world / dt / 25.0, 3),
             'smpl_verts_per_sec': round(B_SEQ * T_SEQ * V / (ms_dense * 1e-3), 1),
             'smpl_dense_fwd_ms': round(ms_dense, 4),
             'roofline': skin_roofline(dev, npz),
         }
+        if strong is not None:
+            res['strong'] = strong
+        if coll is not None:
+            res['rccl'] = coll
+        if world == 1 and not args.no_lbfgs:
+            del fc
+            fc = None
+            torch.cuda.empty_cache()
+            res['lbfgs'] = lbfgs_profile(dev, npz)
+        if world == 1 and not args.no_rccl_check:
+            res['rccl'] = rccl_selfcheck(dev, npz)
         if world == 1 and not args.no_c5:
             # BASELINE config C5 (batch 256 x 120 frames): LBS GB/s, pose-blend and decoder/prior MLP fp32-MFMA utilisation
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import bench_c5
-            del fc
+            fc = None
             torch.cuda.empty_cache()
             res['c5_rooflines'] = bench_c5.measure(256, 120, dev)
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 of the 1-GPU run only

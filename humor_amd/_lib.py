@@ -60,6 +60,8 @@ _SIGS = {
     'ha_rodrigues_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ha_rotmat_to_aa_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ha_rotmat_to_aa_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_rot6d_to_rotmat_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_rot6d_to_rotmat_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ha_humor_net_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(MlpDesc), C.POINTER(MlpDesc)]),
     'ha_humor_net_destroy': (C.c_int, [C.c_void_p]),
     'ha_humor_rollout_workspace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
@@ -67,6 +69,8 @@ _SIGS = {
     'ha_humor_rollout_sample': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_humor_rollout_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_fit_loss': (C.c_int, [C.POINTER(FitArgs), C.c_void_p]),
+    'ha_chamfer_forward': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]),
+    'ha_chamfer_backward': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
 }
 
 

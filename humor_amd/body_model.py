@@ -247,15 +247,26 @@ class BodyModel(nn.Module):
         ref = given[0]
         zeros = lambda d: torch.zeros(N, d, dtype=torch.float32, device=ref.device)
         h = self._handle_for(ref.device)
-        nbody = 3 * (min(h.J, 22) - 1)
+        if h.J != self.num_joints + 1:
+            raise _lib.HumorAmdError(f"model_type='{self.model_type}' expects {self.num_joints + 1} joints, the model file has {h.J}")
+        # SMPL keeps its two hand joints in body_pose (69 values, smplx.SMPL.forward); SMPL+H / SMPL-X split them off
+        nbody = 3 * (h.J - 1) if self.model_type == 'smpl' else 3 * (min(h.J, 22) - 1)
         root_orient = zeros(3) if root_orient is None else root_orient
         pose_body = zeros(nbody) if pose_body is None else pose_body
         betas = zeros(h.NB) if betas is None else betas
         trans_in = zeros(3) if trans is None else trans
         has_hands = self.model_type in ['smplh', 'smplx']
         nhand = 2 * NUM_HAND_JOINTS * 3 if has_hands else 0
-        rest = h.J * 3 - 3 - nbody - nhand       # SMPL's two hand joints live in body_pose (69 values)
-        if pose_hand is None:
+        rest = h.J * 3 - 3 - nbody - nhand
+        for name, t, width in (('root_orient', root_orient, 3), ('pose_body', pose_body, nbody), ('betas', betas, h.NB), ('trans', trans_in, 3)):
+            if t.dim() != 2 or t.shape[1] != width:
+                raise ValueError(f"BodyModel.forward: {name} must be [N, {width}] for model_type='{self.model_type}', got {tuple(t.shape)}")
+        if pose_hand is not None and (not has_hands or pose_hand.dim() != 2 or pose_hand.shape[1] != nhand):
+            raise ValueError(f"BodyModel.forward: pose_hand must be [N, {nhand}] for model_type='{self.model_type}'")
+        if pose_hand is None and not has_hands:
+            n_active, pose_hand_out = h.J, None
+            full_pose = torch.cat([root_orient, pose_body], dim=1)
+        elif pose_hand is None:
             n_active = 1 + nbody // 3
             # constant zero padding (hands at rest), cached per (N, device): this runs several times per fitting closure
             key = (N, nhand + rest, str(ref.device))
@@ -285,6 +296,8 @@ class BodyModel(nn.Module):
                 self._sel_cache[key] = torch.tensor(self._selector, dtype=torch.long, device=ref.device)
             cfg['selector_t'] = self._sel_cache[key]
             cfg['slot_sel'] = h.subset_slot(self._selector)
+        if full_pose.shape[1] != h.J * 3:
+            raise _lib.HumorAmdError(f'BodyModel.forward: assembled pose has {full_pose.shape[1]} values, the model needs {h.J * 3}')
         v, joints = _SmplFunction.apply(full_pose.float(), betas.float(), trans_in.float(), cfg)
 
         out = {

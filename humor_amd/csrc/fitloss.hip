@@ -335,30 +335,31 @@ __global__ __launch_bounds__(64) void fit_loss_kernel(ha_fit_args a) {
   }
 }
 
-// terms[k] = sum over frames (fixed order), loss = sum_k weff_k terms[k]
-__global__ __launch_bounds__(256) void fit_reduce_kernel(ha_fit_args a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];     // [256] tree reduction | [NT] term values
-  float* s_red = smem;
-  float* s_terms = smem + 256;
-  const int tid = threadIdx.x, F = a.B * a.T;
-  for (int k = 0; k < NT; ++k) {
-    float s = 0.f;
-    for (int f = tid; f < F; f += 256) s += a.partial[(size_t)f * NT + k];
-    s_red[tid] = s;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-      if (tid < off) s_red[tid] += s_red[tid + off];
-      __syncthreads();
+// terms[k] = sum over frames (fixed order), loss = sum_k weff_k terms[k].  One wave per term (lane-strided partial sums, then
+// an xor-shuffle tree: a fixed association, so the value is bit-reproducible), no block barriers in the summation.
+__global__ __launch_bounds__(1024) void fit_reduce_kernel(ha_fit_args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [NT] term values
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, F = a.B * a.T;
+  for (int k = wave; k < NT; k += 16) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int f = lane;
+    for (; f + 192 < F; f += 256) {
+      s0 += a.partial[(size_t)f * NT + k];
+      s1 += a.partial[(size_t)(f + 64) * NT + k];
+      s2 += a.partial[(size_t)(f + 128) * NT + k];
+      s3 += a.partial[(size_t)(f + 192) * NT + k];
     }
-    if (tid == 0) s_terms[k] = s_red[0];
-    __syncthreads();
+    for (; f < F; f += 64) s0 += a.partial[(size_t)f * NT + k];
+    const float s = wsum((s0 + s1) + (s2 + s3));
+    if (lane == 0) smem[k] = s;
   }
-  if (tid == 0) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
     float loss = 0.f;
     for (int k = 0; k < NT; ++k) {
-      a.terms[k] = s_terms[k];
+      a.terms[k] = smem[k];
       const float scale = (k == HA_FIT_SHAPE_PRIOR || k == HA_FIT_FLOOR_REG) ? a.nsteps : 1.f;
-      loss += a.w[k] * scale * s_terms[k];
+      loss += a.w[k] * scale * smem[k];
     }
     a.loss[0] = loss;
   }
@@ -381,7 +382,7 @@ extern "C" int ha_fit_loss(const ha_fit_args* args, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(fit_loss_kernel, dim3(a.B * a.T), dim3(64), (128 + 66) * sizeof(float), st, a);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fit_reduce_kernel, dim3(1), dim3(256), (256 + NT) * sizeof(float), st, a);
+  hipLaunchKernelGGL(fit_reduce_kernel, dim3(1), dim3(1024), NT * sizeof(float), st, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

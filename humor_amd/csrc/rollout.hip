@@ -1276,6 +1276,29 @@ __global__ void rotmat_to_aa_bwd_kernel(int n, const float* __restrict__ R, cons
   for (int k = 0; k < 9; ++k) gR[(size_t)i * 9 + k] = o[k];
 }
 
+__global__ void rot6d_fwd_kernel(int n, const float* __restrict__ x, float* __restrict__ R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v[6], M[9];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = x[(size_t)i * 6 + k];
+  rot6d_to_rotmat(v, M);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = M[k];
+}
+__global__ void rot6d_bwd_kernel(int n, const float* __restrict__ x, const float* __restrict__ gR, float* __restrict__ gx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v[6], g[9], o[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = x[(size_t)i * 6 + k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g[k] = gR[(size_t)i * 9 + k];
+  rot6d_to_rotmat_bwd(v, g, o);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) gx[(size_t)i * 6 + k] = o[k];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side: weight packing, stash layout, orchestration
 // ---------------------------------------------------------------------------------------------------
@@ -1866,4 +1889,12 @@ extern "C" int ha_rotmat_to_aa_fwd(int n, const float* R, float* aa, void* strea
 extern "C" int ha_rotmat_to_aa_bwd(int n, const float* R, const float* g_aa, float* gR, void* stream) {
   HA_REQUIRE(R && g_aa && gR, "ha_rotmat_to_aa_bwd: null argument");
   HA_ROT_ENTRY("ha_rotmat_to_aa_bwd", rotmat_to_aa_bwd_kernel, R, g_aa, gR);
+}
+extern "C" int ha_rot6d_to_rotmat_fwd(int n, const float* x, float* R, void* stream) {
+  HA_REQUIRE(x && R, "ha_rot6d_to_rotmat_fwd: null argument");
+  HA_ROT_ENTRY("ha_rot6d_to_rotmat_fwd", rot6d_fwd_kernel, x, R);
+}
+extern "C" int ha_rot6d_to_rotmat_bwd(int n, const float* x, const float* gR, float* gx, void* stream) {
+  HA_REQUIRE(x && gR && gx, "ha_rot6d_to_rotmat_bwd: null argument");
+  HA_ROT_ENTRY("ha_rot6d_to_rotmat_bwd", rot6d_bwd_kernel, x, gR, gx);
 }

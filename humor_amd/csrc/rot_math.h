@@ -174,4 +174,59 @@ HA_HD void w2a_bwd(const W2A& o, const float gW[9], float& g_p0, float& g_p3) {
   g_p3 = -g_ry;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// 6-D rotation representation -> rotation matrix (Zhou et al.), restating rot6d_to_rotmat (humor/utils/transforms.py:201-220):
+// x viewed as [3][2]: a1 = column 0 = (x0, x2, x4), a2 = column 1 = (x1, x3, x5); b1 = a1 / max(|a1|, 1e-12) (F.normalize),
+// b2 = normalize(a2 - (b1 . a2) b1), b3 = b1 x b2; R = [b1 | b2 | b3] (columns).
+// ---------------------------------------------------------------------------------------------------
+HA_HD void rot6d_to_rotmat(const float x[6], float R[9]) {
+  const float a1[3] = {x[0], x[2], x[4]}, a2[3] = {x[1], x[3], x[5]};
+  const float l1 = sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+  const float n1 = l1 > 1e-12f ? l1 : 1e-12f;
+  const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+  const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+  const float v[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+  const float l2 = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const float n2 = l2 > 1e-12f ? l2 : 1e-12f;
+  const float b2[3] = {v[0] / n2, v[1] / n2, v[2] / n2};
+  const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { R[i * 3] = b1[i]; R[i * 3 + 1] = b2[i]; R[i * 3 + 2] = b3[i]; }
+}
+
+HA_HD void rot6d_to_rotmat_bwd(const float x[6], const float gR[9], float gx[6]) {
+  const float a1[3] = {x[0], x[2], x[4]}, a2[3] = {x[1], x[3], x[5]};
+  const float l1 = sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+  const bool c1 = l1 > 1e-12f;
+  const float n1 = c1 ? l1 : 1e-12f;
+  const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+  const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+  const float v[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+  const float l2 = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const bool c2 = l2 > 1e-12f;
+  const float n2 = c2 ? l2 : 1e-12f;
+  const float b2[3] = {v[0] / n2, v[1] / n2, v[2] / n2};
+  float gb1[3] = {gR[0], gR[3], gR[6]}, gb2[3] = {gR[1], gR[4], gR[7]};
+  const float gb3[3] = {gR[2], gR[5], gR[8]};
+  // b3 = b1 x b2
+  gb1[0] += b2[1] * gb3[2] - b2[2] * gb3[1]; gb1[1] += b2[2] * gb3[0] - b2[0] * gb3[2]; gb1[2] += b2[0] * gb3[1] - b2[1] * gb3[0];
+  gb2[0] += gb3[1] * b1[2] - gb3[2] * b1[1]; gb2[1] += gb3[2] * b1[0] - gb3[0] * b1[2]; gb2[2] += gb3[0] * b1[1] - gb3[1] * b1[0];
+  // b2 = v / max(|v|, eps): the clamped branch is a plain scaling
+  const float p2 = c2 ? gb2[0] * b2[0] + gb2[1] * b2[1] + gb2[2] * b2[2] : 0.f;
+  const float gv[3] = {(gb2[0] - p2 * b2[0]) / n2, (gb2[1] - p2 * b2[1]) / n2, (gb2[2] - p2 * b2[2]) / n2};
+  // v = a2 - d b1, d = b1 . a2
+  const float gd = -(gv[0] * b1[0] + gv[1] * b1[1] + gv[2] * b1[2]);
+  float ga2[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    ga2[i] = gv[i] + gd * b1[i];
+    gb1[i] += -d * gv[i] + gd * a2[i];
+  }
+  const float p1 = c1 ? gb1[0] * b1[0] + gb1[1] * b1[1] + gb1[2] * b1[2] : 0.f;
+  const float ga1[3] = {(gb1[0] - p1 * b1[0]) / n1, (gb1[1] - p1 * b1[1]) / n1, (gb1[2] - p1 * b1[2]) / n1};
+  gx[0] = ga1[0]; gx[2] = ga1[1]; gx[4] = ga1[2];
+  gx[1] = ga2[0]; gx[3] = ga2[1]; gx[5] = ga2[2];
+}
+
 }  // namespace ha

@@ -37,6 +37,28 @@ def perspective_projection(points, focal_length, camera_center):
     return proj * focal_length.unsqueeze(1) + camera_center.unsqueeze(1)
 
 
+def robust_std(res):
+    """Robust standard deviation from the median absolute deviation, per batch row (fitting_utils.py:212-227).  res [B,N] -> [B,1]."""
+    B = res.size(0)
+    med = torch.median(res, dim=-1)[0].reshape((B, 1))
+    mad = torch.median(torch.abs(res - med), dim=-1)[0].reshape((B, 1))
+    return mad / 0.67449
+
+
+def bisquare_robust_weights(res, tune_const=4.6851):
+    """Tukey bisquare weights of non-negative residuals (fitting_utils.py:229-249)."""
+    norm_res = res / (robust_std(res) * tune_const)
+    w = (1.0 - norm_res ** 2) ** 2
+    return torch.where(norm_res >= 1.0, torch.zeros_like(w), w)
+
+
+def apply_robust_weighting(res, robust_loss_type='bisquare', robust_tuning_const=4.6851):
+    """Robustly weighted squared residuals; no gradient through the weights (fitting_utils.py:192-210)."""
+    det = res.detach()
+    w = torch.ones_like(det) if robust_loss_type == 'none' else bisquare_robust_weights(det, tune_const=robust_tuning_const)
+    return w * (res ** 2), w
+
+
 def _masked_sq(obs, pred):
     """0.5 * sum over visible entries of (obs - pred)^2; entries whose observation is +-inf are invisible (a NaN
     observation poisons the loss, as in the reference's get_visible_mask = ~isinf, fitting_loss.py:311-315)."""
@@ -90,8 +112,10 @@ class FittingLoss(nn.Module):
         if self.can_reproj:
             self.cam_f = self.cam_f.reshape((-1, 1, 2))
             self.cam_cent = self.cam_cent.reshape((-1, 1, 2))
+        self.chamfer_dist = None
         if use_chamfer:
-            raise NotImplementedError('point-cloud (chamfer) fitting is outside the BASELINE configs (SURVEY.md 8(f) rank 1)')
+            from .chamfer import ChamferDistance
+            self.chamfer_dist = ChamferDistance(_lib_override=_lib_override)
         total = {k: sum(w[k] for w in self.all_stage_loss_weights) for k in self.loss_weights}
         self.init_motion_prior = None
         if init_motion_prior is not None and total['init_motion_prior'] > 0.0:
@@ -298,7 +322,9 @@ class FittingLoss(nn.Module):
             loss = loss + W['verts3d'] * cur
             stats['verts3d'] = cur
         if 'points3d' in observed_data and 'points3d' in pred_data and W['points3d'] > 0.0:
-            raise NotImplementedError('points3d (chamfer) term: SURVEY.md 8(f) rank 1, not in the BASELINE configs')
+            cur = self.points3d_loss(observed_data['points3d'], pred_data['points3d'])
+            loss = loss + W['points3d'] * cur
+            stats['points3d'] = cur
         if 'joints2d' in observed_data and 'joints3d' in pred_data and 'joints3d_extra' in pred_data and W['joints2d'] > 0.0:
             if not self.can_reproj:
                 raise RuntimeError('Must provide camera intrinsics and SMPL to OpenPose joint map to use re-projection loss!')
@@ -492,6 +518,16 @@ class FittingLoss(nn.Module):
 
     def verts3d_loss(self, verts3d_obs, verts3d_pred):
         return _masked_sq(verts3d_obs, verts3d_pred)
+
+    def points3d_loss(self, points3d_obs, points3d_pred):
+        """One-way (observation -> body) chamfer term with robust weighting per sequence (fitting_loss.py:378-396)."""
+        if self.chamfer_dist is None:
+            raise RuntimeError('FittingLoss(use_chamfer=True) is needed for the points3d term')
+        B, T, N_obs, _ = points3d_obs.size()
+        obs2pred, _ = self.chamfer_dist(points3d_obs.reshape(B * T, -1, 3), points3d_pred.reshape(B * T, -1, 3))
+        obs2pred = obs2pred.reshape(B, T * N_obs)
+        weighted, _ = apply_robust_weighting(obs2pred.sqrt(), robust_loss_type=self.robust_loss, robust_tuning_const=self.robust_tuning_const)
+        return 0.5 * torch.sum(weighted)
 
     def joints3d_smooth_loss(self, joints3d_pred):
         d = joints3d_pred[:, 1:] - joints3d_pred[:, :-1]

@@ -254,6 +254,41 @@ class HumorModel(nn.Module):
         B = x_past.size(0)
         return self.infer_step(x_past.reshape(B, -1), x_t.reshape(B, -1))
 
+    def decode(self, z, past_in):
+        """One decoder evaluation + residual composition in plain PyTorch (humor_model.py:445-498): the canonical-frame state after
+        one step, [B, 339 (+9 contact logits)].  Off the hot path: roll_out runs the same arithmetic in the HIP kernels."""
+        from .frames import _rodrigues_torch
+        B = z.size(0)
+        past_in = past_in.reshape(B, -1)
+        raw = self.decoder(torch.cat([past_in, z], dim=1))
+        if not (self.output_delta and self.in_rot_rep == 'mat' and self.out_rot_rep == 'aa'):
+            raise NotImplementedError("decode implements output_delta=True, in_rot_rep='mat', out_rot_rep='aa'")
+        dR = _rodrigues_torch(raw[:, 6:9])
+        R_root = torch.matmul(dR, past_in[:, 6:15].reshape(B, 3, 3)).reshape(B, 9)
+        dB = _rodrigues_torch(raw[:, 12:75].reshape(B * NUM_BODY_JOINTS, 3)).reshape(B, NUM_BODY_JOINTS, 3, 3)
+        R_body = torch.matmul(dB, past_in[:, 18:207].reshape(B, NUM_BODY_JOINTS, 3, 3)).reshape(B, NUM_BODY_JOINTS * 9)
+        out = torch.cat([raw[:, 0:3] + past_in[:, 0:3], raw[:, 3:6] + past_in[:, 3:6], R_root, raw[:, 9:12] + past_in[:, 15:18], R_body,
+                         raw[:, 75:141] + past_in[:, 207:273], raw[:, 141:207] + past_in[:, 273:339]], dim=1)
+        if self.pred_contacts:
+            out = torch.cat([out, raw[:, 207:216]], dim=1)
+        return out
+
+    def sample_step(self, past_in, t_in=None, use_mean=False, z=None, return_prior=False, return_z=False):
+        """One sampling step in plain PyTorch (humor_model.py:1019-1059): z ~ prior(past_in) (or its mean, or the given z),
+        then decode.  Returns {'decoder_out': [B, 1, D]} (+ 'prior', 'z')."""
+        B = past_in.size(0)
+        past_in = past_in.reshape(B, -1)
+        pm, pv = self.prior(past_in) if self.use_conditional_prior else (torch.zeros(B, self.latent_size, device=past_in.device),
+                                                                          torch.ones(B, self.latent_size, device=past_in.device))
+        if z is None:
+            z = pm if use_mean else self.rsample(pm, pv)
+        out = {'decoder_out': self.decode(z, past_in).reshape(B, 1, -1)}
+        if return_prior:
+            out['prior'] = (pm, pv)
+        if return_z:
+            out['z'] = z
+        return out
+
     def split_output(self, decoder_out, convert_rots=True):
         B = decoder_out.size(0)
         decoder_out = decoder_out.reshape(B, self.steps_out, -1)
@@ -290,6 +325,8 @@ class HumorModel(nn.Module):
                                       "output_delta=True, 'smpl+joints(+contacts)' (the fitting configuration)")
         if not self.use_conditional_prior:
             raise NotImplementedError('roll-out kernels expect the conditional prior network')
+        if not self.pred_contacts:
+            raise NotImplementedError("roll-out kernels expect the contact head (model_data_config='smpl+joints+contacts': 216 decoder outputs)")
 
     def _net_handle(self, device):
         lib = self._lib if self._lib is not None else _lib.get_lib()
@@ -315,10 +352,12 @@ class HumorModel(nn.Module):
         Returns a dict of world-frame [B, num_steps, D] tensors (rotations as matrices), optionally (prior mean, var).
         '''
         self._check_rollout_config()
-        if x_past is not None and not canonicalize_input:
+        if x_past is not None:
             past_in = x_past.reshape(x_past.size(0), -1)
-        else:
+        elif init_input_dict is not None:
             past_in = torch.cat([init_input_dict[k][:, -1, :] for k in self.data_names], dim=1)
+        else:
+            raise ValueError('roll_out needs the initial state: x_past [B, steps_in, D] or init_input_dict {name: [B, steps_in, d]}')
         B = past_in.size(0)
         uncanon = None
         if canonicalize_input:

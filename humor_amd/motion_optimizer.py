@@ -52,19 +52,24 @@ class MotionOptimizer():
         # whole-closure hipGraph capture (replay costs ~1.5 us of node hand-off per kernel, eager costs host time that the
         # roll-out's long launches partly hide: which one wins depends on the host -- bench.py times both)
         self.use_graphs = bool(use_graphs) and torch.device(device).type == 'cuda'
+        if self.use_graphs and shard is not None:
+            # capturing the closure would put the halo all-gather / gradient all-reduce (and, with gloo, host staging) inside the
+            # graph; a rank-divergent capture failure leaves collectives in flight.  Sharded closures always launch eagerly.
+            print('humor_amd: use_graphs is ignored for a sharded MotionOptimizer (collectives are not captured)')
+            self.use_graphs = False
         self.closure_evals = 0
+        self.stage_profile = None   # set to {} before run(): wall time / closure evaluations / outer iterations per stage (3 syncs per phase)
         self.loss_trace = None      # set to a list to record (stage, loss) of every closure evaluation (host sync per eval)
         if motion_prior is None:
             raise ValueError('Need the motion prior to use all-implicit parameterization!')
-        if use_chamfer or 'points3d' in observed_modalities:
-            raise NotImplementedError('point-cloud fitting (chamfer) is outside the BASELINE configs (SURVEY.md 8(f))')
-
-        # the body model evaluates only what the losses consume; share the packed constants with the model we were given
+        # the body model evaluates only what the losses consume (43 key vertices + 21 selector vertices) unless a point-cloud term
+        # needs the whole surface; it shares the packed constants with the model we were given
+        self.dense_smpl = bool(use_chamfer) or 'points3d' in observed_modalities
         self.body_model = body_model
         if isinstance(body_model, BodyModel):
             self.fit_bm = BodyModel(body_model.bm_path, num_betas=num_betas, batch_size=B * T,
                                     use_vtx_selector=body_model.use_vtx_selector, model_type=body_model.model_type,
-                                    vertex_subset=KEYPT_VERTS, _lib_override=body_model._lib)
+                                    vertex_subset=None if self.dense_smpl else KEYPT_VERTS, _lib_override=body_model._lib)
         else:
             raise TypeError('humor_amd.MotionOptimizer needs a humor_amd.BodyModel')
 
@@ -104,7 +109,7 @@ class MotionOptimizer():
             cam_f, cam_c = shard.sl(cam_f), shard.sl(cam_c)
         self.fitting_loss = FittingLoss(loss_weights, self.init_motion_prior, self.smpl2op_map, OP_IGNORE_JOINTS, cam_f, cam_c,
                                         robust_loss_type, robust_tuning_const, joints2d_sigma=joint2d_sigma,
-                                        use_chamfer=use_chamfer, fused=fused_loss, _lib_override=self.fit_bm._lib).to(device)
+                                        use_chamfer=self.dense_smpl, fused=fused_loss, _lib_override=self.fit_bm._lib).to(device)
 
     # ------------------------------------------------------------------------------------------------
     # small helpers
@@ -209,6 +214,18 @@ class MotionOptimizer():
             return state['loss']
         return closure
 
+    def _mark(self, key, iters=0):
+        """Stage timing for bench.py: closes the interval `key` (seconds since the previous mark, closure evaluations, outer iterations)."""
+        if self.stage_profile is None:
+            return
+        if self.device is not None and torch.device(self.device).type == 'cuda':
+            torch.cuda.synchronize()
+        now = time.perf_counter()
+        prev = self.stage_profile.get('_last', (now, self.closure_evals))
+        if key is not None:
+            self.stage_profile[key] = {'seconds': now - prev[0], 'closure_evals': self.closure_evals - prev[1], 'outer_iters': iters}
+        self.stage_profile['_last'] = (now, self.closure_evals)
+
     @staticmethod
     def _with_dep(loss, halo):
         return loss + halo['dep'] if halo is not None and 'dep' in halo else loss
@@ -216,11 +233,11 @@ class MotionOptimizer():
     def _finish_closure(self, loss, params, stats=None):
         loss.backward()
         self.closure_evals += 1
-        if self.loss_trace is not None and self.shard is None:
-            self.loss_trace.append((self.fitting_loss.cur_stage_idx, float(loss)))
         if self.shard is not None:
             from .distributed import allreduce_loss_and_grads
             loss = allreduce_loss_and_grads(loss, params, self.shard.group)
+        if self.loss_trace is not None:
+            self.loss_trace.append((self.fitting_loss.cur_stage_idx, float(loss.detach())))
         if self.verbose and stats is not None:
             print('LOSS: %f' % loss.item(), {k: float(v) for k, v in stats.items()})
         return loss
@@ -233,7 +250,9 @@ class MotionOptimizer():
         fp = observed_data['floor_plane']
         self.floor_plane = (fp[:, :3] * fp[:, 3:]).to(torch.float).clone().detach()
         self.floor_plane.requires_grad = True
-        if 'joints2d' in observed_data:
+        if 'points3d' in observed_data:
+            self.trans = torch.mean(observed_data['points3d'], dim=2).clone().detach()      # mean of the point cloud (motion_optimizer.py:152-156)
+        elif 'joints2d' in observed_data:
             body_pose = self.latent2pose(self.latent_pose[:, :1])
             pred, _ = self.smpl_results(self.trans[:, :1], self.root_orient[:, :1], body_pose, self.betas)
             full = torch.cat([pred['joints3d'], pred['joints3d_extra']], dim=2)
@@ -273,10 +292,12 @@ class MotionOptimizer():
         params = [self.trans, self.root_orient]
         optim = torch.optim.LBFGS(params, max_iter=lbfgs_max_iter, lr=lr, line_search_fn=LINE_SEARCH)
         closure1 = self.make_closure(lambda: self._stage1_objective(obs_local, has_overlap), params, optim)
+        self._mark(None)
         for i in range(num_iter[0]):
             self.fitting_loss.cur_optim_step = i
 
             optim.step(closure1)
+        self._mark('stage1', num_iter[0])
         per_stage_outputs['stage1'] = self._stage_snapshot(stages_res_out, 'stage1_results.npz')
 
         # ---- Stage II: full pose and shape ------------------------------------------------------------
@@ -286,9 +307,16 @@ class MotionOptimizer():
         params = [self.trans, self.root_orient, self.betas, self.latent_pose]
         optim = torch.optim.LBFGS(params, max_iter=lbfgs_max_iter, lr=lr, line_search_fn=LINE_SEARCH)
         closure2 = self.make_closure(lambda: self._stage2_objective(obs_local, has_overlap), params, optim)
+        self._mark(None)
         for i in range(num_iter[1]):
             optim.step(closure2)
+        self._mark('stage2', num_iter[1])
         per_stage_outputs['stage2'] = self._stage_snapshot(stages_res_out, 'stage2_results.npz')
+        stage2_cam = None
+        if self.optim_floor and stages_res_out is not None:
+            with torch.no_grad():
+                stage2_cam = {'trans': self.trans.clone().detach(), 'root_orient': self.root_orient.clone().detach(),
+                              'pose_body': self.latent2pose(self.latent_pose).clone().detach(), 'betas': self.betas.clone().detach()}
 
         # ---- Stage III set-up -------------------------------------------------------------------------
         self.fitting_loss.set_stage(2)
@@ -302,6 +330,13 @@ class MotionOptimizer():
             if 'contacts' in rr:
                 init_pred['contacts'] = rr['contacts']
         per_stage_outputs['stage3_init'] = init_pred
+        if stages_res_out is not None:
+            # camera-frame and (with a floor) prior-frame state the motion stage starts from (motion_optimizer.py:422-456)
+            self._save_dicts(stages_res_out, 'stage3_init_results.npz', self.betas, cam_rr['trans'], cam_rr['root_orient'], cam_rr['pose_body'],
+                             contacts=rr.get('contacts'), floor=self.floor_plane if self.optim_floor else None)
+            if self.optim_floor:
+                self._save_dicts(stages_res_out, 'stage3_init_results_prior.npz', self.betas, rr['trans'], rr['root_orient'], cam_rr['pose_body'],
+                                 contacts=rr.get('contacts'))
 
         mk = lambda ps: torch.optim.LBFGS(ps, max_iter=lbfgs_max_iter, lr=lr, line_search_fn=LINE_SEARCH)
         motion_optim = mk(motion_params)
@@ -317,6 +352,8 @@ class MotionOptimizer():
         obs_init = self._local_obs(observed_data, nsteps=n_init)
         closures3 = {}
 
+        self._mark(None)
+        last_phase_name, phase_iters = None, 0
         for i in range(num_iter[2]):
             tune_phase = self.stage3_tune_init_state and i < self.stage3_tune_init_freeze_start
             if self.stage3_tune_init_state and self.stage3_tune_init_freeze_start <= i < self.stage3_tune_init_freeze_end:
@@ -341,12 +378,19 @@ class MotionOptimizer():
             # one closure (and one captured graph) per phase: tune-init / frozen-init / refine
             phase = (tune_phase, motion_optim is optim_frozen, init_motion_scale,
                      self.fitting_loss.loss_weights['contact_height'], self.fitting_loss.loss_weights['contact_vel'])
+            phase_name = 'stage3_tune_init' if tune_phase else ('stage3_frozen_init' if motion_optim is optim_frozen else 'stage3_refine')
+            if last_phase_name is not None and phase_name != last_phase_name:
+                self._mark(last_phase_name, phase_iters)
+                phase_iters = 0
+            last_phase_name, phase_iters = phase_name, phase_iters + 1
             if phase not in closures3:
                 closures3[phase] = self.make_closure(
                     lambda tp=tune_phase, ims=init_motion_scale: self._stage3_objective(
                         obs_local, obs_init, prior_opt_params, tp, n_init, ims, og_overlap_w, has_overlap, fit_gender),
                     motion_params, None)
             motion_optim.step(closures3[phase])
+        if last_phase_name is not None:
+            self._mark(last_phase_name, phase_iters)
 
         # ---- final roll-out and results ----------------------------------------------------------------
         with torch.no_grad():
@@ -373,6 +417,17 @@ class MotionOptimizer():
             final['contacts'] = rr['contacts']
         if stages_res_out is not None:
             self._save_stage(stages_res_out, 'stage3_results.npz', body_pose, contacts=rr.get('contacts'))
+            if stage2_cam is not None:
+                # the stage-2 result in the prior frame of the FINAL floor (motion_optimizer.py:651-674), read by viz_fitting_rgb
+                with torch.no_grad():
+                    smpl2, _ = self.smpl_results(stage2_cam['trans'], stage2_cam['root_orient'], stage2_cam['pose_body'], stage2_cam['betas'])
+                    ar = np.arange(self.batch_size)
+                    R2, t2, h2 = frames.compute_cam2prior(
+                        self.floor_plane, stage2_cam['trans'][ar, self.init_fidx],
+                        ops.batch_rodrigues(stage2_cam['root_orient'][ar, self.init_fidx], _lib_override=self.fit_bm._lib),
+                        smpl2['joints3d'][ar, self.init_fidx])
+                    pri2 = self.apply_cam2prior(stage2_cam, R2, t2, h2, stage2_cam['pose_body'], stage2_cam['betas'], self.init_fidx)
+                self._save_dicts(stages_res_out, 'stage2_results_prior.npz', self.betas, pri2['trans'], pri2['root_orient'], stage2_cam['pose_body'])
         return final, per_stage_outputs
 
     def setup_stage3(self, data_fps=30):
@@ -501,6 +556,20 @@ class MotionOptimizer():
                 d['contacts'] = arr(contacts[b])
             if self.optim_floor:
                 d['floor_plane'] = arr(self.floor_plane[b])
+            np.savez(os.path.join(out_dir, fname), **d)
+
+    def _save_dicts(self, stages_res_out, fname, betas, trans, root_orient, pose_body, contacts=None, floor=None):
+        """One npz per sequence in the reference's layout: betas[NB], trans[T,3], root_orient[T,3], pose_body[T,63] (+ contacts, floor)."""
+        arr = lambda t: t.detach().cpu().numpy()
+        be, tr, ro, bp = arr(betas), arr(trans), arr(root_orient), arr(pose_body)
+        co = arr(contacts) if contacts is not None else None
+        fl = arr(floor) if floor is not None else None
+        for b, out_dir in enumerate(stages_res_out):
+            d = dict(betas=be[b], trans=tr[b], root_orient=ro[b], pose_body=bp[b])
+            if co is not None:
+                d['contacts'] = co[b]
+            if fl is not None:
+                d['floor_plane'] = fl[b]
             np.savez(os.path.join(out_dir, fname), **d)
 
     def apply_cam2prior(self, data_dict, R, t, root_height, body_pose, betas, key_frame_idx, inverse=False):
@@ -635,6 +704,11 @@ class MotionOptimizer():
         B, T, _ = body_pose.size()
         return self.pose_prior.encode(body_pose.reshape(-1, J_BODY * 3)).mean.reshape(B, T, self.latent_pose_dim)
 
+    def _keypt_idx(self, device):
+        if getattr(self, '_keypt_t', None) is None or self._keypt_t.device != device:
+            self._keypt_t = torch.as_tensor(KEYPT_VERTS, dtype=torch.long, device=device)
+        return self._keypt_t
+
     def smpl_results(self, trans, root_orient, body_pose, beta):
         '''
         SMPL forward for [B,T,.] parameters (T = 1 or any length): joints3d [B,T,22,3], joints3d_extra, verts3d [B,T,43,3].
@@ -645,6 +719,12 @@ class MotionOptimizer():
                            root_orient=root_orient.reshape(B * T, -1), trans=trans.reshape(B * T, -1))
         joints = body.Jtr.reshape(B, T, -1, 3)
         nj = len(SMPL_JOINTS)
-        pred = {'joints3d': joints[:, :, :nj], 'joints3d_extra': joints[:, :, nj:], 'verts3d': body.v.reshape(B, T, -1, 3),
-                'faces': body.f, 'jtr': joints}          # 'jtr': the undivided joint tensor (what the fused loss kernel reads)
+        verts = body.v.reshape(B, T, -1, 3)
+        pred = {'joints3d': joints[:, :, :nj], 'joints3d_extra': joints[:, :, nj:], 'faces': body.f,
+                'jtr': joints}          # 'jtr': the undivided joint tensor (what the fused loss kernel reads)
+        if self.dense_smpl:
+            pred['points3d'] = verts                                   # every vertex (chamfer term), key vertices gathered from it
+            pred['verts3d'] = verts.index_select(2, self._keypt_idx(verts.device))
+        else:
+            pred['verts3d'] = verts
         return pred, body

@@ -1,6 +1,7 @@
 """Autograd wrappers of the stand-alone rotation kernels of libhumor_amd.so.
 
   batch_rodrigues(aa)                  replaces humor/utils/transforms.py:139-170
+  rot6d_to_rotmat(x)                   replaces humor/utils/transforms.py:201-220
   rotation_matrix_to_angle_axis(R)     replaces humor/utils/transforms.py:243-389
 Same names, argument meaning and output shapes as the reference functions; GPU tensors only (no CPU fallback).
 """
@@ -54,6 +55,30 @@ class _RotToAA(torch.autograd.Function):
         gR = torch.empty_like(R)
         ctx.lib.call('ha_rotmat_to_aa_bwd', R.shape[0], _lib.ptr(R), _lib.ptr(g_aa), _lib.ptr(gR), _lib.stream_ptr(R))
         return gR.view(-1, 3, 3), None
+
+
+class _Rot6d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lib):
+        x = x.contiguous().float()
+        R = torch.empty(x.shape[0], 9, dtype=torch.float32, device=x.device)
+        lib.call('ha_rot6d_to_rotmat_fwd', x.shape[0], _lib.ptr(x), _lib.ptr(R), _lib.stream_ptr(x))
+        ctx.lib = lib
+        ctx.save_for_backward(x)
+        return R.view(-1, 3, 3)
+
+    @staticmethod
+    def backward(ctx, gR):
+        x, = ctx.saved_tensors
+        gR = gR.contiguous().float().view(-1, 9)
+        g = torch.empty_like(x)
+        ctx.lib.call('ha_rot6d_to_rotmat_bwd', x.shape[0], _lib.ptr(x), _lib.ptr(gR), _lib.ptr(g), _lib.stream_ptr(x))
+        return g, None
+
+
+def rot6d_to_rotmat(x, _lib_override=None):
+    """[N,6] (or anything viewable as [-1,3,2]) -> [N,3,3]: humor/utils/transforms.py:201-220."""
+    return _Rot6d.apply(x.reshape(-1, 6), _lib_for(x, _lib_override))
 
 
 def batch_rodrigues(rot_vecs, _lib_override=None):

@@ -105,6 +105,10 @@ int ha_rodrigues_fwd(int n, const float* aa /*[n,3]*/, float* R /*[n,9]*/, void*
 int ha_rodrigues_bwd(int n, const float* aa, const float* gR /*[n,9]*/, float* g_aa /*[n,3]*/, void* stream);
 int ha_rotmat_to_aa_fwd(int n, const float* R /*[n,9]*/, float* aa /*[n,3]*/, void* stream);
 int ha_rotmat_to_aa_bwd(int n, const float* R, const float* g_aa, float* gR, void* stream);
+/* 6-D representation -> rotation matrix (humor/utils/transforms.py:201-220 rot6d_to_rotmat; the decoder of VPoser and
+ * HumorModel(out_rot_rep='6d') end in it): x [n,6] viewed as [3,2] (columns a1, a2) -> R [n,9] = [b1 | b2 | b1 x b2]. */
+int ha_rot6d_to_rotmat_fwd(int n, const float* x /*[n,6]*/, float* R /*[n,9]*/, void* stream);
+int ha_rot6d_to_rotmat_bwd(int n, const float* x, const float* gR /*[n,9]*/, float* gx /*[n,6]*/, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HuMoR CVAE roll-out (replaces HumorModel.roll_out / sample_step / prior / decode / MLP.forward /
@@ -227,6 +231,19 @@ typedef struct ha_fit_args {
 } ha_fit_args;
 
 int ha_fit_loss(const ha_fit_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Chamfer distance (replaces humor/utils/chamfer_distance/chamfer_distance.cu: ChamferDistanceKernelLauncher :140-157 and
+ * ChamferDistanceGradKernelLauncher :189-208, i.e. chamfer_distance.py's cd.forward_cuda / cd.backward_cuda).
+ *   xyz1 [b,n,3], xyz2 [b,m,3];  dist1[b,n] / idx1[b,n]: squared distance to, and index of, the nearest point of xyz2 for every
+ *   point of xyz1 (ties -> lowest index); dist2 / idx2 [b,m] the other direction.  Distances are (dx*dx + dy*dy) + dz*dz in
+ *   fp32 without FMA contraction = the reference's CPU path (chamfer_distance.cpp:59-87) bit for bit.
+ * Backward: grad_xyz1 [b,n,3] and grad_xyz2 [b,m,3] are fully written (no pre-zeroing needed).
+ * ---------------------------------------------------------------------------------------------- */
+int ha_chamfer_forward(int b, int n, const float* xyz1, int m, const float* xyz2, float* dist1, int32_t* idx1, float* dist2,
+                       int32_t* idx2, void* stream);
+int ha_chamfer_backward(int b, int n, const float* xyz1, int m, const float* xyz2, const float* grad_dist1, const int32_t* idx1,
+                        const float* grad_dist2, const int32_t* idx2, float* grad_xyz1, float* grad_xyz2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -298,3 +298,48 @@ def check_sampling_golden(lib, device):
     for unc, key in ((True, 'world_canon_uncanon'), (False, 'world_canon')):
         oc = hm.roll_out(None, d, z.shape[1], z_seq=z, canonicalize_input=True, uncanonicalize_output=unc)
         assert np.abs(world_of(oc).cpu().numpy() - gd[key]).max() < 2e-4
+
+
+def check_rot6d(lib, device, n=2000, seed=0):
+    """rot6d_to_rotmat kernel (fwd + adjoint) against the restated formula of transforms.py:201-220 evaluated by PyTorch autograd."""
+    g = torch.Generator().manual_seed(seed)
+    xc = torch.randn(n, 6, generator=g)
+    xc[0] = torch.tensor([1.0, 0.0, 0.0, 1.0, 0.0, 0.0])
+    xc = xc.requires_grad_(True)
+    x = xc.detach().clone().to(device).requires_grad_(True)
+    v = xc.view(-1, 3, 2)
+    a1, a2 = v[:, :, 0], v[:, :, 1]
+    b1 = torch.nn.functional.normalize(a1)
+    b2 = torch.nn.functional.normalize(a2 - torch.einsum('bi,bi->b', b1, a2).unsqueeze(-1) * b1)
+    R_ref = torch.stack((b1, b2, torch.cross(b1, b2, dim=1)), dim=-1)
+    Rm = ops.rot6d_to_rotmat(x, _lib_override=lib)
+    assert (Rm.detach().cpu() - R_ref).abs().max().item() < 1e-6
+    gR = torch.randn(n, 3, 3, generator=g)
+    ga = torch.autograd.grad((Rm * gR.to(device)).sum(), x)[0].cpu()
+    ga_ref = torch.autograd.grad((R_ref * gR).sum(), xc)[0]
+    assert (ga - ga_ref).abs().max().item() < 1e-4 * max(1.0, ga_ref.abs().max().item())
+    return R_ref
+
+
+def check_rot_to_aa_near_pi(lib, device, n=3000, seed=0):
+    """R -> axis-angle forward AND gradient right at the seam the optimiser starts from (root_orient = (pi, 0, 0)):
+    rotation angles in [2.6, pi - 1e-4] plus exact pi-rotations about the coordinate axes, against the oracle (bit-pinned to
+    transforms.py:243-389).  The 4-branch quaternion extraction is well conditioned there: flat 1e-5 / 1e-4-relative bars."""
+    g = torch.Generator().manual_seed(seed)
+    axis = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    th = torch.cat([2.6 + (3.1415 - 2.6) * torch.rand(n - 600, 1, generator=g), 3.13 + 0.0115 * torch.rand(600, 1, generator=g)], 0)
+    aa = torch.cat([axis * th, torch.tensor([[3.14159265, 0.0, 0.0], [0.0, 3.14159265, 0.0], [0.0, 0.0, 3.14159265], [3.1415, 1e-3, -1e-3]])], 0)
+    R = L.batch_rodrigues(aa)
+    Rc = R.clone().requires_grad_(True)
+    Rd = R.clone().to(device).requires_grad_(True)
+    b_ref = H.rot_to_aa(Rc)
+    b = ops.rotation_matrix_to_angle_axis(Rd, _lib_override=lib)
+    assert (b.detach().cpu() - b_ref).abs().max().item() < 1e-5
+    gb = torch.randn(b_ref.shape, generator=g)
+    gr = torch.autograd.grad((b * gb.to(device)).sum(), Rd)[0].cpu()
+    gr_ref = torch.autograd.grad((b_ref * gb).sum(), Rc)[0]
+    ok = torch.isfinite(gr_ref).all(dim=(1, 2))
+    sc = gr_ref[ok].abs().amax(dim=(1, 2)).clamp(min=1.0)
+    e = (gr[ok] - gr_ref[ok]).abs().amax(dim=(1, 2)) / sc
+    assert e.max().item() < 1e-4, e.max().item()
+    return e.max().item()

@@ -40,7 +40,10 @@ def test_amass_style_fit_reduces_joint_error(gpu_lib, dev, smplh_npz, tmp_path, 
     opt = FC.build(gpu_lib, dev, 'amass', B, T, smplh_npz)
     opt.use_graphs = use_graphs
     opt.loss_trace = []
-    final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[6, 10, 8], lbfgs_max_iter=20)
+    out_dirs = [str(tmp_path / f'seq{b}') for b in range(B)]
+    for d in out_dirs:
+        os.makedirs(d, exist_ok=True)
+    final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[6, 10, 8], lbfgs_max_iter=20, stages_res_out=out_dirs)
     err0 = (joints - 0.0).norm(dim=-1).mean().item()
     err2 = (stages['stage2']['joints3d'] - joints).norm(dim=-1).mean().item()
     err3 = (stages['stage3']['joints3d'] - joints).norm(dim=-1).mean().item()
@@ -55,14 +58,15 @@ def test_amass_style_fit_reduces_joint_error(gpu_lib, dev, smplh_npz, tmp_path, 
     assert final['trans'].shape == (B, T, 3) and final['pose_body'].shape == (B, T, 63)
     assert final['latent_motion'].shape == (B, T - 1, 48) and final['contacts'].shape == (B, T, 22)
     assert set(torch.unique(final['contacts']).tolist()) <= {0.0, 1.0}
-    out_dirs = [str(tmp_path / f'seq{b}') for b in range(B)]
     results.save_optim_result(out_dirs, final, stages, gt_data=gt, observed_data=obs, data_type='AMASS', optim_floor=False)
     d = np.load(os.path.join(out_dirs[0], 'stage3_results.npz'))
     assert d['trans'].shape == (T, 3) and d['pose_body'].shape == (T, 63) and d['betas'].shape == (16,) and d['contacts'].shape == (T, 22)
     assert os.path.exists(os.path.join(out_dirs[1], 'gt_results.npz')) and os.path.exists(os.path.join(out_dirs[1], 'observations.npz'))
+    for f in ('stage1_results.npz', 'stage2_results.npz', 'stage3_init_results.npz'):       # files eval_fitting_* / viz_fitting_rgb list
+        assert os.path.exists(os.path.join(out_dirs[0], f)), f
 
 
-def test_rgb_style_fit_runs_all_phases(gpu_lib, dev, smplh_npz):
+def test_rgb_style_fit_runs_all_phases(gpu_lib, dev, smplh_npz, tmp_path):
     """fit_rgb_demo_use_split-shaped problem (config C3/C4 shape): 2D keypoints, floor optimisation, overlapping
     sub-sequences; exercises the tune-init / frozen-init / refine phases of stage 3 and the floor outputs."""
     from oracle import closure_cases as CC
@@ -73,7 +77,15 @@ def test_rgb_style_fit_runs_all_phases(gpu_lib, dev, smplh_npz):
     opt.loss_trace = []
     obs = {k: v.to(dev) for k, v in CC.make_case('rgb', B, T, seed=4)['obs'].items()}
     obs['seq_interval'] = torch.tensor([[b * (T - 5), b * (T - 5) + T] for b in range(B)])
-    final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[3, 4, 6], lbfgs_max_iter=10)
+    out_dirs = [str(tmp_path / f'seq{b}') for b in range(B)]
+    for d in out_dirs:
+        os.makedirs(d, exist_ok=True)
+    final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[3, 4, 6], lbfgs_max_iter=10, stages_res_out=out_dirs)
+    # every per-stage file the reference writes and its eval / viz scripts list (motion_optimizer.py:260-270, 422-456, 651-674)
+    for f in ('stage1_results.npz', 'stage2_results.npz', 'stage3_init_results.npz', 'stage3_init_results_prior.npz',
+              'stage2_results_prior.npz', 'stage3_results.npz'):
+        d = np.load(os.path.join(out_dirs[1], f))
+        assert d['trans'].shape == (T, 3) and d['root_orient'].shape == (T, 3) and d['pose_body'].shape == (T, 63), f
     assert final['floor_plane'].shape == (B, 4)
     assert 'prior_trans' in stages['stage3'] and 'prior_joints3d_rollout' in stages['stage3']
     assert all(torch.isfinite(v).all() for v in final.values())
@@ -117,3 +129,43 @@ def test_sharded_run_is_identical_on_all_ranks(gpu_lib, dev, smplh_npz, tmp_path
     for k in r0:
         assert torch.isfinite(r0[k]).all(), k
         assert torch.equal(r0[k], r1[k]), f'{k} differs between ranks'
+
+
+def test_stitched_rgb_result_round_trip(gpu_lib, dev, smplh_npz, tmp_path):
+    """save_rgb_stitched_result (fitting_utils.py:398-523): a known 50-frame sequence cut into three overlapping sub-sequence
+    result directories is stitched back frame for frame; the prior-frame copy puts frame 0's root over the origin, upright."""
+    from humor_amd import results, synth
+    T, ov = 20, 5
+    N = 3 * T - 2 * ov
+    root, body, trans = synth.smooth_pose_sequence(1, N, seed=3)
+    root, body, trans = root[0] + torch.tensor([np.pi, 0.0, 0.0]), body[0], trans[0] + torch.tensor([0.0, 0.0, 3.0])
+    g = torch.Generator().manual_seed(0)
+    betas = 0.3 * torch.randn(16, generator=g)
+    contacts = (torch.rand(N, 22, generator=g) > 0.5).float()
+    j2d = torch.rand(N, 25, 3, generator=g)
+    ivals, dirs = [], []
+    for b in range(3):
+        s = b * (T - ov)
+        ivals.append((s, s + T))
+        d = tmp_path / f'seq{b}'
+        d.mkdir()
+        dirs.append(str(d))
+        np.savez(str(d / 'stage3_results.npz'), betas=betas.numpy(), trans=trans[s:s + T].numpy(), root_orient=root[s:s + T].numpy(),
+                 pose_body=body[s:s + T].numpy(), contacts=contacts[s:s + T].numpy(), floor_plane=np.array([0.0, -1.0, 0.0, -0.9 - 0.01 * b], dtype=np.float32))
+        np.savez(str(d / 'gt_results.npz'), cam_mtx=np.eye(3))
+        np.savez(str(d / 'observations.npz'), joints2d=j2d[s:s + T].numpy(), img_paths=np.array([f'f{i:04d}.png' for i in range(s, s + T)]))
+        (d / 'meta.txt').write_text('gender neutral')
+    out = results.save_rgb_stitched_result(ivals, dirs, str(tmp_path), dev, smplh_npz, 16, True)
+    r = np.load(os.path.join(out, 'stage3_results.npz'))
+    assert r['trans'].shape == (N, 3) and r['betas'].shape == (N, 16) and r['contacts'].shape == (N, 22)
+    assert np.array_equal(r['trans'], trans.numpy()) and np.array_equal(r['pose_body'], body.numpy()) and np.array_equal(r['contacts'], contacts.numpy())
+    assert np.allclose(r['floor_plane'], [0.0, -1.0, 0.0, -0.9])
+    o = np.load(os.path.join(out, 'observations.npz'))
+    assert np.array_equal(o['joints2d'], j2d.numpy()) and list(o['img_paths']) == [f'f{i:04d}.png' for i in range(N)]
+    assert os.path.exists(os.path.join(out, 'meta.txt')) and os.path.exists(os.path.join(out, 'gt_results.npz'))
+    p = np.load(os.path.join(out, 'stage3_results_prior.npz'))
+    assert p['trans'].shape == (N, 3) and np.abs(p['trans'][0, :2]).max() < 1e-5 and np.isfinite(p['root_orient']).all()
+    # rigid map: pairwise root distances are preserved
+    d_cam = np.linalg.norm(trans.numpy()[1:] - trans.numpy()[:-1], axis=1)
+    d_pri = np.linalg.norm(p['trans'][1:] - p['trans'][:-1], axis=1)
+    assert np.abs(d_cam - d_pri).max() < 1e-4

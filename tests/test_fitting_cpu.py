@@ -141,3 +141,18 @@ def test_emu_fused_fit_loss_equals_term_by_term(emu_lib):
     import fitloss_checks as FL
     worst = FL.check_fused_vs_terms(emu_lib, CPU, B=3, T=5)
     print('fused fit loss: worst relative gradient difference', worst)
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason='reference tree only exists in the build container')
+def test_robust_weighting_matches_reference():
+    """apply_robust_weighting / bisquare weights / MAD std of the points3d term against fitting_utils.py:192-249, bit for bit."""
+    from humor_amd import fitting_loss as FLM
+    R = ref_loader.load()
+    g = torch.Generator().manual_seed(0)
+    res = torch.rand(3, 500, generator=g) * 0.2
+    res[1, :7] = 5.0                     # outliers
+    for kind in ('bisquare', 'none'):
+        a, wa = FLM.apply_robust_weighting(res.clone().requires_grad_(True), kind, 4.6851)
+        b, wb = R.fitting_utils.apply_robust_weighting(res.clone().requires_grad_(True), kind, 4.6851)
+        assert torch.equal(a, b) and torch.equal(wa, wb)
+    assert torch.equal(FLM.robust_std(res), R.fitting_utils.robust_std(res))

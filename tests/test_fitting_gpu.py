@@ -125,3 +125,53 @@ def test_fused_fit_loss_equals_term_by_term(gpu_lib, dev):
     import fitloss_checks as FL
     for B, T, seed in ((3, 7, 0), (8, 60, 1), (1, 90, 2)):
         print('fused fit loss', B, T, 'worst rel grad diff', FL.check_fused_vs_terms(gpu_lib, dev, B=B, T=T, seed=seed))
+
+
+def test_points3d_chamfer_term_through_the_optimizer(gpu_lib, dev, smplh_npz):
+    """Point-cloud fitting (fit_proxd-style): MotionOptimizer with the 'points3d' modality evaluates the dense 6890-vertex SMPL, the
+    chamfer kernels and the robust weighting.  The loss equals a re-evaluation with the ORACLE's nearest-neighbour indices; the
+    gradient w.r.t. the root translation matches central finite differences of the (locally smooth) objective."""
+    from humor_amd import synth
+    from humor_amd.body_model import BodyModel
+    from humor_amd.configs import stage_weights
+    from humor_amd.fitting_loss import apply_robust_weighting
+    from humor_amd.humor_model import HumorModel
+    from humor_amd.motion_optimizer import MotionOptimizer
+    from oracle import chamfer_restated as CR
+    B, T, NOBS = 2, 3, 700
+    bm = BodyModel(smplh_npz, num_betas=16, batch_size=B * T, use_vtx_selector=False)
+    hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
+    hm.load_state_dict(synth.humor_state_dict(seed=0))
+    hm = hm.to(dev).eval()
+    w, mu, cov = synth.make_gmm(seed=0)
+    weights = stage_weights([{'points3d': 1.0}] * 3)
+    opt = MotionOptimizer(dev, bm, 16, B, T, ['points3d'], weights, synth.SynthVPoser(seed=0).to(dev), hm,
+                          {'gmm': (w.to(dev), mu.to(dev), cov.to(dev))}, robust_loss_type='bisquare', use_chamfer=True)
+    g = torch.Generator().manual_seed(0)
+    opt.trans = (0.1 * torch.randn(B, T, 3, generator=g)).to(dev).requires_grad_(True)
+    opt.root_orient = (torch.tensor([0.3, 0.1, -0.2]) + 0.1 * torch.randn(B, T, 3, generator=g)).to(dev).requires_grad_(True)
+    with torch.no_grad():
+        pred, _ = opt.smpl_results(opt.trans, opt.root_orient, opt.latent2pose(opt.latent_pose), opt.betas)
+    assert pred['points3d'].shape == (B, T, 6890, 3) and pred['verts3d'].shape == (B, T, 43, 3)
+    pick = torch.randint(0, 6890, (B, T, NOBS), generator=g).to(dev)
+    cloud = torch.gather(pred['points3d'], 2, pick.unsqueeze(-1).expand(B, T, NOBS, 3)) + 0.02 * torch.randn(B, T, NOBS, 3, generator=g).to(dev)
+    obs = {'points3d': cloud}
+    opt.fitting_loss.set_stage(0)
+    loss, stats = opt._stage1_objective(opt._local_obs(obs), False)
+    gt, = torch.autograd.grad(loss, [opt.trans])
+    # re-evaluation with the oracle's indices
+    i1 = CR.nnsearch(cloud.reshape(B * T, NOBS, 3).cpu().numpy(), pred['points3d'].reshape(B * T, 6890, 3).cpu().numpy())[1]
+    near = torch.gather(pred['points3d'].reshape(B * T, 6890, 3), 1, torch.from_numpy(i1).long().to(dev).unsqueeze(-1).expand(B * T, NOBS, 3))
+    d = ((cloud.reshape(B * T, NOBS, 3) - near) ** 2).sum(-1).reshape(B, T * NOBS)
+    ref = 0.5 * apply_robust_weighting(d.sqrt(), 'bisquare', 4.6851)[0].sum()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()), (loss.item(), ref.item())
+    eps = 1e-3
+    for (b, t, c) in ((0, 0, 0), (1, 2, 1), (0, 1, 2)):
+        vals = []
+        for sgn in (1.0, -1.0):
+            with torch.no_grad():
+                opt.trans[b, t, c] += sgn * eps
+                vals.append(opt._stage1_objective(opt._local_obs(obs), False)[0].item())
+                opt.trans[b, t, c] -= sgn * eps
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        assert abs(fd - gt[b, t, c].item()) <= 0.05 * max(1.0, abs(fd)), (b, t, c, fd, gt[b, t, c].item())

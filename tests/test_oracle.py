@@ -264,3 +264,105 @@ def test_restated_closure_matches_reference_fixture(smplh_struct, kind):
     g = torch.autograd.grad(loss, [var['latent_motion'], var['betas']])
     assert np.abs(g[0].numpy() - gd['s2_g_latent_motion']).max() <= 2e-3 * max(1.0, np.abs(gd['s2_g_latent_motion']).max())
     assert np.abs(g[1].numpy() - gd['s2_g_betas']).max() <= 2e-3 * max(1.0, np.abs(gd['s2_g_betas']).max())
+
+
+def test_chamfer_restatement_matches_compiled_reference():
+    """oracle/chamfer_restated.py against the reference's own chamfer_distance.cpp compiled into oracle/_ref (oracle/build_ref.py):
+    indices and distances bit-exact (ties included), gradients to rounding."""
+    from oracle import build_ref, chamfer_restated as CR
+    cd = build_ref.load()
+    if cd is None:
+        pytest.skip('neither /root/reference nor a prebuilt oracle/_ref is available')
+    g = torch.Generator().manual_seed(0)
+    b, n, m = 3, 257, 700
+    x1, x2 = torch.randn(b, n, 3, generator=g), torch.randn(b, m, 3, generator=g)
+    x2[:, 10] = x2[:, 5]
+    x1[:, 3] = x2[:, 5]
+    d1, d2 = torch.zeros(b, n), torch.zeros(b, m)
+    i1, i2 = torch.zeros(b, n, dtype=torch.int), torch.zeros(b, m, dtype=torch.int)
+    cd.forward(x1, x2, d1, d2, i1, i2)
+    r = CR.forward(x1.numpy(), x2.numpy())
+    assert np.array_equal(r[1], i1.numpy()) and np.array_equal(r[3], i2.numpy())
+    assert np.array_equal(r[0], d1.numpy()) and np.array_equal(r[2], d2.numpy())
+    assert i1[0, 3].item() == 5          # the tie goes to the lower index
+    g1, g2 = torch.randn(b, n, generator=g), torch.randn(b, m, generator=g)
+    gx1, gx2 = torch.zeros(b, n, 3), torch.zeros(b, m, 3)
+    cd.backward(x1, x2, gx1, gx2, g1, g2, i1, i2)
+    rg = CR.backward(x1.numpy(), x2.numpy(), g1.numpy(), i1.numpy(), g2.numpy(), i2.numpy())
+    assert np.abs(rg[0] - gx1.numpy()).max() < 1e-5 and np.abs(rg[1] - gx2.numpy()).max() < 1e-5
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason='reference tree only exists in the build container')
+def test_rot6d_formula_matches_reference_live():
+    """The formula tests/rollout_checks.check_rot6d holds the kernel to is the reference's rot6d_to_rotmat (transforms.py:201-220), bit for bit."""
+    R = ref_loader.load()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(64, 6, generator=g)          # (not 3 rows: the reference's dim-less torch.cross, SURVEY G1)
+    v = x.view(-1, 3, 2)
+    a1, a2 = v[:, :, 0], v[:, :, 1]
+    b1 = torch.nn.functional.normalize(a1)
+    b2 = torch.nn.functional.normalize(a2 - torch.einsum('bi,bi->b', b1, a2).unsqueeze(-1) * b1)
+    ours = torch.stack((b1, b2, torch.cross(b1, b2, dim=1)), dim=-1)
+    assert torch.equal(ours, R.transforms.rot6d_to_rotmat(x))
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason='reference tree only exists in the build container')
+def test_infer_global_seq_and_velocities_match_reference_live():
+    """SURVEY 8(a) a15, directly: HumorModel.infer_global_seq (all T-1 frame pairs canonicalised and pushed through prior + posterior
+    in one batch) against the reference's per-frame Python loop (humor_model.py:1061-1203), and the finite-difference velocity
+    estimators against motion_optimizer.py:766-800."""
+    from humor_amd import frames
+    from humor_amd.humor_model import HumorModel
+    R = ref_loader.load()
+    sd = synth.humor_state_dict(seed=0)
+    ours = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
+    ref = R.humor_model.HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
+    ours.load_state_dict(sd)
+    ref.load_state_dict(sd)
+    ours.eval()
+    ref.eval()
+    B, T = 2, 9
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s, sc=1.0: sc * torch.randn(*s, generator=g)
+    seq = {'trans': r(B, T, 3, sc=0.5), 'trans_vel': r(B, T, 3, sc=0.3),
+           'root_orient': L.batch_rodrigues(r(B * T, 3, sc=0.7)).reshape(B, T, 9), 'root_orient_vel': r(B, T, 3, sc=0.3),
+           'pose_body': L.batch_rodrigues(r(B * T * 21, 3, sc=0.4)).reshape(B, T, 189), 'joints': r(B, T, 66, sc=0.4), 'joints_vel': r(B, T, 66, sc=0.3)}
+    with torch.no_grad():
+        (pm, pv), (qm, qv) = ours.infer_global_seq({k: v.clone() for k, v in seq.items()})
+        (pm_r, pv_r), (qm_r, qv_r) = ref.infer_global_seq({k: v.clone() for k, v in seq.items()})
+    for a, b_, name in ((pm, pm_r, 'prior mean'), (pv, pv_r, 'prior var'), (qm, qm_r, 'posterior mean'), (qv, qv_r, 'posterior var')):
+        assert a.shape == b_.shape == (B, T - 1, 48), name
+        assert (a - b_).abs().max().item() < 2e-5 * max(1.0, b_.abs().max().item()), (name, (a - b_).abs().max().item())
+    # velocity estimators (the reference methods do not touch `self`)
+    h = 1.0 / 30
+    x = r(B, T, 22, 3)
+    assert torch.equal(frames.estimate_linear_velocity(x, h), R.motion_optimizer.MotionOptimizer.estimate_linear_velocity(None, x, h))
+    rot = L.batch_rodrigues(r(B * T, 3, sc=0.8)).reshape(B, T, 3, 3)
+
+    class _S:
+        estimate_linear_velocity = staticmethod(lambda d, hh: R.motion_optimizer.MotionOptimizer.estimate_linear_velocity(None, d, hh))
+    w_ref = R.motion_optimizer.MotionOptimizer.estimate_angular_velocity(_S, rot, h)
+    assert (frames.estimate_angular_velocity(rot, h) - w_ref).abs().max().item() < 1e-6
+
+
+def test_lbs_restatement_matches_independent_paper_derivation(smplh_npz, smplh_struct):
+    """The smplx restatement (written from the smplx op sequence) against oracle/smpl_paper_numpy.py, an fp64 numpy derivation
+    written from the SMPL paper's equations with a different structure: breaks common-mode error between the restatement and the
+    kernels while the real package is unavailable ("parity unpinned")."""
+    from oracle import smpl_paper_numpy as SP
+    data = np.load(smplh_npz)
+    N = 3
+    g = torch.Generator().manual_seed(4)
+    r = lambda *s, sc=1.0: sc * torch.randn(*s, generator=g)
+    inp = dict(global_orient=r(N, 3, sc=0.6).double(), body_pose=r(N, 63, sc=0.5).double(), left_hand_pose=r(N, 45, sc=0.3).double(),
+               right_hand_pose=r(N, 45, sc=0.3).double(), betas=r(N, 16).double(), transl=r(N, 3).double())
+    layer = L.SMPLHLayer(data_struct=smplh_struct, num_betas=16, batch_size=N, vertex_ids=L.VERTEX_IDS_SMPLH, dtype=torch.float64)
+    out = layer(**inp)
+    kin = np.asarray(data['kintree_table'])[0].astype(np.int64)
+    model = dict(v_template=data['v_template'], shapedirs=data['shapedirs'], posedirs=data['posedirs'], J_regressor=data['J_regressor'],
+                 weights=data['weights'], parents=[-1] + [int(p) for p in kin[1:]])
+    for i in range(N):
+        pose = np.concatenate([inp[k][i].numpy() for k in ('global_orient', 'body_pose', 'left_hand_pose', 'right_hand_pose')])
+        v, j = SP.smpl_frame(model, pose, inp['betas'][i].numpy(), inp['transl'][i].numpy())
+        assert np.abs(out.vertices[i].numpy() - v).max() < 1e-7
+        assert np.abs(out.joints[i, :52].numpy() - j).max() < 1e-7

@@ -10,6 +10,8 @@ CPU = torch.device('cpu')
 def test_emu_rotation_kernels(emu_lib):
     RC.check_rot_random(emu_lib, CPU, n=512)
     RC.check_rotations_golden(emu_lib, CPU)
+    RC.check_rot6d(emu_lib, CPU, n=300)
+    RC.check_rot_to_aa_near_pi(emu_lib, CPU, n=900)
 
 
 @pytest.mark.slow

@@ -54,6 +54,8 @@ def test_rollout_determinism(gpu_lib, dev):
 def test_rotation_kernels(gpu_lib, dev):
     RC.check_rot_random(gpu_lib, dev, n=100000)
     RC.check_rotations_golden(gpu_lib, dev)
+    RC.check_rot6d(gpu_lib, dev, n=50000)
+    print('R->aa gradient near pi: worst relative error', RC.check_rot_to_aa_near_pi(gpu_lib, dev, n=50000))
 
 
 def test_c5_size_rollout(gpu_lib, dev):

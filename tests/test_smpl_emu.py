@@ -41,3 +41,10 @@ def test_no_cpu_fallback(smplh_npz):
 
 def test_emu_skin_kernel_variants(emu_lib, smplh_npz, smplh_struct):
     SC.check_skin_variants(emu_lib, smplh_npz, smplh_struct, torch.device('cpu'), N=2, variants=(5, 4, 2))
+
+
+def test_emu_chamfer_kernels(emu_lib):
+    """chamfer.hip on the SIMT emulator: indices / distances bit-exact vs the oracle incl. ties; a cloud larger than one LDS chunk."""
+    import chamfer_checks as CC
+    CC.check_chamfer(emu_lib, torch.device('cpu'), b=2, n=37, m=1100, seed=0)
+    CC.check_chamfer(emu_lib, torch.device('cpu'), b=1, n=300, m=29, seed=1)

@@ -95,3 +95,12 @@ def test_c5_size_dense_smpl(gpu_lib, smplh_npz, smplh_struct, dev):
 
 def test_skin_kernel_variants(gpu_lib, smplh_npz, smplh_struct, dev):
     SC.check_skin_variants(gpu_lib, smplh_npz, smplh_struct, dev, N=5)
+
+
+def test_chamfer_kernels(gpu_lib):
+    """Chamfer nearest-neighbour search + gradient at the sizes of the point-cloud term (observed cloud vs 6890 SMPL vertices): int32
+    indices and squared distances bit-exact against the oracle, ties included."""
+    import chamfer_checks as CC
+    dev = torch.device('cuda:0')
+    for b, n, m, seed in ((2, 1024, 6890, 0), (3, 37, 1100, 1), (1, 4096, 6890, 2), (5, 300, 29, 3)):
+        print('chamfer', b, n, m, CC.check_chamfer(gpu_lib, dev, b, n, m, seed))

@@ -33,11 +33,14 @@ def main():
     print('launches', n.value)
     names = ['entry', 'loads issued', 'loads landed', 'GN done', 'MFMA+LDS wr', 'barrier 1', 'stored', 'barrier 2']
     last = n.value
-    print('slot  blocks(t0,t1)  ' + '  '.join(f'{x:>12s}' for x in names[1:]))
-    for k in range(max(0, last - 40), last):
+    print('slot  blocks   ' + '  '.join(f'{x:>12s}' for x in names[1:]) + '   entry-to-entry us (100 MHz wall clock)')
+    prev = None
+    for k in range(max(0, last - 48), last):
         r = [buf[(k & 63) * 10 + i] for i in range(10)]
-        nb0, nb1 = r[9] >> 32, r[9] & 0xffffffff
-        print(f'{k:4d}  ({nb0:4d},{nb1:4d})   ' + '  '.join(f'{(r[i] - r[0]):12d}' for i in range(1, 8)))
+        nb0 = r[9] >> 32
+        gap = '' if prev is None else f'{(r[8] - prev) / 100.0:10.2f}'
+        prev = r[8]
+        print(f'{k:4d}  ({nb0:4d})   ' + '  '.join(f'{(r[i] - r[0]):12d}' for i in range(1, 8)) + '   ' + gap)
 
 
 if __name__ == '__main__':
