@@ -251,9 +251,9 @@ def rccl_selfcheck(dev, npz):
         os.environ.setdefault('MASTER_PORT', str(29400 + os.getpid() % 500))
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
         fc = FitClosure(dev, npz, 1, 0, dist.group.WORLD, use_graphs=False)
-        l0 = float(fc.step())
+        l0 = float(fc.step().detach())
         ref = FitClosure(dev, npz, 1, 0, None, use_graphs=False)
-        l1 = float(ref.step())
+        l1 = float(ref.step().detach())
         out['sharded_closure_loss_rel_diff_vs_unsharded'] = abs(l0 - l1) / abs(l1)
         n = sum(p.numel() for p in fc.params) + 1
         packed = torch.zeros(n, device=dev)
@@ -278,7 +278,7 @@ def rccl_selfcheck(dev, npz):
 def cpu_baseline(npz):
     """oracle/closure_restated.py (restatement of the reference closure: dense smplx-style SMPL on the expanded B*T batch,
     Python roll-out loop) on the host cores, at the FULL C4 size (32 x 60), forward + backward.  The thread count is swept once
-    ({32, 64, 128, all visible}: one timed evaluation each after a warm-up) and the best one is timed for the reported value."""
+    ({16, 32, 64}: one timed evaluation each after a warm-up) and the best one is timed for the reported value."""
     from humor_amd import synth
     from oracle.closure_restated import RestatedFit
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
@@ -304,14 +304,18 @@ def cpu_baseline(npz):
     def step():
         loss = fit.objective(var, obs)
         torch.autograd.grad(loss, list(var.values()), allow_unused=True)
+    # measured once on the 256-core box (profiles/r02_*): 32 threads 4.9 s, 64: 6.7 s, 128: 13.5 s, 256: 656 s per evaluation --
+    # torch's intra-op pool degrades badly when oversubscribed, so the sweep stays at the low end and stops once it gets slower
     sweep = {}
-    for n in sorted({min(avail, c) for c in (32, 64, 128, avail)}):
+    for n in sorted({min(avail, c) for c in (16, 32, 64)}):
         torch.set_num_threads(n)
         if not sweep:
             step()                 # warm-up (allocator, first-touch)
         t0 = time.time()
         step()
         sweep[n] = time.time() - t0
+        if len(sweep) > 1 and sweep[n] > 1.3 * min(sweep.values()):
+            break
     ncores = min(sweep, key=sweep.get)
     torch.set_num_threads(ncores)
     reps, t0 = 0, time.time()
@@ -329,6 +333,27 @@ def cpu_baseline(npz):
 
 def main():
     args = parse()
+    # the contract is ONE JSON line on stdout: libraries that print to the C-level stdout (RCCL's version banner) are sent to
+    # stderr for the duration of the run; fd 1 is restored for the final line only
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run(args)
+    finally:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    if line is not None:
+        print(line, flush=True)
+
+
+def run(args):
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -467,10 +492,13 @@ def main():
             res['c5_rooflines'] = bench_c5.measure(256, 120, dev)
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 of the 1-GPU run only
             res['cpu_baseline'] = cpu_baseline(npz)
-        print(json.dumps(res), flush=True)
+        line = json.dumps(res)
+    else:
+        line = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return line
 
 
 if __name__ == '__main__':

@@ -69,6 +69,7 @@ _SIGS = {
     'ha_humor_rollout_sample': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_humor_rollout_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_fit_loss': (C.c_int, [C.POINTER(FitArgs), C.c_void_p]),
+    'ha_lbfgs_coeffs': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     'ha_chamfer_forward': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]),
     'ha_chamfer_backward': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
 }

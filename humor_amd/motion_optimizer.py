@@ -35,7 +35,7 @@ class MotionOptimizer():
                  motion_prior=None, init_motion_prior=None, optim_floor=False, camera_matrix=None, robust_loss_type='none',
                  robust_tuning_const=4.6851, joint2d_sigma=100, stage3_tune_init_state=True, stage3_tune_init_num_frames=15,
                  stage3_tune_init_freeze_start=30, stage3_tune_init_freeze_end=50, stage3_contact_refine_only=False,
-                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs=False, fused_loss=True):
+                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs=False, fused_loss=True, lbfgs='fused'):
         B, T = batch_size, seq_len
         self.device = device
         self.batch_size, self.seq_len = B, T
@@ -57,6 +57,11 @@ class MotionOptimizer():
             # graph; a rank-divergent capture failure leaves collectives in flight.  Sharded closures always launch eagerly.
             print('humor_amd: use_graphs is ignored for a sharded MotionOptimizer (collectives are not captured)')
             self.use_graphs = False
+        # 'fused': humor_amd.lbfgs.LBFGS (same algorithm as torch.optim.LBFGS, a handful of launches per inner iteration);
+        # 'torch': torch.optim.LBFGS itself (what the reference uses; ~4 launches per stored pair and iteration)
+        if lbfgs not in ('fused', 'torch'):
+            raise ValueError("lbfgs must be 'fused' or 'torch'")
+        self.lbfgs_impl = lbfgs
         self.closure_evals = 0
         self.stage_profile = None   # set to {} before run(): wall time / closure evaluations / outer iterations per stage (3 syncs per phase)
         self.loss_trace = None      # set to a list to record (stage, loss) of every closure evaluation (host sync per eval)
@@ -76,11 +81,12 @@ class MotionOptimizer():
         # optimisation variables (motion_optimizer.py:70-84)
         self.pose_prior = pose_prior
         self.latent_pose_dim = pose_prior.latentD
-        self.latent_pose = torch.zeros((B, T, self.latent_pose_dim), device=device)
-        self.trans = torch.zeros((B, T, 3), device=device)
-        self.root_orient = torch.zeros((B, T, 3), device=device)
+        # stage-1/2 variables back to back in one allocation, in the order the stage-2 optimiser lists them (stage 1 = a prefix):
+        # the fused L-BFGS then works on the flat buffer without copying (humor_amd/lbfgs.py)
+        from .lbfgs import flat_arena
+        _, (self.trans, self.root_orient, self.betas, self.latent_pose) = flat_arena(
+            [(B, T, 3), (B, T, 3), (B, num_betas), (B, T, self.latent_pose_dim)], device)
         self.root_orient[:, :, 0] = np.pi
-        self.betas = torch.zeros((B, num_betas), device=device)
         self.motion_prior = motion_prior
         self.init_motion_prior = init_motion_prior
         self.latent_motion = None
@@ -242,6 +248,12 @@ class MotionOptimizer():
             print('LOSS: %f' % loss.item(), {k: float(v) for k, v in stats.items()})
         return loss
 
+    def _make_lbfgs(self, params, lr, max_iter):
+        if self.lbfgs_impl == 'torch':
+            return torch.optim.LBFGS(params, max_iter=max_iter, lr=lr, line_search_fn=LINE_SEARCH)
+        from .lbfgs import LBFGS
+        return LBFGS(params, max_iter=max_iter, lr=lr, line_search_fn=LINE_SEARCH, _lib_override=self.fit_bm._lib)
+
     # ------------------------------------------------------------------------------------------------
     def initialize(self, observed_data):
         '''Floor from the observation; depth from the focal length and bone-length ratio (motion_optimizer.py:141-199).'''
@@ -290,7 +302,7 @@ class MotionOptimizer():
         self.betas.requires_grad = False
         self.latent_pose.requires_grad = False
         params = [self.trans, self.root_orient]
-        optim = torch.optim.LBFGS(params, max_iter=lbfgs_max_iter, lr=lr, line_search_fn=LINE_SEARCH)
+        optim = self._make_lbfgs(params, lr, lbfgs_max_iter)
         closure1 = self.make_closure(lambda: self._stage1_objective(obs_local, has_overlap), params, optim)
         self._mark(None)
         for i in range(num_iter[0]):
@@ -305,7 +317,7 @@ class MotionOptimizer():
         self.betas.requires_grad = True
         self.latent_pose.requires_grad = True
         params = [self.trans, self.root_orient, self.betas, self.latent_pose]
-        optim = torch.optim.LBFGS(params, max_iter=lbfgs_max_iter, lr=lr, line_search_fn=LINE_SEARCH)
+        optim = self._make_lbfgs(params, lr, lbfgs_max_iter)
         closure2 = self.make_closure(lambda: self._stage2_objective(obs_local, has_overlap), params, optim)
         self._mark(None)
         for i in range(num_iter[1]):
@@ -338,7 +350,7 @@ class MotionOptimizer():
                 self._save_dicts(stages_res_out, 'stage3_init_results_prior.npz', self.betas, rr['trans'], rr['root_orient'], cam_rr['pose_body'],
                                  contacts=rr.get('contacts'))
 
-        mk = lambda ps: torch.optim.LBFGS(ps, max_iter=lbfgs_max_iter, lr=lr, line_search_fn=LINE_SEARCH)
+        mk = lambda ps: self._make_lbfgs(ps, lr, lbfgs_max_iter)
         motion_optim = mk(motion_params)
         optim_frozen = optim_refine = None
         if self.stage3_tune_init_state:
@@ -450,20 +462,25 @@ class MotionOptimizer():
                                           self.cam2prior_root_height, cur_body_pose, self.betas, self.init_fidx)
                 vel_trans, vel_root = pd['trans'], pd['root_orient']
             tv, jv, rv = self.estimate_velocities(vel_trans, vel_root, cur_body_pose, self.betas, data_fps)
-        self.latent_motion.requires_grad = True
-        self.trans_vel = tv[:, :1].detach().clone().requires_grad_(True)
-        self.joints_vel = jv[:, :1].detach().clone().requires_grad_(True)
-        self.root_orient_vel = rv[:, :1].detach().clone().requires_grad_(True)
+        # stage-3 variables back to back in one allocation; the variables of the frozen-init phase (latent motion, betas, floor)
+        # come first so that both optimiser variable lists are contiguous (the fused L-BFGS binds them without copying)
+        from .lbfgs import flat_arena
+        src = [self.latent_motion, self.betas] + ([self.floor_plane] if self.optim_floor else []) + \
+              [self.trans[:, :1], self.root_orient[:, :1], self.latent_pose[:, :1], tv[:, :1], jv[:, :1], rv[:, :1]]
+        _, views = flat_arena([tuple(t.shape) for t in src], src[0].device)
+        with torch.no_grad():
+            for v, t in zip(views, src):
+                v.copy_(t.detach())
+        for v in views:
+            v.requires_grad_(True)
+        it = iter(views)
+        self.latent_motion, self.betas = next(it), next(it)
+        if self.optim_floor:
+            self.floor_plane = next(it)
+        self.trans, self.root_orient, self.latent_pose = next(it), next(it), next(it)
+        self.trans_vel, self.joints_vel, self.root_orient_vel = next(it), next(it), next(it)
         prior_opt_params = [self.trans_vel, self.joints_vel, self.root_orient_vel]
-        self.trans = self.trans[:, :1].detach().clone().requires_grad_(True)
-        self.root_orient = self.root_orient[:, :1].detach().clone().requires_grad_(True)
-        self.latent_pose = self.latent_pose[:, :1].detach().clone().requires_grad_(True)
-        if self.optim_floor:
-            self.floor_plane.requires_grad = True
-        self.betas.requires_grad = True
-        motion_params = [self.trans, self.root_orient, self.latent_pose, self.betas, self.latent_motion] + prior_opt_params
-        if self.optim_floor:
-            motion_params.append(self.floor_plane)
+        motion_params = views
 
         return motion_params, prior_opt_params
 

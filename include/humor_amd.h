@@ -245,6 +245,16 @@ int ha_chamfer_forward(int b, int n, const float* xyz1, int m, const float* xyz2
 int ha_chamfer_backward(int b, int n, const float* xyz1, int m, const float* xyz2, const float* grad_dist1, const int32_t* idx1,
                         const float* grad_dist2, const int32_t* idx2, float* grad_xyz1, float* grad_xyz2, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * L-BFGS direction (the two-loop recursion of torch.optim.LBFGS.step, which the reference drives from
+ * humor/fitting/motion_optimizer.py:233-254, 284-310, 461-512) in coefficient form: given the Gram matrix
+ * G [2h,2h] of the stored pairs M = [s slots (h rows) ; y slots (h rows)], Mg = M g [2h] and the initial
+ * Hessian scale, writes coef [2h] such that  d = M^T coef - h_diag * g.  `order` (HOST, num_old entries) lists the
+ * physical slots from the oldest to the newest pair; slots not listed get coefficient 0.  hist <= 128.
+ * ---------------------------------------------------------------------------------------------- */
+int ha_lbfgs_coeffs(int hist, int num_old, const int32_t* order, const float* G, const float* Mg, float h_diag, float* coef,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

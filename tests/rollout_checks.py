@@ -313,11 +313,18 @@ def check_rot6d(lib, device, n=2000, seed=0):
     b2 = torch.nn.functional.normalize(a2 - torch.einsum('bi,bi->b', b1, a2).unsqueeze(-1) * b1)
     R_ref = torch.stack((b1, b2, torch.cross(b1, b2, dim=1)), dim=-1)
     Rm = ops.rot6d_to_rotmat(x, _lib_override=lib)
-    assert (Rm.detach().cpu() - R_ref).abs().max().item() < 1e-6
+    # Gram-Schmidt amplifies rounding by 1 / sin(angle(a1, a2)) (and the gradient by its square): rows are judged at their conditioning
+    sin = (a2 - torch.einsum('bi,bi->b', b1, a2).unsqueeze(-1) * b1).norm(dim=1).detach() / a2.norm(dim=1).detach()
+    cond = (1.0 / sin.clamp(min=1e-6))
+    e = (Rm.detach().cpu() - R_ref).abs().amax(dim=(1, 2))
+    assert (e <= 1e-6 * cond).all(), (e / cond).max().item()
     gR = torch.randn(n, 3, 3, generator=g)
     ga = torch.autograd.grad((Rm * gR.to(device)).sum(), x)[0].cpu()
     ga_ref = torch.autograd.grad((R_ref * gR).sum(), xc)[0]
-    assert (ga - ga_ref).abs().max().item() < 1e-4 * max(1.0, ga_ref.abs().max().item())
+    well = sin > 0.1
+    eg = (ga - ga_ref).abs().amax(dim=1) / ga_ref.abs().amax(dim=1).clamp(min=1.0)
+    assert eg[well].max().item() < 1e-4, eg[well].max().item()
+    assert (eg <= 1e-4 * cond * cond).all()
     return R_ref
 
 
