@@ -43,6 +43,24 @@ class FitArgs(C.Structure):
                 ('g_prev_tail', C.c_void_p), ('g_prev_betas', C.c_void_p), ('g_prev_floor', C.c_void_p), ('partial', C.c_void_p)]
 
 
+class FitPreArgs(C.Structure):
+    """ha_fit_pre_args (include/humor_amd.h)."""
+    _fields_ = [('B', C.c_int)] + [(n, C.c_void_p) for n in (
+        'floor', 'trans0', 'root0', 'pose0', 'jcam', 'trans_vel', 'joints_vel', 'root_orient_vel',
+        'past_in', 'trans_p', 'root_p', 'joints_p', 'c2p_R', 'c2p_t', 'root_height',
+        'g_past_in', 'g_trans_p', 'g_root_p', 'g_joints_p', 'g_c2p_R', 'g_c2p_t', 'g_root_height',
+        'g_floor', 'g_trans0', 'g_root0', 'g_pose0', 'g_jcam', 'g_trans_vel', 'g_joints_vel', 'g_root_orient_vel')]
+
+
+class RolloutPostArgs(C.Structure):
+    """ha_rollout_post_args (include/humor_amd.h)."""
+    _fields_ = [('B', C.c_int), ('S', C.c_int)] + [(n, C.c_void_p) for n in (
+        'world', 'trans0', 'root0', 'pose0', 'joints0', 'c2p_R', 'c2p_t',
+        'trans', 'root_orient', 'pose_body', 'joints', 'contacts_conf', 'contacts', 'cam_trans', 'cam_root_orient',
+        'g_trans', 'g_root_orient', 'g_pose_body', 'g_joints', 'g_contacts_conf', 'g_cam_trans', 'g_cam_root_orient',
+        'g_world', 'g_trans0', 'g_root0', 'g_pose0', 'g_joints0', 'g_c2p_R', 'g_c2p_t', 'partial')]
+
+
 _SIGS = {
     'ha_last_error': (C.c_char_p, []),
     'ha_abi_version': (C.c_int, []),
@@ -69,6 +87,10 @@ _SIGS = {
     'ha_humor_rollout_sample': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_humor_rollout_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_fit_loss': (C.c_int, [C.POINTER(FitArgs), C.c_void_p]),
+    'ha_fit_pre_forward': (C.c_int, [C.POINTER(FitPreArgs), C.c_void_p]),
+    'ha_fit_pre_backward': (C.c_int, [C.POINTER(FitPreArgs), C.c_void_p]),
+    'ha_rollout_post_forward': (C.c_int, [C.POINTER(RolloutPostArgs), C.c_void_p]),
+    'ha_rollout_post_backward': (C.c_int, [C.POINTER(RolloutPostArgs), C.c_void_p]),
     'ha_lbfgs_coeffs': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     'ha_chamfer_forward': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]),
     'ha_chamfer_backward': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),

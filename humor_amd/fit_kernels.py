@@ -87,3 +87,103 @@ class FusedFit(torch.autograd.Function):
         scaled = ctx.flat[:ctx.ng] * g_loss           # one launch for all inputs
         out = [None if v is None else scaled[v[0]:v[0] + v[1]].view(v[2]) for v in ctx.views]
         return (None, None) + tuple(out)
+
+
+class RolloutPost(torch.autograd.Function):
+    """(world [B,S,348], trans0 [B,3], root0 [B,3], pose0 [B,63], joints0 [B,22,3], c2p_R [B,3,3] | None, c2p_t [B,3] | None) ->
+    (trans, root_orient, pose_body [B,T,.], joints [B,T,22,3], contacts_conf, contacts [B,T,22], cam_trans, cam_root_orient [B,T,3] | None):
+    ha_rollout_post_forward / _backward (include/humor_amd.h), one launch per direction (+ a per-sequence reduction)."""
+
+    @staticmethod
+    def forward(ctx, lib, world, trans0, root0, pose0, joints0, c2p_R, c2p_t):
+        c = lambda x: None if x is None else x.detach().contiguous().float()
+        world, trans0, root0, pose0, joints0, c2p_R, c2p_t = (c(x) for x in (world, trans0, root0, pose0, joints0, c2p_R, c2p_t))
+        B, S = world.shape[0], world.shape[1]
+        T, dev = S + 1, world.device
+        new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        out = dict(trans=new(B, T, 3), root_orient=new(B, T, 3), pose_body=new(B, T, 63), joints=new(B, T, 22, 3),
+                   contacts_conf=new(B, T, 22), contacts=new(B, T, 22))
+        cam = c2p_R is not None
+        if cam:
+            out.update(cam_trans=new(B, T, 3), cam_root_orient=new(B, T, 3))
+        a = _lib.RolloutPostArgs()
+        a.B, a.S = B, S
+        for k, v in dict(world=world, trans0=trans0, root0=root0, pose0=pose0, joints0=joints0, c2p_R=c2p_R, c2p_t=c2p_t, **out).items():
+            if v is not None:
+                setattr(a, k, v.data_ptr())
+        lib.call('ha_rollout_post_forward', C.byref(a), _lib.stream_ptr(world))
+        ctx.lib, ctx.cam, ctx.dims = lib, cam, (B, S)
+        ctx.save_for_backward(world, trans0, root0, c2p_R, c2p_t, out['root_orient'], out['contacts_conf'])
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(out['contacts'])
+        return (out['trans'], out['root_orient'], out['pose_body'], out['joints'], out['contacts_conf'], out['contacts'],
+                out.get('cam_trans'), out.get('cam_root_orient'))
+
+    @staticmethod
+    def backward(ctx, g_trans, g_root, g_pose, g_joints, g_conf, _g_lab, g_ct, g_cr):
+        world, trans0, root0, c2p_R, c2p_t, root_orient, conf = ctx.saved_tensors
+        B, S = ctx.dims
+        T, dev = S + 1, world.device
+        new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        gw, gt0, gr0, gp0, gj0 = new(B, S, 348), new(B, 3), new(B, 3), new(B, 63), new(B, 22, 3)
+        gR, gt = (new(B, 3, 3), new(B, 3)) if ctx.cam else (None, None)
+        partial = new(B * T, 15)
+        a = _lib.RolloutPostArgs()
+        a.B, a.S = B, S
+        keep = []
+        c = lambda x: None if x is None else x.contiguous().float()
+        fields = dict(world=world, trans0=trans0, root0=root0, c2p_R=c2p_R, c2p_t=c2p_t, root_orient=root_orient, contacts_conf=conf,
+                      g_trans=c(g_trans), g_root_orient=c(g_root), g_pose_body=c(g_pose), g_joints=c(g_joints), g_contacts_conf=c(g_conf),
+                      g_cam_trans=c(g_ct), g_cam_root_orient=c(g_cr), g_world=gw, g_trans0=gt0, g_root0=gr0, g_pose0=gp0, g_joints0=gj0,
+                      g_c2p_R=gR, g_c2p_t=gt, partial=partial)
+        for k, v in fields.items():
+            if v is not None:
+                keep.append(v)
+                setattr(a, k, v.data_ptr())
+        ctx.lib.call('ha_rollout_post_backward', C.byref(a), _lib.stream_ptr(world))
+        return None, gw, gt0, gr0, gp0, gj0, gR, gt
+
+
+class FitPre(torch.autograd.Function):
+    """(floor [B,3], trans0 [B,3], root0 [B,3], pose0 [B,63], jcam [B,22,3], trans_vel [B,3], joints_vel [B,22,3], root_orient_vel [B,3])
+    -> (past_in [B,339], trans_p [B,3], root_p [B,3], joints_p [B,22,3], c2p_R [B,3,3], c2p_t [B,3], root_height [B,1]):
+    ha_fit_pre_forward / _backward (include/humor_amd.h)."""
+    IN = ['floor', 'trans0', 'root0', 'pose0', 'jcam', 'trans_vel', 'joints_vel', 'root_orient_vel']
+
+    @staticmethod
+    def forward(ctx, lib, *ins):
+        ins = [x.detach().contiguous().float() for x in ins]
+        B, dev = ins[0].shape[0], ins[0].device
+        new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        out = dict(past_in=new(B, 339), trans_p=new(B, 3), root_p=new(B, 3), joints_p=new(B, 22, 3), c2p_R=new(B, 3, 3), c2p_t=new(B, 3),
+                   root_height=new(B, 1))
+        a = _lib.FitPreArgs()
+        a.B = B
+        for k, v in zip(FitPre.IN, ins):
+            setattr(a, k, v.data_ptr())
+        for k, v in out.items():
+            setattr(a, k, v.data_ptr())
+        lib.call('ha_fit_pre_forward', C.byref(a), _lib.stream_ptr(ins[0]))
+        ctx.lib = lib
+        ctx.save_for_backward(*ins)
+        ctx.set_materialize_grads(False)
+        return tuple(out.values())
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ins = ctx.saved_tensors
+        a = _lib.FitPreArgs()
+        a.B = ins[0].shape[0]
+        keep = []
+        for k, v in zip(FitPre.IN, ins):
+            setattr(a, k, v.data_ptr())
+        for k, g in zip(('g_past_in', 'g_trans_p', 'g_root_p', 'g_joints_p', 'g_c2p_R', 'g_c2p_t', 'g_root_height'), gs):
+            if g is not None:
+                g = g.contiguous().float()
+                keep.append(g)
+                setattr(a, k, g.data_ptr())
+        outs = [torch.empty_like(x) for x in ins]
+        for k, v in zip(FitPre.IN, outs):
+            setattr(a, 'g_' + k, v.data_ptr())
+        ctx.lib.call('ha_fit_pre_backward', C.byref(a), _lib.stream_ptr(ins[0]))
+        return (None,) + tuple(outs)

@@ -344,7 +344,7 @@ class HumorModel(nn.Module):
         return self._net_handles[key][1]
 
     def roll_out(self, x_past, init_input_dict, num_steps, use_mean=False, z_seq=None, return_prior=False, gender=None,
-                 betas=None, return_z=False, canonicalize_input=False, uncanonicalize_output=False, eps_seq=None):
+                 betas=None, return_z=False, canonicalize_input=False, uncanonicalize_output=False, eps_seq=None, return_world=False):
         '''
         Rolls the model out from the initial state (humor_model.py:785-1017): with the given latent sequence (differentiable,
         the fitting path) or, with z_seq=None, sampling z_t = mu_t + eps_t * sigma_t from the conditional prior at every step
@@ -382,6 +382,9 @@ class HumorModel(nn.Module):
         if canonicalize_input and uncanonicalize_output:
             from .frames import uncanonicalize_world
             world = uncanonicalize_world(world, *uncanon)
+        if return_world:
+            # the undivided [B, S, 348] world-frame state (what the fused post-processing kernel reads) instead of the dict
+            return (world, (pm, pv)) if return_prior else world
         # one split (views forward, a single cat backward) instead of one slice + zero-fill + add per output
         dims = list(self.delta_output_dim_list)
         rest = world.size(2) - sum(dims)

@@ -35,7 +35,7 @@ class MotionOptimizer():
                  motion_prior=None, init_motion_prior=None, optim_floor=False, camera_matrix=None, robust_loss_type='none',
                  robust_tuning_const=4.6851, joint2d_sigma=100, stage3_tune_init_state=True, stage3_tune_init_num_frames=15,
                  stage3_tune_init_freeze_start=30, stage3_tune_init_freeze_end=50, stage3_contact_refine_only=False,
-                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs=False, fused_loss=True, lbfgs='fused'):
+                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs=False, fused_loss=True, lbfgs='fused', fused_post=True, fused_pre=True):
         B, T = batch_size, seq_len
         self.device = device
         self.batch_size, self.seq_len = B, T
@@ -62,6 +62,8 @@ class MotionOptimizer():
         if lbfgs not in ('fused', 'torch'):
             raise ValueError("lbfgs must be 'fused' or 'torch'")
         self.lbfgs_impl = lbfgs
+        self.fused_post = bool(fused_post)
+        self.fused_pre = bool(fused_pre)
         self.closure_evals = 0
         self.stage_profile = None   # set to {} before run(): wall time / closure evaluations / outer iterations per stage (3 syncs per phase)
         self.loss_trace = None      # set to a list to record (stage, loss) of every closure evaluation (host sync per eval)
@@ -512,19 +514,32 @@ class MotionOptimizer():
         trans, root_orient, betas = L(self.trans), L(self.root_orient), L(self.betas)
         cur_body_pose = self.latent2pose(L(self.latent_pose))
         floor = L(self.floor_plane) if self.optim_floor else None
-        cam2prior = None
+        cam2prior, pre = None, None
+        local_prior_params = [L(p) for p in prior_opt_params]
+        lib = self.fit_bm._lib
         if self.optim_floor:
             cam_smpl, _ = self.smpl_results(trans, root_orient, cur_body_pose, betas)
-            cam2prior = frames.compute_cam2prior(floor, trans[:, 0], ops.batch_rodrigues(root_orient[:, 0], _lib_override=self.fit_bm._lib),
-                                                 cam_smpl['joints3d'][:, 0])
+            if self.fused_pre and (trans.is_cuda or (lib is not None and lib.emulator)):
+                # cam2prior, the key frame in the prior frame and the initial roll-out state in one kernel (csrc/fitpre.hip); the
+                # prior-frame joints are the rigid image of the camera-frame ones: this is the only frame-0 SMPL evaluation
+                from . import _lib as _libmod
+                from .fit_kernels import FitPre
+                B = trans.size(0)
+                o = FitPre.apply(lib if lib is not None else _libmod.get_lib(), floor, trans.reshape(B, 3), root_orient.reshape(B, 3),
+                                 cur_body_pose.reshape(B, J_BODY * 3), cam_smpl['joints3d'].reshape(B, 22, 3), local_prior_params[0].reshape(B, 3),
+                                 local_prior_params[1].reshape(B, 22, 3), local_prior_params[2].reshape(B, 3))
+                pre = {'past_in': o[0], 'trans': o[1].reshape(B, 1, 3), 'root_orient': o[2].reshape(B, 1, 3), 'joints': o[3].reshape(B, 1, 22, 3)}
+                cam2prior = (o[4], o[5], o[6])
+            else:
+                cam2prior = frames.compute_cam2prior(floor, trans[:, 0], ops.batch_rodrigues(root_orient[:, 0], _lib_override=lib),
+                                                     cam_smpl['joints3d'][:, 0])
             if self.shard is None:
                 self.cam2prior_R, self.cam2prior_t, self.cam2prior_root_height = cam2prior
         latent_motion = L(self.latent_motion)
         if tune_phase:
             latent_motion = latent_motion[:, :(n_init - 1)]
-        local_prior_params = [L(p) for p in prior_opt_params]
         rr, cam_rr = self.rollout_latent_motion(trans, root_orient, cur_body_pose, betas, local_prior_params, latent_motion,
-                                                return_prior=self.cond_prior, fit_gender=fit_gender, cam2prior=cam2prior)
+                                                return_prior=self.cond_prior, fit_gender=fit_gender, cam2prior=cam2prior, pre=pre)
         # the reference encodes the rolled-out poses with VPoser on every evaluation (motion_optimizer.py:571) but only the pose
         # prior reads the result, and no stage-3 configuration weights it: skipped when its weight is zero (same loss value)
         pose_prior_on = self.fitting_loss.loss_weights['pose_prior'] > 0.0
@@ -646,7 +661,7 @@ class MotionOptimizer():
 
     def rollout_latent_motion(self, trans, root_orient, body_pose, betas, prior_opt_params, latent_motion, return_prior=False,
                               return_vel=False, fit_gender='neutral', use_mean=False, num_steps=-1, canonicalize_input=False,
-                              cam2prior=None):
+                              cam2prior=None, pre=None):
         '''
         Initial SMPL state + latent sequence -> full SMPL sequence through the motion prior
         (motion_optimizer.py:876-1019).  Returns (prior-frame dict, camera-frame dict).
@@ -657,17 +672,40 @@ class MotionOptimizer():
         B, Tm1 = trans.size(0), latent_motion.size(1)
         cam2prior = cam2prior if cam2prior is not None else ((self.cam2prior_R, self.cam2prior_t, self.cam2prior_root_height)
                                                               if self.optim_floor else None)
-        if self.optim_floor:
-            pd = self.apply_cam2prior({'trans': trans, 'root_orient': root_orient}, cam2prior[0], cam2prior[1], cam2prior[2],
-                                      body_pose, betas, self.init_fidx[:B])
-            trans, root_orient = pd['trans'], pd['root_orient']
         trans_vel, joints_vel, root_orient_vel = prior_opt_params
-        smpl0, _ = self.smpl_results(trans, root_orient, body_pose, betas)      # one frame per sequence (B rows)
-        joints = smpl0['joints3d']
-        R_root = ops.batch_rodrigues(root_orient.reshape(-1, 3), _lib_override=lib).reshape(B, 9)
-        R_body = ops.batch_rodrigues(body_pose.reshape(-1, 3), _lib_override=lib).reshape(B, J_BODY * 9)
-        past_in = torch.cat([trans.reshape(B, 3), trans_vel.reshape(B, 3), R_root, root_orient_vel.reshape(B, 3), R_body,
-                             joints.reshape(B, -1), joints_vel.reshape(B, -1)], dim=1)
+        if pre is not None:
+            # prior-frame key frame and initial state already assembled by ha_fit_pre (see _stage3_objective)
+            trans, root_orient, joints, past_in = pre['trans'], pre['root_orient'], pre['joints'], pre['past_in']
+        else:
+            if self.optim_floor:
+                pd = self.apply_cam2prior({'trans': trans, 'root_orient': root_orient}, cam2prior[0], cam2prior[1], cam2prior[2],
+                                          body_pose, betas, self.init_fidx[:B])
+                trans, root_orient = pd['trans'], pd['root_orient']
+            smpl0, _ = self.smpl_results(trans, root_orient, body_pose, betas)      # one frame per sequence (B rows)
+            joints = smpl0['joints3d']
+            R_root = ops.batch_rodrigues(root_orient.reshape(-1, 3), _lib_override=lib).reshape(B, 9)
+            R_body = ops.batch_rodrigues(body_pose.reshape(-1, 3), _lib_override=lib).reshape(B, J_BODY * 9)
+            past_in = torch.cat([trans.reshape(B, 3), trans_vel.reshape(B, 3), R_root, root_orient_vel.reshape(B, 3), R_body,
+                                 joints.reshape(B, -1), joints_vel.reshape(B, -1)], dim=1)
+        fused_post = self.fused_post and not return_vel and (past_in.is_cuda or (lib is not None and lib.emulator)) and getattr(self.motion_prior, 'pred_contacts', False)
+        if fused_post:
+            # everything between the roll-out and the SMPL evaluations in ONE kernel per direction (csrc/fitpost.hip): R -> axis-angle,
+            # frame 0 prepended, contact confidences / labels, and the camera-frame copy of the root trajectory
+            from .fit_kernels import RolloutPost
+            from . import _lib as _libmod
+            res = self.motion_prior.roll_out(past_in.unsqueeze(1), None, Tm1, z_seq=latent_motion, return_prior=return_prior,
+                                             canonicalize_input=canonicalize_input, return_world=True)
+            world, prior_out = res if return_prior else (res, None)
+            c2p_R = cam2prior[0] if self.optim_floor else None
+            c2p_t = cam2prior[1] if self.optim_floor else None
+            o = RolloutPost.apply(lib if lib is not None else _libmod.get_lib(), world, trans.reshape(B, 3), root_orient.reshape(B, 3),
+                                  body_pose.reshape(B, J_BODY * 3), joints.reshape(B, 22, 3), c2p_R, c2p_t)
+            out = {'trans': o[0], 'root_orient': o[1], 'pose_body': o[2], 'joints': o[3], 'contacts_conf': o[4], 'contacts': o[5]}
+            if return_prior:
+                out['cond_prior'] = prior_out
+            cam = {'trans': o[6], 'root_orient': o[7]} if self.optim_floor else {'trans': o[0], 'root_orient': o[1]}
+            cam['pose_body'] = out['pose_body']
+            return out, cam
         res = self.motion_prior.roll_out(past_in.unsqueeze(1), None, Tm1, z_seq=latent_motion, return_prior=return_prior,
                                          canonicalize_input=canonicalize_input)
         pred, prior_out = res if return_prior else (res, None)

@@ -233,6 +233,55 @@ typedef struct ha_fit_args {
 int ha_fit_loss(const ha_fit_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Stage-3 set-up of one closure evaluation with an optimised floor: compute_cam2prior (humor/fitting/fitting_utils.py:149-190),
+ * the forward apply_cam2prior of the key frame (humor/fitting/motion_optimizer.py:678-742) and the initial roll-out state
+ * (motion_optimizer.py:905-942), from ONE camera-frame SMPL evaluation (the prior-frame joints are its rigid image).
+ *   inputs  floor [B,3] (normal * offset), trans0 / root0 [B,3] (camera frame, axis-angle), pose0 [B,63], jcam [B,22,3] camera-
+ *           frame SMPL joints of frame 0, trans_vel [B,3], joints_vel [B,22,3], root_orient_vel [B,3]
+ *   outputs past_in [B,339], trans_p / root_p [B,3] (prior frame), joints_p [B,22,3], c2p_R [B,9], c2p_t [B,3], root_height [B]
+ * Backward: g_* of the outputs may be NULL (= zero); every input gradient is fully written.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ha_fit_pre_args {
+  int B;
+  const float* floor; const float* trans0; const float* root0; const float* pose0; const float* jcam;
+  const float* trans_vel; const float* joints_vel; const float* root_orient_vel;
+  float* past_in; float* trans_p; float* root_p; float* joints_p; float* c2p_R; float* c2p_t; float* root_height;
+  const float* g_past_in; const float* g_trans_p; const float* g_root_p; const float* g_joints_p; const float* g_c2p_R;
+  const float* g_c2p_t; const float* g_root_height;
+  float* g_floor; float* g_trans0; float* g_root0; float* g_pose0; float* g_jcam; float* g_trans_vel; float* g_joints_vel;
+  float* g_root_orient_vel;
+} ha_fit_pre_args;
+int ha_fit_pre_forward(const ha_fit_pre_args* args, void* stream);
+int ha_fit_pre_backward(const ha_fit_pre_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Roll-out post-processing (replaces the op chain of MotionOptimizer.rollout_latent_motion after roll_out,
+ * humor/fitting/motion_optimizer.py:950-1019, and apply_cam2prior(inverse=True), :678-742): R -> axis-angle of the root and
+ * body rotations, the optimised frame 0 prepended (T = S + 1 frames), contact logits -> confidences / labels on the 22 SMPL
+ * joints (CONTACT_INDS, amass_utils.py:21-23; frame 0 repeats frame 1), and the root trajectory mapped back into the camera
+ * frame (cam_root = aa(R^T rodrigues(root)), cam_trans = R^T (trans - trans_0) - t) when c2p_R / c2p_t are given.
+ * The same struct serves both directions; gradient inputs may be NULL (= zero), every gradient output is fully written.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ha_rollout_post_args {
+  int B, S;
+  const float* world;                               /* [B,S,348] world-frame roll-out output */
+  const float* trans0; const float* root0; const float* pose0; const float* joints0;   /* frame 0: [B,3] [B,3] [B,63] [B,22,3] */
+  const float* c2p_R; const float* c2p_t;           /* [B,9], [B,3] or NULL */
+  /* forward outputs (inputs of the backward call) */
+  float* trans; float* root_orient; float* pose_body; float* joints;   /* [B,T,3] [B,T,3] [B,T,63] [B,T,22,3] */
+  float* contacts_conf; float* contacts;            /* [B,T,22] */
+  float* cam_trans; float* cam_root_orient;         /* [B,T,3] or NULL */
+  /* backward: gradients of the outputs ... */
+  const float* g_trans; const float* g_root_orient; const float* g_pose_body; const float* g_joints; const float* g_contacts_conf;
+  const float* g_cam_trans; const float* g_cam_root_orient;
+  /* ... and of the inputs */
+  float* g_world; float* g_trans0; float* g_root0; float* g_pose0; float* g_joints0; float* g_c2p_R; float* g_c2p_t;
+  float* partial;                                   /* workspace [B*T, 15] */
+} ha_rollout_post_args;
+int ha_rollout_post_forward(const ha_rollout_post_args* args, void* stream);
+int ha_rollout_post_backward(const ha_rollout_post_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Chamfer distance (replaces humor/utils/chamfer_distance/chamfer_distance.cu: ChamferDistanceKernelLauncher :140-157 and
  * ChamferDistanceGradKernelLauncher :189-208, i.e. chamfer_distance.py's cd.forward_cuda / cd.backward_cuda).
  *   xyz1 [b,n,3], xyz2 [b,m,3];  dist1[b,n] / idx1[b,n]: squared distance to, and index of, the nearest point of xyz2 for every

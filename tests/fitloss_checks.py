@@ -90,3 +90,124 @@ def check_fused_vs_terms(lib, device, B=3, T=7, seed=0):
                 worst = max(worst, e)
                 assert e <= 1e-4, (kind, halo, cond, k, e)
     return worst
+
+
+def check_rollout_post(lib, device, B=3, S=6, seed=0, cam=True):
+    """ha_rollout_post (one kernel per direction) against the op-by-op chain it replaces in MotionOptimizer.rollout_latent_motion
+    (R -> axis-angle kernels, cats, sigmoid / index_add contacts, apply_cam2prior(inverse=True)): every output and every gradient."""
+    from humor_amd import ops
+    from humor_amd.fit_kernels import RolloutPost
+    from humor_amd.tables import CONTACT_INDS
+    from oracle import lbs_restated as L
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: sc * torch.randn(*s, generator=g)
+    T = S + 1
+    world = r(B, S, 348, sc=0.5)
+    world[:, :, 6:15] = L.batch_rodrigues(r(B * S, 3, sc=1.5)).reshape(B, S, 9)
+    world[:, :, 18:207] = L.batch_rodrigues(r(B * S * 21, 3, sc=0.8)).reshape(B, S, 189)
+    c2p_R = L.batch_rodrigues(r(B, 3, sc=1.0)).reshape(B, 3, 3) if cam else None
+    base = dict(world=world, trans0=r(B, 3), root0=r(B, 3, sc=0.8), pose0=r(B, 63, sc=0.4), joints0=r(B, 22, 3), c2p_R=c2p_R, c2p_t=r(B, 3) if cam else None)
+
+    def leaves():
+        return {k: (None if v is None else v.clone().to(device).requires_grad_(True)) for k, v in base.items()}
+
+    def reference(x):
+        aa_root = ops.rotation_matrix_to_angle_axis(x['world'][:, :, 6:15].reshape(-1, 3, 3), _lib_override=lib).reshape(B, S, 3)
+        aa_body = ops.rotation_matrix_to_angle_axis(x['world'][:, :, 18:207].reshape(-1, 3, 3), _lib_override=lib).reshape(B, S, 63)
+        trans = torch.cat([x['trans0'].reshape(B, 1, 3), x['world'][:, :, 0:3]], 1)
+        root = torch.cat([x['root0'].reshape(B, 1, 3), aa_root], 1)
+        pose = torch.cat([x['pose0'].reshape(B, 1, 63), aa_body], 1)
+        joints = torch.cat([x['joints0'].reshape(B, 1, 22, 3), x['world'][:, :, 207:273].reshape(B, S, 22, 3)], 1)
+        conf9 = torch.sigmoid(x['world'][:, :, 339:348])
+        idx = torch.as_tensor(CONTACT_INDS, dtype=torch.long, device=device)
+        conf = torch.zeros(B, S, 22, device=device).index_add(2, idx, conf9)
+        lab = torch.zeros(B, S, 22, device=device).index_add(2, idx, (conf9 > 0.5).float())
+        conf, lab = torch.cat([conf[:, :1], conf], 1), torch.cat([lab[:, :1], lab], 1)
+        ct = cr = None
+        if cam:
+            Rm = ops.batch_rodrigues(root.reshape(-1, 3), _lib_override=lib).reshape(B, T, 3, 3)
+            Rl = x['c2p_R'].unsqueeze(1).transpose(3, 2)
+            newR = (Rl.unsqueeze(-1) * Rm.unsqueeze(-3)).sum(-2)
+            cr = ops.rotation_matrix_to_angle_axis(newR.reshape(-1, 3, 3), _lib_override=lib).reshape(B, T, 3)
+            ct = (Rl * (trans - trans[:, 0:1]).unsqueeze(-2)).sum(-1) - x['c2p_t'].unsqueeze(1)
+        return trans, root, pose, joints, conf, lab, ct, cr
+
+    xa, xb = leaves(), leaves()
+    oa = RolloutPost.apply(lib, *[xa[k] for k in ('world', 'trans0', 'root0', 'pose0', 'joints0', 'c2p_R', 'c2p_t')])
+    ob = reference(xb)
+    names = ['trans', 'root_orient', 'pose_body', 'joints', 'contacts_conf', 'contacts', 'cam_trans', 'cam_root_orient']
+    la = lb = 0.0
+    for i, (n, a, b_) in enumerate(zip(names, oa, ob)):
+        if b_ is None:
+            assert a is None, n
+            continue
+        assert a.shape == b_.shape, (n, a.shape, b_.shape)
+        assert (a.detach() - b_.detach()).abs().max().item() < 1e-6, (n, (a.detach() - b_.detach()).abs().max().item())
+        if n != 'contacts':
+            wgt = CC.det_weights(a.shape, 0.1 * (i + 1)).to(device)
+            la, lb = la + (a * wgt).sum(), lb + (b_ * wgt).sum()
+    ks = [k for k in base if base[k] is not None]
+    ga = torch.autograd.grad(la, [xa[k] for k in ks])
+    gb = torch.autograd.grad(lb, [xb[k] for k in ks])
+    worst = 0.0
+    for k, p, q in zip(ks, ga, gb):
+        e = (p - q).abs().max().item() / max(1.0, q.abs().max().item())
+        worst = max(worst, e)
+        assert e < 1e-5, (k, e)
+    return worst
+
+
+def check_fit_pre(lib, device, npz, B=3, seed=0):
+    """ha_fit_pre (cam2prior + key frame in the prior frame + initial roll-out state from ONE SMPL evaluation) against the op chain it
+    replaces, which evaluates SMPL three times (compute_cam2prior -> apply_cam2prior -> initial joints): every output and the
+    gradients w.r.t. floor, trans, root orientation, body pose, betas and the initial velocities."""
+    from humor_amd import frames, ops
+    from humor_amd.body_model import BodyModel
+    from humor_amd.fit_kernels import FitPre
+    from humor_amd.tables import KEYPT_VERTS
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: sc * torch.randn(*s, generator=g)
+    base = dict(floor=torch.tensor([[0.02, 0.5, 0.03]]) + r(B, 3, sc=0.03), trans0=torch.cat([r(B, 2, sc=0.3), 4.0 + r(B, 1, sc=0.3)], 1),
+                root0=torch.tensor([np.pi, 0.0, 0.0]) + r(B, 3, sc=0.3), pose0=r(B, 63, sc=0.3), betas=r(B, 16, sc=0.5),
+                trans_vel=r(B, 3, sc=0.3), joints_vel=r(B, 22, 3, sc=0.3), root_orient_vel=r(B, 3, sc=0.3))
+    bm = BodyModel(npz, num_betas=16, batch_size=B, use_vtx_selector=True, vertex_subset=KEYPT_VERTS, _lib_override=lib)
+    smpl_j = lambda tr, ro, po, be: bm(pose_body=po, pose_hand=None, betas=be, root_orient=ro, trans=tr).Jtr[:, :22]
+
+    def leaves():
+        return {k: v.clone().to(device).requires_grad_(True) for k, v in base.items()}
+
+    def fused(x):
+        jcam = smpl_j(x['trans0'], x['root0'], x['pose0'], x['betas'])
+        return FitPre.apply(lib, x['floor'], x['trans0'], x['root0'], x['pose0'], jcam, x['trans_vel'], x['joints_vel'], x['root_orient_vel'])
+
+    def chain(x):
+        jcam = smpl_j(x['trans0'], x['root0'], x['pose0'], x['betas'])
+        Rc = ops.batch_rodrigues(x['root0'], _lib_override=lib)
+        R, t, h = frames.compute_cam2prior(x['floor'], x['trans0'], Rc, jcam)
+        root_p = ops.rotation_matrix_to_angle_axis(torch.matmul(R, Rc), _lib_override=lib)
+        tr = torch.matmul(R, (x['trans0'] + t).unsqueeze(-1)).squeeze(-1)
+        cur_h = smpl_j(tr, root_p, x['pose0'], x['betas'])[:, 0, 2:3]
+        tr = tr + torch.cat([torch.zeros(B, 2, device=device), h - cur_h], 1)
+        joints_p = smpl_j(tr, root_p, x['pose0'], x['betas'])
+        R_root = ops.batch_rodrigues(root_p, _lib_override=lib).reshape(B, 9)
+        R_body = ops.batch_rodrigues(x['pose0'].reshape(-1, 3), _lib_override=lib).reshape(B, 189)
+        past_in = torch.cat([tr, x['trans_vel'], R_root, x['root_orient_vel'], R_body, joints_p.reshape(B, 66), x['joints_vel'].reshape(B, 66)], 1)
+        return past_in, tr, root_p, joints_p, R, t, h
+
+    xa, xb = leaves(), leaves()
+    oa, ob = fused(xa), chain(xb)
+    la = lb = 0.0
+    for i, (a, b_) in enumerate(zip(oa, ob)):
+        assert a.shape == b_.shape, (i, a.shape, b_.shape)
+        assert (a.detach() - b_.detach()).abs().max().item() < 2e-5, (i, (a.detach() - b_.detach()).abs().max().item())
+        wgt = CC.det_weights(a.shape, 0.3 * (i + 1)).to(device)
+        la, lb = la + (a * wgt).sum(), lb + (b_ * wgt).sum()
+    ks = list(base.keys())
+    ga = torch.autograd.grad(la, [xa[k] for k in ks])
+    gb = torch.autograd.grad(lb, [xb[k] for k in ks])
+    worst = 0.0
+    for k, p, q in zip(ks, ga, gb):
+        e = (p - q).abs().max().item() / max(1.0, q.abs().max().item())
+        worst = max(worst, e)
+        assert e < 2e-4, (k, e, q.abs().max().item())
+    return worst

@@ -156,3 +156,16 @@ def test_robust_weighting_matches_reference():
         b, wb = R.fitting_utils.apply_robust_weighting(res.clone().requires_grad_(True), kind, 4.6851)
         assert torch.equal(a, b) and torch.equal(wa, wb)
     assert torch.equal(FLM.robust_std(res), R.fitting_utils.robust_std(res))
+
+
+def test_emu_rollout_post_kernel_equals_op_chain(emu_lib):
+    """ha_rollout_post_forward / _backward on the SIMT emulator against the op-by-op chain of rollout_latent_motion."""
+    import fitloss_checks as FL
+    for cam in (True, False):
+        print('rollout post (cam=%s): worst relative gradient difference' % cam, FL.check_rollout_post(emu_lib, CPU, B=2, S=4, seed=3, cam=cam))
+
+
+def test_emu_fit_pre_kernel_equals_op_chain(emu_lib, smplh_npz):
+    """ha_fit_pre on the SIMT emulator against compute_cam2prior + apply_cam2prior + the initial-state assembly with three SMPL calls."""
+    import fitloss_checks as FL
+    print('fit pre: worst relative gradient difference', FL.check_fit_pre(emu_lib, CPU, smplh_npz, B=2, seed=1))

@@ -179,3 +179,43 @@ def test_points3d_chamfer_term_through_the_optimizer(gpu_lib, dev, smplh_npz):
                 opt.trans[b, t, c] -= sgn * eps
         fd = (vals[0] - vals[1]) / (2 * eps)
         assert abs(fd - gt[b, t, c].item()) <= 0.05 * max(1.0, abs(fd)), (b, t, c, fd, gt[b, t, c].item())
+
+
+def test_rollout_post_kernel_equals_op_chain(gpu_lib, dev, smplh_npz):
+    """Fused roll-out post-processing against the op chain it replaces, stand-alone (C4-like sizes) and through the stage-3 objective."""
+    import fitloss_checks as FL
+    from oracle import closure_cases as CC
+    for B, S, cam in ((3, 6, True), (8, 59, True), (2, 89, False)):
+        print('rollout post', B, S, cam, FL.check_rollout_post(gpu_lib, dev, B=B, S=S, seed=B, cam=cam))
+    B, T = 4, 12
+    case = CC.make_case('rgb', B, T, seed=5)
+    res = []
+    for fused in (True, False):
+        opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
+        opt.fused_post = fused
+        res.append(FC.eval_stage(opt, case, 2, dev))
+    assert abs(res[0]['loss'].item() - res[1]['loss'].item()) <= 1e-6 * abs(res[1]['loss'].item())
+    for k in res[0]:
+        if k != 'loss':
+            e = (res[0][k] - res[1][k]).abs().max().item() / max(1.0, res[1][k].abs().max().item())
+            assert e < 1e-4, (k, e)
+
+
+def test_fit_pre_kernel_equals_op_chain(gpu_lib, dev, smplh_npz):
+    """Fused stage-3 set-up against the op chain it replaces, stand-alone and through the stage-3 objective."""
+    import fitloss_checks as FL
+    from oracle import closure_cases as CC
+    for B, seed in ((3, 0), (32, 1)):
+        print('fit pre', B, FL.check_fit_pre(gpu_lib, dev, smplh_npz, B=B, seed=seed))
+    B, T = 4, 12
+    case = CC.make_case('rgb', B, T, seed=6)
+    res = []
+    for fused in (True, False):
+        opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
+        opt.fused_pre = fused
+        res.append(FC.eval_stage(opt, case, 2, dev))
+    assert abs(res[0]['loss'].item() - res[1]['loss'].item()) <= 1e-5 * abs(res[1]['loss'].item())
+    for k in res[0]:
+        if k != 'loss':
+            e = (res[0][k] - res[1][k]).abs().max().item() / max(1.0, res[1][k].abs().max().item())
+            assert e < 2e-4, (k, e)
