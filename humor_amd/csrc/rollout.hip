@@ -36,6 +36,7 @@ __device__ __forceinline__ size_t qoff(int c) { return (size_t)(c >> 2) * 128 + 
 
 // layer-kernel launch policy picked up by ha_humor_net_create (ha_tune_set "layer_spb" / "layer_nw"; 0 = default)
 int g_layer_spb = 0, g_layer_nw = 0, g_layer_finish = 1;
+int g_layer_hsum = 1;  // summed pre-activation write-back for the adjoint (ha_tune_set "layer_hsum")
 int g_gemm_rm = 0;    // row tiles per wave of the batched prior GEMM (ha_tune_set "gemm_rm"; 0 = by size)
 
 struct PackedLayer {
@@ -70,6 +71,7 @@ struct LayerTask {
   const float* gamma; const float* beta; int group; float inv_group;
   const float* hsrc; int nsplit_h; int Ch;          // mode 3: forward pre-activation slabs of the same channels ([..][Ch][32])
   float* dst;                                       // [nsplit_dst][RT][Nout_pad][32]
+  float* hsum_dst;                                  // mode 1: the summed pre-activations of the source go back as ONE slab [RT][Csrc][32] (or null)
   int spb, nsplit_dst;                              // K-slices per block, ceil(nslices / spb)
   int nblocks;                                      // ntiles * nsplit_dst * RT
 };
@@ -265,6 +267,16 @@ __global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
     }
     HA_TS(1, false);
     HA_TS(2, true);
+    if (!LEAN && is_main && T.mode == 1 && T.hsum_dst && tile == 0 && T.nsplit_src > 1) {
+      // The producer left split-K partial slabs; this block has just summed its slices of them.  The blocks of output tile 0 (they
+      // cover every slice once) write the sums back as one slab: the adjoint pass then reads ONE slab of pre-activations
+      // instead of nsplit (its launches are bound by the ~1 KB-per-instruction issue rate of those loads).
+      const int c0 = cbase + 32 * hi;
+      float* hd = T.hsum_dst + (size_t)rt * T.Csrc * 32 + (size_t)(c0 >> 2) * 128 + (size_t)(lane & 31) * 4;
+#pragma unroll
+      for (int jq = 0; jq < 8; ++jq)
+        if (c0 + 4 * jq < T.Csrc) *reinterpret_cast<vf4*>(hd + (size_t)jq * 128) = vf4{a[4 * jq], a[4 * jq + 1], a[4 * jq + 2], a[4 * jq + 3]};
+    }
     if (has_gn) {
       // GroupNorm over groups of T.group (64 or 32) channels: the lane holds one half-slice of its row
       const float inv_n = T.inv_group;
@@ -1391,6 +1403,7 @@ struct StashLayout {
   size_t xT = 0;                  // input states of all steps, contiguous: [(S+1)][RT][D_INP][32] (the batched prior's A operand)
   size_t off_G = 0;
   size_t off_dec[MAXL];
+  size_t off_hsum[MAXL];          // per step: summed pre-activations of decoder layer l (one slab), written by layer l+1's forward launch
   // batched prior network: pre-activations of every layer for all steps, [S*RT][Nout_pad][32] each (kept for the adjoint)
   size_t pri_h[MAXL];
   size_t pri_act[2];              // finished activations / adjoints of consecutive layers (ping-pong), [S*RT][1024][32]
@@ -1401,6 +1414,7 @@ struct StashLayout {
   size_t bwd_dec[MAXL];
   size_t fin[1] = {0};         // finished-activation scratch of a launch's task (finishing-pass policy only)
   bool finish = false;
+  bool hsum = false;             // forward launches write the summed pre-activations back (one-row-tile policy: no finishing pass)
   size_t total = 0;
 };
 
@@ -1426,6 +1440,7 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   auto ptake = [&](size_t n) { size_t r = p; p += (n + 63) / 64 * 64; return r; };
   L.off_G = ptake(RT * 32 * 12);
   for (int i = 0; i < net->n_dec; ++i) L.off_dec[i] = ptake((size_t)L.nsf_dec[i] * RT * net->dec[i].Nout_pad * 32);
+  for (int i = 0; i + 1 < net->n_dec; ++i) L.off_hsum[i] = ptake(RT * net->dec[i].Nout_pad * 32);
   L.per_step = p;
   L.steps = take(p * (size_t)(S + 1));
   size_t widest = 0;
@@ -1446,6 +1461,7 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   for (int i = 0; i < net->n_dec; ++i) L.bwd_dec[i] = take((size_t)L.nsb_dec[i] * RT * net->dec[i].Nin_pad * 32);
   // GroupNorm prologues once per activation in gn_finish_kernel (see there and the policy note above)
   L.finish = (L.RT >= 2 && g_layer_finish != 0) || g_layer_finish == 2;     // 0: never, 2: always (A/B runs)
+  L.hsum = !L.finish && g_layer_hsum != 0;
   if (L.finish)
     L.fin[0] = take(RT * 1280 * 32);     // widest operand: K <= 1280 (checked at pack time)
   L.total = o;
@@ -1677,6 +1693,7 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
       const PackedLayer& P = net->dec[l];
       const float* src = l == 0 ? x_ptr(t) : sp + L.off_dec[l - 1];
       fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
+      if (l > 0 && L.hsum) LL.t[0].hsum_dst = sp + L.off_hsum[l - 1];
       int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
     }
@@ -1850,6 +1867,9 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
       const PackedLayer& P = net->dec[l];
       if (l == nd - 1)
         bwd_task(LL.t[LL.ntasks++], P, stash + L.g_dec_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
+      else if (L.hsum && L.nsf_dec[l] > 1)      // the forward pass left the summed pre-activations of layer l as one slab
+        bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_dec[l + 1], L.nsb_dec[l + 1], net->dec[l + 1].Nin_pad, &net->dec[l + 1],
+                 sp + L.off_hsum[l], 1, stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
       else
         bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_dec[l + 1], L.nsb_dec[l + 1], net->dec[l + 1].Nin_pad, &net->dec[l + 1],
                  sp + L.off_dec[l], L.nsf_dec[l], stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);

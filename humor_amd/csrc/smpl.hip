@@ -39,7 +39,7 @@ namespace ha {
 // ha_tune_set("skin_variant"): -1 = auto; else bits 0-1: waves per block 4 << b; +4: non-temporal stores;
 // +8 / +16: profiling modes of the streaming kernel (LDS-transposed copy only / every lane gathers bone 0)
 int g_skin_variant = -1;
-extern int g_layer_spb, g_layer_nw, g_layer_finish, g_gemm_rm;   // rollout.hip
+extern int g_layer_spb, g_layer_nw, g_layer_finish, g_gemm_rm, g_layer_hsum;   // rollout.hip
 }
 extern "C" int ha_tune_set(const char* key, int value) {
   HA_REQUIRE(key, "ha_tune_set: null key");
@@ -48,6 +48,7 @@ extern "C" int ha_tune_set(const char* key, int value) {
   if (strcmp(key, "layer_nw") == 0) { ha::g_layer_nw = value; return HA_OK; }
   if (strcmp(key, "layer_finish") == 0) { ha::g_layer_finish = value; return HA_OK; }
   if (strcmp(key, "gemm_rm") == 0) { ha::g_gemm_rm = value; return HA_OK; }
+  if (strcmp(key, "layer_hsum") == 0) { ha::g_layer_hsum = value; return HA_OK; }
   ha::set_error("ha_tune_set: unknown key '%s'", key);
   return HA_ERR_INVALID_ARG;
 }

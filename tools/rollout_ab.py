@@ -32,9 +32,12 @@ def main():
     past = torch.randn(B, 339, device=dev, requires_grad=True)
     z = torch.randn(B, S, 48, device=dev, requires_grad=True)
     ref = None
-    for spb, nw in cfgs:
+    for cfg in cfgs:
+        spb, nw = cfg[0], cfg[1]
+        hsum = cfg[2] if len(cfg) > 2 else 1                                       # third number: summed-h write-back (default on)
         lib.call('ha_tune_set', b'layer_spb', spb)
         lib.call('ha_tune_set', b'layer_finish', nw if nw in (0, 1, 2) else 1)   # second number: 0 off, 1 auto, 2 forced
+        lib.call('ha_tune_set', b'layer_hsum', hsum)
         hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', model_data_config='smpl+joints+contacts')
         hm.load_state_dict(sd)
         hm = hm.to(dev).eval()
@@ -53,7 +56,7 @@ def main():
             ref = w
         it = 5 if B * S > 4000 else 10
         tf, tb = timed(fwd, it), timed(fwdbwd, it)
-        print(f'B={B} S={S} spb={spb} nw={nw}: fwd {tf:8.3f} ms  fwd+bwd {tb:8.3f} ms   max|joints - first cfg| (step<=8) '
+        print(f'B={B} S={S} spb={spb} nw={nw} hsum={hsum}: fwd {tf:8.3f} ms  fwd+bwd {tb:8.3f} ms   max|joints - first cfg| (step<=8) '
               f'{(w - ref).abs().max().item():.2e}', flush=True)
 
 
