@@ -43,8 +43,10 @@ SKIN_BYTES_PER_FRAME = V * 12 * 2 + J * 48
 # tools/skin_once.py via tools/pmc_lbs.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM', WRITE_SIZE as reported, KiB;
 # both calibrated in the same passes on a device copy of exactly 155,025 KiB): 2 * 88692.8 + 155148.1 KiB.
 # Offline measurement (counters cannot be read inside bench.py); see profiles/r01_run6_pmc_lbs/SUMMARY.txt.
-PMC_TRAFFIC_BYTES = int((2 * 88692.8 + 155148.1) * 1024)
-PMC_TRAFFIC_SOURCE = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_run6_pmc_lbs (FETCH x2 gfx950 correction, copy-calibrated)'
+PMC_TRAFFIC_BYTES = int((2 * 88696.2 + 155175.2) * 1024)
+# the same passes at the C5 size (N = 30720 frames, operands >> the 256 MiB Infinity Cache): profiles/r02_pmc_lbs/SUMMARY.txt
+PMC_TRAFFIC_BYTES_C5 = int((2 * 1345686.9 + 2480400.8) * 1024)
+PMC_TRAFFIC_SOURCE = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r02_pmc_lbs (re-run on the shipped kernel; FETCH x2 gfx950 correction)'
 
 
 def parse():
@@ -167,13 +169,13 @@ def time_events(fn, iters, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
-def skin_roofline(dev, npz):
-    """The streaming LBS kernel alone (ha_lbs_skin) at N = 1920 frames: algorithmic bytes / event-timed launch duration.
-    Launched on torch's current stream, so the HIP events bracket exactly these launches."""
+def skin_roofline(dev, npz, N=B_SEQ * T_SEQ, traffic=PMC_TRAFFIC_BYTES):
+    """The streaming LBS kernel alone (ha_lbs_skin) at N frames: algorithmic bytes / event-timed launch duration.
+    Launched on torch's current stream, so the HIP events bracket exactly these launches.  N = 1920 is the metric's batch
+    (32 x 60; its 159 MB operands partly live in the 256 MiB Infinity Cache), N = 30720 (C5) is cache-free."""
     from humor_amd import _lib
     from humor_amd.body_model import BodyModel
     lib = _lib.get_lib()
-    N = B_SEQ * T_SEQ
     h = BodyModel(npz, num_betas=16)._handle_for(dev)
     vposed = torch.randn(N * V * 3 + 4, device=dev)
     A = torch.randn(N, J, 12, device=dev)
@@ -183,11 +185,11 @@ def skin_roofline(dev, npz):
 
     def launch():
         lib.call('ha_lbs_skin', h.ptr, N, _lib.ptr(vposed), _lib.ptr(A), _lib.ptr(transl), _lib.ptr(verts), st)
-    ms = time_events(launch, iters=50, warm=5)
+    ms = time_events(launch, iters=50 if N <= 4096 else 12, warm=5 if N <= 4096 else 3)
     nbytes = SKIN_BYTES_PER_FRAME * N
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {'kernel': 'lbs_skin (ha_lbs_skin)', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': PMC_TRAFFIC_BYTES, 'traffic_source': PMC_TRAFFIC_SOURCE,
+            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': PMC_TRAFFIC_SOURCE,
             'avg_launch_us': round(ms * 1e3, 2),
             'bytes_per_launch': nbytes, 'frames_per_launch': N}
 
@@ -484,6 +486,13 @@ def run(args):
         if world == 1 and not args.no_rccl_check:
             res['rccl'] = rccl_selfcheck(dev, npz)
         if world == 1 and not args.no_c5:
+            # the roofline kernel again at the C5 size: operands far beyond the Infinity Cache, i.e. the cache-free figure
+            fc = None
+            torch.cuda.empty_cache()
+            res['roofline_c5'] = skin_roofline(dev, npz, N=256 * 120, traffic=PMC_TRAFFIC_BYTES_C5)
+            res['roofline_c5']['note'] = ('cache-free size (5.2 GB per launch); at this size the kernel\'s own copy-only mode reaches 5.77 TB/s '
+                                          'and a torch device copy 4.94 TB/s (profiles/r02_pmc_lbs/SUMMARY.txt)')
+            res['roofline']['note'] = 'the metric\'s batch (32 x 60): 159 MB operands, partly served by the 256 MiB Infinity Cache; see roofline_c5'
             # BASELINE config C5 (batch 256 x 120 frames): LBS GB/s, pose-blend and decoder/prior MLP fp32-MFMA utilisation
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import bench_c5
