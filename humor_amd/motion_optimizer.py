@@ -35,7 +35,7 @@ class MotionOptimizer():
                  motion_prior=None, init_motion_prior=None, optim_floor=False, camera_matrix=None, robust_loss_type='none',
                  robust_tuning_const=4.6851, joint2d_sigma=100, stage3_tune_init_state=True, stage3_tune_init_num_frames=15,
                  stage3_tune_init_freeze_start=30, stage3_tune_init_freeze_end=50, stage3_contact_refine_only=False,
-                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs=False, fused_loss=True, lbfgs='fused', fused_post=True, fused_pre=True):
+                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs='auto', fused_loss=True, lbfgs='fused', fused_post=True, fused_pre=True):
         B, T = batch_size, seq_len
         self.device = device
         self.batch_size, self.seq_len = B, T
@@ -51,11 +51,15 @@ class MotionOptimizer():
         self.verbose = verbose
         # whole-closure hipGraph capture (replay costs ~1.5 us of node hand-off per kernel, eager costs host time that the
         # roll-out's long launches partly hide: which one wins depends on the host -- bench.py times both)
-        self.use_graphs = bool(use_graphs) and torch.device(device).type == 'cuda'
+        # use_graphs: False | True (every closure) | 'auto' (the short, host-bound closures only: stages 1-2 and the 15-frame
+        # tune-init phase of stage 3 replay 2-3x faster than they launch; the full-length stage-3 closure is GPU-bound and its
+        # ~1100 graph nodes cost more in node hand-off than eager launches cost in host time)
+        self.use_graphs = (use_graphs if use_graphs == 'auto' else bool(use_graphs)) if torch.device(device).type == 'cuda' else False
         if self.use_graphs and shard is not None:
             # capturing the closure would put the halo all-gather / gradient all-reduce (and, with gloo, host staging) inside the
             # graph; a rank-divergent capture failure leaves collectives in flight.  Sharded closures always launch eagerly.
-            print('humor_amd: use_graphs is ignored for a sharded MotionOptimizer (collectives are not captured)')
+            if self.use_graphs is True:
+                print('humor_amd: use_graphs is ignored for a sharded MotionOptimizer (collectives are not captured)')
             self.use_graphs = False
         # 'fused': humor_amd.lbfgs.LBFGS (same algorithm as torch.optim.LBFGS, a handful of launches per inner iteration);
         # 'torch': torch.optim.LBFGS itself (what the reference uses; ~4 launches per stored pair and iteration)
@@ -165,11 +169,11 @@ class MotionOptimizer():
                 halo['prev_floor'] = prev[n + self.num_betas:n + self.num_betas + 3]
         return halo
 
-    def make_closure(self, objective, params, optim=None):
-        """Returns the L-BFGS closure for `objective()` -> (loss, stats).  With use_graphs the objective, its backward and
-        the gradient all-reduce are captured once into a hipGraph (torch.cuda.graphs) and replayed per evaluation: a
-        closure is ~3000 small launches and otherwise host-bound."""
-        if not self.use_graphs:
+    def make_closure(self, objective, params, optim=None, short=True):
+        """Returns the L-BFGS closure for `objective()` -> (loss, stats).  With use_graphs the objective and its backward are
+        captured once into a hipGraph (torch.cuda.graphs) and replayed per evaluation; `short` marks the closures that
+        use_graphs='auto' captures (see __init__)."""
+        if not self.use_graphs or (self.use_graphs == 'auto' and not short):
             def closure():
                 for p in params:          # = optim.zero_grad(set_to_none=True) of the reference closures
                     p.grad = None
@@ -189,6 +193,10 @@ class MotionOptimizer():
                 return eager()
             if state['graph'] is None:
                 try:
+                    # warm-up evaluations and the capture itself are not closure evaluations of the optimiser: keep them out of
+                    # the evaluation counter and the loss trace
+                    evals, trace = self.closure_evals, self.loss_trace
+                    self.loss_trace = None
                     side = torch.cuda.Stream()
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
@@ -197,8 +205,6 @@ class MotionOptimizer():
                     torch.cuda.current_stream().wait_stream(side)
                     for p in params:
                         p.grad = None
-                    evals, trace = self.closure_evals, self.loss_trace
-                    self.loss_trace = None
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         loss, _ = objective()
@@ -208,6 +214,7 @@ class MotionOptimizer():
                     state['grads'] = [p.grad for p in params]
                     state['graph'] = g
                 except Exception as e:          # capture is an optimisation: fall back to eager evaluation
+                    self.closure_evals, self.loss_trace = evals, trace
                     print('humor_amd: hipGraph capture of the closure failed (%s: %s); running eagerly' % (type(e).__name__, str(e)[:600]))
                     state['failed'] = True
                     self.graph_failures = getattr(self, 'graph_failures', 0) + 1
@@ -401,7 +408,7 @@ class MotionOptimizer():
                 closures3[phase] = self.make_closure(
                     lambda tp=tune_phase, ims=init_motion_scale: self._stage3_objective(
                         obs_local, obs_init, prior_opt_params, tp, n_init, ims, og_overlap_w, has_overlap, fit_gender),
-                    motion_params, None)
+                    motion_params, None, short=tune_phase)
             motion_optim.step(closures3[phase])
         if last_phase_name is not None:
             self._mark(last_phase_name, phase_iters)
@@ -507,34 +514,46 @@ class MotionOptimizer():
         loss, stats = self.fitting_loss.smpl_fit(obs_local, pred, self.seq_len, halo=halo)
         return self._with_dep(loss, halo), stats
 
+    def _pre_stage3_eager(self, latent_pose, trans, root_orient, betas, floor, trans_vel, joints_vel, root_orient_vel):
+        from . import _lib as _libmod
+        from .fit_kernels import FitPre
+        lib = self.fit_bm._lib
+        B = trans.size(0)
+        cur_body_pose = self.latent2pose(latent_pose)
+        cam_smpl, _ = self.smpl_results(trans, root_orient, cur_body_pose, betas)
+        o = FitPre.apply(lib if lib is not None else _libmod.get_lib(), floor, trans.reshape(B, 3), root_orient.reshape(B, 3),
+                         cur_body_pose.reshape(B, J_BODY * 3), cam_smpl['joints3d'].reshape(B, 22, 3), trans_vel.reshape(B, 3),
+                         joints_vel.reshape(B, 22, 3), root_orient_vel.reshape(B, 3))
+        return (cur_body_pose,) + tuple(o)
+
     def _stage3_objective(self, obs_local, obs_init, prior_opt_params, tune_phase, n_init, init_motion_scale, og_overlap_w,
                           has_overlap, fit_gender):
         """One stage-3 objective evaluation on this rank's sequences (motion_optimizer.py:514-605)."""
         L = self._local
         trans, root_orient, betas = L(self.trans), L(self.root_orient), L(self.betas)
-        cur_body_pose = self.latent2pose(L(self.latent_pose))
         floor = L(self.floor_plane) if self.optim_floor else None
         cam2prior, pre = None, None
         local_prior_params = [L(p) for p in prior_opt_params]
         lib = self.fit_bm._lib
-        if self.optim_floor:
-            cam_smpl, _ = self.smpl_results(trans, root_orient, cur_body_pose, betas)
-            if self.fused_pre and (trans.is_cuda or (lib is not None and lib.emulator)):
-                # cam2prior, the key frame in the prior frame and the initial roll-out state in one kernel (csrc/fitpre.hip); the
-                # prior-frame joints are the rigid image of the camera-frame ones: this is the only frame-0 SMPL evaluation
-                from . import _lib as _libmod
-                from .fit_kernels import FitPre
-                B = trans.size(0)
-                o = FitPre.apply(lib if lib is not None else _libmod.get_lib(), floor, trans.reshape(B, 3), root_orient.reshape(B, 3),
-                                 cur_body_pose.reshape(B, J_BODY * 3), cam_smpl['joints3d'].reshape(B, 22, 3), local_prior_params[0].reshape(B, 3),
-                                 local_prior_params[1].reshape(B, 22, 3), local_prior_params[2].reshape(B, 3))
-                pre = {'past_in': o[0], 'trans': o[1].reshape(B, 1, 3), 'root_orient': o[2].reshape(B, 1, 3), 'joints': o[3].reshape(B, 1, 22, 3)}
-                cam2prior = (o[4], o[5], o[6])
-            else:
+        fused_pre = self.optim_floor and self.fused_pre and (trans.is_cuda or (lib is not None and lib.emulator))
+        if fused_pre:
+            # VPoser decode -> frame-0 SMPL -> ha_fit_pre (cam2prior, key frame in the prior frame, initial roll-out state; the prior-
+            # frame joints are the rigid image of the camera-frame ones, so this is the only frame-0 SMPL evaluation).
+            # (Replaying this ~60-launch segment as its own pair of hipGraphs -- torch.cuda.make_graphed_callables -- was measured:
+            # the closure went from 5.3 to 6.5 ms; two extra graph launches per direction cost more than the launches they replace.)
+            out = self._pre_stage3_eager(L(self.latent_pose), trans, root_orient, betas, floor, *local_prior_params)
+            cur_body_pose, o = out[0], out[1:]
+            B = trans.size(0)
+            pre = {'past_in': o[0], 'trans': o[1].reshape(B, 1, 3), 'root_orient': o[2].reshape(B, 1, 3), 'joints': o[3].reshape(B, 1, 22, 3)}
+            cam2prior = (o[4], o[5], o[6])
+        else:
+            cur_body_pose = self.latent2pose(L(self.latent_pose))
+            if self.optim_floor:
+                cam_smpl, _ = self.smpl_results(trans, root_orient, cur_body_pose, betas)
                 cam2prior = frames.compute_cam2prior(floor, trans[:, 0], ops.batch_rodrigues(root_orient[:, 0], _lib_override=lib),
                                                      cam_smpl['joints3d'][:, 0])
-            if self.shard is None:
-                self.cam2prior_R, self.cam2prior_t, self.cam2prior_root_height = cam2prior
+        if self.optim_floor and self.shard is None:
+            self.cam2prior_R, self.cam2prior_t, self.cam2prior_root_height = cam2prior
         latent_motion = L(self.latent_motion)
         if tune_phase:
             latent_motion = latent_motion[:, :(n_init - 1)]
