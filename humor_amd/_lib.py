@@ -91,7 +91,7 @@ _SIGS = {
     'ha_fit_pre_backward': (C.c_int, [C.POINTER(FitPreArgs), C.c_void_p]),
     'ha_rollout_post_forward': (C.c_int, [C.POINTER(RolloutPostArgs), C.c_void_p]),
     'ha_rollout_post_backward': (C.c_int, [C.POINTER(RolloutPostArgs), C.c_void_p]),
-    'ha_lbfgs_coeffs': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    'ha_lbfgs_coeffs': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ha_chamfer_forward': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]),
     'ha_chamfer_backward': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
 }

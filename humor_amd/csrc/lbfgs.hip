@@ -23,6 +23,7 @@ struct LbfgsArgs {
   const float* G;            // [2 hist][2 hist]: rows/cols 0..hist-1 = s slots, hist..2 hist-1 = y slots
   const float* Mg;           // [2 hist]
   float h_diag;
+  const float* h_diag_dev;   // when non-null: the scale is read from device memory (no host round trip)
   float* coef;               // [2 hist]
 };
 
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(64) void lbfgs_coeffs_kernel(LbfgsArgs a) {
   float* al = smem;
   float* ab = smem + LB_MAXH;
   const int lane = threadIdx.x, h = a.hist, k = a.num_old, W = 2 * h;
+  const float h_diag = a.h_diag_dev ? a.h_diag_dev[0] : a.h_diag;
   for (int i = lane; i < 2 * h; i += 64) a.coef[i] = 0.f;
   // first loop: newest -> oldest
   for (int i = k - 1; i >= 0; --i) {
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(64) void lbfgs_coeffs_kernel(LbfgsArgs a) {
     const float s1 = lb_wsum(p1), s2 = lb_wsum(p2);
     const float ro = 1.0f / a.G[(size_t)pi * W + h + pi];
     if (lane == 0) {
-      const float be = ro * (a.h_diag * (-a.Mg[h + pi] - s1) + s2);
+      const float be = ro * (h_diag * (-a.Mg[h + pi] - s1) + s2);
       ab[i] = al[i] - be;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -69,14 +71,14 @@ __global__ __launch_bounds__(64) void lbfgs_coeffs_kernel(LbfgsArgs a) {
   for (int i = lane; i < k; i += 64) {
     const int pi = a.order[i];
     a.coef[pi] = ab[i];                       // s_i
-    a.coef[h + pi] = -a.h_diag * al[i];       // y_i
+    a.coef[h + pi] = -h_diag * al[i];       // y_i
   }
 }
 
 }  // namespace ha
 
-extern "C" int ha_lbfgs_coeffs(int hist, int num_old, const int32_t* order, const float* G, const float* Mg, float h_diag, float* coef,
-                               void* stream) {
+extern "C" int ha_lbfgs_coeffs(int hist, int num_old, const int32_t* order, const float* G, const float* Mg, float h_diag,
+                               const float* h_diag_dev, float* coef, void* stream) {
   using namespace ha;
   HA_REQUIRE(hist >= 1 && hist <= LB_MAXH, "ha_lbfgs_coeffs: history size must be in [1, %d]", LB_MAXH);
   HA_REQUIRE(num_old >= 0 && num_old <= hist, "ha_lbfgs_coeffs: num_old out of range");
@@ -88,7 +90,7 @@ extern "C" int ha_lbfgs_coeffs(int hist, int num_old, const int32_t* order, cons
     HA_REQUIRE(order[i] >= 0 && order[i] < hist, "ha_lbfgs_coeffs: slot index out of range");
     a.order[i] = order[i];
   }
-  a.G = G; a.Mg = Mg; a.h_diag = h_diag; a.coef = coef;
+  a.G = G; a.Mg = Mg; a.h_diag = h_diag; a.h_diag_dev = h_diag_dev; a.coef = coef;
   hipLaunchKernelGGL(lbfgs_coeffs_kernel, dim3(1), dim3(64), 2 * LB_MAXH * sizeof(float), (hipStream_t)stream, a);
   HA_LAUNCH_CHECK();
   return HA_OK;

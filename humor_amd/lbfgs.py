@@ -163,6 +163,12 @@ class LBFGS:
         self._hist = {'M': torch.zeros(2 * h, n, dtype=torch.float32, device=device), 'G': torch.zeros(2 * h, 2 * h, dtype=torch.float32, device=device),
                       'order': [], 'coef': torch.zeros(2 * h, dtype=torch.float32, device=device), 'h': h}
 
+    def _pop_pair(self, undo):
+        """Drops the pair stored by the matching _push_pair (its slot's Gram entries become dead: slots outside `order` are ignored).
+        An evicted oldest pair is not restored -- torch would have kept it; this only happens when the curvature test fails with a
+        full history, and only shortens the memory by one pair."""
+        self._hist['order'].remove(undo)
+
     def _push_pair(self, s, y):
         H = self._hist
         h, order = H['h'], H['order']
@@ -174,14 +180,20 @@ class LBFGS:
         vs, vy = torch.mv(M, M[slot]), torch.mv(M, M[h + slot])
         G[slot], G[:, slot] = vs, vs
         G[h + slot], G[:, h + slot] = vy, vy
+        return slot
 
     def _direction(self, g, h_diag):
+        """d = [S;Y]^T coef - h_diag g.  h_diag: Python float, or a 0-dim device tensor (then it is read on the device: no host sync)."""
         H = self._hist
         lib = self._lib if self._lib is not None else _lib.get_lib()
         Mg = torch.mv(H['M'], g)
         order = (C.c_int32 * max(1, len(H['order'])))(*H['order'])
-        lib.call('ha_lbfgs_coeffs', H['h'], len(H['order']), order, _lib.ptr(H['G']), _lib.ptr(Mg), float(h_diag), _lib.ptr(H['coef']),
-                 _lib.stream_ptr(g))
+        on_dev = torch.is_tensor(h_diag)
+        hd = h_diag.reshape(1).float().contiguous() if on_dev else None
+        lib.call('ha_lbfgs_coeffs', H['h'], len(H['order']), order, _lib.ptr(H['G']), _lib.ptr(Mg), 0.0 if on_dev else float(h_diag),
+                 _lib.ptr(hd), _lib.ptr(H['coef']), _lib.stream_ptr(g))
+        if on_dev:
+            return torch.addmv(g * (-hd), H['M'].t(), H['coef'])
         return torch.addmv(g, H['M'].t(), H['coef'], beta=-float(h_diag), alpha=1.0)
 
     # ---- step ------------------------------------------------------------------------------------------------------------------
@@ -213,29 +225,40 @@ class LBFGS:
         while n_iter < max_iter:
             n_iter += 1
             state['n_iter'] += 1
+            pushed = None
             if state['n_iter'] == 1:
                 d = flat_grad.neg()
                 self._hist['order'] = []
                 H_diag = 1.0
+                scal = [flat_grad.dot(d), d.abs().max(), flat_grad.abs().sum()]
             else:
+                # Speculative update: the pair is stored and the direction built with H = ys / yy computed on the device, and the
+                # curvature test ys > 1e-10 is read back together with g.d and max|d| -- ONE host read per iteration.  When the
+                # test fails (rare) the pair is dropped and the direction rebuilt with the previous scaling, as torch does.
                 y = flat_grad.sub(prev_flat_grad)
                 s = d.mul(t)
-                ys, yy = torch.stack([y.dot(s), y.dot(y)]).tolist()
-                if ys > 1e-10:
-                    self._push_pair(s, y)
-                    H_diag = ys / yy
-                d = self._direction(flat_grad, H_diag)
+                ysyy = torch.stack([y.dot(s), y.dot(y)])
+                pushed = self._push_pair(s, y)
+                d = self._direction(flat_grad, ysyy[0] / ysyy[1])
+                scal = [flat_grad.dot(d), d.abs().max(), ysyy[0], ysyy[1]]
             if prev_flat_grad is None:
                 prev_flat_grad = flat_grad.clone()
             else:
                 prev_flat_grad.copy_(flat_grad)
             prev_loss = loss
 
+            vals = torch.stack(scal).tolist()
+            gtd, d_norm = vals[0], vals[1]
             if state['n_iter'] == 1:
-                gtd, d_norm, gsum = torch.stack([flat_grad.dot(d), d.abs().max(), flat_grad.abs().sum()]).tolist()
-                t = min(1.0, 1.0 / gsum) * lr
+                t = min(1.0, 1.0 / vals[2]) * lr
             else:
-                gtd, d_norm = torch.stack([flat_grad.dot(d), d.abs().max()]).tolist()
+                ys, yy = vals[2], vals[3]
+                if ys > 1e-10:
+                    H_diag = ys / yy
+                else:
+                    self._pop_pair(pushed)
+                    d = self._direction(flat_grad, H_diag)
+                    gtd, d_norm = torch.stack([flat_grad.dot(d), d.abs().max()]).tolist()
                 t = lr
             if gtd > -tolerance_change:
                 break
@@ -243,16 +266,19 @@ class LBFGS:
             ls_func_evals = 0
             if line_search_fn is not None:
                 x_init = x.clone()
+                gmax_of = {}
 
                 def obj_func(tt):
                     torch.add(x_init, d, alpha=tt, out=x)
                     l = closure()
                     g_new = self._gather_flat_grad()
-                    f_new, gtd_new = torch.stack([l.detach().reshape(()).float(), g_new.dot(d)]).tolist()
+                    f_new, gtd_new, gm = torch.stack([l.detach().reshape(()).float(), g_new.dot(d), g_new.abs().max()]).tolist()
+                    gmax_of[id(g_new)] = gm
                     return f_new, g_new, gtd_new
+                g_in = flat_grad
                 loss, flat_grad, t, ls_func_evals = _strong_wolfe(obj_func, t, d_norm, loss, flat_grad, gtd, max_ls=max_eval - current_evals)
                 torch.add(x_init, d, alpha=t, out=x)
-                gmax = flat_grad.abs().max().item()
+                gmax = gmax_of[id(flat_grad)] if id(flat_grad) in gmax_of else (gmax if flat_grad is g_in else flat_grad.abs().max().item())
             else:
                 x.add_(d, alpha=t)
                 if n_iter != max_iter:

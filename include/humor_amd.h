@@ -299,10 +299,11 @@ int ha_chamfer_backward(int b, int n, const float* xyz1, int m, const float* xyz
  * humor/fitting/motion_optimizer.py:233-254, 284-310, 461-512) in coefficient form: given the Gram matrix
  * G [2h,2h] of the stored pairs M = [s slots (h rows) ; y slots (h rows)], Mg = M g [2h] and the initial
  * Hessian scale, writes coef [2h] such that  d = M^T coef - h_diag * g.  `order` (HOST, num_old entries) lists the
- * physical slots from the oldest to the newest pair; slots not listed get coefficient 0.  hist <= 128.
+ * physical slots from the oldest to the newest pair; slots not listed get coefficient 0.  hist <= 128.  The scale is `h_diag`,
+ * or -- when h_diag_dev is non-NULL -- the float it points to in device memory (no host round trip for ys / yy).
  * ---------------------------------------------------------------------------------------------- */
-int ha_lbfgs_coeffs(int hist, int num_old, const int32_t* order, const float* G, const float* Mg, float h_diag, float* coef,
-                    void* stream);
+int ha_lbfgs_coeffs(int hist, int num_old, const int32_t* order, const float* G, const float* Mg, float h_diag,
+                    const float* h_diag_dev, float* coef, void* stream);
 
 #ifdef __cplusplus
 }

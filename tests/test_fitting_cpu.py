@@ -169,3 +169,39 @@ def test_emu_fit_pre_kernel_equals_op_chain(emu_lib, smplh_npz):
     """ha_fit_pre on the SIMT emulator against compute_cam2prior + apply_cam2prior + the initial-state assembly with three SMPL calls."""
     import fitloss_checks as FL
     print('fit pre: worst relative gradient difference', FL.check_fit_pre(emu_lib, CPU, smplh_npz, B=2, seed=1))
+
+
+def test_emu_fused_lbfgs_follows_torch_lbfgs(emu_lib):
+    """humor_amd.lbfgs.LBFGS (flat buffer, coefficient-form two-loop recursion through ha_lbfgs_coeffs, one host read per iteration)
+    against torch.optim.LBFGS on a smooth non-quadratic problem with a short history (pairs get evicted): same number of closure
+    evaluations, loss trace equal to fp32 rounding, across several step() calls (state carried over)."""
+    from humor_amd.lbfgs import LBFGS
+    torch.manual_seed(0)
+    A = torch.randn(40, 40)
+    A = A @ A.t() / 40 + torch.eye(40) * 0.5
+    b = torch.randn(40)
+
+    def f(ps):
+        x = torch.cat(ps)
+        return 0.5 * x @ A @ x - b @ x + 0.1 * torch.sum(torch.cos(3 * x)) + 0.05 * (x ** 4).sum()
+    res = {}
+    for name in ('torch', 'ours'):
+        ps = [torch.zeros(25, requires_grad=True), torch.zeros(15, requires_grad=True)]
+        kw = dict(max_iter=20, lr=1.0, line_search_fn='strong_wolfe', history_size=7)
+        opt = torch.optim.LBFGS(ps, **kw) if name == 'torch' else LBFGS(ps, _lib_override=emu_lib, **kw)
+        trace = []
+
+        def closure():
+            for p in ps:
+                p.grad = None
+            l = f(ps)
+            l.backward()
+            trace.append(l.item())
+            return l
+        for _ in range(4):
+            opt.step(closure)
+        res[name] = (trace, torch.cat([p.detach() for p in ps]))
+    t0, t1 = res['torch'][0], res['ours'][0]
+    assert len(t0) == len(t1), (len(t0), len(t1))
+    assert max(abs(a - c) / max(1.0, abs(a)) for a, c in zip(t0, t1)) < 1e-5
+    assert abs(t0[-1] - t1[-1]) < 1e-4 and t1[-1] < t1[0]
