@@ -114,7 +114,7 @@ def build_optimizer(dev, npz, B, shard=None, use_graphs=False):
     for p in hm.parameters():
         p.requires_grad_(False)
     w, mu, cov = synth.make_gmm(seed=0)
-    return MotionOptimizer(dev, bm, 16, B, T_SEQ, ['joints2d'], loss_weights(), synth.SynthVPoser(seed=0).to(dev), hm,
+    return MotionOptimizer(dev, bm, 16, B, T_SEQ, ['joints2d'], loss_weights(), synth.SynthVPoser(seed=0).to(dev).eval(), hm,
                            {'gmm': (w.to(dev), mu.to(dev), cov.to(dev))}, optim_floor=True, camera_matrix=camera_matrix(B, dev),
                            robust_loss_type='bisquare', joint2d_sigma=100, shard=shard, use_graphs=use_graphs)
 

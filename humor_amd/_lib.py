@@ -86,6 +86,11 @@ _SIGS = {
     'ha_humor_rollout_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p]),
     'ha_humor_rollout_sample': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_humor_rollout_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
+    'ha_mlp_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(MlpDesc), C.c_int, C.c_float]),
+    'ha_mlp_destroy': (C.c_int, [C.c_void_p]),
+    'ha_mlp_workspace': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
+    'ha_mlp_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_mlp_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ha_fit_loss': (C.c_int, [C.POINTER(FitArgs), C.c_void_p]),
     'ha_fit_pre_forward': (C.c_int, [C.POINTER(FitPreArgs), C.c_void_p]),
     'ha_fit_pre_backward': (C.c_int, [C.POINTER(FitPreArgs), C.c_void_p]),

@@ -427,6 +427,8 @@ struct GemmTask {
   const float* src; int Csrc;             // A operand: finished slab [row tiles][Csrc][32]
   int nrt;                                // row tiles
   int epi;                                // 0 raw -> dst_h | 1 raw -> dst_h, ReLU(GroupNorm(.)) -> dst_a | 3 GroupNorm-ReLU adjoint (with hsrc) -> dst_a
+                                          // 4 LeakyReLU(raw) -> dst_a | 5 LeakyReLU adjoint (hsrc = the forward's activation) -> dst_a
+  float slope;                            // epi 4 / 5: negative slope
   const float* gamma; const float* beta; int group;
   const float* hsrc; int Ch;              // epi 3: forward pre-activations of the same channels [row tiles][Ch][32]
   float* dst_h; float* dst_a; int Cdst;   // output slabs [row tiles][Cdst][32]
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(256) void prior_gemm_kernel(GemmTask T) {
   const int ct = hh ? ct0 + 1 : ct0;                  // this lane's column tile
   const bool ct_ok = ct < T.ntiles;
   float gam[32], bet[32];
-  if (T.epi != 0 && ct_ok) {
+  if ((T.epi == 1 || T.epi == 3) && ct_ok) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const vf4 g4 = *reinterpret_cast<const vf4*>(T.gamma + ct * 32 + 4 * j);
@@ -569,8 +571,21 @@ __global__ __launch_bounds__(256) void prior_gemm_kernel(GemmTask T) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) *reinterpret_cast<vf4*>(base + o + (size_t)j * 128) = vf4{x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]};
     };
-    if (T.epi != 3 && live) store32(T.dst_h, v);
-    if (T.epi == 1) {
+    if (T.epi <= 1 && live) store32(T.dst_h, v);
+    if (T.epi == 4) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * T.slope;
+      if (live) store32(T.dst_a, v);
+    } else if (T.epi == 5) {       // sign(LeakyReLU(h)) = sign(h): the stored activation stands in for the pre-activation
+      const float* hp = T.hsrc + (size_t)rt[m] * T.Ch * 32 + (size_t)((ct_ok ? ct : ct0) * 8) * 128 + (size_t)row * 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const vf4 q = *reinterpret_cast<const vf4*>(hp + (size_t)j * 128);
+        v[4 * j] *= q.x > 0.f ? 1.f : T.slope; v[4 * j + 1] *= q.y > 0.f ? 1.f : T.slope;
+        v[4 * j + 2] *= q.z > 0.f ? 1.f : T.slope; v[4 * j + 3] *= q.w > 0.f ? 1.f : T.slope;
+      }
+      if (live) store32(T.dst_a, v);
+    } else if (T.epi == 1) {
       const float inv_n = 1.0f / (float)T.group;
       if (T.group == SLICE) gn_apply<1>(1, gam, bet, inv_n, v, v);       // (all lanes: the cross-half shuffle is wave-wide)
       else gn_apply<2>(1, gam, bet, inv_n, v, v);
@@ -1538,7 +1553,7 @@ static int launch_layers(LayerLaunch& LL, const StashLayout& L, float* stash, hi
 
 // one batched prior layer (forward l >= 0 / adjoint) over nrt = S * RT row tiles
 static int launch_prior_gemm(GemmTask& T, hipStream_t st) {
-  HA_REQUIRE(T.epi == 0 || (T.ntiles % 2 == 0 && (T.group == 32 || T.group == 64)), "prior GEMM: GroupNorm epilogue needs whole 64-column pairs");
+  HA_REQUIRE((T.epi != 1 && T.epi != 3) || (T.ntiles % 2 == 0 && (T.group == 32 || T.group == 64)), "prior GEMM: GroupNorm epilogue needs whole 64-column pairs");
   // RM = 2 (64 x 64 per wave) once there are enough row tiles to keep every SIMD busy with the larger tile
   const int ncb = ceil_div(T.ntiles, 8);
   const int rm = g_gemm_rm == 1 || g_gemm_rm == 2 ? g_gemm_rm : ((T.nrt / 2) * ncb >= 2 * 256 ? 2 : 1);
@@ -1917,4 +1932,220 @@ extern "C" int ha_rot6d_to_rotmat_fwd(int n, const float* x, float* R, void* str
 extern "C" int ha_rot6d_to_rotmat_bwd(int n, const float* x, const float* gR, float* gx, void* stream) {
   HA_REQUIRE(x && gR && gx, "ha_rot6d_to_rotmat_bwd: null argument");
   HA_ROT_ENTRY("ha_rot6d_to_rotmat_bwd", rot6d_bwd_kernel, x, gR, gx);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Frozen MLPs on N independent rows: the VPoser decoder / encoder that bracket every stage-3 evaluation (motion_optimizer.py:
+// 1041-1063: Linear + LeakyReLU(0.2), the decoder followed by 6-D -> rotation matrix -> axis-angle) and HuMoR's posterior encoder
+// (humor_model.py:180-190: Linear + GroupNorm(16) + ReLU, evaluated once per fit by infer_global_seq).  Same packed layers and the
+// same batched GEMM kernel as the prior network: one launch per layer over all ceil(N/32) row tiles, the activation function (or its
+// adjoint) in the epilogue.
+// ---------------------------------------------------------------------------------------------------
+struct ha_mlp {
+  int device = 0, n = 0, act = 0, in_dim = 0, out_dim = 0, in_pad = 0, wmax = 0;
+  float slope = 0.f;
+  ha::PackedLayer L[ha::MAXL];
+};
+
+namespace ha {
+
+struct MlpLayout {
+  int nrt = 0;
+  size_t xT = 0, keep[MAXL], pp[2], out = 0, gx = 0, total = 0;
+};
+
+static MlpLayout mlp_layout(const ha_mlp* m, int N) {
+  MlpLayout W;
+  W.nrt = ceil_div(N, 32);
+  size_t o = 0;
+  auto take = [&](size_t ch) { const size_t at = o; o += (size_t)W.nrt * ch * 32; return at; };
+  W.xT = take(m->in_pad);
+  for (int l = 0; l + 1 < m->n; ++l) W.keep[l] = take(m->L[l].Nout_pad);      // act 0: pre-activations, act 1: LeakyReLU outputs
+  W.pp[0] = take(m->wmax);
+  W.pp[1] = take(m->wmax);
+  W.out = take(m->L[m->n - 1].Nout_pad);
+  W.gx = take(m->L[0].Nin_pad);
+  W.total = o;
+  return W;
+}
+
+// output slab [nrt][Cpad][32] -> y: tail 0 row-major [N][C]; tail 1 every 6 channels are a 6-D rotation -> axis-angle, [N][C/6][3]
+__global__ void mlp_out_kernel(const float* __restrict__ slab, float* __restrict__ y, int N, int C, int Cpad, int tail) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tail == 0) {
+    if (i >= (size_t)N * C) return;
+    const int r = (int)(i / C), c = (int)(i % C);
+    y[i] = slab[(size_t)(r >> 5) * Cpad * 32 + (size_t)(r & 31) * 4 + qoff(c)];
+  } else {
+    const int J = C / 6;
+    if (i >= (size_t)N * J) return;
+    const int r = (int)(i / J), j = (int)(i % J);
+    const float* s = slab + (size_t)(r >> 5) * Cpad * 32 + (size_t)(r & 31) * 4;
+    float v[6], R[9], aa[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = s[qoff(6 * j + k)];
+    rot6d_to_rotmat(v, R);
+    rotmat_to_aa(R, aa);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) y[i * 3 + k] = aa[k];
+  }
+}
+
+// g_y -> adjoint slab [nrt][Cpad][32] of the network output (zero in padded rows / channels); tail 1 goes back through
+// axis-angle <- rotation matrix <- 6-D with the forward's raw output (`slab`)
+__global__ void mlp_gout_kernel(const float* __restrict__ g_y, const float* __restrict__ slab, float* __restrict__ g, int N, int nrt, int C,
+                                int Cpad, int tail) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tail == 0) {
+    if (i >= (size_t)nrt * 32 * Cpad) return;
+    const int r = (int)(i / Cpad), c = (int)(i % Cpad);
+    g[(size_t)(r >> 5) * Cpad * 32 + (size_t)(r & 31) * 4 + qoff(c)] = (r < N && c < C) ? g_y[(size_t)r * C + c] : 0.f;
+  } else {
+    const int J = C / 6, Jp = (Cpad + 5) / 6;
+    if (i >= (size_t)nrt * 32 * Jp) return;
+    const int r = (int)(i / Jp), j = (int)(i % Jp);
+    const size_t base = (size_t)(r >> 5) * Cpad * 32 + (size_t)(r & 31) * 4;
+    float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < N && j < J) {
+      float v[6], R[9], gR[9];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v[k] = slab[base + qoff(6 * j + k)];
+      rot6d_to_rotmat(v, R);
+      const float ga[3] = {g_y[((size_t)r * J + j) * 3], g_y[((size_t)r * J + j) * 3 + 1], g_y[((size_t)r * J + j) * 3 + 2]};
+      rotmat_to_aa_bwd(R, ga, gR);
+      rot6d_to_rotmat_bwd(v, gR, o);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (6 * j + k < Cpad) g[base + qoff(6 * j + k)] = o[k];
+  }
+}
+
+}  // namespace ha
+
+extern "C" int ha_mlp_create(ha_mlp** out, int device, const ha_mlp_desc* desc, int act, float slope) {
+  HA_REQUIRE(out && desc, "ha_mlp_create: null argument");
+  HA_REQUIRE(act == HA_MLP_GN_RELU || act == HA_MLP_LEAKY_RELU, "ha_mlp_create: act must be HA_MLP_GN_RELU or HA_MLP_LEAKY_RELU (got %d)", act);
+  HA_REQUIRE(desc->skip_dim == 0, "ha_mlp_create: skip connections are only supported by the roll-out network");
+  HA_REQUIRE(desc->n_linear >= 1 && desc->n_linear <= MAXL, "ha_mlp_create: n_linear=%d out of range", desc->n_linear);
+  HA_REQUIRE(act != HA_MLP_LEAKY_RELU || slope > 0.f, "ha_mlp_create: the LeakyReLU slope must be > 0 (the adjoint reads the sign from the activation)");
+  DeviceGuard guard(device);
+  HA_REQUIRE(guard.ok, "ha_mlp_create: cannot select device %d", device);
+  ha_mlp* m = new ha_mlp();
+  m->device = device; m->n = desc->n_linear; m->act = act; m->slope = slope;
+  m->in_dim = desc->in_dim; m->out_dim = desc->out_dims[desc->n_linear - 1];
+  m->in_pad = ceil_div(desc->in_dim, 4) * 4;
+  int rc = HA_OK;
+  if (act == HA_MLP_GN_RELU) rc = pack_mlp(m->L, desc, "ha_mlp_create");
+  else {
+    int cin = desc->in_dim;
+    for (int i = 0; i < desc->n_linear && rc == HA_OK; ++i) {
+      if (!(desc->w[i] && desc->b[i])) { ha::set_error("ha_mlp_create: layer %d weights missing", i); rc = HA_ERR_INVALID_ARG; break; }
+      rc = pack_layer(m->L[i], desc->w[i], desc->b[i], nullptr, nullptr, cin, 0, desc->out_dims[i], false);
+      cin = desc->out_dims[i];
+    }
+  }
+  if (rc != HA_OK) { ha_mlp_destroy(m); return rc; }
+  for (int i = 0; i < m->n; ++i) {
+    if (m->L[i].Nout_pad > m->wmax) m->wmax = m->L[i].Nout_pad;
+    if (m->L[i].Nin_pad > m->wmax) m->wmax = m->L[i].Nin_pad;
+  }
+  *out = m;
+  return HA_OK;
+}
+
+extern "C" int ha_mlp_destroy(ha_mlp* m) {
+  if (!m) return HA_OK;
+  DeviceGuard guard(m->device);
+  for (int i = 0; i < MAXL; ++i) {
+    PackedLayer& P = m->L[i];
+    float* ptrs[5] = {P.Wf, P.Wb, P.bias, P.gamma, P.beta};
+    for (float* p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+  delete m;
+  return HA_OK;
+}
+
+extern "C" int ha_mlp_workspace(const ha_mlp* m, int N, int64_t* ws_floats) {
+  HA_REQUIRE(m && ws_floats && N >= 1, "ha_mlp_workspace: bad argument");
+  *ws_floats = (int64_t)mlp_layout(m, N).total;
+  return HA_OK;
+}
+
+extern "C" int ha_mlp_forward(const ha_mlp* m, int N, const float* x, int tail, float* y, float* ws, void* stream) {
+  HA_REQUIRE(m && x && y && ws && N >= 1, "ha_mlp_forward: bad argument");
+  HA_REQUIRE(tail == HA_MLP_TAIL_NONE || (tail == HA_MLP_TAIL_ROT6D_AA && m->out_dim % 6 == 0), "ha_mlp_forward: tail %d needs an output width that is a multiple of 6", tail);
+  DeviceGuard guard(m->device);
+  hipStream_t st = (hipStream_t)stream;
+  const MlpLayout W = mlp_layout(m, N);
+  hipLaunchKernelGGL(transpose_in_kernel, dim3(ceil_div((int)((size_t)W.nrt * m->in_pad * 32), 256)), dim3(256), 0, st, x, ws + W.xT, N, 1, m->in_dim,
+                     m->in_pad, W.nrt);
+  HA_LAUNCH_CHECK();
+  for (int l = 0; l < m->n; ++l) {
+    const PackedLayer& P = m->L[l];
+    const bool last = l + 1 == m->n;
+    GemmTask T;
+    memset(&T, 0, sizeof(T));
+    T.Wp = P.Wf; T.bias = P.bias;
+    T.ntiles = P.ntiles_f; T.nslices = P.nslices_f; T.Nout = P.Nout;
+    T.nrt = W.nrt; T.Cdst = P.Nout_pad;
+    T.Csrc = l == 0 ? m->in_pad : m->L[l - 1].Nout_pad;
+    if (m->act == HA_MLP_LEAKY_RELU) {
+      T.src = l == 0 ? ws + W.xT : ws + W.keep[l - 1];
+      if (last) { T.epi = 0; T.dst_h = ws + W.out; }
+      else { T.epi = 4; T.slope = m->slope; T.dst_a = ws + W.keep[l]; }
+    } else {
+      T.src = l == 0 ? ws + W.xT : ws + W.pp[(l - 1) & 1];
+      if (last) { T.epi = 0; T.dst_h = ws + W.out; }
+      else {
+        const PackedLayer& Nx = m->L[l + 1];
+        T.epi = 1; T.gamma = Nx.gamma; T.beta = Nx.beta; T.group = Nx.group;
+        T.dst_h = ws + W.keep[l]; T.dst_a = ws + W.pp[l & 1];
+      }
+    }
+    int rc = launch_prior_gemm(T, st);
+    if (rc != HA_OK) return rc;
+  }
+  const int C = m->out_dim, Cpad = m->L[m->n - 1].Nout_pad;
+  const size_t items = tail == HA_MLP_TAIL_NONE ? (size_t)N * C : (size_t)N * (C / 6);
+  hipLaunchKernelGGL(mlp_out_kernel, dim3((unsigned)ceil_div((int)items, 256)), dim3(256), 0, st, ws + W.out, y, N, C, Cpad, tail);
+  HA_LAUNCH_CHECK();
+  return HA_OK;
+}
+
+extern "C" int ha_mlp_backward(const ha_mlp* m, int N, const float* g_y, int tail, float* ws, float* g_x, void* stream) {
+  HA_REQUIRE(m && g_y && g_x && ws && N >= 1, "ha_mlp_backward: bad argument");
+  HA_REQUIRE(tail == HA_MLP_TAIL_NONE || (tail == HA_MLP_TAIL_ROT6D_AA && m->out_dim % 6 == 0), "ha_mlp_backward: tail %d needs an output width that is a multiple of 6", tail);
+  DeviceGuard guard(m->device);
+  hipStream_t st = (hipStream_t)stream;
+  const MlpLayout W = mlp_layout(m, N);
+  const int C = m->out_dim, Cpad = m->L[m->n - 1].Nout_pad;
+  // the adjoint of the output goes to pp[(n-1)&1]; layer l's task reads pp[l&1] and writes pp[(l-1)&1]
+  float* g_out = ws + W.pp[(m->n - 1) & 1];
+  const size_t items = tail == HA_MLP_TAIL_NONE ? (size_t)W.nrt * 32 * Cpad : (size_t)W.nrt * 32 * ceil_div(Cpad, 6);
+  hipLaunchKernelGGL(mlp_gout_kernel, dim3((unsigned)ceil_div((int)items, 256)), dim3(256), 0, st, g_y, ws + W.out, g_out, N, W.nrt, C, Cpad, tail);
+  HA_LAUNCH_CHECK();
+  for (int l = m->n - 1; l >= 0; --l) {
+    const PackedLayer& P = m->L[l];
+    GemmTask T;
+    memset(&T, 0, sizeof(T));
+    T.Wp = P.Wb; T.bias = nullptr;
+    T.ntiles = P.ntiles_b; T.nslices = P.nslices_b; T.Nout = P.Cin;
+    T.src = ws + W.pp[l & 1]; T.Csrc = P.Nout_pad;
+    T.nrt = W.nrt; T.Cdst = P.Nin_pad;
+    if (l == 0) { T.epi = 0; T.dst_h = ws + W.gx; }
+    else {
+      T.hsrc = ws + W.keep[l - 1]; T.Ch = m->L[l - 1].Nout_pad;
+      T.dst_a = ws + W.pp[(l - 1) & 1];
+      if (m->act == HA_MLP_LEAKY_RELU) { T.epi = 5; T.slope = m->slope; }
+      else { T.epi = 3; T.gamma = P.gamma; T.beta = P.beta; T.group = P.group; }
+    }
+    int rc = launch_prior_gemm(T, st);
+    if (rc != HA_OK) return rc;
+  }
+  hipLaunchKernelGGL(mlp_out_kernel, dim3((unsigned)ceil_div((int)((size_t)N * m->in_dim), 256)), dim3(256), 0, st, ws + W.gx, g_x, N, m->in_dim,
+                     m->L[0].Nin_pad, 0);
+  HA_LAUNCH_CHECK();
+  return HA_OK;
 }

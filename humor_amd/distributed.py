@@ -5,9 +5,10 @@ Design: *replicated optimiser, sharded closure*.  Every rank holds all optimisat
 runs the identical torch.optim.LBFGS; inside the closure a rank evaluates loss and gradient only for its contiguous
 slice of sub-sequences, then ONE all-reduce(SUM) of the packed [flat gradient | loss] vector makes the result -- and
 therefore every line-search decision -- identical on all ranks.  The overlap-consistency terms couple sequence b-1 and b;
-when b-1 lives on the previous rank its predicted tail is obtained with a differentiable all-gather (forward all_gather,
-backward all-reduce of the gathered gradient), so gradients are exact and each pair is counted once.
-=> 2 small collectives per closure forward (+1 in backward), all latency-bound (<= 170 KB).
+when they live on different ranks BOTH ranks evaluate the pair from a forward-only all_gather of the boundary sequences'
+overlapping frames (SURVEY.md 8(e) option B): the owner of b counts its value, the owner of b-1 adds only its own gradient
+(the terms are squared differences), so gradients are exact, each pair is counted once and the backward pass has no collective.
+=> 2 small collectives per closure evaluation (halo all_gather <= 90 KB, gradient all-reduce <= 0.4 MB), both latency-bound.
 """
 import torch
 import torch.distributed as dist
@@ -44,26 +45,16 @@ def _all_gather(out, x, group):
         dist.all_gather(out, x, group=group)
 
 
-class _AllGatherGrad(torch.autograd.Function):
-    """x [L] -> [world, L]; backward all-reduces the gathered gradient and returns this rank's row."""
-
-    @staticmethod
-    def forward(ctx, x, group):
-        ctx.group = group
-        world = dist.get_world_size(group)
-        out = [torch.empty_like(x) for _ in range(world)]
-        _all_gather(out, x.contiguous(), group)
-        return torch.stack(out, dim=0)
-
-    @staticmethod
-    def backward(ctx, g):
-        g = g.contiguous()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return g[dist.get_rank(ctx.group)], None
-
-
-def all_gather_with_grad(x, group=None):
-    return _AllGatherGrad.apply(x, group)
+def all_gather_flat(x, group=None):
+    """x [L] (no gradient) -> [world, L].  One collective: all_gather_into_tensor on RCCL, the list form through gloo."""
+    world = dist.get_world_size(group)
+    x = x.detach().contiguous()
+    out = torch.empty(world, x.numel(), dtype=x.dtype, device=x.device)
+    if dist.get_backend(group) == 'gloo':
+        _all_gather(list(out.unbind(0)), x, group)
+    else:
+        dist.all_gather_into_tensor(out, x, group=group)
+    return out
 
 
 def allreduce_loss_and_grads(loss, params, group=None):

@@ -385,6 +385,28 @@ class FittingLoss(nn.Module):
                 vel = vel + self.verts3d_loss(prev_pos[1:] - prev_pos[:-1], cur_pos[1:] - cur_pos[:-1])
         return pos, vel
 
+    def add_next_side(self, loss, kind, cam_pred_data, halo):
+        """Sharded closures, halo option (B): the consistency terms between this rank's LAST sequence and the next rank's first one
+        (`halo['next_*']`, detached copies).  The pair's value is counted by the rank that owns the later sequence; here it only
+        contributes its gradient w.r.t. this rank's variables (the terms are squared differences, fitting_loss.py:135-157,
+        211-215, 296-300), so `g - g.detach()` is added: zero value, exact gradient."""
+        W = self.loss_weights['rgb_overlap_consist']
+        if halo is None or halo.get('next_head') is None or W <= 0.0:
+            return loss
+        g = loss.new_zeros(())
+        ov = halo['ov_next']
+        if ov > 0 and 'verts3d' in cam_pred_data:
+            prev_pos, cur_pos = cam_pred_data['verts3d'][-1, -ov:], halo['next_head'][:ov]
+            g = g + self.verts3d_loss(prev_pos, cur_pos)
+            if ov > 1:
+                g = g + self.verts3d_loss(prev_pos[1:] - prev_pos[:-1], cur_pos[1:] - cur_pos[:-1])
+        if kind != 'root' and 'betas' in cam_pred_data:
+            g = g + self.joints3d_loss(cam_pred_data['betas'][-1], halo['next_betas'])
+        if kind == 'motion' and 'floor_plane' in cam_pred_data and halo.get('next_floor') is not None:
+            g = g + self.joints3d_loss(cam_pred_data['floor_plane'][-1], halo['next_floor'])
+        g = W * g
+        return loss + (g - g.detach())
+
     def smpl_fit(self, observed_data, pred_data, nsteps, halo=None):
         '''
         For fitting full shape and pose of SMPL (fitting_loss.py:183-224).  nsteps scales single-step terms.

@@ -229,14 +229,30 @@ class HumorModel(nn.Module):
         self._net_handles = {}
 
     # ------------------------------------------------------------------------------------------------
-    # single-step API (PyTorch ops; off the hot path)
+    # single-step API (off the hot path; the prior / posterior MLPs run through ha_mlp_* on a HIP device)
     # ------------------------------------------------------------------------------------------------
+    def _fused_forward(self, name, x):
+        """The skip-free GroupNorm MLP `name` ('encoder' / 'prior_net') through ha_mlp_* (humor_amd/mlp.py) for inputs on a HIP device
+        (or the emulator tier); the module's own PyTorch forward for host tensors."""
+        net = getattr(self, name)
+        on_dev = x.is_cuda or (self._lib is not None and self._lib.emulator)
+        if not on_dev or net.skip_input_idx is not None:
+            return net(x)
+        from .mlp import humor_mlp
+        lib = self._lib if self._lib is not None else _lib.get_lib()
+        ver = tuple(p._version for p in net.parameters())
+        key = (name, x.device.type, x.device.index or 0)
+        cached = self._net_handles.get(key)
+        if cached is None or cached[0] != ver:
+            self._net_handles[key] = cached = (ver, humor_mlp(lib, x.device.index or 0, net))
+        return cached[1](x)
+
     def prior(self, past_in):
-        out = self.prior_net(past_in)
+        out = self._fused_forward('prior_net', past_in)
         return out[:, :self.latent_size], torch.exp(out[:, self.latent_size:])
 
     def posterior(self, past_in, t_in):
-        out = self.encoder(torch.cat([past_in, t_in], dim=1))
+        out = self._fused_forward('encoder', torch.cat([past_in, t_in], dim=1))
         return out[:, :self.latent_size], torch.exp(out[:, self.latent_size:])
 
     def rsample(self, mu, var):

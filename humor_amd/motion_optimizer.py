@@ -35,7 +35,7 @@ class MotionOptimizer():
                  motion_prior=None, init_motion_prior=None, optim_floor=False, camera_matrix=None, robust_loss_type='none',
                  robust_tuning_const=4.6851, joint2d_sigma=100, stage3_tune_init_state=True, stage3_tune_init_num_frames=15,
                  stage3_tune_init_freeze_start=30, stage3_tune_init_freeze_end=50, stage3_contact_refine_only=False,
-                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs='auto', fused_loss=True, lbfgs='fused', fused_post=True, fused_pre=True):
+                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs='auto', fused_loss=True, lbfgs='fused', fused_post=True, fused_pre=True, fused_vposer=True):
         B, T = batch_size, seq_len
         self.device = device
         self.batch_size, self.seq_len = B, T
@@ -68,6 +68,9 @@ class MotionOptimizer():
         self.lbfgs_impl = lbfgs
         self.fused_post = bool(fused_post)
         self.fused_pre = bool(fused_pre)
+        # VPoser decode (+ 6-D -> R -> axis-angle) / encode through ha_mlp_* instead of the module's ATen ops (humor_amd/mlp.py)
+        self.fused_vposer = bool(fused_vposer)
+        self._vposer_handle = None
         self.closure_evals = 0
         self.stage_profile = None   # set to {} before run(): wall time / closure evaluations / outer iterations per stage (3 syncs per phase)
         self.loss_trace = None      # set to a list to record (stage, loss) of every closure evaluation (host sync per eval)
@@ -141,32 +144,55 @@ class MotionOptimizer():
                     out[k] = self._local(v)
                 else:
                     out[k] = v[self.shard.b0 - 1:self.shard.b1]
+                if self.shard is not None:
+                    iv = v.tolist()
+                    ovs = [int(iv[b - 1][1]) - int(iv[b][0]) for b in range(1, len(iv))]
+                    b1 = self.shard.b1
+                    # frames exchanged per side (identical on every rank) and this rank's overlap with the NEXT rank's first sequence
+                    self._pair_info = {'ovm': max(1, min(self.seq_len, max(ovs))) if ovs else 1,
+                                       'ov_next': ovs[b1 - 1] if b1 < len(iv) else None}
             else:
                 v = self._local(v)
                 out[k] = v[:, :nsteps] if nsteps is not None else v
         return out
 
     def _halo(self, pred_verts3d, betas, floor_plane, active):
-        """Differentiable exchange of each rank's LAST sequence (predicted key vertices, betas, floor) -> the halo the
-        consistency terms of this rank's FIRST sequence need."""
+        """Forward-only exchange (SURVEY 8(e) option B) of the sequences at the rank boundaries: ONE all_gather of each rank's
+        [tail of its last sequence | head of its first sequence] (predicted key vertices of the frames that can overlap, betas, floor).
+        A rank evaluates the consistency pair (b-1, b) that straddles its lower boundary from the gathered copy of b-1 (counted in
+        the loss) and the pair at its upper boundary from the copy of the next rank's first sequence (FittingLoss.
+        overlap_next_side: gradient only, zero value), so every pair is counted once, every variable gets its exact gradient
+        from its own rank, and no collective runs in the backward pass."""
         if self.shard is None:
             return None
+        sh = self.shard
         if not active:
-            return {'first': self.shard.rank == 0, 'prev_tail': None, 'prev_betas': None, 'prev_floor': None}
-        from .distributed import all_gather_with_grad
-        T = pred_verts3d.size(1)
-        fp = floor_plane[-1] if floor_plane is not None else pred_verts3d.new_zeros(3)
-        packed = torch.cat([pred_verts3d[-1].reshape(-1), betas[-1].reshape(-1), fp.reshape(-1)])
-        allg = all_gather_with_grad(packed, self.shard.group)
-        # every rank must run the gather's backward collective, also the ones whose loss does not read the halo
-        halo = {'first': self.shard.rank == 0, 'prev_tail': None, 'prev_betas': None, 'prev_floor': None, 'dep': 0.0 * allg.sum()}
-        if self.shard.rank > 0:
-            prev = allg[self.shard.rank - 1]
-            n = T * len(KEYPT_VERTS) * 3
-            halo['prev_tail'] = prev[:n].reshape(T, len(KEYPT_VERTS), 3)
-            halo['prev_betas'] = prev[n:n + self.num_betas]
+            return {'first': sh.rank == 0, 'prev_tail': None, 'prev_betas': None, 'prev_floor': None}
+        from .distributed import all_gather_flat
+        T, nb = pred_verts3d.size(1), self.num_betas
+        ovm = min(self._pair_info['ovm'], T)
+        zf = pred_verts3d.new_zeros(3)
+        with torch.no_grad():
+            packed = torch.cat([pred_verts3d[-1, T - ovm:].reshape(-1), betas[-1].reshape(-1), floor_plane[-1].reshape(-1) if floor_plane is not None else zf,
+                                pred_verts3d[0, :ovm].reshape(-1), betas[0].reshape(-1), floor_plane[0].reshape(-1) if floor_plane is not None else zf])
+            allg = all_gather_flat(packed, sh.group)
+        nv = ovm * len(KEYPT_VERTS) * 3
+        half = nv + nb + 3
+        halo = {'first': sh.rank == 0, 'prev_tail': None, 'prev_betas': None, 'prev_floor': None}
+        if sh.rank > 0:
+            prev = allg[sh.rank - 1, :half]
+            tail = prev[:nv].reshape(ovm, len(KEYPT_VERTS), 3)
+            # the loss reads the predecessor as a whole [T,43,3] sequence and takes its last `overlap` frames
+            halo['prev_tail'] = tail if ovm == T else torch.cat([tail.new_zeros(T - ovm, len(KEYPT_VERTS), 3), tail], dim=0)
+            halo['prev_betas'] = prev[nv:nv + nb]
             if floor_plane is not None:
-                halo['prev_floor'] = prev[n + self.num_betas:n + self.num_betas + 3]
+                halo['prev_floor'] = prev[nv + nb:half]
+        if sh.rank < sh.world - 1 and self._pair_info['ov_next'] is not None:
+            nxt = allg[sh.rank + 1, half:]
+            halo['next_head'] = nxt[:nv].reshape(ovm, len(KEYPT_VERTS), 3)
+            halo['next_betas'] = nxt[nv:nv + nb]
+            halo['next_floor'] = nxt[nv + nb:half] if floor_plane is not None else None
+            halo['ov_next'] = min(self._pair_info['ov_next'], T)
         return halo
 
     def make_closure(self, objective, params, optim=None, short=True):
@@ -240,10 +266,6 @@ class MotionOptimizer():
         if key is not None:
             self.stage_profile[key] = {'seconds': now - prev[0], 'closure_evals': self.closure_evals - prev[1], 'outer_iters': iters}
         self.stage_profile['_last'] = (now, self.closure_evals)
-
-    @staticmethod
-    def _with_dep(loss, halo):
-        return loss + halo['dep'] if halo is not None and 'dep' in halo else loss
 
     def _finish_closure(self, loss, params, stats=None):
         loss.backward()
@@ -500,7 +522,7 @@ class MotionOptimizer():
         halo = self._halo(pred['verts3d'], self._local(self.betas), None,
                           has_overlap and self.fitting_loss.loss_weights['rgb_overlap_consist'] > 0.0)
         loss, stats = self.fitting_loss.root_fit(obs_local, pred, halo=halo)
-        return self._with_dep(loss, halo), stats
+        return self.fitting_loss.add_next_side(loss, 'root', pred, halo), stats
 
     def _stage2_objective(self, obs_local, has_overlap):
         """Stage-2 objective on this rank's sequences (motion_optimizer.py:291-304)."""
@@ -512,7 +534,7 @@ class MotionOptimizer():
         halo = self._halo(pred['verts3d'], pred['betas'], None,
                           has_overlap and self.fitting_loss.loss_weights['rgb_overlap_consist'] > 0.0)
         loss, stats = self.fitting_loss.smpl_fit(obs_local, pred, self.seq_len, halo=halo)
-        return self._with_dep(loss, halo), stats
+        return self.fitting_loss.add_next_side(loss, 'smpl', pred, halo), stats
 
     def _pre_stage3_eager(self, latent_pose, trans, root_orient, betas, floor, trans_vel, joints_vel, root_orient_vel):
         from . import _lib as _libmod
@@ -584,9 +606,10 @@ class MotionOptimizer():
                           has_overlap and self.fitting_loss.loss_weights['rgb_overlap_consist'] > 0.0)
         loss, stats = self.fitting_loss.motion_fit(obs, pred, cam_pred, nsteps, cond_prior=rr.get('cond_prior'),
                                                    init_motion_scale=init_motion_scale, halo=halo)
+        loss = self.fitting_loss.add_next_side(loss, 'motion', cam_pred, halo)
         if tune_phase:
             self.fitting_loss.loss_weights['rgb_overlap_consist'] = og_overlap_w
-        return self._with_dep(loss, halo), stats
+        return loss, stats
 
     # ------------------------------------------------------------------------------------------------
     def _stage_snapshot(self, stages_res_out, fname):
@@ -768,14 +791,39 @@ class MotionOptimizer():
             res['floor_plane'] = d(frames.parse_floor_plane(self.floor_plane))
         return res
 
+    def _fused_vposer(self, x):
+        """The ha_mlp_* handles of the pose prior for tensors on a HIP device (or the emulator tier), else None."""
+        if not self.fused_vposer:
+            return None
+        lib = self.fit_bm._lib
+        if not (x.is_cuda or (lib is not None and lib.emulator)):
+            return None
+        if self._vposer_handle is None:
+            from . import _lib as _libmod
+            from .mlp import FusedVPoser
+            try:
+                self._vposer_handle = FusedVPoser(self.pose_prior, lib if lib is not None else _libmod.get_lib(), x.device.index or 0)
+            except NotImplementedError as e:
+                import warnings
+                warnings.warn(f'humor_amd: pose prior evaluated through its own PyTorch modules ({e}); call pose_prior.eval() '
+                              f'as run_fitting.py does to enable the fused VPoser kernels')
+                self._vposer_handle = False      # not a VPoser v1.0-shaped module: evaluate it as given
+        return self._vposer_handle or None
+
     def latent2pose(self, latent_pose):
         '''VPoser latent -> axis-angle body pose.  [B,T,D] -> [B,T,63]'''
         B, T, _ = latent_pose.size()
+        fv = self._fused_vposer(latent_pose)
+        if fv is not None:
+            return fv.decode_aa(latent_pose.reshape(-1, self.latent_pose_dim)).reshape(B, T, J_BODY * 3)
         mats = self.pose_prior.decode(latent_pose.reshape(-1, self.latent_pose_dim), output_type='matrot')
         return ops.rotation_matrix_to_angle_axis(mats.reshape(B * T * J_BODY, 3, 3), _lib_override=self.fit_bm._lib).reshape(B, T, J_BODY * 3)
 
     def pose2latent(self, body_pose):
         B, T, _ = body_pose.size()
+        fv = self._fused_vposer(body_pose)
+        if fv is not None:
+            return fv.encode_mean(body_pose.reshape(-1, J_BODY * 3)).reshape(B, T, self.latent_pose_dim)
         return self.pose_prior.encode(body_pose.reshape(-1, J_BODY * 3)).mean.reshape(B, T, self.latent_pose_dim)
 
     def _keypt_idx(self, device):

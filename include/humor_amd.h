@@ -166,6 +166,25 @@ int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float
                               float* stash, float* g_past_in0, float* g_z_seq, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Frozen MLPs on N independent rows (no weight gradients): VPoser v1.0's decoder / encoder as MotionOptimizer.latent2pose /
+ * pose2latent call them in every closure (humor/fitting/motion_optimizer.py:1041-1063; Linear + LeakyReLU(0.2), eval-mode
+ * BatchNorm folded into the Linear layers by the host, the decoder followed by 6-D -> rotation matrix -> axis-angle), and
+ * HuMoR's posterior encoder (humor/models/humor_model.py:180-190, 400-405: Linear + GroupNorm(16) + ReLU on [past | next]).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ha_mlp ha_mlp;
+#define HA_MLP_GN_RELU 0        /* GroupNorm(16) + ReLU before every Linear after the first (desc.gn_gamma / gn_beta) */
+#define HA_MLP_LEAKY_RELU 1     /* LeakyReLU(slope) between the Linear layers */
+#define HA_MLP_TAIL_NONE 0      /* y [N, out] */
+#define HA_MLP_TAIL_ROT6D_AA 1  /* every 6 outputs are a 6-D rotation: y [N, out/6, 3] axis-angle (transforms.py:201-220, 243-389) */
+int ha_mlp_create(ha_mlp** out, int device, const ha_mlp_desc* desc /* skip_dim = 0 */, int act, float slope);
+int ha_mlp_destroy(ha_mlp* mlp);
+int ha_mlp_workspace(const ha_mlp* mlp, int N, int64_t* ws_floats);
+/* x [N, in] -> y; `ws` (ha_mlp_workspace floats) keeps what ha_mlp_backward needs. */
+int ha_mlp_forward(const ha_mlp* mlp, int N, const float* x, int tail, float* y, float* ws, void* stream);
+/* g_y (shape of y) -> g_x [N, in]; `ws` is the forward's (its scratch part is overwritten). */
+int ha_mlp_backward(const ha_mlp* mlp, int N, const float* g_y, int tail, float* ws, float* g_x, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fitting objective: the data / regularisation terms of FittingLoss.root_fit / smpl_fit / motion_fit
  * (humor/fitting/fitting_loss.py:94-309; term definitions :317-484, 504-516; gmof fitting_utils.py:250-258;
  * perspective_projection fitting_utils.py:647-676 with identity extrinsics) and their gradients, in one pass.

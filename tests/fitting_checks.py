@@ -20,7 +20,7 @@ def build(lib, device, kind, B, T, npz, shard=None, state_dict=None):
     hm = hm.to(device).eval()
     for p in hm.parameters():
         p.requires_grad_(False)
-    vp = synth.SynthVPoser(seed=0).to(device)
+    vp = synth.SynthVPoser(seed=0).to(device).eval()      # run_fitting.py:232-234 puts the pose prior in eval mode
     w, mu, cov = synth.make_gmm(seed=0)
     weights = CC.RGB_WEIGHTS if rgb else CC.AMASS_WEIGHTS
     cam = CC.camera_matrix(B).to(device) if rgb else None

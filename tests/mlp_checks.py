@@ -1,0 +1,107 @@
+"""Parity checks of the ha_mlp_* path (VPoser decoder / encoder, HuMoR posterior encoder) against the plain PyTorch modules +
+the oracle's R -> axis-angle (bit-pinned to transforms.py:243-389).  Emulator tier on CPU, gfx950 build on the GPU."""
+import torch
+import torch.nn as nn
+
+from humor_amd import mlp as M
+from humor_amd import synth
+from oracle import humor_restated as H
+
+import rollout_checks as RC
+
+
+class RealShapedVPoser(nn.Module):
+    """Member names and arithmetic of human_body_prior v1.0's VPoser (the snapshot fitting_utils.py:705-732 loads): eval-mode
+    BatchNorm in front of both encoder Linears, dropout, LeakyReLU(0.2), continuous 6-D rotation decoder.  Random weights."""
+    def __init__(self, seed=0, latentD=32, hidden=512, nj=21):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.latentD, self.num_joints, self.use_cont_repr = latentD, nj, True
+        self.bodyprior_enc_bn1 = nn.BatchNorm1d(nj * 3)
+        self.bodyprior_enc_fc1 = nn.Linear(nj * 3, hidden)
+        self.bodyprior_enc_bn2 = nn.BatchNorm1d(hidden)
+        self.bodyprior_enc_fc2 = nn.Linear(hidden, hidden)
+        self.bodyprior_enc_mu = nn.Linear(hidden, latentD)
+        self.bodyprior_enc_logvar = nn.Linear(hidden, latentD)
+        self.dropout = nn.Dropout(p=.1)
+        self.bodyprior_dec_fc1 = nn.Linear(latentD, hidden)
+        self.bodyprior_dec_fc2 = nn.Linear(hidden, hidden)
+        self.bodyprior_dec_out = nn.Linear(hidden, nj * 6)
+        with torch.no_grad():
+            for bn in (self.bodyprior_enc_bn1, self.bodyprior_enc_bn2):
+                bn.running_mean.normal_(0, 0.3)
+                bn.running_var.uniform_(0.5, 1.5)
+                bn.weight.uniform_(0.7, 1.3)
+                bn.bias.normal_(0, 0.1)
+            self.bodyprior_dec_out.weight.mul_(0.3)
+            self.bodyprior_dec_out.bias.copy_(torch.tensor([1., 0., 0., 1., 0., 0.]).repeat(nj))
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def encode(self, Pin):
+        lr = lambda x: nn.functional.leaky_relu(x, negative_slope=.2)
+        x = self.bodyprior_enc_bn1(Pin.reshape(Pin.size(0), -1))
+        x = lr(self.bodyprior_enc_fc1(x))
+        x = self.bodyprior_enc_bn2(x)
+        x = lr(self.bodyprior_enc_fc2(x))
+        return torch.distributions.normal.Normal(self.bodyprior_enc_mu(x), nn.functional.softplus(self.bodyprior_enc_logvar(x)))
+
+    def decode(self, Zin, output_type='matrot'):
+        lr = lambda x: nn.functional.leaky_relu(x, negative_slope=.2)
+        x = lr(self.bodyprior_dec_fc1(Zin))
+        x = self.dropout(x)
+        x = lr(self.bodyprior_dec_fc2(x))
+        x = self.bodyprior_dec_out(x)
+        return synth._rot6d_to_mat(x).reshape(Zin.size(0), 1, -1, 9)
+
+
+def _cmp(a, b, tol, what):
+    e = (a.detach().cpu() - b.detach().cpu()).abs().max().item()
+    s = max(1.0, b.detach().abs().max().item())
+    assert e <= tol * s, f'{what}: max err {e:.3e} (scale {s:.3g})'
+
+
+def check_vposer(lib, device, N=100, seed=0, real_shaped=False):
+    vp = (RealShapedVPoser(seed) if real_shaped else synth.SynthVPoser(seed=seed)).eval()
+    fv = M.FusedVPoser(vp, lib, device.index or 0 if device.type == 'cuda' else 0)
+    g = torch.Generator().manual_seed(seed + 1)
+    # ---- decode: latent -> axis-angle -------------------------------------------------------------------------------------
+    zc = torch.randn(N, vp.latentD, generator=g).requires_grad_(True)
+    z = zc.detach().clone().to(device).requires_grad_(True)
+    aa_ref = H.rot_to_aa(vp.decode(zc).reshape(-1, 3, 3)).reshape(N, -1)
+    aa = fv.decode_aa(z)
+    assert aa.shape == (N, 63)
+    _cmp(aa, aa_ref, 2e-5, 'decode')
+    w = torch.randn(N, 63, generator=g)
+    gz_ref = torch.autograd.grad((aa_ref * w).sum(), zc)[0]
+    gz = torch.autograd.grad((aa * w.to(device)).sum(), z)[0]
+    _cmp(gz, gz_ref, 1e-4, 'decode grad')
+    # ---- encode: axis-angle -> posterior mean ------------------------------------------------------------------------------
+    pc = (0.4 * torch.randn(N, 63, generator=g)).requires_grad_(True)
+    p = pc.detach().clone().to(device).requires_grad_(True)
+    mu_ref = vp.encode(pc).mean
+    mu = fv.encode_mean(p)
+    assert mu.shape == (N, vp.latentD)
+    _cmp(mu, mu_ref, 2e-5, 'encode')
+    w = torch.randn(N, vp.latentD, generator=g)
+    gp_ref = torch.autograd.grad((mu_ref * w).sum(), pc)[0]
+    gp = torch.autograd.grad((mu * w.to(device)).sum(), p)[0]
+    _cmp(gp, gp_ref, 1e-4, 'encode grad')
+
+
+def check_posterior(lib, device, N=70, seed=0):
+    """HuMoR's posterior encoder [past 339 | next 339] -> 96 (GroupNorm(16) + ReLU) against the module's PyTorch forward, with
+    gradients (the fitting path only reads the forward: infer_latent_motion's result is detached, motion_optimizer.py:356)."""
+    hm, _ = RC.make_model(None, torch.device('cpu'), seed=seed, contractive=True)
+    enc = hm.encoder
+    f = M.humor_mlp(lib, device.index or 0 if device.type == 'cuda' else 0, enc)
+    g = torch.Generator().manual_seed(seed + 2)
+    xc = torch.cat([RC.canonical_state(N, g), RC.canonical_state(N, g)], 1).requires_grad_(True)
+    x = xc.detach().clone().to(device).requires_grad_(True)
+    y_ref = enc(xc)
+    y = f(x)
+    _cmp(y, y_ref, 1e-4, 'posterior')
+    w = torch.randn(N, y_ref.shape[1], generator=g)
+    g_ref = torch.autograd.grad((y_ref * w).sum(), xc)[0]
+    gx = torch.autograd.grad((y * w.to(device)).sum(), x)[0]
+    _cmp(gx, g_ref, 1e-3, 'posterior grad')

@@ -118,11 +118,14 @@ def _sharded_worker(rank, world, port, npz, emu_path, out):
     dist.destroy_process_group()
 
 
-def test_sharded_closure_equals_single_process(emu_lib, smplh_npz, tmp_path):
-    """world_size-2 gloo: replicated variables, closure on the local slice, packed all-reduce, differentiable halo."""
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_closure_equals_single_process(emu_lib, smplh_npz, tmp_path, world):
+    """world_size-2/3 gloo: replicated variables, closure on the local slice, packed all-reduce, forward-only halo (option B: both
+    neighbours evaluate the boundary pair; with 3 ranks over 4 sequences the middle ranks own ONE sequence that is both the
+    first and the last of its shard)."""
     out = str(tmp_path / 'sharded.pt')
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_sharded_worker, args=(2, port, smplh_npz, emu_lib.path, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_sharded_worker, args=(world, port, smplh_npz, emu_lib.path, out), nprocs=world, join=True)
     sharded = torch.load(out)
     B, T = 4, 8
     case = CC.make_case('rgb', B, T, seed=1)

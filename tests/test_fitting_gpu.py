@@ -145,7 +145,7 @@ def test_points3d_chamfer_term_through_the_optimizer(gpu_lib, dev, smplh_npz):
     hm = hm.to(dev).eval()
     w, mu, cov = synth.make_gmm(seed=0)
     weights = stage_weights([{'points3d': 1.0}] * 3)
-    opt = MotionOptimizer(dev, bm, 16, B, T, ['points3d'], weights, synth.SynthVPoser(seed=0).to(dev), hm,
+    opt = MotionOptimizer(dev, bm, 16, B, T, ['points3d'], weights, synth.SynthVPoser(seed=0).to(dev).eval(), hm,
                           {'gmm': (w.to(dev), mu.to(dev), cov.to(dev))}, robust_loss_type='bisquare', use_chamfer=True)
     g = torch.Generator().manual_seed(0)
     opt.trans = (0.1 * torch.randn(B, T, 3, generator=g)).to(dev).requires_grad_(True)

@@ -2,6 +2,7 @@
 import pytest
 import torch
 
+import mlp_checks as MC
 import rollout_checks as RC
 
 CPU = torch.device('cpu')
@@ -53,3 +54,12 @@ def test_rollout_refuses_cpu():
 @pytest.mark.slow
 def test_emu_sampling_and_canonicalize(emu_lib):
     RC.check_sampling_rollout(emu_lib, torch.device('cpu'), B=2, S=2, n_mean=1, n_canon=1)
+
+
+def test_emu_fused_vposer_matches_module(emu_lib):
+    MC.check_vposer(emu_lib, CPU, N=40)
+    MC.check_vposer(emu_lib, CPU, N=33, real_shaped=True, seed=3)
+
+
+def test_emu_fused_posterior_encoder_matches_module(emu_lib):
+    MC.check_posterior(emu_lib, CPU, N=37)

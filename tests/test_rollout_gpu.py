@@ -2,6 +2,7 @@
 import pytest
 import torch
 
+import mlp_checks as MC
 import rollout_checks as RC
 
 pytestmark = pytest.mark.gpu
@@ -80,3 +81,16 @@ def test_sampling_and_canonicalize(gpu_lib, dev):
 
 def test_sampling_golden_vectors(gpu_lib, dev):
     RC.check_sampling_golden(gpu_lib, dev)
+
+
+@pytest.mark.parametrize('N', [1, 33, 1920])
+def test_fused_vposer_matches_module(gpu_lib, dev, N):
+    """VPoser decode (+ 6-D -> R -> axis-angle) / encode through ha_mlp_* vs the PyTorch module + oracle R -> aa, forward and
+    gradients (motion_optimizer.py:1041-1063), for the stand-in and for a module with VPoser v1.0's member names (BatchNorm folded)."""
+    MC.check_vposer(gpu_lib, dev, N=N)
+    MC.check_vposer(gpu_lib, dev, N=N, real_shaped=True, seed=3)
+
+
+def test_fused_posterior_encoder_matches_module(gpu_lib, dev):
+    MC.check_posterior(gpu_lib, dev, N=32 * 59)
+    MC.check_posterior(gpu_lib, dev, N=5)
