@@ -120,8 +120,11 @@ class _SmplFunction(torch.autograd.Function):
             nv, nc = C.c_int64(), C.c_int64()
             lib.call('ha_smpl_workspace', h.ptr, N, cfg['n_active'], C.byref(nv), C.byref(nc))
             ws_v, ws_c = new(nv.value), new(nc.value)
+            # algo 0 (auto) resolved here as ha_smpl_forward does (MFMA blend + streaming skinning when the model allows it), so that
+            # the backward knows whether v_posed / A were materialised
+            algo = cfg['algo'] if cfg['algo'] != 0 else (2 if (h.info(3) <= 4 and h.V >= 1024) else 1)
             lib.call('ha_smpl_forward', h.ptr, 0, N, cfg['n_active'], _lib.ptr(pose), _lib.ptr(betas), _lib.ptr(transl),
-                     _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(A), _lib.ptr(ws_v), _lib.ptr(ws_c), cfg['algo'], st)
+                     _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(A), _lib.ptr(ws_v), _lib.ptr(ws_c), algo, st)
             if n_sel:
                 joints = torch.cat([joints, verts.index_select(1, cfg['selector_t'])], dim=1)
             v_out = verts
@@ -134,6 +137,9 @@ class _SmplFunction(torch.autograd.Function):
                 joints = torch.cat([joints, vs[:, :n_sel]], dim=1)
             v_out = vs[:, n_sel:].contiguous()
         ctx.cfg = cfg
+        ctx.dense_ws = None
+        if cfg['mode'] == 'dense' and algo == 2 and cfg.get('dense_bwd', True):
+            ctx.dense_ws = (ws_v, A)        # v_posed and the skinning transforms: inputs of the batched dense backward
         ctx.save_for_backward(pose, betas)
         ctx.set_materialize_grads(False)
         return v_out, joints
@@ -175,6 +181,16 @@ class _SmplFunction(torch.autograd.Function):
         g_pose = torch.empty_like(pose)
         g_betas = torch.empty_like(betas)
         g_transl = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        if cfg['mode'] == 'dense' and slot == 0 and g_set is not None and ctx.dense_ws is not None:
+            # every vertex carries a gradient: batched streaming / MFMA vertex phase instead of the wave-per-frame adjoint
+            nw = C.c_int64()
+            lib.call('ha_smpl_backward_dense_workspace', h.ptr, N, cfg['n_active'], C.byref(nw))
+            ws = torch.empty(nw.value, dtype=torch.float32, device=dev)
+            v_posed, A = ctx.dense_ws
+            lib.call('ha_smpl_backward_dense', h.ptr, N, cfg['n_active'], _lib.ptr(pose), _lib.ptr(betas), _lib.ptr(g_set),
+                     _lib.ptr(g_j52) if g_j52 is not None else None, _lib.ptr(v_posed), _lib.ptr(A), _lib.ptr(ws),
+                     _lib.ptr(g_pose), _lib.ptr(g_betas), _lib.ptr(g_transl), _lib.stream_ptr(pose))
+            return g_pose, g_betas, g_transl, None
         lib.call('ha_smpl_backward', h.ptr, slot, N, cfg['n_active'], _lib.ptr(pose), _lib.ptr(betas),
                  _lib.ptr(g_set) if g_set is not None else None, _lib.ptr(g_j52) if g_j52 is not None else None,
                  _lib.ptr(g_pose), _lib.ptr(g_betas), _lib.ptr(g_transl), _lib.stream_ptr(pose))

@@ -39,11 +39,13 @@ namespace ha {
 // ha_tune_set("skin_variant"): -1 = auto; else bits 0-1: waves per block 4 << b; +4: non-temporal stores;
 // +8 / +16: profiling modes of the streaming kernel (LDS-transposed copy only / every lane gathers bone 0)
 int g_skin_variant = -1;
+int g_dense_bwd_waves = 0;   // ha_tune_set("dense_bwd_waves"): wave-count target of the dense backward's K split (0 = default)
 extern int g_layer_spb, g_layer_nw, g_layer_finish, g_gemm_rm, g_layer_hsum;   // rollout.hip
 }
 extern "C" int ha_tune_set(const char* key, int value) {
   HA_REQUIRE(key, "ha_tune_set: null key");
   if (strcmp(key, "skin_variant") == 0) { ha::g_skin_variant = value; return HA_OK; }
+  if (strcmp(key, "dense_bwd_waves") == 0) { ha::g_dense_bwd_waves = value; return HA_OK; }
   if (strcmp(key, "layer_spb") == 0) { ha::g_layer_spb = value; return HA_OK; }
   if (strcmp(key, "layer_nw") == 0) { ha::g_layer_nw = value; return HA_OK; }
   if (strcmp(key, "layer_finish") == 0) { ha::g_layer_finish = value; return HA_OK; }
@@ -93,7 +95,7 @@ static int build_set(ha_smpl_model* m, int slot, const int32_t* ids, int n) {
   s.npad = s.nchunks * kChunk;
   const int K = m->Kfull, V = m->V, nnz = m->nnz;
   std::vector<float> pd((size_t)s.nchunks * K * 3 * kChunk, 0.0f);
-  const int Kp = ceil_div(K, 64) * 64;
+  const int Kp = ceil_div(K, 128) * 128;   // whole 128-coefficient groups (dense_gco_kernel reads them as one)
   std::vector<float> pdk((size_t)s.nchunks * 3 * kChunk * Kp, 0.0f);   // coefficient-major copy for the adjoint
   std::vector<float> w((size_t)s.nchunks * nnz * kChunk, 0.0f);
   std::vector<int32_t> ix((size_t)s.nchunks * nnz * kChunk, 0);
@@ -245,6 +247,11 @@ extern "C" int ha_smpl_model_create(ha_smpl_model** out, int device, int V, int 
     }
     if ((rc = upload(&m->w4, w4)) != HA_OK) return fail(rc);
     if ((rc = upload(&m->idx4, i4)) != HA_OK) return fail(rc);
+    // dense skinning weights [Vpad][64] (B operand of the dense backward's dL/dA product)
+    std::vector<float> wd((size_t)m->Vpad * 64, 0.0f);
+    for (int v = 0; v < V; ++v)
+      for (int q = 0; q < nnz; ++q) wd[(size_t)v * 64 + m->h_idx[(size_t)v * nnz + q]] += m->h_w[(size_t)v * nnz + q];
+    if ((rc = upload(&m->Wd, wd)) != HA_OK) return fail(rc);
   }
   *out = m;
   return HA_OK;
@@ -254,7 +261,7 @@ extern "C" int ha_smpl_model_destroy(ha_smpl_model* m) {
   if (!m) return HA_OK;
   DeviceGuard guard(m->device);
   for (int s = 0; s < kMaxSubsets; ++s) free_set(m->sets[s]);
-  void* ptrs[] = {m->Jt, m->Js, m->parents, m->jdepth, m->child_start, m->child_idx, m->Pd_m, m->w4, m->idx4};
+  void* ptrs[] = {m->Jt, m->Js, m->parents, m->jdepth, m->child_start, m->child_idx, m->Pd_m, m->w4, m->idx4, m->Wd};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete[] m->h_Pd;
@@ -310,6 +317,9 @@ struct FrameParams {
   // backward io
   const float* g_verts; const float* g_joints;
   float* g_pose; float* g_betas; float* g_transl;
+  // dense backward (ha_smpl_backward_dense): the vertex phase ran in the streaming / MFMA kernels, this kernel only consumes
+  // its results: dL/dA [N][J][12], K-split partials of dL/dcoeff [gco_ks][gco_rows][gco_ld], partial vertex-gradient sums
+  const float* gA_in; const float* gco_part; int gco_ks, gco_rows, gco_ld; const float* gtl_part; int gtl_np;
 };
 
 constexpr int FW = 4;  // waves (= frames) per block
@@ -600,6 +610,22 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
         }
       }
       __syncthreads();
+    }
+  }
+  if (p.gA_in) {
+    if (isj) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) gA[lane * 12 + i] = p.gA_in[((size_t)f * J + lane) * 12 + i];
+    }
+#pragma unroll
+    for (int m = 0; m < kMaxKM; ++m) {
+      const int k = 256 * (m >> 2) + 4 * lane + (m & 3);
+      if (k < p.gco_ld)
+        for (int ks = 0; ks < p.gco_ks; ++ks) gco_reg[m] += p.gco_part[((size_t)ks * p.gco_rows + f) * p.gco_ld + k];   // fixed order
+    }
+    if (lane < p.gtl_np) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gtl[c] += p.gtl_part[((size_t)f * p.gtl_np + lane) * 3 + c];
     }
   }
 #pragma unroll
@@ -938,13 +964,226 @@ __global__ __launch_bounds__(64 * NW) void lbs_skin_wave_kernel(const float* __r
     skin_wave_body<NT, DIAG, NW, false>(v_posed, A, transl, w4, idx4, verts, N, V, J, smem);
 }
 
+// ===================================================================================================
+// dense backward (all V vertices carry a gradient: point-cloud / chamfer terms).  The wave-per-frame adjoint re-blends every
+// vertex and walks the blend matrix twice per frame (2 x 18 MB of L2 traffic per frame at V = 6890); here the vertex phase
+// is three batched kernels over all frames, and smpl_frame_bwd_kernel only finishes the kinematic chain:
+//   (1) dense_gvp_kernel   dL/dv_posed = T_R^T g (streaming, HBM-bound), written K-major for the GEMM below
+//   (2) dense_gA_kernel    dL/dA_j = sum_v w_vj [g_v (x) v_posed_v | g_v]: per frame a (12 x V) x (V x 64) product with the dense
+//                          skinning-weight matrix, v_mfma_f32_16x16x4_f32, the A operand formed on the fly from g and v_posed
+//   (3) dense_gco_kernel   dL/dcoeff [N, Kc] = dL/dv_posed [N, 3 V] x Pd^T: v_mfma_f32_32x32x2_f32, K split over waves
+// ===================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kGvpChunksPerBlock = 27;      // 4 blocks per frame at V = 6890 (108 chunks)
+
+// grid (chunk groups, N), 4 waves; wave w of block y takes chunks y * 27 + w, + 4, ...
+__global__ __launch_bounds__(256) void dense_gvp_kernel(const float* __restrict__ g_verts, const float* __restrict__ A,
+                                                        const float4* __restrict__ w4, const uint32_t* __restrict__ idx4,
+                                                        float* __restrict__ gvpT, float* __restrict__ gtl_part, int V, int J,
+                                                        int nchunks, int np) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int f = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < J * 12; i += 256) smem[i] = A[(size_t)f * J * 12 + i];
+  __syncthreads();
+  float gs[3] = {0.f, 0.f, 0.f};
+  const int c0 = blockIdx.x * kGvpChunksPerBlock;
+  const int c1 = c0 + kGvpChunksPerBlock < nchunks ? c0 + kGvpChunksPerBlock : nchunks;
+  for (int ch = c0 + wave; ch < c1; ch += 4) {
+    const int v = ch * 64 + lane;
+    float g[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f};
+    if (v < V) {
+      const float* src = g_verts + ((size_t)f * V + v) * 3;
+      g[0] = src[0]; g[1] = src[1]; g[2] = src[2];
+      const float4 wv = w4[v];
+      const uint32_t id = idx4[v];
+      const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+      float T[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) T[i] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* a = smem + ((id >> (8 * q)) & 0xff) * 12;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) T[i] = fmaf(wq[q], a[i], T[i]);
+      }
+      mat3_tvec(T, g, gv);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      gs[c] += g[c];
+      gvpT[((size_t)f * nchunks + ch) * 192 + c * 64 + lane] = gv[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float vsum = gs[c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vsum += __shfl_xor(vsum, off);
+    if (lane == 0) gtl_part[((size_t)f * np + blockIdx.x * 4 + wave) * 3 + c] = vsum;
+  }
+}
+
+// One block per frame; wave w accumulates the 16-vertex groups w, w + 4, ...  Rows of the MFMA tile: (a, b) = (row >> 2, row & 3),
+// a < 3 the gradient component, b < 3 the v_posed component and b = 3 the translation column; columns: joint 4 (l & 15) + tile.
+__global__ __launch_bounds__(256) void dense_gA_kernel(const float* __restrict__ g_verts, const float* __restrict__ v_posed,
+                                                       const float* __restrict__ Wd, float* __restrict__ gA_out, int V, int Vpad, int J) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [4 waves][64 joints][12]
+  const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int row = lane & 15, kq = lane >> 4, a = row >> 2, b = row & 3, col = lane & 15;
+  const float* gf = g_verts + (size_t)f * V * 3;
+  const float* vf = v_posed + (size_t)f * V * 3;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int v0 = wave * 16; v0 < Vpad; v0 += 64) {
+    float av[4];
+    vf4 bw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int v = v0 + 4 * e + kq;
+      const bool live = v < V && a < 3;
+      const float gval = live ? gf[(size_t)v * 3 + a] : 0.f;
+      const float pval = (live && b < 3) ? vf[(size_t)v * 3 + b] : 1.f;
+      av[e] = gval * pval;
+      bw[e] = *reinterpret_cast<const vf4*>(Wd + (size_t)v * 64 + 4 * col);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].w, acc[3], 0, 0, 0);
+    }
+  }
+  // accumulator register r of lane l, tile t: row 4 (l >> 4) + r = (a = l >> 4, b = r), joint 4 (l & 15) + t
+  if (kq < 3) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float* d = smem + (wave * 64 + 4 * col + t) * 12;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) d[kq * 3 + r] = acc[t][r];
+      d[9 + kq] = acc[t][3];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < J * 12; i += 256)
+    gA_out[(size_t)f * J * 12 + i] = (smem[i] + smem[768 + i]) + (smem[1536 + i] + smem[2304 + i]);
+}
+
+// dL/dcoeff partials: out[ks][f][n] = sum over the k-split's chunks of gvpT[f][k] * Pd_k[k][n].  A wave owns 64 frames x one 128-
+// coefficient group (tile t of the group <-> coefficients 4 c + t: one 16-byte load of a Pd_k row feeds four MFMA column
+// tiles and the four accumulators of a lane are four consecutive coefficients -> 16-byte stores).  Blocks of one k-split
+// run on one XCD (its Pd_k panel stays in that L2).
+__global__ __launch_bounds__(256) void dense_gco_kernel(const float* __restrict__ gvpT, const float* __restrict__ Pd_k, float* __restrict__ out,
+                                                        int N, int nchunks, int Kp, int ngroups, int n_rp, int KS, int cps, int rows_out, int ld_out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int items_per_ks = n_rp * ngroups;
+  const int bpk = (items_per_ks + 3) / 4;                       // blocks per k-split
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int ks = 8 * (jb / bpk) + xcd;
+  const int item = (jb % bpk) * 4 + wave;
+  if (ks >= KS || item >= items_per_ks) return;
+  const int rp = item / ngroups, grp = item % ngroups;
+  const int c0 = ks * cps, c1 = c0 + cps < nchunks ? c0 + cps : nchunks;
+  const size_t Ktot = (size_t)nchunks * 192;
+  const int hi = lane >> 5, ln = lane & 31;
+  int fr[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) { const int f = rp * 64 + 32 * m + ln; fr[m] = f < N ? f : N - 1; }
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
+  const float* a0 = gvpT + (size_t)fr[0] * Ktot + 4 * hi;
+  const float* a1 = gvpT + (size_t)fr[1] * Ktot + 4 * hi;
+  const float* bp = Pd_k + (size_t)(4 * hi) * Kp + 128 * grp + 4 * ln;
+  auto load = [&](int kb, vf4 (&av)[2], vf4 (&bv)[4]) {
+    av[0] = *reinterpret_cast<const vf4*>(a0 + kb);
+    av[1] = *reinterpret_cast<const vf4*>(a1 + kb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = *reinterpret_cast<const vf4*>(bp + (size_t)(kb + e) * Kp);
+  };
+  auto mma = [&](const vf4 (&av)[2], const vf4 (&bv)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bv[e].x, acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bv[e].y, acc[m][1], 0, 0, 0);
+        acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bv[e].z, acc[m][2], 0, 0, 0);
+        acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bv[e].w, acc[m][3], 0, 0, 0);
+      }
+  };
+  // 8 k-values per iteration (k = kb + 4 hi + e), the next iteration's operands in flight under the 32 MFMAs of the current one
+  const int kb0 = c0 * 192, kb1 = c1 * 192;
+  vf4 avA[2], bvA[4], avB[2], bvB[4];
+  load(kb0, avA, bvA);
+  for (int kb = kb0; kb < kb1; kb += 16) {
+    const int k1 = kb + 8 < kb1 ? kb + 8 : kb;
+    load(k1, avB, bvB);
+    HA_SCHED_FENCE();
+    mma(avA, bvA);
+    HA_SCHED_FENCE();
+    if (kb + 8 < kb1) {
+      const int k2 = kb + 16 < kb1 ? kb + 16 : kb + 8;
+      load(k2, avA, bvA);
+      HA_SCHED_FENCE();
+      mma(avB, bvB);
+      HA_SCHED_FENCE();
+    }
+  }
+  // accumulator register i of lane l: row (i & 3) + 8 (i >> 2) + 4 (l >> 5), column l & 31 <-> coefficients 128 grp + 4 (l & 31) + t
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = rp * 64 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hi;
+      if (f < N)
+        *reinterpret_cast<vf4*>(out + ((size_t)ks * rows_out + f) * ld_out + 128 * grp + 4 * ln) =
+            vf4{acc[m][0][i], acc[m][1][i], acc[m][2][i], acc[m][3][i]};
+    }
+}
+
+// launch plan of the dense backward (shared by the workspace query and the launch)
+struct DenseBwdPlan {
+  int nchunks, np, ngroups, ld, n_rp, KS, cps;
+  size_t off_gvp, off_gA, off_gtl, off_gco, total;
+};
+static DenseBwdPlan dense_bwd_plan(const ha_smpl_model* m, int N, int n_active) {
+  DenseBwdPlan P;
+  const int Kc = m->NB + 1 + (n_active - 1) * 9;
+  P.nchunks = m->sets[0].nchunks;
+  P.np = ceil_div(P.nchunks, kGvpChunksPerBlock) * 4;
+  P.ngroups = ceil_div(Kc, 128);
+  P.ld = P.ngroups * 128;
+  P.n_rp = ceil_div(N, 64);
+  const int want = g_dense_bwd_waves > 0 ? g_dense_bwd_waves : 1600;      // resident-wave target (256 CUs x 4 SIMDs x ~1.6)
+  int KS = ceil_div(want, P.n_rp * P.ngroups);
+  if (KS < 1) KS = 1;
+  if (KS > P.nchunks) KS = P.nchunks;
+  P.cps = ceil_div(P.nchunks, KS);
+  P.KS = ceil_div(P.nchunks, P.cps);
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
+  P.off_gvp = take((size_t)N * P.nchunks * 192);
+  P.off_gA = take((size_t)N * m->J * 12);
+  P.off_gtl = take((size_t)N * P.np * 3);
+  P.off_gco = take((size_t)P.KS * N * P.ld);
+  P.total = o;
+  return P;
+}
+
 static void fill_model(FrameParams& p, const ha_smpl_model* m, int slot) {
   memset(&p, 0, sizeof(p));
   p.Jt = m->Jt; p.Js = m->Js; p.parents = m->parents; p.jdepth = m->jdepth;
   p.child_start = m->child_start; p.child_idx = m->child_idx;
   p.J = m->J; p.NB = m->NB; p.Kfull = m->Kfull; p.Kfull_pad = m->Kfull_pad; p.kf4 = (m->Kfull_pad + 3) & ~3; p.depth = m->depth;
   const VertexSet& s = m->sets[slot];
-  p.Pd_v = s.Pd_v; p.Pd_k = s.Pd_k; p.Kp = ceil_div(m->Kfull, 64) * 64; p.w = s.w; p.idx = s.idx;
+  p.Pd_v = s.Pd_v; p.Pd_k = s.Pd_k; p.Kp = ceil_div(m->Kfull, 128) * 128; p.w = s.w; p.idx = s.idx;
   p.nverts = s.n; p.nchunks = s.nchunks; p.nnz = m->nnz;
 }
 
@@ -1063,6 +1302,57 @@ extern "C" int ha_smpl_backward(const ha_smpl_model* m, int slot, int N, int n_a
   p.g_pose = g_pose; p.g_betas = g_betas; p.g_transl = g_transl;
   const size_t lds = (size_t)FW * (2 * ((m->Kfull_pad + 3) & ~3) + m->J * (12 * 3 + 16) + 192) * sizeof(float);
   hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
+  HA_LAUNCH_CHECK();
+  return HA_OK;
+}
+
+extern "C" int ha_smpl_backward_dense_workspace(const ha_smpl_model* m, int N, int n_active, int64_t* ws_floats) {
+  int rc = check_common("ha_smpl_backward_dense_workspace", m, 0, N, n_active);
+  if (rc != HA_OK) return rc;
+  HA_REQUIRE(ws_floats, "ha_smpl_backward_dense_workspace: null argument");
+  *ws_floats = (int64_t)dense_bwd_plan(m, N, n_active).total;
+  return HA_OK;
+}
+
+extern "C" int ha_smpl_backward_dense(const ha_smpl_model* m, int N, int n_active, const float* pose, const float* betas,
+                                      const float* g_verts, const float* g_joints, const float* v_posed, const float* A, float* ws,
+                                      float* g_pose, float* g_betas, float* g_transl, void* stream) {
+  int rc = check_common("ha_smpl_backward_dense", m, 0, N, n_active);
+  if (rc != HA_OK) return rc;
+  HA_REQUIRE(pose && betas && g_verts && v_posed && A && ws, "ha_smpl_backward_dense: null argument");
+  if (m->nnz > 4 || !m->Wd) {
+    set_error("ha_smpl_backward_dense: needs <=4 skinning influences per vertex (model has nnz=%d)", m->nnz);
+    return HA_ERR_UNSUPPORTED;
+  }
+  DeviceGuard guard(m->device);
+  hipStream_t st = (hipStream_t)stream;
+  const DenseBwdPlan P = dense_bwd_plan(m, N, n_active);
+  HA_REQUIRE(P.np <= 64, "ha_smpl_backward_dense: V=%d too large for the partial-sum layout", m->V);
+  const VertexSet& s0 = m->sets[0];
+  const int Kp = ceil_div(m->Kfull, 128) * 128;
+  hipLaunchKernelGGL(dense_gvp_kernel, dim3(P.np / 4, N), dim3(256), (size_t)m->J * 12 * sizeof(float), st, g_verts, A, m->w4, m->idx4,
+                     ws + P.off_gvp, ws + P.off_gtl, m->V, m->J, P.nchunks, P.np);
+  HA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dense_gA_kernel, dim3(N), dim3(256), (size_t)4 * 64 * 12 * sizeof(float), st, g_verts, v_posed, m->Wd, ws + P.off_gA, m->V,
+                     m->Vpad, m->J);
+  HA_LAUNCH_CHECK();
+  {
+    const int bpk = ceil_div(P.n_rp * P.ngroups, 4);
+    const int nblk = 8 * ceil_div(P.KS, 8) * bpk;
+    hipLaunchKernelGGL(dense_gco_kernel, dim3(nblk), dim3(256), 0, st, ws + P.off_gvp, s0.Pd_k, ws + P.off_gco, N, P.nchunks, Kp, P.ngroups, P.n_rp,
+                       P.KS, P.cps, N, P.ld);
+    HA_LAUNCH_CHECK();
+  }
+  FrameParams p;
+  fill_model(p, m, 0);
+  p.N = N; p.n_active = n_active; p.Kc = m->NB + 1 + (n_active - 1) * 9;
+  p.pose = pose; p.betas = betas;
+  p.g_verts = nullptr; p.g_joints = g_joints;
+  p.g_pose = g_pose; p.g_betas = g_betas; p.g_transl = g_transl;
+  p.gA_in = ws + P.off_gA; p.gco_part = ws + P.off_gco; p.gco_ks = P.KS; p.gco_rows = N; p.gco_ld = P.ld;
+  p.gtl_part = ws + P.off_gtl; p.gtl_np = P.np;
+  const size_t lds = (size_t)FW * (2 * ((m->Kfull_pad + 3) & ~3) + m->J * (12 * 3 + 16) + 192) * sizeof(float);
+  hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, st, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

@@ -19,7 +19,7 @@ struct VertexSet {
   int nchunks = 0;
   // wave-per-frame layout: [nchunks][Kfull][3][64]
   float* Pd_v = nullptr;
-  // coefficient-major copy for the adjoint: [nchunks][3*64][Kp], Kp = Kfull rounded up to 64
+  // coefficient-major copy for the adjoint: [nchunks][3*64][Kp], Kp = Kfull rounded up to 128
   float* Pd_k = nullptr;
   // skinning weights / joint indices, general form: [nchunks][nnz][64]
   float* w = nullptr;
@@ -48,6 +48,7 @@ struct ha_smpl_model {
   float* Pd_m = nullptr;      // MFMA B-operand layout [Vpad/32][KQ][3][64][4] (KQ = k-pair quads)
   float4* w4 = nullptr;       // [V] (nnz <= 4 fast path)
   uint32_t* idx4 = nullptr;   // [V] 4 x uint8 joint ids
+  float* Wd = nullptr;        // [Vpad][64] dense skinning weights (nnz <= 4 models; dense backward)
   ha::VertexSet sets[ha::kMaxSubsets];
   // host copies kept for defining subsets later
   std::string* host_blob = nullptr;  // unused placeholder (keeps struct trivially extendable)

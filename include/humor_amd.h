@@ -91,6 +91,16 @@ int ha_smpl_backward(const ha_smpl_model* m, int slot, int N, int n_active_joint
                      const float* g_verts, const float* g_joints,
                      float* g_pose, float* g_betas, float* g_transl, void* stream);
 
+/* Backward of the DENSE forward (slot 0, every vertex carries a gradient: the point-cloud / chamfer term of
+ * humor/fitting/fitting_loss.py:378-396 back through BodyModel): g_verts [N, V, 3] is required; v_posed [N, V, 3] and
+ * A [N, J, 12] are the forward's `ws_vposed` / `A_out`.  The vertex phase runs as batched kernels over all frames
+ * (dL/dv_posed streaming pass; dL/dA and dL/dcoeff = dL/dv_posed x Pd^T on the fp32 MFMA units), then the per-frame
+ * kinematic-chain adjoint.  Same outputs as ha_smpl_backward; `ws` holds ha_smpl_backward_dense_workspace floats. */
+int ha_smpl_backward_dense_workspace(const ha_smpl_model* m, int N, int n_active_joints, int64_t* ws_floats);
+int ha_smpl_backward_dense(const ha_smpl_model* m, int N, int n_active_joints, const float* pose, const float* betas,
+                           const float* g_verts, const float* g_joints, const float* v_posed, const float* A, float* ws,
+                           float* g_pose, float* g_betas, float* g_transl, void* stream);
+
 /* The streaming linear-blend-skinning kernel on its own (the HBM-roofline kernel):
  * verts[n,v,:] = (sum_i w[v,i] * A[n, idx[v,i]]) * [v_posed[n,v,:]; 1] + transl[n].
  * v_posed and verts are [N, V, 3] (v_posed allocated with the +4 floats ha_smpl_workspace reports). */

@@ -48,3 +48,35 @@ def test_emu_chamfer_kernels(emu_lib):
     import chamfer_checks as CC
     CC.check_chamfer(emu_lib, torch.device('cpu'), b=2, n=37, m=1100, seed=0)
     CC.check_chamfer(emu_lib, torch.device('cpu'), b=1, n=300, m=29, seed=1)
+
+
+def _small_model(tmp_path, num_verts):
+    import numpy as np
+    from humor_amd import synth
+    npz = synth.write_smplh_npz(str(tmp_path / f'model_{num_verts}.npz'), seed=1, num_verts=num_verts)
+    data = np.load(npz)
+
+    class DS:
+        pass
+    ds = DS()
+    for k in data.files:
+        setattr(ds, k, data[k])
+    return npz, ds
+
+
+def test_emu_dense_backward_kernels(emu_lib, tmp_path):
+    """ha_smpl_backward_dense (streaming dL/dv_posed, 16x16x4 MFMA dL/dA, 32x32x2 MFMA dL/dcoeff with K split, chain adjoint) behind the
+    MFMA forward: every vertex carries a gradient.  1100-vertex model (ragged last chunk), hands on (52 active joints, 476 blend
+    coefficients = four 128-column groups), then body only (206 coefficients) with a coarser K split."""
+    npz, ds = _small_model(tmp_path, 1100)
+    SC.check_forward_backward(emu_lib, npz, ds, N=3, device=CPU, hands=True, selector=False, algo=2, dense_grad=True)
+    emu_lib.call('ha_tune_set', b'dense_bwd_waves', 10)
+    try:
+        SC.check_forward_backward(emu_lib, npz, ds, N=2, device=CPU, hands=False, selector=False, algo=2, dense_grad=True, seed=3)
+    finally:
+        emu_lib.call('ha_tune_set', b'dense_bwd_waves', 0)
+
+
+@pytest.mark.slow
+def test_emu_dense_backward_full_model(emu_lib, smplh_npz, smplh_struct):
+    SC.check_forward_backward(emu_lib, smplh_npz, smplh_struct, N=3, device=CPU, hands=True, selector=False, algo=2, dense_grad=True)

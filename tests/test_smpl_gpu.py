@@ -29,6 +29,13 @@ def test_hands_and_dense_gradient(gpu_lib, smplh_npz, smplh_struct, dev):
     SC.check_forward_backward(gpu_lib, smplh_npz, smplh_struct, N=9, device=dev, hands=True, selector=True, algo=2, dense_grad=True)
 
 
+@pytest.mark.parametrize('N,hands', [(70, False), (130, True)])
+def test_dense_backward_kernels(gpu_lib, smplh_npz, smplh_struct, dev, N, hands):
+    """Every vertex carries a gradient (point-cloud / chamfer term): ha_smpl_backward_dense (streaming dL/dv_posed, MFMA dL/dA and
+    dL/dcoeff with K split, chain adjoint) against the oracle's autograd; frame counts that leave a ragged 64-frame row pair."""
+    SC.check_forward_backward(gpu_lib, smplh_npz, smplh_struct, N=N, device=dev, seed=N, hands=hands, selector=not hands, algo=2, dense_grad=True)
+
+
 def test_golden_vectors(gpu_lib, smplh_npz, dev):
     SC.check_golden(gpu_lib, smplh_npz, dev)
 
