@@ -11,7 +11,7 @@ terms, 32 sub-sequences per GPU.  With N GPUs the job is ONE video of 32*N coupl
 overlap terms and one packed all-reduce of [flat gradient | loss] per closure (humor_amd/distributed.py).
 
 One "step" = one evaluation of the stage-3 fitting closure (objective forward + backward + gradient all-reduce): VPoser
-decode/encode, 5 SMPL evaluations, HuMoR roll-out (59 steps, prior + decoder) with its adjoint, all loss terms -- the
+decode, 3 SMPL evaluations (64-vertex subset kernels), HuMoR roll-out (59 steps, prior + decoder) with its adjoint, all loss terms -- the
 deterministic unit of "fitting-iter/sec" (an L-BFGS outer iteration is ~25 of these).  Inputs are resident in HBM.
 `value` = closure evaluations per second x (global batch / 32), i.e. aggregate 32x60-batch closure evaluations per second.
 Also reported: `smpl_verts_per_sec` (dense 6890-vertex SMPL forward, N=1920), the `roofline` of the streaming LBS kernel
@@ -185,7 +185,9 @@ def skin_roofline(dev, npz, N=B_SEQ * T_SEQ, traffic=PMC_TRAFFIC_BYTES):
 
     def launch():
         lib.call('ha_lbs_skin', h.ptr, N, _lib.ptr(vposed), _lib.ptr(A), _lib.ptr(transl), _lib.ptr(verts), st)
-    ms = time_events(launch, iters=50 if N <= 4096 else 12, warm=5 if N <= 4096 else 3)
+    # cache-free sizes: the first ~20 back-to-back launches ride a power-management transient (0.93 ms, then a hump up to 1.3 ms, then
+    # a steady ~0.98 ms; tools/skin_jitter.py, profiles/r02_run20_skin_jitter.txt) -- the sustained figure is the one reported
+    ms = time_events(launch, iters=50 if N <= 4096 else 30, warm=5 if N <= 4096 else 30)
     nbytes = SKIN_BYTES_PER_FRAME * N
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {'kernel': 'lbs_skin (ha_lbs_skin)', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

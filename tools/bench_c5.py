@@ -58,7 +58,8 @@ def measure(B=256, T=120, dev=None):
 
     def chain_only():
         lib.call('ha_smpl_forward', h.ptr, 0, N, 22, p(pose), p(betas), p(tr), None, p(joints), p(A), p(ws_v), p(ws_c), 2, st)
-    ms_dense, ms_skin, ms_chain = ev(dense), ev(skin), ev(chain_only)
+    # sustained figures: the first ~20 launches at this size ride a power-management transient (tools/skin_jitter.py)
+    ms_dense, ms_skin, ms_chain = ev(dense, 10, 10), ev(skin, 20, 20), ev(chain_only, 10, 3)
     ms_blend = ms_dense - ms_skin - ms_chain
     Kc = NB + 1 + 21 * 9
     blend_flops = 2.0 * N * Kc * V * 3
