@@ -25,6 +25,15 @@ namespace ha {
 
 void set_error(const char* fmt, ...);
 
+// returnless hardware fp32 add at the L2 / memory side (global_atomic_add_f32; no compare-and-swap loop)
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+#ifdef HA_SIMT_EMU
+  atomicAdd(p, v);
+#else
+  unsafeAtomicAdd(p, v);
+#endif
+}
+
 #define HA_CHECK_HIP(expr)                                                                        \
   do {                                                                                            \
     hipError_t _e = (expr);                                                                       \

@@ -37,7 +37,20 @@ __device__ __forceinline__ size_t qoff(int c) { return (size_t)(c >> 2) * 128 + 
 // layer-kernel launch policy picked up by ha_humor_net_create (ha_tune_set "layer_spb" / "layer_nw"; 0 = default)
 int g_layer_spb = 0, g_layer_nw = 0, g_layer_finish = 1;
 int g_layer_hsum = 1;  // summed pre-activation write-back for the adjoint (ha_tune_set "layer_hsum")
+// ha_tune_set "layer_acc" (experiment, default off): one-row-tile policy only.  1: the K-split blocks of a decoder layer ADD their
+// partial tiles into ONE pre-zeroed slab with hardware fp32 atomics (global_atomic_add_f32) instead of writing nsplit partial
+// slabs, so that every consumer block reads one slab instead of up to five.  Measured (profiles/experiments/README.md, round 2):
+// the consumers' load phase shrinks by 2-3 k cycles as predicted, but 1024 atomics per block drain in 2.5-5 k cycles and delay the
+// next launch: 32x59 fwd+bwd 4.55 -> 4.43 ms only, and the sum order of the partials (hence the last bit) varies run to run.
+int g_layer_acc = 0;
 int g_gemm_rm = 0;    // row tiles per wave of the batched prior GEMM (ha_tune_set "gemm_rm"; 0 = by size)
+// ha_tune_set "rollout_groups": 0 = auto, n >= 1 = split the batch into (at most) n row groups that run the chain side by side on
+// their own HIP streams (fork / join on the caller's stream with events; capturable), each with its own stash region and its steps
+// issued round-robin.  Sequences are independent, but side-by-side chains only pay where they change the launch policy: dispatch is
+// the bound (host ~3.5 us per launch eager; hipGraph replay of 2 / 4 groups at 256 x 119 is no faster either -- profiles/experiments/
+// README.md), so auto uses two groups only for exactly two row tiles (each then runs the one-row-tile policy: 64 x 59 fwd+bwd
+// 5.97 -> 5.15 ms) and one group otherwise.  Must not change between a forward call and its backward.
+int g_rollout_groups = 0;
 
 struct PackedLayer {
   int Cin = 0, skip = 0, Nout = 0;
@@ -73,6 +86,7 @@ struct LayerTask {
   float* dst;                                       // [nsplit_dst][RT][Nout_pad][32]
   float* hsum_dst;                                  // mode 1: the summed pre-activations of the source go back as ONE slab [RT][Csrc][32] (or null)
   int spb, nsplit_dst;                              // K-slices per block, ceil(nslices / spb)
+  int acc;                                          // 1: all K-splits add into slab 0 of dst (pre-zeroed) with fp32 atomics
   int nblocks;                                      // ntiles * nsplit_dst * RT
 };
 
@@ -312,8 +326,15 @@ __global__ __launch_bounds__(NWT * 64) void mlp_layer_kernel(LayerLaunch L) {
       for (int e = 0; e < 4; ++e)
         if (n + e < T.Nout) o[e] += T.bias[n + e];
     }
-    float* dst = T.dst + ((size_t)ks * L.RT + rt) * T.Nout_pad * 32 + (size_t)(n >> 2) * 128 + row * 4;
-    *reinterpret_cast<vf4*>(dst) = o;
+    if (!LEAN && T.acc) {
+      // accumulate policy: the slab was zeroed before the roll-out; returnless global_atomic_add_f32, complete at the kernel boundary
+      float* dst = T.dst + (size_t)rt * T.Nout_pad * 32 + (size_t)(n >> 2) * 128 + row * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomic_add_f32(dst + e, o[e]);
+    } else {
+      float* dst = T.dst + ((size_t)ks * L.RT + rt) * T.Nout_pad * 32 + (size_t)(n >> 2) * 128 + row * 4;
+      *reinterpret_cast<vf4*>(dst) = o;
+    }
   }
   HA_TS(6, true);
   HA_TS(7, false);
@@ -1430,10 +1451,18 @@ struct StashLayout {
   size_t fin[1] = {0};         // finished-activation scratch of a launch's task (finishing-pass policy only)
   bool finish = false;
   bool hsum = false;             // forward launches write the summed pre-activations back (one-row-tile policy: no finishing pass)
+  // accumulate policy (g_layer_acc, one-row-tile policy): every decoder activation / adjoint is ONE slab that the K-split blocks add
+  // into.  The slabs must be zero before the chain starts, so the adjoint's scratch is kept per step too and both regions are
+  // cleared by one memset per pass ((S+1) x 0.36 MB forward, S x 0.4 MB backward at one row tile).
+  bool acc = false;
+  size_t bwd_set = 0;            // acc: floats per step of the adjoint scratch (bwd_dec[] are offsets of step 0's set); else 0
+  size_t bwd_begin = 0, bwd_floats = 0;
+  int rd_f(int i) const { return acc ? 1 : nsf_dec[i]; }     // partial slabs a consumer of decoder layer i's output reads
+  int rd_b(int i) const { return acc ? 1 : nsb_dec[i]; }
   size_t total = 0;
 };
 
-static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
+static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, bool allow_acc = true) {
   L.RT = ceil_div(B, 32);
   const size_t RT = L.RT;
   // K is split over blocks of 4 slices (the fp32 MFMA rate is 256 FLOP/clk/CU: the work has to be spread over the chip).  At
@@ -1445,6 +1474,10 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   L.nw = 4;
   for (int i = 0; i < net->n_pri; ++i) L.nsf_pri[i] = ceil_div(net->pri[i].nslices_f, L.spb);
   for (int i = 0; i < net->n_dec; ++i) { L.nsf_dec[i] = ceil_div(net->dec[i].nslices_f, L.spb); L.nsb_dec[i] = ceil_div(net->dec[i].nslices_b, L.spb); }
+  // GroupNorm prologues once per activation in gn_finish_kernel (see there and the policy note above)
+  L.finish = (L.RT >= 2 && g_layer_finish != 0) || g_layer_finish == 2;     // 0: never, 2: always (A/B runs)
+  L.acc = allow_acc && !L.finish && g_layer_acc != 0;
+  L.hsum = !L.finish && !L.acc && g_layer_hsum != 0;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
   L.zT = take((size_t)S * RT * ZD * 32);
@@ -1454,8 +1487,8 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   size_t p = 0;
   auto ptake = [&](size_t n) { size_t r = p; p += (n + 63) / 64 * 64; return r; };
   L.off_G = ptake(RT * 32 * 12);
-  for (int i = 0; i < net->n_dec; ++i) L.off_dec[i] = ptake((size_t)L.nsf_dec[i] * RT * net->dec[i].Nout_pad * 32);
-  for (int i = 0; i + 1 < net->n_dec; ++i) L.off_hsum[i] = ptake(RT * net->dec[i].Nout_pad * 32);
+  for (int i = 0; i < net->n_dec; ++i) L.off_dec[i] = ptake((size_t)L.rd_f(i) * RT * net->dec[i].Nout_pad * 32);
+  for (int i = 0; i + 1 < net->n_dec; ++i) L.off_hsum[i] = L.hsum ? ptake(RT * net->dec[i].Nout_pad * 32) : 0;
   L.per_step = p;
   L.steps = take(p * (size_t)(S + 1));
   size_t widest = 0;
@@ -1473,10 +1506,13 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L) {
   L.carry = take(RT * 32 * 16);
   L.g_dec_out = take(RT * net->dec[net->n_dec - 1].Nout_pad * 32);
   L.g_pri_out = take((size_t)S * RT * net->pri[net->n_pri - 1].Nout_pad * 32);   // prior-output adjoints of all steps
-  for (int i = 0; i < net->n_dec; ++i) L.bwd_dec[i] = take((size_t)L.nsb_dec[i] * RT * net->dec[i].Nin_pad * 32);
-  // GroupNorm prologues once per activation in gn_finish_kernel (see there and the policy note above)
-  L.finish = (L.RT >= 2 && g_layer_finish != 0) || g_layer_finish == 2;     // 0: never, 2: always (A/B runs)
-  L.hsum = !L.finish && g_layer_hsum != 0;
+  L.bwd_begin = o;
+  for (int i = 0; i < net->n_dec; ++i) L.bwd_dec[i] = take((size_t)L.rd_b(i) * RT * net->dec[i].Nin_pad * 32);
+  if (L.acc) {
+    L.bwd_set = o - L.bwd_begin;
+    take(L.bwd_set * (size_t)(S - 1));          // sets of steps 1 .. S-1 behind step 0's
+    L.bwd_floats = o - L.bwd_begin;
+  }
   if (L.finish)
     L.fin[0] = take(RT * 1280 * 32);     // widest operand: K <= 1280 (checked at pack time)
   L.total = o;
@@ -1496,6 +1532,9 @@ static void fwd_task(LayerTask& T, const PackedLayer& L, const float* src, int n
   T.spb = spb; T.nsplit_dst = nsplit_dst;
   T.nblocks = L.ntiles_f * nsplit_dst;          // x RT in launch_layers
 }
+
+// accumulate policy: more than one K-split block per output tile -> they add into the (pre-zeroed) single slab
+static void set_acc(LayerTask& T, bool acc) { T.acc = acc && T.nsplit_dst > 1 ? 1 : 0; }
 
 // backward through layer L: A = dh (adjoint of L's raw output), output = adjoint of L's input activation slabs.
 // `Lnext_gn` describes the GroupNorm that follows L (i.e. the consumer layer's gamma/beta/group) when dh has to be
@@ -1618,6 +1657,25 @@ static int prior_backward_batched(const ha_humor_net* net, const StashLayout& L,
   return HA_OK;
 }
 
+constexpr int MAX_GROUPS = 8;
+
+// rows per group (whole 32-row tiles) and the group count for a batch of B sequences
+static void group_plan(int B, int& ngroups, int& rows_per_group) {
+  const int RT = ceil_div(B, 32);
+  int n = g_rollout_groups > 0 ? g_rollout_groups : (RT == 2 ? 2 : 1);
+  if (n > MAX_GROUPS) n = MAX_GROUPS;
+  if (n > RT) n = RT;
+  rows_per_group = ceil_div(RT, n) * 32;
+  ngroups = ceil_div(B, rows_per_group);
+}
+
+static size_t group_stash_floats(const ha_humor_net* net, int rows, int S) {
+  StashLayout L, Ls;
+  make_layout(net, rows, S, L);
+  make_layout(net, rows, S, Ls, false);
+  return L.total > Ls.total ? L.total : Ls.total;
+}
+
 }  // namespace ha
 
 using namespace ha;
@@ -1669,36 +1727,42 @@ extern "C" int ha_debug_layer_timing(unsigned long long* out /* [64][10] */, uns
 extern "C" int ha_humor_rollout_workspace(const ha_humor_net* net, int B, int S, int64_t* stash_floats) {
   HA_REQUIRE(net && stash_floats, "ha_humor_rollout_workspace: null argument");
   HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_workspace: B and S must be >= 1");
-  StashLayout L;
-  make_layout(net, B, S, L);
-  *stash_floats = (int64_t)L.total;
+  // whole batch (sampling roll-out: one chain; its slabs never accumulate) or the row groups of forward / backward side by side
+  int ng, rpg;
+  group_plan(B, ng, rpg);
+  const size_t whole = group_stash_floats(net, B, S), grouped = ng > 1 ? (size_t)ng * group_stash_floats(net, rpg, S) : 0;
+  *stash_floats = (int64_t)(whole > grouped ? whole : grouped);
   return HA_OK;
 }
 
-extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, const float* past_in0, const float* z_seq,
-                                        float* world, float* prior_mu, float* prior_var, float* stash, void* stream) {
-  HA_REQUIRE(net && past_in0 && z_seq && world && stash, "ha_humor_rollout_forward: null argument");
-  HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_forward: B and S must be >= 1");
-  HA_REQUIRE((prior_mu == nullptr) == (prior_var == nullptr), "ha_humor_rollout_forward: prior_mu and prior_var go together");
-  DeviceGuard guard(net->device);
-  hipStream_t st = (hipStream_t)stream;
+// One phase of the forward pass of one row group: PH_BEGIN (input transposes, initial state), PH_STEP (decoder layers + glue of
+// step t), PH_END (the prior network for all steps).  The caller walks the phases; with several row groups it interleaves their
+// steps so that the groups' chains advance side by side on their streams.
+enum { PH_BEGIN = 0, PH_STEP = 1, PH_END = 2 };
+
+static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const float* past_in0, const float* z_seq,
+                                float* world, float* prior_mu, float* prior_var, float* stash, hipStream_t st, int phase, int t) {
   StashLayout L;
   make_layout(net, B, S, L);
   const int RT = L.RT, rows = RT * 32;
   auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
   auto x_ptr = [&](int t) { return stash + L.xT + (size_t)t * RT * D_INP * 32; };
 
-  hipLaunchKernelGGL(transpose_in_kernel, dim3(256), dim3(256), 0, st, z_seq, stash + L.zT, B, S, ZD, ZD, RT);
-  HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, x_ptr(0), B, 1, D_IN, D_INP, RT);
-  HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
-  HA_LAUNCH_CHECK();
+  if (phase == PH_BEGIN) {
+    if (L.acc) HA_CHECK_HIP(hipMemsetAsync(stash + L.steps, 0, (size_t)(S + 1) * L.per_step * sizeof(float), st));
+    hipLaunchKernelGGL(transpose_in_kernel, dim3(256), dim3(256), 0, st, z_seq, stash + L.zT, B, S, ZD, ZD, RT);
+    HA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, x_ptr(0), B, 1, D_IN, D_INP, RT);
+    HA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
+    HA_LAUNCH_CHECK();
+    return HA_OK;
+  }
 
   const bool with_prior = prior_mu != nullptr;
   const int nd = net->n_dec, np = net->n_pri;
   // the recurrence: decoder layers + glue per step (the prior only consumes the states: it runs afterwards for all steps at once)
-  for (int t = 0; t < S; ++t) {
+  if (phase == PH_STEP) {
     float* sp = step_ptr(t);
     const float* zT = stash + L.zT + (size_t)t * RT * ZD * 32;
     for (int l = 0; l < nd; ++l) {
@@ -1707,7 +1771,8 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
       LL.RT = RT;
       const PackedLayer& P = net->dec[l];
       const float* src = l == 0 ? x_ptr(t) : sp + L.off_dec[l - 1];
-      fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.nsf_dec[l - 1], zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
+      fwd_task(LL.t[LL.ntasks++], P, src, l == 0 ? 1 : L.rd_f(l - 1), zT, sp + L.off_dec[l], L.spb, L.nsf_dec[l]);
+      set_acc(LL.t[0], L.acc);
       if (l > 0 && L.hsum) LL.t[0].hsum_dst = sp + L.off_hsum[l - 1];
       int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
@@ -1718,13 +1783,14 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
     g.xT = x_ptr(t);
     g.xT_next = x_ptr(t + 1);
     const PackedLayer& DL = net->dec[net->n_dec - 1];
-    g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = L.nsf_dec[net->n_dec - 1]; g.dec_pad = DL.Nout_pad;
+    g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = L.rd_f(net->n_dec - 1); g.dec_pad = DL.Nout_pad;
     g.Gs = sp + L.off_G;
     g.Gs_next = step_ptr(t + 1) + L.off_G;
     g.t2j = stash + L.t2j;
     g.world = world;
     hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(192), S_TOTAL_BWD * sizeof(float), st, g);
     HA_LAUNCH_CHECK();
+    return HA_OK;
   }
   if (with_prior) {
     int rc = prior_forward_batched(net, L, stash, S, st);
@@ -1748,7 +1814,7 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
   DeviceGuard guard(net->device);
   hipStream_t st = (hipStream_t)stream;
   StashLayout L;
-  make_layout(net, B, S, L);
+  make_layout(net, B, S, L, false);
   const int RT = L.RT, rows = RT * 32;
   auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
   auto x_ptr = [&](int t) { return stash + L.xT + (size_t)t * RT * D_INP * 32; };
@@ -1806,14 +1872,9 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
   return HA_OK;
 }
 
-extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float* z_seq, const float* g_world,
-                                         const float* g_prior_mu, const float* g_prior_var, float* stash, float* g_past_in0,
-                                         float* g_z_seq, void* stream) {
-  HA_REQUIRE(net && stash && g_past_in0 && g_z_seq, "ha_humor_rollout_backward: null argument");
-  HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_backward: B and S must be >= 1");
-  (void)z_seq;
-  DeviceGuard guard(net->device);
-  hipStream_t st = (hipStream_t)stream;
+static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const float* g_world,
+                                 const float* g_prior_mu, const float* g_prior_var, float* stash, float* g_past_in0,
+                                 float* g_z_seq, hipStream_t st, int phase, int t) {
   StashLayout L;
   make_layout(net, B, S, L);
   const int RT = L.RT, rows = RT * 32;
@@ -1823,9 +1884,12 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
   const PackedLayer& DL = net->dec[net->n_dec - 1];
   const int nd = net->n_dec, np = net->n_pri;
   const int gxp_pad = net->pri[0].Nin_pad;
+  // adjoint scratch of decoder layer l at step t (accumulate policy: one pre-zeroed set per step; else one set reused by every step)
+  auto bd = [&](int l, int t) { return stash + L.bwd_dec[l] + (size_t)(t < 0 ? 0 : (t >= S ? S - 1 : t)) * L.bwd_set; };
+  if (L.acc && phase == PH_BEGIN) HA_CHECK_HIP(hipMemsetAsync(stash + L.bwd_begin, 0, L.bwd_floats * sizeof(float), st));
 
   // the prior's contribution to dL/dx_t for every step, before the reverse scan (it does not depend on the scan)
-  if (with_prior) {
+  if (with_prior && phase == PH_BEGIN) {
     PriorIOParams q;
     memset(&q, 0, sizeof(q));
     q.B = B; q.S = S; q.RT = RT;
@@ -1849,19 +1913,19 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
     // step t+1 products (consumed when t < S-1)
     g.gx_dir_in = stash + L.gx_dir[(t + 1) & 1];
     g.gx_dir_out = stash + L.gx_dir[t & 1];
-    g.gxp_dec = stash + L.bwd_dec[0]; g.gxp_dec_nsplit = L.nsb_dec[0]; g.gxp_dec_pad = net->dec[0].Nin_pad;
+    g.gxp_dec = bd(0, t + 1); g.gxp_dec_nsplit = L.rd_b(0); g.gxp_dec_pad = net->dec[0].Nin_pad;
     if (with_prior && t + 1 < S) {
       g.gxp_pri = stash + L.gx_pri + (size_t)(t + 1) * RT * gxp_pad * 32; g.gxp_pri_nsplit = 1; g.gxp_pri_pad = gxp_pad;
     }
     g.dz_n = net->n_dec;
     for (int i = 0; i < net->n_dec; ++i) {
-      g.dz_src[i] = stash + L.bwd_dec[i]; g.dz_nsplit[i] = L.nsb_dec[i]; g.dz_pad[i] = net->dec[i].Nin_pad;
+      g.dz_src[i] = bd(i, t + 1); g.dz_nsplit[i] = L.rd_b(i); g.dz_pad[i] = net->dec[i].Nin_pad;
       g.dz_off[i] = net->dec[i].Cin;
     }
     if (t >= 0) {
       float* sp = step_ptr(t);
       g.xT = x_ptr(t);
-      g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = L.nsf_dec[net->n_dec - 1]; g.dec_pad = DL.Nout_pad;
+      g.dec_out = sp + L.off_dec[net->n_dec - 1]; g.dec_nsplit = L.rd_f(net->n_dec - 1); g.dec_pad = DL.Nout_pad;
       g.Gs = sp + L.off_G;
       g.g_world = g_world;
       g.g_dec_out = stash + L.g_dec_out;
@@ -1869,7 +1933,8 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
     }
   };
 
-  for (int t = S - 1; t >= 0; --t) {
+  if (phase == PH_BEGIN) return HA_OK;
+  if (phase == PH_STEP) {
     GlueParams g;
     fill_glue(g, t);
     hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(256), S_TOTAL_BWD * sizeof(float), st, g);
@@ -1881,22 +1946,121 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
       LL.RT = RT;
       const PackedLayer& P = net->dec[l];
       if (l == nd - 1)
-        bwd_task(LL.t[LL.ntasks++], P, stash + L.g_dec_out, 1, P.Nout_pad, nullptr, nullptr, 0, stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
+        bwd_task(LL.t[LL.ntasks++], P, stash + L.g_dec_out, 1, P.Nout_pad, nullptr, nullptr, 0, bd(l, t), L.spb, L.nsb_dec[l]);
       else if (L.hsum && L.nsf_dec[l] > 1)      // the forward pass left the summed pre-activations of layer l as one slab
-        bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_dec[l + 1], L.nsb_dec[l + 1], net->dec[l + 1].Nin_pad, &net->dec[l + 1],
-                 sp + L.off_hsum[l], 1, stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
+        bwd_task(LL.t[LL.ntasks++], P, bd(l + 1, t), L.rd_b(l + 1), net->dec[l + 1].Nin_pad, &net->dec[l + 1],
+                 sp + L.off_hsum[l], 1, bd(l, t), L.spb, L.nsb_dec[l]);
       else
-        bwd_task(LL.t[LL.ntasks++], P, stash + L.bwd_dec[l + 1], L.nsb_dec[l + 1], net->dec[l + 1].Nin_pad, &net->dec[l + 1],
-                 sp + L.off_dec[l], L.nsf_dec[l], stash + L.bwd_dec[l], L.spb, L.nsb_dec[l]);
+        bwd_task(LL.t[LL.ntasks++], P, bd(l + 1, t), L.rd_b(l + 1), net->dec[l + 1].Nin_pad, &net->dec[l + 1],
+                 sp + L.off_dec[l], L.rd_f(l), bd(l, t), L.spb, L.nsb_dec[l]);
+      set_acc(LL.t[0], L.acc);
       int rc = launch_layers(LL, L, stash, st);
       if (rc != HA_OK) return rc;
     }
+    return HA_OK;
   }
   GlueParams g;
   fill_glue(g, -1);
   hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(256), S_TOTAL_BWD * sizeof(float), st, g);
   HA_LAUNCH_CHECK();
   return HA_OK;
+}
+
+// ---- row groups on side streams ---------------------------------------------------------------------
+namespace ha {
+
+// side streams + fork/join events, created once per device
+struct SidePool {
+  bool ready = false;
+  hipStream_t stream[MAX_GROUPS];
+  hipEvent_t fork, join[MAX_GROUPS];
+};
+static SidePool g_side[16];
+
+static int side_pool(int device, SidePool** out) {
+  HA_REQUIRE(device >= 0 && device < 16, "roll-out: device index %d out of range", device);
+  SidePool& P = g_side[device];
+  if (!P.ready) {
+    HA_CHECK_HIP(hipEventCreateWithFlags(&P.fork, hipEventDisableTiming));
+    for (int i = 0; i < MAX_GROUPS; ++i) {
+      HA_CHECK_HIP(hipStreamCreateWithFlags(&P.stream[i], hipStreamNonBlocking));
+      HA_CHECK_HIP(hipEventCreateWithFlags(&P.join[i], hipEventDisableTiming));
+    }
+    P.ready = true;
+  }
+  *out = &P;
+  return HA_OK;
+}
+
+// runs fn(group, first row, rows, stream, phase, t) over every group and phase: group 0 on the caller's stream, the others on side
+// streams that wait for everything already queued on the caller's stream and are joined back into it.  The steps are issued
+// round-robin over the groups (the host issues ~3 us per launch, a chain advances one launch per ~6 us: issuing one group's
+// whole chain first would leave the others waiting for the host).
+template <typename F>
+static int for_each_group(int device, int B, int S, bool reverse, hipStream_t st, F&& fn) {
+  int ng, rpg;
+  group_plan(B, ng, rpg);
+  SidePool* P = nullptr;
+  if (ng > 1) {
+    int rc = side_pool(device, &P);
+    if (rc != HA_OK) return rc;
+    HA_CHECK_HIP(hipEventRecord(P->fork, st));
+    for (int g = 1; g < ng; ++g) HA_CHECK_HIP(hipStreamWaitEvent(P->stream[g], P->fork, 0));
+  }
+  auto run = [&](int phase, int t) {
+    for (int g = 0; g < ng; ++g) {
+      const int r0 = g * rpg, rows = ng == 1 ? B : ((B - r0) < rpg ? (B - r0) : rpg);
+      const int rc = fn(g, r0, rows, g == 0 ? st : P->stream[g], phase, t);
+      if (rc != HA_OK) return rc;
+    }
+    return (int)HA_OK;
+  };
+  int rc = run(PH_BEGIN, 0);
+  for (int i = 0; i < S && rc == HA_OK; ++i) rc = run(PH_STEP, reverse ? S - 1 - i : i);
+  if (rc == HA_OK) rc = run(PH_END, 0);
+  if (rc != HA_OK) return rc;
+  for (int g = 1; g < ng; ++g) {
+    HA_CHECK_HIP(hipEventRecord(P->join[g], P->stream[g]));
+    HA_CHECK_HIP(hipStreamWaitEvent(st, P->join[g], 0));
+  }
+  return HA_OK;
+}
+
+}  // namespace ha
+
+extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, const float* past_in0, const float* z_seq,
+                                        float* world, float* prior_mu, float* prior_var, float* stash, void* stream) {
+  HA_REQUIRE(net && past_in0 && z_seq && world && stash, "ha_humor_rollout_forward: null argument");
+  HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_forward: B and S must be >= 1");
+  HA_REQUIRE((prior_mu == nullptr) == (prior_var == nullptr), "ha_humor_rollout_forward: prior_mu and prior_var go together");
+  DeviceGuard guard(net->device);
+  int ng, rpg;
+  group_plan(B, ng, rpg);
+  const size_t gs = ng > 1 ? group_stash_floats(net, rpg, S) : 0;
+  return for_each_group(net->device, B, S, false, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
+    const size_t r = (size_t)r0;
+    return rollout_forward_impl(net, rows, S, past_in0 + r * D_IN, z_seq + r * S * ZD, world + r * S * D_STATE,
+                                prior_mu ? prior_mu + r * S * ZD : nullptr, prior_var ? prior_var + r * S * ZD : nullptr,
+                                stash + (size_t)g * gs, st, phase, t);
+  });
+}
+
+extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float* z_seq, const float* g_world,
+                                         const float* g_prior_mu, const float* g_prior_var, float* stash, float* g_past_in0,
+                                         float* g_z_seq, void* stream) {
+  HA_REQUIRE(net && stash && g_past_in0 && g_z_seq, "ha_humor_rollout_backward: null argument");
+  HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_backward: B and S must be >= 1");
+  (void)z_seq;
+  DeviceGuard guard(net->device);
+  int ng, rpg;
+  group_plan(B, ng, rpg);
+  const size_t gs = ng > 1 ? group_stash_floats(net, rpg, S) : 0;
+  return for_each_group(net->device, B, S, true, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
+    const size_t r = (size_t)r0;
+    return rollout_backward_impl(net, rows, S, g_world ? g_world + r * S * D_STATE : nullptr,
+                                 g_prior_mu ? g_prior_mu + r * S * ZD : nullptr, g_prior_var ? g_prior_var + r * S * ZD : nullptr,
+                                 stash + (size_t)g * gs, g_past_in0 + r * D_IN, g_z_seq + r * S * ZD, st, phase, t);
+  });
 }
 
 // ---- rotation conversions -------------------------------------------------------------------------

@@ -126,6 +126,15 @@ class LBFGS:
         self._lib = _lib_override
         self._flat = None
         self._hist = None
+        # optional host-side timeline (tools/lbfgs_eval_breakdown.py): set to a dict to accumulate seconds per phase
+        self.profile = None
+
+    def _tick(self, key, t0):
+        import time
+        t1 = time.perf_counter()
+        if self.profile is not None:
+            self.profile[key] = self.profile.get(key, 0.0) + (t1 - t0)
+        return t1
 
     # ---- flat parameter buffer ------------------------------------------------------------------------------------------------
     def _bind(self):
@@ -222,10 +231,13 @@ class LBFGS:
         prev_flat_grad, prev_loss = state.get('prev_flat_grad'), state.get('prev_loss')
 
         n_iter = 0
+        import time
+        tp = time.perf_counter()
         while n_iter < max_iter:
             n_iter += 1
             state['n_iter'] += 1
             pushed = None
+            tp = self._tick('other', tp)
             if state['n_iter'] == 1:
                 d = flat_grad.neg()
                 self._hist['order'] = []
@@ -247,7 +259,9 @@ class LBFGS:
                 prev_flat_grad.copy_(flat_grad)
             prev_loss = loss
 
+            tp = self._tick('direction_issue', tp)
             vals = torch.stack(scal).tolist()
+            tp = self._tick('direction_wait', tp)
             gtd, d_norm = vals[0], vals[1]
             if state['n_iter'] == 1:
                 t = min(1.0, 1.0 / vals[2]) * lr
@@ -269,14 +283,19 @@ class LBFGS:
                 gmax_of = {}
 
                 def obj_func(tt):
+                    t0 = self._tick('other', time.perf_counter()) if self.profile is None else self._tick('other', self._tp)
                     torch.add(x_init, d, alpha=tt, out=x)
                     l = closure()
                     g_new = self._gather_flat_grad()
+                    t0 = self._tick('closure_issue', t0)
                     f_new, gtd_new, gm = torch.stack([l.detach().reshape(()).float(), g_new.dot(d), g_new.abs().max()]).tolist()
+                    self._tp = self._tick('closure_wait', t0)
                     gmax_of[id(g_new)] = gm
                     return f_new, g_new, gtd_new
+                self._tp = tp
                 g_in = flat_grad
                 loss, flat_grad, t, ls_func_evals = _strong_wolfe(obj_func, t, d_norm, loss, flat_grad, gtd, max_ls=max_eval - current_evals)
+                tp = self._tp
                 torch.add(x_init, d, alpha=t, out=x)
                 gmax = gmax_of[id(flat_grad)] if id(flat_grad) in gmax_of else (gmax if flat_grad is g_in else flat_grad.abs().max().item())
             else:

@@ -160,6 +160,12 @@ static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+typedef int hipEvent_t;
+enum { hipEventDisableTiming = 2, hipStreamNonBlocking = 1 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = hipStream_t(); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { std::snprintf(p->gcnArchName, 64, "simt_emu"); return hipSuccess; }
 

@@ -52,6 +52,51 @@ def test_rollout_determinism(gpu_lib, dev):
     assert torch.equal(a, b)
 
 
+def test_rollout_accumulate_policy(gpu_lib, dev):
+    """ha_tune_set("layer_acc", 1) (fp32-atomic accumulation of the K-split partial tiles, off by default) against the fixed-order
+    partial-slab path: same values and gradients up to the summation order of <= 5 partials per element."""
+    hm, _ = RC.make_model(gpu_lib, dev, contractive=True)
+    g = torch.Generator().manual_seed(2)
+    past = RC.canonical_state(8, g).to(dev)
+    z = torch.randn(8, 20, 48, generator=g).to(dev)
+    res = []
+    try:
+        for acc in (0, 1, 1):
+            gpu_lib.call('ha_tune_set', b'layer_acc', acc)
+            p, zz = past.clone().requires_grad_(True), z.clone().requires_grad_(True)
+            out, (pm, pv) = hm.roll_out(p, None, 20, z_seq=zz, return_prior=True)
+            (out['joints'].square().sum() + pm.sum() + pv.sum()).backward()
+            res.append((RC.world_of(out).detach(), p.grad.clone(), zz.grad.clone()))
+    finally:
+        gpu_lib.call('ha_tune_set', b'layer_acc', 0)
+    for k in (1, 2):
+        for a, b in zip(res[0], res[k]):
+            assert (a - b).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
+
+
+@pytest.mark.parametrize('B,groups', [(70, 2), (70, 3), (130, 4)])
+def test_rollout_row_groups(gpu_lib, dev, B, groups):
+    """ha_tune_set("rollout_groups", n): the batch split into row groups on side streams (own stash regions, fork / join on the
+    caller's stream) against the single-chain evaluation -- values, prior outputs and every gradient."""
+    hm, _ = RC.make_model(gpu_lib, dev, contractive=True)
+    g = torch.Generator().manual_seed(B)
+    past = RC.canonical_state(B, g).to(dev)
+    z = torch.randn(B, 12, 48, generator=g).to(dev)
+    res = []
+    try:
+        for n in (1, groups):
+            gpu_lib.call('ha_tune_set', b'rollout_groups', n)
+            p, zz = past.clone().requires_grad_(True), z.clone().requires_grad_(True)
+            out, (pm, pv) = hm.roll_out(p, None, 12, z_seq=zz, return_prior=True)
+            w = RC.world_of(out)
+            (w.square().sum() + pm.square().sum() + pv.sum()).backward()
+            res.append((w.detach(), pm.detach(), pv.detach(), p.grad.clone(), zz.grad.clone()))
+    finally:
+        gpu_lib.call('ha_tune_set', b'rollout_groups', 0)
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item())
+
+
 def test_rotation_kernels(gpu_lib, dev):
     RC.check_rot_random(gpu_lib, dev, n=100000)
     RC.check_rotations_golden(gpu_lib, dev)

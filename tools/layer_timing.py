@@ -17,6 +17,7 @@ def main():
     B, S = int(os.environ.get('B', 32)), 4
     dev = torch.device('cuda:0')
     lib = _lib.load(os.path.join(ROOT, 'tools', 'microbench', 'libhumor_amd_timing.so'))
+    lib.call('ha_tune_set', b'layer_acc', int(os.environ.get('ACC', 0)))
     hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', model_data_config='smpl+joints+contacts', _lib_override=lib)
     hm.load_state_dict(synth.humor_state_dict(seed=0))
     hm = hm.to(dev).eval()

@@ -1,0 +1,7 @@
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/r02_run22
+rm -rf $OUT && mkdir -p $OUT
+cd $R
+timeout 300 python tools/rollout_ab.py 32 59 4,1,1,0 4,1,1,1 4,1,1,0 4,1,1,1 > $OUT/rollout_ab_32.txt 2>&1; grep "B=" $OUT/rollout_ab_32.txt
+timeout 300 python tools/rollout_ab.py 4 59 4,1,1,0 4,1,1,1 > $OUT/rollout_ab_4.txt 2>&1; grep "B=" $OUT/rollout_ab_4.txt
+timeout 900 python -m pytest tests/test_rollout_gpu.py -q -x > $OUT/pytest_rollout.txt 2>&1; tail -5 $OUT/pytest_rollout.txt | cut -c1-300

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A/B of the roll-out layer-kernel launch policy (slices per block, waves per block): event-timed forward and
-forward+backward of HumorModel.roll_out.  usage: rollout_ab.py B S "spb,finish" ["spb,finish" ...]   (spb 0 = default; finish 0 off / 1 auto / 2 forced)"""
+forward+backward of HumorModel.roll_out.  usage: rollout_ab.py B S "spb,finish[,hsum[,acc]]" ...   (spb 0 = default; finish 0 off / 1 auto / 2 forced; hsum / acc 0 / 1)"""
 import os
 import sys
 
@@ -35,6 +35,10 @@ def main():
     for cfg in cfgs:
         spb, nw = cfg[0], cfg[1]
         hsum = cfg[2] if len(cfg) > 2 else 1                                       # third number: summed-h write-back (default on)
+        acc = cfg[3] if len(cfg) > 3 else 0                                        # fourth number: fp32-atomic accumulate policy (default off)
+        lib.call('ha_tune_set', b'layer_acc', acc)
+        groups = cfg[4] if len(cfg) > 4 else 0                                     # fifth number: row groups on side streams (0 = auto)
+        lib.call('ha_tune_set', b'rollout_groups', groups)
         lib.call('ha_tune_set', b'layer_spb', spb)
         lib.call('ha_tune_set', b'layer_finish', nw if nw in (0, 1, 2) else 1)   # second number: 0 off, 1 auto, 2 forced
         lib.call('ha_tune_set', b'layer_hsum', hsum)
@@ -56,7 +60,7 @@ def main():
             ref = w
         it = 5 if B * S > 4000 else 10
         tf, tb = timed(fwd, it), timed(fwdbwd, it)
-        print(f'B={B} S={S} spb={spb} nw={nw} hsum={hsum}: fwd {tf:8.3f} ms  fwd+bwd {tb:8.3f} ms   max|joints - first cfg| (step<=8) '
+        print(f'B={B} S={S} spb={spb} nw={nw} hsum={hsum} acc={acc} groups={groups}: fwd {tf:8.3f} ms  fwd+bwd {tb:8.3f} ms   max|joints - first cfg| (step<=8) '
               f'{(w - ref).abs().max().item():.2e}', flush=True)
 
 
