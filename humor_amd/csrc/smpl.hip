@@ -1163,7 +1163,10 @@ static DenseBwdPlan dense_bwd_plan(const ha_smpl_model* m, int N, int n_active) 
   P.ngroups = ceil_div(Kc, 128);
   P.ld = P.ngroups * 128;
   P.n_rp = ceil_div(N, 64);
-  const int want = g_dense_bwd_waves > 0 ? g_dense_bwd_waves : 1600;      // resident-wave target (256 CUs x 4 SIMDs x ~1.6)
+  // wave target of the dL/dcoeff kernel's K split: ~1.6 waves per SIMD at small N; at large N at least 6 K-splits per (row panel,
+  // column group) -- each wave's chunk loop is a latency chain, and with 2 splits N = 30720 took 19.4 ms against 10.9 ms with 7
+  const int base = 6 * P.n_rp * P.ngroups;
+  const int want = g_dense_bwd_waves > 0 ? g_dense_bwd_waves : (base > 1600 ? base : 1600);
   int KS = ceil_div(want, P.n_rp * P.ngroups);
   if (KS < 1) KS = 1;
   if (KS > P.nchunks) KS = P.nchunks;
