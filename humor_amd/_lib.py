@@ -99,6 +99,10 @@ _SIGS = {
     'ha_rollout_post_forward': (C.c_int, [C.POINTER(RolloutPostArgs), C.c_void_p]),
     'ha_rollout_post_backward': (C.c_int, [C.POINTER(RolloutPostArgs), C.c_void_p]),
     'ha_lbfgs_coeffs': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_lbfgs_gram': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_lbfgs_gram_workspace': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    'ha_lbfgs_pair_coeffs': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_lbfgs_scalars': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ha_chamfer_forward': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]),
     'ha_chamfer_backward': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
 }

@@ -169,8 +169,13 @@ class LBFGS:
     # ---- history (device Gram matrix) ------------------------------------------------------------------------------------------
     def _init_history(self, n, device):
         h = self.param_groups[0]['history_size']
-        self._hist = {'M': torch.zeros(2 * h, n, dtype=torch.float32, device=device), 'G': torch.zeros(2 * h, 2 * h, dtype=torch.float32, device=device),
-                      'order': [], 'coef': torch.zeros(2 * h, dtype=torch.float32, device=device), 'h': h}
+        lib = self._lib if self._lib is not None else _lib.get_lib()
+        npart = C.c_int64()
+        lib.call('ha_lbfgs_gram_workspace', n, 2 * h, C.byref(npart))
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
+        # M: rows 0..h-1 the s slots, h..2h-1 the y slots, row 2h the current gradient (it doubles as torch's prev_flat_grad)
+        self._hist = {'M': z(2 * h + 1, n), 'G': z(2 * h, 2 * h), 'order': [], 'coef': z(2 * h + 1), 'h': h, 'Mg': z(2 * h),
+                      'P': z(2 * h, 3), 'part': z(npart.value), 'scal': z(8)}
 
     def _pop_pair(self, undo):
         """Drops the pair stored by the matching _push_pair (its slot's Gram entries become dead: slots outside `order` are ignored).
@@ -178,32 +183,48 @@ class LBFGS:
         full history, and only shortens the memory by one pair."""
         self._hist['order'].remove(undo)
 
-    def _push_pair(self, s, y):
+    def _alloc_slot(self):
         H = self._hist
         h, order = H['h'], H['order']
         slot = order.pop(0) if len(order) == h else next(i for i in range(h) if i not in order)
         order.append(slot)
-        M, G = H['M'], H['G']
-        M[slot].copy_(s)
-        M[h + slot].copy_(y)
-        vs, vy = torch.mv(M, M[slot]), torch.mv(M, M[h + slot])
-        G[slot], G[:, slot] = vs, vs
-        G[h + slot], G[:, h + slot] = vy, vy
         return slot
 
     def _direction(self, g, h_diag):
         """d = [S;Y]^T coef - h_diag g.  h_diag: Python float, or a 0-dim device tensor (then it is read on the device: no host sync)."""
         H = self._hist
         lib = self._lib if self._lib is not None else _lib.get_lib()
-        Mg = torch.mv(H['M'], g)
+        M2 = H['M'][:2 * H['h']]
+        Mg = torch.mv(M2, g)
         order = (C.c_int32 * max(1, len(H['order'])))(*H['order'])
         on_dev = torch.is_tensor(h_diag)
         hd = h_diag.reshape(1).float().contiguous() if on_dev else None
         lib.call('ha_lbfgs_coeffs', H['h'], len(H['order']), order, _lib.ptr(H['G']), _lib.ptr(Mg), 0.0 if on_dev else float(h_diag),
                  _lib.ptr(hd), _lib.ptr(H['coef']), _lib.stream_ptr(g))
         if on_dev:
-            return torch.addmv(g * (-hd), H['M'].t(), H['coef'])
-        return torch.addmv(g, H['M'].t(), H['coef'], beta=-float(h_diag), alpha=1.0)
+            return torch.addmv(g * (-hd), M2.t(), H['coef'][:2 * H['h']])
+        return torch.addmv(g, M2.t(), H['coef'][:2 * H['h']], beta=-float(h_diag), alpha=1.0)
+
+    def _scalars(self, a, b, extra=None, out=None):
+        """[a.b, max|a|, sum|a|, extra] (ha_lbfgs_scalars) as a device buffer of 4 floats; the caller reads it with ONE .tolist()."""
+        lib = self._lib if self._lib is not None else _lib.get_lib()
+        out = torch.empty(4, dtype=torch.float32, device=a.device) if out is None else out
+        lib.call('ha_lbfgs_scalars', a.numel(), _lib.ptr(a), _lib.ptr(b), _lib.ptr(extra) if extra is not None else None, _lib.ptr(out),
+                 _lib.stream_ptr(a))
+        return out
+
+    def _pair_direction(self, slot):
+        """Installs the pair already written to rows slot / h + slot of M (gradient in row 2h) and returns the new direction
+        d = M^T coef (coef[2h] = -y.s / y.y); scal[4:6] = (y.s, y.y).  Four launches: Gram pass, its reduction, coefficients, GEMV."""
+        H = self._hist
+        lib = self._lib if self._lib is not None else _lib.get_lib()
+        h, M = H['h'], H['M']
+        st = _lib.stream_ptr(M)
+        lib.call('ha_lbfgs_gram', M.shape[1], 2 * h, _lib.ptr(M), slot, h + slot, 2 * h, _lib.ptr(H['part']), _lib.ptr(H['P']), st)
+        order = (C.c_int32 * len(H['order']))(*H['order'])
+        lib.call('ha_lbfgs_pair_coeffs', h, len(H['order']), order, slot, _lib.ptr(H['P']), _lib.ptr(H['G']), _lib.ptr(H['Mg']),
+                 _lib.ptr(H['coef']), _lib.ptr(H['scal'][4:]), st)
+        return torch.mv(M.t(), H['coef'])
 
     # ---- step ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -219,16 +240,21 @@ class LBFGS:
 
         orig_loss = closure()
         flat_grad = self._gather_flat_grad()
-        loss, gmax = torch.stack([orig_loss.detach().reshape(()).float(), flat_grad.abs().max()]).tolist()
+        if self._hist is None or self._hist['M'].shape[1] != x.numel() or self._hist['M'].device != x.device:
+            self._init_history(x.numel(), x.device)
+            state['n_iter'] = 0          # a new variable vector: the stored pairs (and torch's persistent direction) no longer apply
+        Hh = self._hist
+        M, hsz, scal = Hh['M'], Hh['h'], Hh['scal']
+        g_row = M[2 * hsz]               # the previous gradient (torch's prev_flat_grad) until it is overwritten below
+        loss_t = orig_loss.detach().reshape(1).float()
+        gg, gmax, gsum, loss = self._scalars(flat_grad, flat_grad, loss_t, scal[:4]).tolist()
         current_evals = 1
         state['func_evals'] += 1
         if gmax <= tolerance_grad:
             return orig_loss
-        if self._hist is None or self._hist['M'].shape[1] != x.numel() or self._hist['M'].device != x.device:
-            self._init_history(x.numel(), x.device)
         d, t = state.get('d'), state.get('t')
         H_diag = state.get('H_diag', 1.0)
-        prev_flat_grad, prev_loss = state.get('prev_flat_grad'), state.get('prev_loss')
+        prev_loss = state.get('prev_loss')
 
         n_iter = 0
         import time
@@ -240,39 +266,36 @@ class LBFGS:
             tp = self._tick('other', tp)
             if state['n_iter'] == 1:
                 d = flat_grad.neg()
-                self._hist['order'] = []
+                Hh['order'] = []
                 H_diag = 1.0
-                scal = [flat_grad.dot(d), d.abs().max(), flat_grad.abs().sum()]
+                g_row.copy_(flat_grad)
             else:
                 # Speculative update: the pair is stored and the direction built with H = ys / yy computed on the device, and the
                 # curvature test ys > 1e-10 is read back together with g.d and max|d| -- ONE host read per iteration.  When the
                 # test fails (rare) the pair is dropped and the direction rebuilt with the previous scaling, as torch does.
-                y = flat_grad.sub(prev_flat_grad)
-                s = d.mul(t)
-                ysyy = torch.stack([y.dot(s), y.dot(y)])
-                pushed = self._push_pair(s, y)
-                d = self._direction(flat_grad, ysyy[0] / ysyy[1])
-                scal = [flat_grad.dot(d), d.abs().max(), ysyy[0], ysyy[1]]
-            if prev_flat_grad is None:
-                prev_flat_grad = flat_grad.clone()
-            else:
-                prev_flat_grad.copy_(flat_grad)
+                pushed = self._alloc_slot()
+                torch.sub(flat_grad, g_row, out=M[hsz + pushed])             # y = g - g_prev
+                torch.mul(d, t, out=M[pushed])                                # s = t d
+                g_row.copy_(flat_grad)
+                d = self._pair_direction(pushed)
+                self._scalars(d, flat_grad, None, scal[:4])                   # g.d, max|d|
             prev_loss = loss
 
             tp = self._tick('direction_issue', tp)
-            vals = torch.stack(scal).tolist()
-            tp = self._tick('direction_wait', tp)
-            gtd, d_norm = vals[0], vals[1]
             if state['n_iter'] == 1:
-                t = min(1.0, 1.0 / vals[2]) * lr
+                gtd, d_norm = -gg, gmax              # d = -g: g.d, max|d| and sum|g| came with the first evaluation's read
+                t = min(1.0, 1.0 / gsum) * lr
             else:
-                ys, yy = vals[2], vals[3]
+                vals = scal.tolist()
+                tp = self._tick('direction_wait', tp)
+                gtd, d_norm = vals[0], vals[1]
+                ys, yy = vals[4], vals[5]
                 if ys > 1e-10:
                     H_diag = ys / yy
                 else:
                     self._pop_pair(pushed)
                     d = self._direction(flat_grad, H_diag)
-                    gtd, d_norm = torch.stack([flat_grad.dot(d), d.abs().max()]).tolist()
+                    gtd, d_norm = self._scalars(d, flat_grad).tolist()[:2]
                 t = lr
             if gtd > -tolerance_change:
                 break
@@ -287,8 +310,9 @@ class LBFGS:
                     torch.add(x_init, d, alpha=tt, out=x)
                     l = closure()
                     g_new = self._gather_flat_grad()
+                    ev = self._scalars(g_new, d, l.detach().reshape(1).float())
                     t0 = self._tick('closure_issue', t0)
-                    f_new, gtd_new, gm = torch.stack([l.detach().reshape(()).float(), g_new.dot(d), g_new.abs().max()]).tolist()
+                    gtd_new, gm, _, f_new = ev.tolist()
                     self._tp = self._tick('closure_wait', t0)
                     gmax_of[id(g_new)] = gm
                     return f_new, g_new, gtd_new
@@ -303,7 +327,7 @@ class LBFGS:
                 if n_iter != max_iter:
                     l = closure()
                     flat_grad = self._gather_flat_grad()
-                    loss, gmax = torch.stack([l.detach().reshape(()).float(), flat_grad.abs().max()]).tolist()
+                    _, gmax, _, loss = self._scalars(flat_grad, flat_grad, l.detach().reshape(1).float()).tolist()
                     ls_func_evals = 1
             current_evals += ls_func_evals
             state['func_evals'] += ls_func_evals
@@ -320,7 +344,7 @@ class LBFGS:
                 break
 
         state['d'], state['t'], state['H_diag'] = d, t, H_diag
-        state['prev_flat_grad'], state['prev_loss'] = prev_flat_grad, prev_loss
+        state['prev_loss'] = prev_loss
         return orig_loss
 
     def zero_grad(self, set_to_none=True):

@@ -334,6 +334,22 @@ int ha_chamfer_backward(int b, int n, const float* xyz1, int m, const float* xyz
 int ha_lbfgs_coeffs(int hist, int num_old, const int32_t* order, const float* G, const float* Mg, float h_diag,
                     const float* h_diag_dev, float* coef, void* stream);
 
+/* The rest of one L-BFGS inner iteration between two closure evaluations (torch/optim/lbfgs.py: y = g - g_prev, s = t d, the
+ * curvature test y.s > 1e-10, H = y.s / y.y, the direction, g.d, max|d| -- ~25 small launches and three reads of the history),
+ * as four launches with a fixed summation order (the replicated multi-GPU optimiser needs bit-identical directions on all ranks).
+ * M is the history [rows_total][n], row-major: rows 0..h-1 the s slots, h..2h-1 the y slots, row 2h the current gradient.
+ *   ha_lbfgs_gram         P [rows][3] = M[r] . (M[i0], M[i1], M[i2]) for r < rows, one read of M; `part` is scratch of
+ *                         ha_lbfgs_gram_workspace floats
+ *   ha_lbfgs_pair_coeffs  ha_lbfgs_coeffs after installing the pair in `slot` from P (Gram rows / columns, Mg = P[:,2]) with the scale
+ *                         H = y.s / y.y taken from P; additionally coef[2h] = -H (so that d = M[:2h+1]^T coef) and scal = (y.s, y.y)
+ *   ha_lbfgs_scalars      out[0] = a.b, out[1] = max|a|, out[2] = sum|a|, out[3] = *extra (0 if NULL): what the line search reads
+ *                         after a closure evaluation (a = gradient, b = direction, extra = loss) or a direction update */
+int ha_lbfgs_gram(int n, int rows, const float* M, int i0, int i1, int i2, float* part, float* P, void* stream);
+int ha_lbfgs_gram_workspace(int n, int rows, int64_t* part_floats);
+int ha_lbfgs_pair_coeffs(int hist, int num_old, const int32_t* order, int slot, const float* P, float* G, float* Mg, float* coef,
+                         float* scal, void* stream);
+int ha_lbfgs_scalars(int n, const float* a, const float* b, const float* extra, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
