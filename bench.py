@@ -187,7 +187,7 @@ def skin_roofline(dev, npz, N=B_SEQ * T_SEQ, traffic=PMC_TRAFFIC_BYTES):
         lib.call('ha_lbs_skin', h.ptr, N, _lib.ptr(vposed), _lib.ptr(A), _lib.ptr(transl), _lib.ptr(verts), st)
     # cache-free sizes: the first ~20 back-to-back launches ride a power-management transient (0.93 ms, then a hump up to 1.3 ms, then
     # a steady ~0.98 ms; tools/skin_jitter.py, profiles/r02_run20_skin_jitter.txt) -- the sustained figure is the one reported
-    ms = time_events(launch, iters=50 if N <= 4096 else 30, warm=5 if N <= 4096 else 30)
+    ms = time_events(launch, iters=50 if N <= 4096 else 30, warm=20 if N <= 4096 else 30)
     nbytes = SKIN_BYTES_PER_FRAME * N
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {'kernel': 'lbs_skin (ha_lbs_skin)', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -205,7 +205,43 @@ def dense_smpl_ms(dev, npz):
     args = dict(root_orient=root.reshape(N, 3).to(dev), pose_body=body.reshape(N, 63).to(dev), trans=trans.reshape(N, 3).to(dev),
                 betas=torch.randn(N, 16, device=dev))
     with torch.no_grad():
-        return time_events(lambda: bm(**args), iters=10, warm=2)
+        ms_fwd = time_events(lambda: bm(**args), iters=10, warm=2)
+    # forward + backward with a gradient on every vertex (point-cloud / mesh terms): dense MFMA adjoint behind ha_smpl_backward_dense
+    gargs = {k: v.clone().requires_grad_(True) for k, v in args.items()}
+
+    def fwd_bwd():
+        for v in gargs.values():
+            v.grad = None
+        o = bm(**gargs)
+        (o.v.sum() + o.Jtr.sum()).backward()
+    return ms_fwd, time_events(fwd_bwd, iters=10, warm=2)
+
+
+def rollout_c4_ms(dev):
+    """HumorModel.roll_out alone at the metric's batch (32 sequences x 59 steps, prior + decoder): forward and forward + backward."""
+    from humor_amd import synth
+    from humor_amd.humor_model import HumorModel
+    hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
+    hm.load_state_dict(synth.humor_state_dict(seed=0))
+    hm = hm.to(dev).eval()
+    for p in hm.parameters():
+        p.requires_grad_(False)
+    S = T_SEQ - 1
+    past = torch.randn(B_SEQ, 339, device=dev, requires_grad=True)
+    z = torch.randn(B_SEQ, S, 48, device=dev, requires_grad=True)
+
+    def fwd():
+        with torch.no_grad():
+            hm.roll_out(past, None, S, z_seq=z, return_prior=True)
+
+    def fwd_bwd():
+        past.grad = None
+        z.grad = None
+        out, (pm, pv) = hm.roll_out(past, None, S, z_seq=z, return_prior=True)
+        (out['trans'].sum() + out['joints'].sum() + pm.sum()).backward()
+    tf, tb = time_events(fwd, iters=10, warm=2), time_events(fwd_bwd, iters=10, warm=2)
+    return {'fwd_ms': round(tf, 3), 'fwd_bwd_ms': round(tb, 3), 'steps_per_sec_fwd': round(B_SEQ * S / (tf * 1e-3), 1),
+            'steps_per_sec_fwd_bwd': round(B_SEQ * S / (tb * 1e-3), 1), 'batch': B_SEQ, 'steps': S}
 
 
 def lbfgs_profile(dev, npz, k=5):
@@ -461,7 +497,8 @@ def run(args):
                 'collectives_per_closure': '1 differentiable halo all-gather (+ its all-reduce in backward) + 1 packed [gradient | loss] all-reduce'}
 
     if rank == 0:
-        ms_dense = dense_smpl_ms(dev, npz)
+        roof = skin_roofline(dev, npz)          # first among the side measurements: same chip state as in earlier rounds
+        ms_dense, ms_dense_fb = dense_smpl_ms(dev, npz)
         res = {
             'metric': 'fitting closure evaluations/s (stage-3 objective fwd+bwd), batch=32 seq=60 per GPU',
             'value': round(args.steps * world / dt, 3), 'unit': 'closure-evals/s (32x60-batch equivalents)',
@@ -475,7 +512,10 @@ def run(args):
             'closure_mode': closure_mode(args, fc),
             'smpl_verts_per_sec': round(B_SEQ * T_SEQ * V / (ms_dense * 1e-3), 1),
             'smpl_dense_fwd_ms': round(ms_dense, 4),
-            'roofline': skin_roofline(dev, npz),
+            'smpl_dense_fwd_bwd_ms': round(ms_dense_fb, 4),
+            'smpl_verts_per_sec_fwd_bwd': round(B_SEQ * T_SEQ * V / (ms_dense_fb * 1e-3), 1),
+            'rollout': rollout_c4_ms(dev),
+            'roofline': roof,
         }
         if strong is not None:
             res['strong'] = strong

@@ -40,6 +40,10 @@ def main():
         c = b['cpu_baseline']
         out.append(f"cpu_baseline: {c['value']} {c['unit']} on {c['cores']} threads ({c['kind']}) -> GPU/CPU = {b['value'] / c['value']:.0f}x")
     out.append(f"dense SMPL forward (6890 verts, N=1920): {b['smpl_dense_fwd_ms']} ms = {b['smpl_verts_per_sec'] / 1e9:.1f} G verts/s")
+    if 'smpl_dense_fwd_bwd_ms' in b:
+        out.append(f"dense SMPL forward + backward (gradient on every vertex): {b['smpl_dense_fwd_bwd_ms']} ms = {b['smpl_verts_per_sec_fwd_bwd'] / 1e9:.1f} G verts/s")
+    if 'rollout' in b:
+        out.append('roll-out 32 x 59 alone: ' + json.dumps(b['rollout']))
     open(os.path.join(d, 'SUMMARY.txt'), 'w').write('\n'.join(out) + '\n')
     print('\n'.join(out))
 
