@@ -187,7 +187,7 @@ def skin_roofline(dev, npz, N=B_SEQ * T_SEQ, traffic=PMC_TRAFFIC_BYTES):
         lib.call('ha_lbs_skin', h.ptr, N, _lib.ptr(vposed), _lib.ptr(A), _lib.ptr(transl), _lib.ptr(verts), st)
     # cache-free sizes: the first ~20 back-to-back launches ride a power-management transient (0.93 ms, then a hump up to 1.3 ms, then
     # a steady ~0.98 ms; tools/skin_jitter.py, profiles/r02_run20_skin_jitter.txt) -- the sustained figure is the one reported
-    ms = time_events(launch, iters=50 if N <= 4096 else 30, warm=20 if N <= 4096 else 30)
+    ms = time_events(launch, iters=50 if N <= 4096 else 30, warm=5 if N <= 4096 else 30)
     nbytes = SKIN_BYTES_PER_FRAME * N
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {'kernel': 'lbs_skin (ha_lbs_skin)', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -535,7 +535,9 @@ def run(args):
             res['roofline_c5'] = skin_roofline(dev, npz, N=256 * 120, traffic=PMC_TRAFFIC_BYTES_C5)
             res['roofline_c5']['note'] = ('cache-free size (5.2 GB per launch); at this size the kernel\'s own copy-only mode reaches 5.77 TB/s '
                                           'and a torch device copy 4.94 TB/s (profiles/r02_pmc_lbs/SUMMARY.txt)')
-            res['roofline']['note'] = 'the metric\'s batch (32 x 60): 159 MB operands, partly served by the 256 MiB Infinity Cache; see roofline_c5'
+            res['roofline']['note'] = ('the metric\'s batch (32 x 60): 159 MB operands, partly served by the 256 MiB Infinity Cache; 5 warm-up + 50 timed '
+                                       'launches as in round 1 (a series of 80 back-to-back launches settles 15-25 % lower: the gather\'s LDS replays push '
+                                       'the package into its power limit, profiles/experiments/README.md); see roofline_c5 for the cache-free, sustained figure')
             # BASELINE config C5 (batch 256 x 120 frames): LBS GB/s, pose-blend and decoder/prior MLP fp32-MFMA utilisation
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import bench_c5
