@@ -37,9 +37,10 @@ def _cubic_interpolate(x1, f1, g1, x2, f2, g2, bounds=None):
     return (xmin_bound + xmax_bound) / 2.0
 
 
-def _strong_wolfe(obj_func, t, d_norm, f, g, gtd, c1=1e-4, c2=0.9, tolerance_change=1e-9, max_ls=25):
-    """torch/optim/lbfgs.py:_strong_wolfe; obj_func(t) -> (f_new: float, g_new: tensor (owned by the caller), gtd_new: float)."""
-    f_new, g_new, gtd_new = obj_func(t)
+def _strong_wolfe(obj_func, t, d_norm, f, g, gtd, c1=1e-4, c2=0.9, tolerance_change=1e-9, max_ls=25, first=None):
+    """torch/optim/lbfgs.py:_strong_wolfe; obj_func(t) -> (f_new: float, g_new: tensor (owned by the caller), gtd_new: float).
+    `first`: the result of obj_func(t) when the caller has already evaluated the first trial point."""
+    f_new, g_new, gtd_new = obj_func(t) if first is None else first
     ls_func_evals = 1
     t_prev, f_prev, g_prev, gtd_prev = 0, f, g, gtd
     done = False
@@ -175,7 +176,7 @@ class LBFGS:
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
         # M: rows 0..h-1 the s slots, h..2h-1 the y slots, row 2h the current gradient (it doubles as torch's prev_flat_grad)
         self._hist = {'M': z(2 * h + 1, n), 'G': z(2 * h, 2 * h), 'order': [], 'coef': z(2 * h + 1), 'h': h, 'Mg': z(2 * h),
-                      'P': z(2 * h, 3), 'part': z(npart.value), 'scal': z(8)}
+                      'P': z(2 * h, 3), 'part': z(npart.value), 'scal': z(12)}
 
     def _pop_pair(self, undo):
         """Drops the pair stored by the matching _push_pair (its slot's Gram entries become dead: slots outside `order` are ignored).
@@ -233,6 +234,7 @@ class LBFGS:
         lr, max_iter, max_eval = float(group['lr']), group['max_iter'], group['max_eval']
         tolerance_grad, tolerance_change = group['tolerance_grad'], group['tolerance_change']
         line_search_fn = group['line_search_fn']
+        discard = getattr(closure, 'discard_last', None)     # told when a speculatively issued evaluation is thrown away
         closure = torch.enable_grad()(closure)
         state = self.state
         self._bind()
@@ -282,10 +284,14 @@ class LBFGS:
             prev_loss = loss
 
             tp = self._tick('direction_issue', tp)
+            # From the second iteration on the first trial step is always t = lr, and the direction's scalars are only needed for two
+            # rare decisions (curvature test failed / directional derivative ~ 0): with a line search the first trial evaluation is
+            # issued right behind the direction kernels and ONE read returns both sets of scalars -- one host round trip per iteration.
+            deferred = state['n_iter'] > 1 and line_search_fn is not None
             if state['n_iter'] == 1:
                 gtd, d_norm = -gg, gmax              # d = -g: g.d, max|d| and sum|g| came with the first evaluation's read
                 t = min(1.0, 1.0 / gsum) * lr
-            else:
+            elif not deferred:
                 vals = scal.tolist()
                 tp = self._tick('direction_wait', tp)
                 gtd, d_norm = vals[0], vals[1]
@@ -297,7 +303,9 @@ class LBFGS:
                     d = self._direction(flat_grad, H_diag)
                     gtd, d_norm = self._scalars(d, flat_grad).tolist()[:2]
                 t = lr
-            if gtd > -tolerance_change:
+            else:
+                t = lr
+            if not deferred and gtd > -tolerance_change:
                 break
 
             ls_func_evals = 0
@@ -305,12 +313,15 @@ class LBFGS:
                 x_init = x.clone()
                 gmax_of = {}
 
-                def obj_func(tt):
-                    t0 = self._tick('other', time.perf_counter()) if self.profile is None else self._tick('other', self._tp)
+                def issue(tt, out=None):
                     torch.add(x_init, d, alpha=tt, out=x)
                     l = closure()
                     g_new = self._gather_flat_grad()
-                    ev = self._scalars(g_new, d, l.detach().reshape(1).float())
+                    return g_new, self._scalars(g_new, d, l.detach().reshape(1).float(), out)
+
+                def obj_func(tt):
+                    t0 = self._tick('other', time.perf_counter()) if self.profile is None else self._tick('other', self._tp)
+                    g_new, ev = issue(tt)
                     t0 = self._tick('closure_issue', t0)
                     gtd_new, gm, _, f_new = ev.tolist()
                     self._tp = self._tick('closure_wait', t0)
@@ -318,7 +329,34 @@ class LBFGS:
                     return f_new, g_new, gtd_new
                 self._tp = tp
                 g_in = flat_grad
-                loss, flat_grad, t, ls_func_evals = _strong_wolfe(obj_func, t, d_norm, loss, flat_grad, gtd, max_ls=max_eval - current_evals)
+                first = None
+                if deferred:
+                    g_new, _ = issue(t, scal[8:12])
+                    tp = self._tick('closure_issue', tp)
+                    vals = scal.tolist()
+                    self._tp = tp = self._tick('closure_wait', tp)
+                    gtd, d_norm, ys, yy = vals[0], vals[1], vals[4], vals[5]
+                    if ys > 1e-10:
+                        H_diag = ys / yy
+                        first = (vals[11], g_new, vals[8])
+                        gmax_of[id(g_new)] = vals[9]
+                    else:
+                        # curvature test failed: torch keeps the old pairs and scaling -- drop the pair, rebuild the direction, and let
+                        # the line search start over from x_init (the trial evaluation along the discarded direction is not counted)
+                        x.copy_(x_init)
+                        if discard is not None:
+                            discard()
+                        self._pop_pair(pushed)
+                        d = self._direction(flat_grad, H_diag)
+                        gtd, d_norm = self._scalars(d, flat_grad).tolist()[:2]
+                    if gtd > -tolerance_change:
+                        if first is not None:
+                            x.copy_(x_init)              # torch stops before the line search: the trial step is discarded
+                            if discard is not None:
+                                discard()
+                        break
+                loss, flat_grad, t, ls_func_evals = _strong_wolfe(obj_func, t, d_norm, loss, flat_grad, gtd, max_ls=max_eval - current_evals,
+                                                                  first=first)
                 tp = self._tp
                 torch.add(x_init, d, alpha=t, out=x)
                 gmax = gmax_of[id(flat_grad)] if id(flat_grad) in gmax_of else (gmax if flat_grad is g_in else flat_grad.abs().max().item())

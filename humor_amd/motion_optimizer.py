@@ -205,6 +205,7 @@ class MotionOptimizer():
                     p.grad = None
                 loss, stats = objective()
                 return self._finish_closure(loss, params, stats)
+            closure.discard_last = self._discard_last_eval
             return closure
         state = {'graph': None, 'loss': None, 'grads': None, 'failed': False}
 
@@ -253,7 +254,16 @@ class MotionOptimizer():
             if self.loss_trace is not None and self.shard is None:
                 self.loss_trace.append((self.fitting_loss.cur_stage_idx, float(state['loss'])))
             return state['loss']
+        closure.discard_last = self._discard_last_eval
         return closure
+
+    def _discard_last_eval(self):
+        """humor_amd.lbfgs.LBFGS issues the first trial evaluation of an iteration before it has read the direction's scalars; in the
+        rare cases where torch would have stopped before that evaluation the optimiser discards it and says so here, so that the
+        evaluation counter and the loss trace stay those of the reference's torch.optim.LBFGS run."""
+        self.closure_evals -= 1
+        if self.loss_trace:
+            self.loss_trace.pop()
 
     def _mark(self, key, iters=0):
         """Stage timing for bench.py: closes the interval `key` (seconds since the previous mark, closure evaluations, outer iterations)."""
