@@ -39,65 +39,155 @@ __device__ __forceinline__ float lb_wsum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(64) void lbfgs_coeffs_kernel(LbfgsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // al[LB_MAXH] | ab[LB_MAXH] (= al - be)
-  float* al = smem;
-  float* ab = smem + LB_MAXH;
-  const int lane = threadIdx.x, h = a.hist, k = a.num_old, W = 2 * h;
+// The two k-step recurrences are inherently sequential, so what matters is the cost of ONE step.  Walking the Gram matrix in global
+// memory (two dependent round trips + a fenced LDS hand-off per step) cost 149 us at k = 100 -- a quarter of a stage-2 closure
+// evaluation.  Here the block first gathers the three k x k blocks the recurrences read (s_i.y_j, y_i.y_j in age order; y_i.s_j is
+// the transpose of the first) into LDS, all four waves form q_i = sum_j al_j y_i.y_j in parallel between the loops, and wave 0 walks
+// the chains out of LDS: ~0.05 us per step.
+// value of `v` in lane `src` (wave-uniform src) for every lane: v_readlane_b32 on hardware (a scalar register, ~10 cycles; the
+// cross-lane shuffle goes through the LDS crossbar)
+__device__ __forceinline__ float lb_bcast(float v, int src) {
+#ifdef HA_SIMT_EMU
+  return __shfl(v, src);
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+#endif
+}
+
+// packed upper triangle (i <= j) of a k x k matrix
+__device__ __forceinline__ int lb_tri(int i, int j, int k) { return i * k - (i * (i - 1)) / 2 + (j - i); }
+
+__global__ __launch_bounds__(256) void lbfgs_coeffs_kernel(LbfgsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = a.hist, k = a.num_old, W = 2 * h;
+  float* Gsy = smem;                                   // packed upper triangle of s_i . y_j (i <= j: the only entries the loops read)
+  float* al = Gsy + (LB_MAXH * (LB_MAXH + 1)) / 2;     // [LB_MAXH]
+  float* ab = al + LB_MAXH;                            // [LB_MAXH]  al - be
+  float* qv = ab + LB_MAXH;                            // [LB_MAXH]  sum_j al_j y_i.y_j
+  float* mgs = qv + LB_MAXH;                           // [LB_MAXH]  s_i . g
+  float* mgy = mgs + LB_MAXH;                          // [LB_MAXH]  y_i . g
+  int* s_order = reinterpret_cast<int*>(mgy + LB_MAXH);
+  for (int i = tid; i < k; i += 256) s_order[i] = a.order[i];
   float h_diag = a.h_diag_dev ? a.h_diag_dev[0] : a.h_diag;
-  if (a.P) {
-    // the pair (s, y) has just been written to rows slot / hist + slot of M: its Gram rows and columns, M g, and the scale y.s / y.y
-    for (int i = lane; i < W; i += 64) {
-      const float vs = a.P[i * 3], vy = a.P[i * 3 + 1];
-      a.Gw[(size_t)a.slot * W + i] = vs;
-      a.Gw[(size_t)i * W + a.slot] = vs;
-      a.Gw[(size_t)(h + a.slot) * W + i] = vy;
-      a.Gw[(size_t)i * W + h + a.slot] = vy;
-      a.Mgw[i] = a.P[i * 3 + 2];
+  const float* P = a.P;
+  const int slot = a.slot;
+  if (P) {
+    // install the pair just written to `slot`: its Gram rows / columns, M g, and the scale H = y.s / y.y
+    for (int i = tid; i < W; i += 256) {
+      const float vs = P[i * 3], vy = P[i * 3 + 1];
+      a.Gw[(size_t)slot * W + i] = vs;
+      a.Gw[(size_t)i * W + slot] = vs;
+      a.Gw[(size_t)(h + slot) * W + i] = vy;
+      a.Gw[(size_t)i * W + h + slot] = vy;
+      a.Mgw[i] = P[i * 3 + 2];
     }
-    const float ys = a.P[(h + a.slot) * 3], yy = a.P[(h + a.slot) * 3 + 1];
+    const float ys = P[(h + slot) * 3], yy = P[(h + slot) * 3 + 1];
     h_diag = ys / yy;
-    if (lane == 0) { a.scal[0] = ys; a.scal[1] = yy; a.coef[W] = -h_diag; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the Gram entries written above are read back below by other lanes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tid == 0) { a.scal[0] = ys; a.scal[1] = yy; a.coef[W] = -h_diag; }
   }
-  for (int i = lane; i < 2 * h; i += 64) a.coef[i] = 0.f;
-  // first loop: newest -> oldest
-  for (int i = k - 1; i >= 0; --i) {
-    const int pi = a.order[i];
-    float part = 0.f;
-    for (int j = i + 1 + lane; j < k; j += 64) part += al[j] * a.G[(size_t)pi * W + h + a.order[j]];      // al_j s_i.y_j
-    const float s = lb_wsum(part);
-    const float ro = 1.0f / a.G[(size_t)pi * W + h + pi];
-    if (lane == 0) al[i] = ro * (-a.Mg[pi] - s);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // the entries written above are read back below by other threads of this block (same CU: workgroup scope is the right one)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const float* G = a.Gw ? a.Gw : a.G;
+  const float* Mg = a.Mgw ? a.Mgw : a.Mg;
+  // s_i . y_j, i <= j, into LDS: thread = (column j, row parity), eight independent loads per round trip
+  {
+    const int j = tid & 127, ih = tid >> 7;
+    const int pj = j < k ? s_order[j] : 0;
+    for (int i0 = ih; i0 < k; i0 += 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 2 * u;
+        v[u] = (i < k && j < k && i <= j) ? G[(size_t)s_order[i] * W + h + pj] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 2 * u;
+        if (i < k && j < k && i <= j) Gsy[lb_tri(i, j, k)] = v[u];
+      }
+    }
   }
-  // second loop: oldest -> newest
-  for (int i = 0; i < k; ++i) {
-    const int pi = a.order[i];
-    float p1 = 0.f, p2 = 0.f;
-    for (int j = lane; j < k; j += 64) p1 += al[j] * a.G[(size_t)(h + pi) * W + h + a.order[j]];          // al_j y_i.y_j
-    for (int j = lane; j < i; j += 64) p2 += ab[j] * a.G[(size_t)(h + pi) * W + a.order[j]];              // (al_j - be_j) y_i.s_j
-    const float s1 = lb_wsum(p1), s2 = lb_wsum(p2);
-    const float ro = 1.0f / a.G[(size_t)pi * W + h + pi];
-    if (lane == 0) {
-      const float be = ro * (h_diag * (-a.Mg[h + pi] - s1) + s2);
-      ab[i] = al[i] - be;
+  for (int i = tid; i < k; i += 256) {
+    const int pi = s_order[i];
+    mgs[i] = Mg[pi];
+    mgy[i] = Mg[h + pi];
+  }
+  for (int i = tid; i < W; i += 256) a.coef[i] = 0.f;
+  __syncthreads();
+  // first loop: newest -> oldest     al_i = ro_i ( -s_i.g - sum_{j newer than i} al_j s_i.y_j )
+  // Column-oriented: lane l owns rows l and l + 64 and keeps their running sums in registers; a step is the owner's two FMAs, one
+  // readlane broadcast of al_j and one LDS read per owned row -- no cross-lane reduction on the chain (the row-oriented form paid a
+  // six-stage wave reduction + a division per step: 0.45 us x 2 k steps).
+  const int r0 = lane, r1 = lane + 64;
+  const float ro0 = r0 < k ? 1.0f / Gsy[lb_tri(r0, r0, k)] : 0.f, ro1 = r1 < k ? 1.0f / Gsy[lb_tri(r1, r1, k)] : 0.f;
+  if (wave == 0) {
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int j = k - 1; j >= 0; --j) {
+      // al_j by its owner (its sum over the newer pairs is complete), then broadcast
+      const float mine = j < 64 ? ro0 * (-(r0 < k ? mgs[r0] : 0.f) - acc0) : ro1 * (-(r1 < k ? mgs[r1] : 0.f) - acc1);
+      const float aj = lb_bcast(mine, j & 63);
+      if (lane == (j & 63)) al[j] = aj;
+      if (r0 < j) acc0 = fmaf(aj, Gsy[lb_tri(r0, j, k)], acc0);
+      if (r1 < j) acc1 = fmaf(aj, Gsy[lb_tri(r1, j, k)], acc1);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  for (int i = lane; i < k; i += 64) {
-    const int pi = a.order[i];
-    a.coef[pi] = ab[i];                       // s_i
-    a.coef[h + pi] = -h_diag * al[i];       // y_i
+  __syncthreads();
+  // q_i = sum_j al_j y_i.y_j for every i (independent of the second recurrence): all waves, eight rows of the Gram matrix per trip
+  {
+    const int j0 = lane, j1 = lane + 64;
+    const int p0 = j0 < k ? s_order[j0] : 0, p1 = j1 < k ? s_order[j1] : 0;
+    const float a0 = j0 < k ? al[j0] : 0.f, a1 = j1 < k ? al[j1] : 0.f;
+    for (int i0 = wave; i0 < k; i0 += 32) {
+      float g0[8], g1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 4 * u;
+        const float* row = G + (size_t)(h + s_order[i < k ? i : 0]) * W + h;
+        g0[u] = row[p0];
+        g1[u] = row[p1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 4 * u;
+        const float sum = lb_wsum(fmaf(a0, g0[u], a1 * g1[u]));
+        if (lane == 0 && i < k) qv[i] = sum;
+      }
+    }
+  }
+  __syncthreads();
+  // second loop: oldest -> newest    be_i = ro_i ( H ( -y_i.g - q_i ) + sum_{j older than i} (al_j - be_j) y_i.s_j ),  y_i.s_j = s_j.y_i
+  if (wave == 0) {
+    float acc0 = 0.f, acc1 = 0.f;
+    const float c0 = r0 < k ? h_diag * (-mgy[r0] - qv[r0]) : 0.f, c1 = r1 < k ? h_diag * (-mgy[r1] - qv[r1]) : 0.f;
+    const float al0 = r0 < k ? al[r0] : 0.f, al1 = r1 < k ? al[r1] : 0.f;
+    for (int j = 0; j < k; ++j) {
+      const float mine = j < 64 ? al0 - ro0 * (c0 + acc0) : al1 - ro1 * (c1 + acc1);     // al_j - be_j by its owner
+      const float bj = lb_bcast(mine, j & 63);
+      if (lane == (j & 63)) ab[j] = bj;
+      if (r0 > j && r0 < k) acc0 = fmaf(bj, Gsy[lb_tri(j, r0, k)], acc0);
+      if (r1 > j && r1 < k) acc1 = fmaf(bj, Gsy[lb_tri(j, r1, k)], acc1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < k; i += 64) {
+      const int pi = s_order[i];
+      a.coef[pi] = ab[i];                       // s_i
+      a.coef[h + pi] = -h_diag * al[i];       // y_i
+    }
   }
 }
+
+}  // namespace ha
+
+namespace ha {
+constexpr size_t LB_COEFF_LDS = (size_t)((LB_MAXH * (LB_MAXH + 1)) / 2 + 5 * LB_MAXH) * sizeof(float) + LB_MAXH * sizeof(int);
 
 // ---- one pass over the history for the three products the update needs ----------------------------------------------------------
 // P[r][k] = M[r] . V_k for r < rows, V = (M[i0], M[i1], M[i2]) (the new s, the new y and the current gradient row).  torch issues a
@@ -108,6 +198,9 @@ __global__ __launch_bounds__(256) void lbfgs_gram_partial_kernel(const float* __
                                                                  float* __restrict__ part) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c0 = blockIdx.x * GR_CW;
+  // grid.y splits the rows: one block per (column chunk, row group) -- with all 2 h rows in one block only ~570 waves were in flight
+  // for a 60-76 MB read (1.3 TB/s)
+  const int rpb = (rows + gridDim.y - 1) / gridDim.y, rbeg = blockIdx.y * rpb, rend = (rbeg + rpb) < rows ? (rbeg + rpb) : rows;
   float v[3][8];
   const int idx[3] = {i0, i1, i2};
 #pragma unroll
@@ -117,23 +210,32 @@ __global__ __launch_bounds__(256) void lbfgs_gram_partial_kernel(const float* __
       const int c = c0 + (e >> 2) * 256 + lane * 4 + (e & 3);
       v[k][e] = c < n ? M[(size_t)idx[k] * n + c] : 0.f;
     }
-  for (int r = wave; r < rows; r += 4) {
-    float m[8];
+  // four rows (8 x 16-byte... as 4-byte lane-contiguous loads: 32 loads) in flight per trip: the loop is a latency chain otherwise
+  for (int r0 = rbeg + wave; r0 < rend; r0 += 16) {
+    float m[4][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = c0 + (e >> 2) * 256 + lane * 4 + (e & 3);
-      m[e] = c < n ? M[(size_t)r * n + c] : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + 4 * u < rend ? r0 + 4 * u : r0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c0 + (e >> 2) * 256 + lane * 4 + (e & 3);
+        m[u][e] = c < n ? M[(size_t)r * n + c] : 0.f;
+      }
     }
-    float p[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + 4 * u;
+      float p[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) p[k] = fmaf(m[e], v[k][e], p[k]);
+      for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) p[k] = lb_wsum(p[k]);
-    if (lane == 0) {
-      float* dst = part + ((size_t)blockIdx.x * rows + r) * 3;
-      dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+        for (int e = 0; e < 8; ++e) p[k] = fmaf(m[u][e], v[k][e], p[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) p[k] = lb_wsum(p[k]);
+      if (lane == 0 && r < rend) {
+        float* dst = part + ((size_t)blockIdx.x * rows + r) * 3;
+        dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+      }
     }
   }
 }
@@ -160,7 +262,30 @@ __global__ __launch_bounds__(1024) void lbfgs_scalars_kernel(int n, const float*
   float* ss = smem + 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float d = 0.f, m = 0.f, su = 0.f;
-  for (int i = tid; i < n; i += 1024) {
+  // one block streams both vectors (n <= a few 100 k): 16-byte loads, eight pairs in flight per trip, scalar tail
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const bool vec = ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
+  const int n4 = vec ? n >> 2 : 0;
+  const v4* a4 = reinterpret_cast<const v4*>(a);
+  const v4* b4 = reinterpret_cast<const v4*>(b);
+  for (int i0 = tid; i0 < n4; i0 += 8 * 1024) {
+    v4 xa[8], xb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 1024;
+      xa[u] = i < n4 ? a4[i] : v4{0.f, 0.f, 0.f, 0.f};
+      xb[u] = i < n4 ? b4[i] : v4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d = fmaf(xa[u][e], xb[u][e], d);
+        m = fmaxf(m, fabsf(xa[u][e]));
+        su += fabsf(xa[u][e]);
+      }
+  }
+  for (int i = 4 * n4 + tid; i < n; i += 1024) {
     const float x = a[i];
     d = fmaf(x, b[i], d);
     m = fmaxf(m, fabsf(x));
@@ -186,7 +311,7 @@ extern "C" int ha_lbfgs_gram(int n, int rows, const float* M, int i0, int i1, in
   HA_REQUIRE(n >= 1 && rows >= 1 && M && part && P, "ha_lbfgs_gram: bad argument");
   HA_REQUIRE(i0 >= 0 && i1 >= 0 && i2 >= 0, "ha_lbfgs_gram: negative row index");
   const int nb = ceil_div(n, GR_CW);
-  hipLaunchKernelGGL(lbfgs_gram_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, M, n, rows, i0, i1, i2, part);
+  hipLaunchKernelGGL(lbfgs_gram_partial_kernel, dim3(nb, 8), dim3(256), 0, (hipStream_t)stream, M, n, rows, i0, i1, i2, part);
   HA_LAUNCH_CHECK();
   hipLaunchKernelGGL(lbfgs_gram_reduce_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, part, nb, rows, P);
   HA_LAUNCH_CHECK();
@@ -222,7 +347,7 @@ extern "C" int ha_lbfgs_pair_coeffs(int hist, int num_old, const int32_t* order,
   }
   a.G = G; a.Mg = Mg; a.coef = coef;
   a.P = P; a.slot = slot; a.Gw = G; a.Mgw = Mg; a.scal = scal;
-  hipLaunchKernelGGL(lbfgs_coeffs_kernel, dim3(1), dim3(64), 2 * LB_MAXH * sizeof(float), (hipStream_t)stream, a);
+  hipLaunchKernelGGL(lbfgs_coeffs_kernel, dim3(1), dim3(256), LB_COEFF_LDS, (hipStream_t)stream, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -241,7 +366,7 @@ extern "C" int ha_lbfgs_coeffs(int hist, int num_old, const int32_t* order, cons
     a.order[i] = order[i];
   }
   a.G = G; a.Mg = Mg; a.h_diag = h_diag; a.h_diag_dev = h_diag_dev; a.coef = coef;
-  hipLaunchKernelGGL(lbfgs_coeffs_kernel, dim3(1), dim3(64), 2 * LB_MAXH * sizeof(float), (hipStream_t)stream, a);
+  hipLaunchKernelGGL(lbfgs_coeffs_kernel, dim3(1), dim3(256), LB_COEFF_LDS, (hipStream_t)stream, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
