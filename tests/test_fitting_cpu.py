@@ -174,6 +174,14 @@ def test_emu_fit_pre_kernel_equals_op_chain(emu_lib, smplh_npz):
     print('fit pre: worst relative gradient difference', FL.check_fit_pre(emu_lib, CPU, smplh_npz, B=2, seed=1))
 
 
+def test_emu_lbfgs_kernels_long_history(emu_lib):
+    """Gram pass, pair installation + coefficient kernel and the scalars kernel on the SIMT emulator with 90 stored pairs in rotated
+    slots (lanes own two rows of the recurrences) against the float64 two-loop recursion."""
+    import lbfgs_checks as LC
+    print('direction rel. error', LC.check_direction(emu_lib, CPU, n=300, h=100, k=90))
+    print('direction rel. error (k = 128)', LC.check_direction(emu_lib, CPU, n=200, h=128, k=128, seed=1))
+
+
 def test_emu_fused_lbfgs_follows_torch_lbfgs(emu_lib):
     """humor_amd.lbfgs.LBFGS (flat buffer, one Gram pass + coefficient-form two-loop recursion + one GEMV per direction, every scalar
     of an evaluation in one read) against torch.optim.LBFGS on a smooth non-quadratic problem with a short history (pairs get evicted):

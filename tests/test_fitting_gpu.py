@@ -38,6 +38,14 @@ def test_short_run_at_baseline_sizes(gpu_lib, dev, smplh_npz, name, kind):
     FC.check_short_run(gpu_lib, dev, smplh_npz, kind, long_name=name)
 
 
+@pytest.mark.parametrize('n,h,k', [(94752, 100, 100), (73472, 100, 71), (301, 128, 128), (1000, 100, 3)])
+def test_lbfgs_kernels_against_two_loop_recursion(gpu_lib, dev, n, h, k):
+    """ha_lbfgs_gram / ha_lbfgs_pair_coeffs / ha_lbfgs_scalars at the stage-3 and stage-2 vector lengths of the C4 fit with a full
+    history, against the float64 two-loop recursion of torch.optim.LBFGS."""
+    import lbfgs_checks as LC
+    print('direction rel. error', LC.check_direction(gpu_lib, dev, n=n, h=h, k=k, seed=k))
+
+
 def test_graphed_closure_equals_eager(gpu_lib, dev, smplh_npz):
     """hipGraph replay of the stage-3 closure returns the eager loss and gradients bit-for-bit, call after call."""
     from oracle import closure_cases as CC
