@@ -62,4 +62,5 @@ def test_emu_fused_vposer_matches_module(emu_lib):
 
 
 def test_emu_fused_posterior_encoder_matches_module(emu_lib):
-    MC.check_posterior(emu_lib, CPU, N=37)
+    # one 32-row tile here (the two-tile, ragged-tile geometry of the same GEMM kernel is test_emu_fused_vposer_matches_module above)
+    MC.check_posterior(emu_lib, CPU, N=7)
