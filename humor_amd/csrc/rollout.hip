@@ -44,6 +44,10 @@ int g_layer_hsum = 1;  // summed pre-activation write-back for the adjoint (ha_t
 // next launch: 32x59 fwd+bwd 4.55 -> 4.43 ms only, and the sum order of the partials (hence the last bit) varies run to run.
 int g_layer_acc = 0;
 int g_gemm_rm = 0;    // row tiles per wave of the batched prior GEMM (ha_tune_set "gemm_rm"; 0 = by size)
+// ha_tune_set "gemm_ks" (experiment, default 0 = off): 2 = two waves share a tile pair, each walks half of K, partial tiles summed
+// through LDS before the epilogue.  For small GEMMs (VPoser: 1920 x 512 x 512 is 480 waves on 1024 SIMDs) a launch is exactly one
+// wave's serial MFMA chain (512 MFMAs = 13.7 us of the 16 us); to be measured before it becomes a policy.
+int g_gemm_ks = 0;
 // ha_tune_set "rollout_groups": 0 = auto, n >= 1 = split the batch into (at most) n row groups that run the chain side by side on
 // their own HIP streams (fork / join on the caller's stream with events; capturable), each with its own stash region and its steps
 // issued round-robin.  Sequences are independent, but side-by-side chains only pay where they change the launch policy: dispatch is
@@ -458,15 +462,19 @@ struct GemmTask {
 
 constexpr int GEMM_LDS_WAVE = 2 * 8 * 132;    // floats of epilogue staging per wave: [column tile][quad][32 rows x 4 + pad]
 
-template <int RM>
+// KS = 2: waves (2 cw, 2 cw + 1) of a block share tile pair cw of the block's two; wave kpart walks half of the K slices, the partial
+// tiles meet in LDS and the even wave runs the epilogue.
+template <int RM, int KS = 1>
 __global__ __launch_bounds__(256) void prior_gemm_kernel(GemmTask T) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int w = (int)(blockIdx.x & 7) * T.per_xcd + (int)(blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= T.per_xcd || w >= T.nwork) return;
+  if ((int)(blockIdx.x >> 3) >= T.per_xcd || w >= T.nwork) return;      // (block-uniform)
   const int cb = w / T.nrg, rg = w % T.nrg;
-  const int ct0 = (cb * 4 + wave) * 2;
-  if (ct0 >= T.ntiles) return;
+  const int kpart = KS == 1 ? 0 : wave % KS;
+  const int ct0 = KS == 1 ? (cb * 4 + wave) * 2 : (cb * (4 / KS) + wave / KS) * 2;
+  const bool tile_ok = ct0 < T.ntiles;
+  if (KS == 1 && !tile_ok) return;                           // (with a K split the idle waves stay for the block barriers)
   const int ct1 = ct0 + 1 < T.ntiles ? ct0 + 1 : ct0;      // an odd last tile: the second accumulator is computed and dropped
   int rt[RM];
 #pragma unroll
@@ -506,14 +514,18 @@ __global__ __launch_bounds__(256) void prior_gemm_kernel(GemmTask T) {
         acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][kp], b1[kp], acc[m][1], 0, 0, 0);
       }
   };
-  const int nfull = T.Csrc / SLICE < T.nslices ? T.Csrc / SLICE : T.nslices;      // slices whose 64 channels all exist in the slab
-  if (nfull > 0) {
+  const int nfull_all = T.Csrc / SLICE < T.nslices ? T.Csrc / SLICE : T.nslices;      // slices whose 64 channels all exist in the slab
+  // this wave's share of the full slices: [sbeg, nfull)
+  const int per_part = (nfull_all + KS - 1) / KS;
+  const int sbeg = KS == 1 ? 0 : (kpart * per_part < nfull_all ? kpart * per_part : nfull_all);
+  const int nfull = KS == 1 ? nfull_all : ((sbeg + per_part) < nfull_all ? (sbeg + per_part) : nfull_all);
+  if (nfull > sbeg && (KS == 1 || tile_ok)) {
     float aA[RM][32], bA0[32], bA1[32], aB[RM][32], bB0[32], bB1[32];
-    load_b(0, bA0, bA1);
-    load_a(0, aA);
+    load_b(sbeg, bA0, bA1);
+    load_a(sbeg, aA);
     // HA_SCHED_FENCE keeps the compiler from sinking the next slice's loads down to their first use (which serialises every
     // memory round trip behind the MFMAs instead of hiding it under them)
-    for (int slice = 0; slice < nfull; slice += 2) {
+    for (int slice = sbeg; slice < nfull; slice += 2) {
       const int s1 = slice + 1 < nfull ? slice + 1 : slice;
       load_b(s1, bB0, bB1);
       load_a(s1, aB);
@@ -530,12 +542,12 @@ __global__ __launch_bounds__(256) void prior_gemm_kernel(GemmTask T) {
       }
     }
   }
-  if (nfull < T.nslices) {
+  if (nfull_all < T.nslices && kpart == KS - 1 && (KS == 1 || tile_ok)) {
     // ragged K tail (339 = 5 x 64 + 19 state channels, 96 = 64 + 32 prior outputs): quads beyond the slab width read as zero
     float a[RM][32], b0[32], b1[32];
-    load_b(nfull, b0, b1);
+    load_b(nfull_all, b0, b1);
 #pragma unroll
-    for (int m = 0; m < RM; ++m) load_frag_n<true>(T.src, 1, 0, T.Csrc, rt[m], nfull * SLICE, lane, a[m]);
+    for (int m = 0; m < RM; ++m) load_frag_n<true>(T.src, 1, 0, T.Csrc, rt[m], nfull_all * SLICE, lane, a[m]);
     mma(a, b0, b1);
   }
 
@@ -567,18 +579,31 @@ __global__ __launch_bounds__(256) void prior_gemm_kernel(GemmTask T) {
         const int r = (i & 3) + 8 * (i >> 2) + 4 * hh, col = lane & 31;
         sl[(c * 8 + (col >> 2)) * 132 + r * 4 + (col & 3)] = acc[m][c][i];
       }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (KS == 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      __syncthreads();                                  // the K partners' partial tiles are staged
+    }
     float v[32];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const vf4 q = *reinterpret_cast<const vf4*>(sl + (hh * 8 + j) * 132 + row * 4);
+      vf4 q = *reinterpret_cast<const vf4*>(sl + (hh * 8 + j) * 132 + row * 4);
+      if (KS > 1) {
+#pragma unroll
+        for (int pk = 1; pk < KS; ++pk) q += *reinterpret_cast<const vf4*>(sl + pk * GEMM_LDS_WAVE + (hh * 8 + j) * 132 + row * 4);
+      }
       v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                  // the slice is rewritten by the next row tile
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (KS == 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                  // the slice is rewritten by the next row tile
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      __syncthreads();
+      if (kpart != 0) continue;                         // only the even wave of the pair finishes the tile (no block barrier below)
+    }
     const bool live = ct_ok && rg * RM + m < T.nrt;
     if (T.bias && ct_ok) {       // the packed bias is zero-padded to whole 32-column tiles
 #pragma unroll
@@ -1594,14 +1619,18 @@ static int launch_layers(LayerLaunch& LL, const StashLayout& L, float* stash, hi
 static int launch_prior_gemm(GemmTask& T, hipStream_t st) {
   HA_REQUIRE((T.epi != 1 && T.epi != 3) || (T.ntiles % 2 == 0 && (T.group == 32 || T.group == 64)), "prior GEMM: GroupNorm epilogue needs whole 64-column pairs");
   // RM = 2 (64 x 64 per wave) once there are enough row tiles to keep every SIMD busy with the larger tile
-  const int ncb = ceil_div(T.ntiles, 8);
+  int ncb = ceil_div(T.ntiles, 8);
   const int rm = g_gemm_rm == 1 || g_gemm_rm == 2 ? g_gemm_rm : ((T.nrt / 2) * ncb >= 2 * 256 ? 2 : 1);
+  // K split (experiment knob): only for the one-row-tile-per-wave form and GEMMs that leave most SIMDs idle
+  const int ks = (g_gemm_ks == 2 && rm == 1 && T.nslices >= 4 && ncb * T.nrt * 4 <= 512) ? 2 : 1;
+  if (ks == 2) ncb = ceil_div(T.ntiles, 4);
   T.nrg = ceil_div(T.nrt, rm);
   T.nwork = ncb * T.nrg;
   T.per_xcd = ceil_div(T.nwork, 8);
   const dim3 grid(T.per_xcd * 8), block(256);
   const size_t lds = 4 * GEMM_LDS_WAVE * sizeof(float);
   if (rm == 2) hipLaunchKernelGGL(prior_gemm_kernel<2>, grid, block, lds, st, T);
+  else if (ks == 2) hipLaunchKernelGGL((prior_gemm_kernel<1, 2>), grid, block, lds, st, T);
   else hipLaunchKernelGGL(prior_gemm_kernel<1>, grid, block, lds, st, T);
   HA_LAUNCH_CHECK();
   return HA_OK;

@@ -136,6 +136,16 @@ def test_fused_vposer_matches_module(gpu_lib, dev, N):
     MC.check_vposer(gpu_lib, dev, N=N, real_shaped=True, seed=3)
 
 
+def test_fused_vposer_k_split(gpu_lib, dev):
+    """ha_tune_set("gemm_ks", 2) (experiment knob, off by default): K split over two waves per tile pair in the batched GEMM kernel."""
+    gpu_lib.call('ha_tune_set', b'gemm_ks', 2)
+    try:
+        MC.check_vposer(gpu_lib, dev, N=1920, real_shaped=True, seed=5)
+        MC.check_vposer(gpu_lib, dev, N=33, real_shaped=True, seed=6)
+    finally:
+        gpu_lib.call('ha_tune_set', b'gemm_ks', 0)
+
+
 def test_fused_posterior_encoder_matches_module(gpu_lib, dev):
     MC.check_posterior(gpu_lib, dev, N=32 * 59)
     MC.check_posterior(gpu_lib, dev, N=5)

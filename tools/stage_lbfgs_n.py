@@ -20,6 +20,8 @@ def main():
     dev = torch.device('cuda:0')
     npz = synth.write_smplh_npz(os.path.join(tempfile.mkdtemp(), 'm.npz'), seed=0)
     B = bench.B_SEQ
+    from humor_amd import _lib
+    _lib.get_lib().call('ha_tune_set', b'gemm_ks', int(os.environ.get('GEMM_KS', 0)))      # experiment knob: K split of the small GEMMs
     opt = bench.build_optimizer(dev, npz, B, use_graphs=True)
     obs, init = bench.make_problem(B, bench.T_SEQ, seed=100, device=dev)
     names = ['trans', 'root_orient'] if stage == 1 else ['trans', 'root_orient', 'betas', 'latent_pose']
