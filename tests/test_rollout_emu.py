@@ -67,6 +67,7 @@ def test_emu_fused_vposer_k_split(emu_lib):
     emu_lib.call('ha_tune_set', b'gemm_ks', 2)
     try:
         MC.check_vposer(emu_lib, CPU, N=33, real_shaped=True, seed=5)
+        MC.check_posterior(emu_lib, CPU, N=5)          # the GroupNorm (+ReLU) epilogues and their adjoints behind the split
     finally:
         emu_lib.call('ha_tune_set', b'gemm_ks', 0)
 
