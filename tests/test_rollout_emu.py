@@ -61,6 +61,7 @@ def test_emu_fused_vposer_matches_module(emu_lib):
     MC.check_vposer(emu_lib, CPU, N=33, real_shaped=True, seed=3)
 
 
+@pytest.mark.slow
 def test_emu_fused_vposer_k_split(emu_lib):
     """ha_tune_set("gemm_ks", 2) (experiment knob, off by default): two waves per tile pair, each half of K, partial tiles summed
     through LDS before the epilogue -- same parity bar as the unsplit kernel (forward, LeakyReLU epilogues, 6-D tail, adjoint)."""
