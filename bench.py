@@ -102,6 +102,15 @@ def camera_matrix(B, device):
     return cm(B).to(device)
 
 
+def humor_weights():
+    """Random-init HuMoR weights of the reference architecture, scaled to the well-conditioned regime of the parity fixtures
+    (synth.contractive_state_dict: a default-init 59-step chain amplifies fp32 rounding ~1e4x, so no two fp32 evaluations -- the
+    reference's included -- agree at full length).  Same shapes, same arithmetic, same timing; with these weights the `parity`
+    field of the line (GPU closure vs the oracle closure at the SAME variables) is held to the flat 1e-4 / 1e-3 bars."""
+    from humor_amd import synth
+    return synth.contractive_state_dict(0)
+
+
 def build_optimizer(dev, npz, B, shard=None, use_graphs=False):
     from humor_amd import synth
     from humor_amd.body_model import BodyModel
@@ -109,7 +118,7 @@ def build_optimizer(dev, npz, B, shard=None, use_graphs=False):
     from humor_amd.motion_optimizer import MotionOptimizer
     bm = BodyModel(npz, num_betas=16, batch_size=B * T_SEQ, use_vtx_selector=True)
     hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
-    hm.load_state_dict(synth.humor_state_dict(seed=0))
+    hm.load_state_dict(humor_weights())
     hm = hm.to(dev).eval()
     for p in hm.parameters():
         p.requires_grad_(False)
@@ -145,6 +154,16 @@ class FitClosure:
 
     def step(self):
         return self.closure()
+
+    VAR_NAMES = ('latent_motion', 'betas', 'floor_plane', 'trans', 'root_orient', 'latent_pose', 'trans_vel', 'joints_vel', 'root_orient_vel')
+
+    def snapshot(self):
+        """One evaluation: the variables it was evaluated at, its loss and every gradient, on the host (parity vs the oracle)."""
+        loss = float(self.step().detach())
+        o = self.opt
+        var = {k: getattr(o, k).detach().cpu().clone() for k in self.VAR_NAMES}
+        grad = {k: (getattr(o, k).grad.detach().cpu().clone() if getattr(o, k).grad is not None else torch.zeros_like(var[k])) for k in self.VAR_NAMES}
+        return {'loss': loss, 'var': var, 'grad': grad}
 
 
 def closure_mode(args, fc):
@@ -222,7 +241,7 @@ def rollout_c4_ms(dev):
     from humor_amd import synth
     from humor_amd.humor_model import HumorModel
     hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
-    hm.load_state_dict(synth.humor_state_dict(seed=0))
+    hm.load_state_dict(humor_weights())
     hm = hm.to(dev).eval()
     for p in hm.parameters():
         p.requires_grad_(False)
@@ -316,7 +335,28 @@ def rccl_selfcheck(dev, npz):
     return out
 
 
-def cpu_baseline(npz):
+def oracle_pin(ds):
+    """Chain of custody of the CPU baseline on the timing box (/root/reference does not exist there): before it is timed, the
+    restated closure must reproduce the loss the REFERENCE MotionOptimizer produced for the committed fixture
+    tests/golden/closure_c4.npz (8 x 60, overlap 10; generated in the build container by oracle/make_golden_long.py)."""
+    from humor_amd import synth
+    from oracle import closure_cases as CC
+    from oracle.closure_restated import RestatedFit
+    gd = np.load(os.path.join(ROOT, 'tests', 'golden', 'closure_c4.npz'))
+    B, T, ov = int(gd['B']), int(gd['T']), int(gd['ov'])
+    case = CC.make_case(str(gd['kind']), B, T, seed=int(gd['seed']), ov=ov)
+    fit = RestatedFit(ds, synth.contractive_state_dict(int(gd['weight_seed'])), synth.SynthVPoser(seed=0), synth.make_gmm(seed=0), CC.RGB_WEIGHTS,
+                      B, T, True, CC.camera_matrix(B))
+    var = {k: (v[:, :1] if k in ('trans', 'root_orient', 'latent_pose') else v).clone() for k, v in case['var'].items()}
+    with torch.no_grad():
+        loss = float(fit.objective(var, case['obs']))
+    ref = float(gd['s2_loss'])
+    rel = abs(loss - ref) / abs(ref)
+    assert rel < 1e-4, f'oracle/closure_restated.py does not reproduce the reference fixture closure_c4.npz: {loss} vs {ref}'
+    return {'fixture': 'tests/golden/closure_c4.npz (reference MotionOptimizer stage-3 objective, 8x60)', 'loss_rel': float('%.3g' % rel)}
+
+
+def cpu_baseline(npz, gpu_eval=None):
     """oracle/closure_restated.py (restatement of the reference closure: dense smplx-style SMPL on the expanded B*T batch,
     Python roll-out loop) on the host cores, at the FULL C4 size (32 x 60), forward + backward.  The thread count is swept once
     ({16, 32, 64}: one timed evaluation each after a warm-up) and the best one is timed for the reported value."""
@@ -331,9 +371,27 @@ def cpu_baseline(npz):
     for k in data.files:
         setattr(ds, k, data[k])
     cpu = torch.device('cpu')
+    torch.set_num_threads(min(avail, 32))
+    pin = oracle_pin(ds)
     obs, init = make_problem(B_SEQ, T_SEQ, seed=100, device=cpu)
-    fit = RestatedFit(ds, synth.humor_state_dict(seed=0), synth.SynthVPoser(seed=0), synth.make_gmm(seed=0), loss_weights(),
+    fit = RestatedFit(ds, humor_weights(), synth.SynthVPoser(seed=0), synth.make_gmm(seed=0), loss_weights(),
                       B_SEQ, T_SEQ, True, camera_matrix(B_SEQ, cpu))
+    parity = None
+    if gpu_eval is not None:
+        # the oracle closure at EXACTLY the variables of one GPU closure evaluation of the timed workload: loss and every gradient
+        pv = {k: v.clone().requires_grad_(True) for k, v in gpu_eval['var'].items()}
+        ploss = fit.objective(pv, obs)
+        pg = torch.autograd.grad(ploss, list(pv.values()), allow_unused=True)
+        worst, per = 0.0, {}
+        for (k, v), g in zip(pv.items(), pg):
+            g = torch.zeros_like(v) if g is None else g
+            e = (g - gpu_eval['grad'][k]).abs().max().item() / max(1.0, g.abs().max().item())
+            per[k] = float('%.3g' % e)
+            worst = max(worst, e)
+        parity = {'loss_rel': float('%.3g' % (abs(gpu_eval['loss'] - float(ploss)) / abs(float(ploss)))), 'grad_rel_max': float('%.3g' % worst),
+                  'grad_rel': per, 'oracle_loss': float(ploss), 'gpu_loss': gpu_eval['loss'],
+                  'what': 'GPU stage-3 closure of the timed workload (32x60) vs oracle/closure_restated.py at the same variables; '
+                          'gradient error relative to max(1, max|oracle gradient|) per tensor; bars: loss 1e-4, gradients 1e-3'}
     g = torch.Generator().manual_seed(3)
     var = {'trans': init['trans'][:, :1].clone(), 'root_orient': init['root_orient'][:, :1].clone(),
            'latent_pose': init['latent_pose'][:, :1].clone(), 'betas': init['betas'].clone(),
@@ -364,7 +422,7 @@ def cpu_baseline(npz):
         step()
         reps += 1
     dt = (time.time() - t0) / reps
-    return {'value': round(1.0 / dt, 4), 'unit': 'closure-evals/s', 'cores': ncores, 'kind': 'port',
+    return {'value': round(1.0 / dt, 4), 'unit': 'closure-evals/s', 'cores': ncores, 'kind': 'port', 'pin': pin, 'parity': parity,
             'thread_sweep_seconds_per_eval': {str(k): round(v, 3) for k, v in sweep.items()},
             'sample': f'full C4 batch 32x60, {reps} timed stage-3 closure evaluations (fwd+bwd), {dt * 1e3:.0f} ms each, at the best thread count '
                       f'of a one-evaluation sweep over {sorted(sweep)} threads ({avail} cores visible); '
@@ -372,8 +430,25 @@ def cpu_baseline(npz):
                       f'59-step Python roll-out loop, VPoser, all loss terms), torch CPU'}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves, one per GPU, exactly as the
+    driver's torch.distributed.run command line would, and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     # the contract is ONE JSON line on stdout: libraries that print to the C-level stdout (RCCL's version banner) are sent to
     # stderr for the duration of the run; fd 1 is restored for the final line only
     sys.stdout.flush()
@@ -398,6 +473,7 @@ def run(args):
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus, f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks'
     dist = None
     # validation aid for 1-GPU boxes: HUMOR_AMD_BENCH_BACKEND=gloo HUMOR_AMD_BENCH_ONE_GPU=1 runs all ranks on cuda:0 with host-
     # staged collectives (exercises the sharded code path; the numbers mean nothing).  Default: one GPU per rank over RCCL.
@@ -497,6 +573,7 @@ def run(args):
                 'collectives_per_closure': '1 differentiable halo all-gather (+ its all-reduce in backward) + 1 packed [gradient | loss] all-reduce'}
 
     if rank == 0:
+        gpu_eval = fc.snapshot() if world == 1 and not args.no_cpu_baseline else None      # for the parity field (untimed)
         roof = skin_roofline(dev, npz)          # first among the side measurements: same chip state as in earlier rounds
         ms_dense, ms_dense_fb = dense_smpl_ms(dev, npz)
         res = {
@@ -526,6 +603,8 @@ def run(args):
             fc = None
             torch.cuda.empty_cache()
             res['lbfgs'] = lbfgs_profile(dev, npz)
+            # the "fitting-iter/sec" of BASELINE.json's metric in L-BFGS outer iterations (whole 30/80/70 fit), next to `value`
+            res['outer_iters_per_sec'] = res['lbfgs'].get('whole_fit_outer_iters_per_sec')
         if world == 1 and not args.no_rccl_check:
             res['rccl'] = rccl_selfcheck(dev, npz)
         if world == 1 and not args.no_c5:
@@ -545,7 +624,12 @@ def run(args):
             torch.cuda.empty_cache()
             res['c5_rooflines'] = bench_c5.measure(256, 120, dev)
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 of the 1-GPU run only
-            res['cpu_baseline'] = cpu_baseline(npz)
+            res['cpu_baseline'] = cpu_baseline(npz, gpu_eval)
+            res['parity'] = res['cpu_baseline'].pop('parity')
+        # the contract's keys first (a reader that truncates the line keeps them), the detailed side measurements after
+        head = ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+                'data', 'config', 'roofline', 'cpu_baseline', 'parity', 'outer_iters_per_sec', 'smpl_verts_per_sec', 'closure_mode', 'strong', 'rccl']
+        res = {**{k: res[k] for k in head if k in res}, **{k: v for k, v in res.items() if k not in head}}
         line = json.dumps(res)
     else:
         line = None

@@ -105,6 +105,10 @@ class FittingLoss(nn.Module):
         self.cur_stage_idx = 0
         self.loss_weights = self.all_stage_loss_weights[self.cur_stage_idx]
         self.smpl2op_map = None if smpl2op_map is None else torch.as_tensor(list(smpl2op_map), dtype=torch.long)
+        # ha_fit_loss inverts the map in LDS (one OpenPose joint per SMPL joint, indices below 128): any other map -- legal for the
+        # reference's gather formulation -- is evaluated term by term instead
+        self._smpl2op_fusable = self.smpl2op_map is None or (
+            self.smpl2op_map.unique().numel() == self.smpl2op_map.numel() and int(self.smpl2op_map.min()) >= 0 and int(self.smpl2op_map.max()) < 128)
         self.ignore_op_joints = ignore_op_joints
         self.cam_f, self.cam_cent = cam_f, cam_cent
         self.joints2d_sigma = joints2d_sigma
@@ -141,6 +145,8 @@ class FittingLoss(nn.Module):
     # ------------------------------------------------------------------------------------------------
     def _fusable(self, observed_data, ref):
         if not self.fused or 'prev_batch_overlap_res' in observed_data or 'points3d' in observed_data:
+            return False
+        if 'joints2d' in observed_data and not self._smpl2op_fusable:
             return False
         if ref.is_cuda:
             return True

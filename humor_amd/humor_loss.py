@@ -191,7 +191,9 @@ class HumorLoss(nn.Module):
             if gender is None or betas is None:
                 raise Exception('Must pass gender and betas to MotionVAE loss to use SMPL losses!')
             pred_joints, gt_joints, pred_mesh, gt_mesh, order = self._smpl_bodies(pred_dict, gt_dict, gender, betas)
-            B = order.numel()
+            B = pred_dict['trans'].size(0)           # the reference's reshape size (humor_loss.py:236); `order` then picks the gendered rows
+            if order.numel() != B:
+                raise ValueError('HumorLoss SMPL terms: every row must be male or female (got %d of %d rows)' % (order.numel(), B))
             smpl_terms = []
             if self.smpl_joint_loss_weight > 0.0:
                 smpl_terms.append(('smpl_joint_loss', self.smpl_joint_loss_weight, _mse(pred_joints, gt_joints)))

@@ -236,7 +236,10 @@ class HumorModel(nn.Module):
         (or the emulator tier); the module's own PyTorch forward for host tensors."""
         net = getattr(self, name)
         on_dev = x.is_cuda or (self._lib is not None and self._lib.emulator)
-        if not on_dev or net.skip_input_idx is not None:
+        # the fused path snapshots the weights and returns only dL/dx: it serves the frozen-network uses (fitting, inference).
+        # A caller that needs weight gradients (a training step whose KL term comes from infer()) gets the module's own forward.
+        needs_param_grad = torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())
+        if not on_dev or net.skip_input_idx is not None or needs_param_grad:
             return net(x)
         from .mlp import humor_mlp
         lib = self._lib if self._lib is not None else _lib.get_lib()

@@ -105,3 +105,27 @@ def check_posterior(lib, device, N=70, seed=0):
     g_ref = torch.autograd.grad((y_ref * w).sum(), xc)[0]
     gx = torch.autograd.grad((y * w.to(device)).sum(), x)[0]
     _cmp(gx, g_ref, 1e-3, 'posterior grad')
+
+
+def check_posterior_param_grads(lib, device, N=5, seed=0):
+    """HumorModel.posterior() / prior() in a training setting (parameters require grad, grad mode on): the encoder / prior weights must
+    receive gradients (the fused ha_mlp_* path returns only dL/dx, so it may only serve frozen networks); with frozen parameters or
+    under no_grad the same calls take the fused path and agree with the module's own forward."""
+    hm, _ = RC.make_model(lib, device, seed=seed, contractive=True)
+    hm.train()
+    g = torch.Generator().manual_seed(seed + 3)
+    past, nxt = RC.canonical_state(N, g).to(device), RC.canonical_state(N, g).to(device)
+    (pm, pv), (qm, qv) = hm.infer_step(past, nxt)
+    assert qm.requires_grad and pm.requires_grad
+    (qm.square().sum() + qv.sum() + pm.square().sum() + pv.sum()).backward()
+    for net in (hm.encoder, hm.prior_net):
+        for p in net.parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all()
+        assert any(p.grad.abs().max().item() > 0 for p in net.parameters())
+    ref_q = qm.detach().clone()
+    for p in hm.parameters():
+        p.requires_grad_(False)
+    hm._net_handles.clear()
+    (_, _), (qm2, _) = hm.infer_step(past, nxt)          # frozen: the fused path
+    assert len(hm._net_handles) > 0, 'frozen networks are expected to run through ha_mlp_*'
+    _cmp(qm2, ref_q.cpu(), 1e-4, 'fused posterior vs module')

@@ -163,6 +163,39 @@ def check_rollout_long(lib, device, name):
     return dict(world=float(e_w.max()), prior_mu=float(e_m.max()), prior_var=float(e_v.max()), g_past0=eg0, g_z=egz)
 
 
+def check_rollout_full_tiles(lib, device, B, S, seed=0):
+    """Full row tiles at the BASELINE sizes (32 x 59 = the metric's batch, one complete 32-row tile; 256 x 119 = C5, eight tiles and
+    the finishing-pass policy) against the restated oracle (humor_restated.roll_out, bit-pinned to the reference's roll_out in the CPU
+    tier) with the well-conditioned synthetic weights: flat 1e-4 on every step's state / prior output, 1e-3 relative on the gradients
+    of every sequence whose ORACLE gradient is stable under an fp64 re-evaluation (kink flags as in oracle/make_golden_long.py)."""
+    from oracle import closure_cases as CC
+    hm, sd = make_model(lib, device, seed=seed, contractive=True)
+    g = torch.Generator().manual_seed(1000 + B + S)
+    past_c = canonical_state(B, g).requires_grad_(True)
+    z_c = torch.randn(B, S, 48, generator=g).requires_grad_(True)
+    w_ref, (pm_r, pv_r) = H.roll_out(sd, past_c, z_c)
+    gw, gm, gv = CC.det_weights(w_ref.shape, 0.1), CC.det_weights(pm_r.shape, 0.2), CC.det_weights(pv_r.shape, 0.3)
+    g_ref = torch.autograd.grad((w_ref * gw).sum() + (pm_r * gm).sum() + (pv_r * gv).sum(), [past_c, z_c])
+    p64, z64 = past_c.detach().double().requires_grad_(True), z_c.detach().double().requires_grad_(True)
+    w64, (pm64, pv64) = H.roll_out({k: v.double() for k, v in sd.items()}, p64, z64)
+    g64 = torch.autograd.grad((w64 * gw.double()).sum() + (pm64 * gm.double()).sum() + (pv64 * gv.double()).sum(), [p64, z64])
+    drift = (w_ref.detach().double() - w64.detach()).abs().max().item()
+    assert drift < 2e-5, drift            # the chain itself is well conditioned
+    stable = (per_seq_rel(g_ref[0].numpy(), g64[0].numpy()) < 2e-4) & (per_seq_rel(g_ref[1].numpy(), g64[1].numpy()) < 2e-4)
+    past = past_c.detach().to(device).requires_grad_(True)
+    z = z_c.detach().to(device).requires_grad_(True)
+    out, (pm, pv) = hm.roll_out(past, None, S, z_seq=z, return_prior=True)
+    world = world_of(out)
+    e_w = (world.detach().cpu() - w_ref.detach()).abs().amax(dim=(0, 2))
+    e_m = (pm.detach().cpu() - pm_r.detach()).abs().max().item()
+    e_v = (pv.detach().cpu() - pv_r.detach()).abs().max().item()
+    assert e_w.max().item() < FWD_TOL and e_m < FWD_TOL and e_v < FWD_TOL, (e_w.max().item(), e_m, e_v)
+    g0, gz = torch.autograd.grad((world * gw.to(device)).sum() + (pm * gm.to(device)).sum() + (pv * gv.to(device)).sum(), [past, z])
+    eg0 = assert_grad('g_past0', g0.cpu().numpy(), g_ref[0].numpy(), stable)
+    egz = assert_grad('g_z', gz.cpu().numpy(), g_ref[1].numpy(), stable)
+    return dict(world=float(e_w.max()), prior_mu=e_m, prior_var=e_v, g_past0=eg0, g_z=egz, unstable=int((~stable).sum()), drift64=drift)
+
+
 def check_rollout_golden(lib, device):
     gd = golden('rollout.npz')
     hm, _ = make_model(lib, device, seed=int(gd['weight_seed']))

@@ -27,9 +27,10 @@ def test_short_run_matches_reference(gpu_lib, dev, smplh_npz, kind):
     FC.check_short_run(gpu_lib, dev, smplh_npz, kind)
 
 
-@pytest.mark.parametrize('name', ['c2', 'c3', 'c4'])
+@pytest.mark.parametrize('name', ['c2', 'c3', 'c4', 'c4_full'])
 def test_stage_objectives_at_baseline_sizes(gpu_lib, dev, smplh_npz, name):
-    """C2 (2x60, joints3d), C3 (1x90, joints2d + floor) and a C4 slice (8x60, overlap 10) against the reference MotionOptimizer."""
+    """C2 (2x60, joints3d), C3 (1x90, joints2d + floor), a C4 slice (8x60, overlap 10) and the FULL C4 batch (32x60 = bench.py's
+    workload: one full 32-row tile, split-K policy) against the reference MotionOptimizer."""
     print(name, FC.check_objectives_long(gpu_lib, dev, smplh_npz, name))
 
 

@@ -366,3 +366,22 @@ def test_lbs_restatement_matches_independent_paper_derivation(smplh_npz, smplh_s
         v, j = SP.smpl_frame(model, pose, inp['betas'][i].numpy(), inp['transl'][i].numpy())
         assert np.abs(out.vertices[i].numpy() - v).max() < 1e-7
         assert np.abs(out.joints[i, :52].numpy() - j).max() < 1e-7
+
+
+@needs_ref
+def test_index_tables_equal_the_reference_live():
+    """every fixed index table of humor_amd/tables.py equals the reference's own table, entry for entry
+    (body_model/utils.py:5-19, 53-56; datasets/amass_utils.py:21-23; fitting/fitting_utils.py:678-680)."""
+    from humor_amd import tables as T
+    R = ref_loader.load()
+    assert T.SMPL_JOINTS == R.bm_utils.SMPL_JOINTS
+    assert list(T.SMPL_PARENTS) == list(R.bm_utils.SMPL_PARENTS)
+    assert list(T.KEYPT_VERTS) == list(R.bm_utils.KEYPT_VERTS)
+    assert list(T.CONTACT_ORDERING) == list(R.amass_utils.CONTACT_ORDERING)
+    assert list(T.CONTACT_INDS) == list(R.amass_utils.CONTACT_INDS)
+    op = R.bm_utils.smpl_to_openpose('smplh', use_hands=False, use_face=False, use_face_contour=False, openpose_format='coco25')
+    assert [int(i) for i in op] == list(T.SMPLH_TO_OPENPOSE25)
+    assert T.OP_NUM_JOINTS == R.fitting_utils.OP_NUM_JOINTS
+    assert list(T.OP_IGNORE_JOINTS) == list(R.fitting_utils.OP_IGNORE_JOINTS)
+    assert [list(e) for e in T.OP_EDGE_LIST] == [list(e) for e in R.fitting_utils.OP_EDGE_LIST]
+    assert T.NUM_BODY_JOINTS == len(R.bm_utils.SMPL_JOINTS) - 1

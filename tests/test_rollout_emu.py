@@ -76,3 +76,8 @@ def test_emu_fused_vposer_k_split(emu_lib):
 def test_emu_fused_posterior_encoder_matches_module(emu_lib):
     # one 32-row tile here (the two-tile, ragged-tile geometry of the same GEMM kernel is test_emu_fused_vposer_matches_module above)
     MC.check_posterior(emu_lib, CPU, N=7)
+
+
+def test_emu_posterior_gives_parameter_gradients(emu_lib):
+    """a training-mode infer_step must leave gradients on the encoder / prior weights (module forward), frozen nets run fused."""
+    MC.check_posterior_param_grads(emu_lib, CPU, N=3)

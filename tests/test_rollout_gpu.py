@@ -33,6 +33,12 @@ def test_rollout_baseline_lengths_flat_tolerance(gpu_lib, dev, name):
     print(name, RC.check_rollout_long(gpu_lib, dev, name))
 
 
+@pytest.mark.parametrize('B,S', [(32, 59), (256, 119)])
+def test_rollout_full_tiles_flat_tolerance(gpu_lib, dev, B, S):
+    """The metric's batch (one FULL 32-row tile, 59 steps) and the C5 batch (eight tiles, 119 steps) at the flat 1e-4 / 1e-3 bars."""
+    print(B, S, RC.check_rollout_full_tiles(gpu_lib, dev, B, S))
+
+
 def test_rollout_full_length(gpu_lib, dev):
     """BASELINE size (32 sequences x 59 steps): conditioning-aware parity (see check_rollout_conditioned) plus the
     gradient check on an 8-step chain judged against an fp64 oracle.  (The adjoint is amplified like the forward error:
@@ -149,3 +155,8 @@ def test_fused_vposer_k_split(gpu_lib, dev):
 def test_fused_posterior_encoder_matches_module(gpu_lib, dev):
     MC.check_posterior(gpu_lib, dev, N=32 * 59)
     MC.check_posterior(gpu_lib, dev, N=5)
+
+
+def test_posterior_gives_parameter_gradients(gpu_lib, dev):
+    """a training-mode infer_step must leave gradients on the encoder / prior weights (module forward), frozen nets run fused."""
+    MC.check_posterior_param_grads(gpu_lib, dev, N=9)
