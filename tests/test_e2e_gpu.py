@@ -169,3 +169,24 @@ def test_stitched_rgb_result_round_trip(gpu_lib, dev, smplh_npz, tmp_path):
     d_cam = np.linalg.norm(trans.numpy()[1:] - trans.numpy()[:-1], axis=1)
     d_pri = np.linalg.norm(p['trans'][1:] - p['trans'][:-1], axis=1)
     assert np.abs(d_cam - d_pri).max() < 1e-4
+
+
+def test_bench_starts_n_ranks_itself(gpu_lib):
+    """`python bench.py --gpus 2` with no launcher in front of it must start two ranks (it used to run one and print
+    n_gpus 1).  On the one-GPU test box both ranks share cuda:0 and the collectives go through gloo (host staging): the numbers mean
+    nothing, the line's shape does -- n_gpus = 2, a global batch of 64 sub-sequences, the strong-scaling companion, the collectives."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HUMOR_AMD_BENCH_BACKEND='gloo', HUMOR_AMD_BENCH_ONE_GPU='1')
+    env.pop('WORLD_SIZE', None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['global_batch'] == 64 and res['scaling'] == 'weak'
+    assert res['strong']['global_batch'] == 32 and res['strong']['sequences_per_gpu'] == [16, 16]
+    assert res['rccl']['allreduce_us'] > 0 and res['value'] > 0
