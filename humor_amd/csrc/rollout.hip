@@ -18,6 +18,7 @@
 
 #include <vector>
 
+#include "rollout_persist.h"
 #include "rot_math.h"
 
 namespace ha {
@@ -55,6 +56,10 @@ int g_gemm_ks = 0;
 // README.md), so auto uses two groups only for exactly two row tiles (each then runs the one-row-tile policy: 64 x 59 fwd+bwd
 // 5.97 -> 5.15 ms) and one group otherwise.  Must not change between a forward call and its backward.
 int g_rollout_groups = 0;
+// ha_tune_set "rollout_persist": the forward of a roll-out of <= 32 sequences as ONE persistent launch with the decoder resident in
+// the register files of the XCD teams (rollout_persist.hip) instead of 5 dependent launches per step.  0 = launch chain, 1 = on
+// (granules published with plain stores: team = one XCD = one L2), 3 = on, granules published write-through (sc1).
+int g_rollout_persist = 0;
 
 struct PackedLayer {
   int Cin = 0, skip = 0, Nout = 0;
@@ -74,6 +79,7 @@ struct ha_humor_net {
   int device = 0;
   int n_dec = 0, n_pri = 0;
   ha::PackedLayer dec[ha::MAXL], pri[ha::MAXL];
+  ha::PersistNet* persist = nullptr;      // register-stationary decoder for the persistent forward (null: shape / device not eligible)
 };
 
 namespace ha {
@@ -1480,9 +1486,13 @@ struct StashLayout {
   // into.  The slabs must be zero before the chain starts, so the adjoint's scratch is kept per step too and both regions are
   // cleared by one memset per pass ((S+1) x 0.36 MB forward, S x 0.4 MB backward at one row tile).
   bool acc = false;
+  // persistent forward (rollout_persist.hip): every decoder activation is ONE complete slab (bias included), written by the
+  // persistent kernel; the adjoint reads it like a one-split partial slab
+  bool single = false;
+  size_t persist_ws = 0;         // exchange space of the persistent kernel
   size_t bwd_set = 0;            // acc: floats per step of the adjoint scratch (bwd_dec[] are offsets of step 0's set); else 0
   size_t bwd_begin = 0, bwd_floats = 0;
-  int rd_f(int i) const { return acc ? 1 : nsf_dec[i]; }     // partial slabs a consumer of decoder layer i's output reads
+  int rd_f(int i) const { return (acc || single) ? 1 : nsf_dec[i]; }     // partial slabs a consumer of decoder layer i's output reads
   int rd_b(int i) const { return acc ? 1 : nsb_dec[i]; }
   size_t total = 0;
 };
@@ -1501,8 +1511,9 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, b
   for (int i = 0; i < net->n_dec; ++i) { L.nsf_dec[i] = ceil_div(net->dec[i].nslices_f, L.spb); L.nsb_dec[i] = ceil_div(net->dec[i].nslices_b, L.spb); }
   // GroupNorm prologues once per activation in gn_finish_kernel (see there and the policy note above)
   L.finish = (L.RT >= 2 && g_layer_finish != 0) || g_layer_finish == 2;     // 0: never, 2: always (A/B runs)
-  L.acc = allow_acc && !L.finish && g_layer_acc != 0;
-  L.hsum = !L.finish && !L.acc && g_layer_hsum != 0;
+  L.single = allow_acc && !L.finish && B <= 32 && g_rollout_persist != 0 && persist_usable(net->persist);
+  L.acc = allow_acc && !L.finish && !L.single && g_layer_acc != 0;
+  L.hsum = !L.finish && !L.acc && !L.single && g_layer_hsum != 0;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
   L.zT = take((size_t)S * RT * ZD * 32);
@@ -1540,6 +1551,7 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, b
   }
   if (L.finish)
     L.fin[0] = take(RT * 1280 * 32);     // widest operand: K <= 1280 (checked at pack time)
+  if (L.single) L.persist_ws = take(persist_ws_floats());
   L.total = o;
 }
 
@@ -1723,7 +1735,8 @@ extern "C" int ha_humor_net_create(ha_humor_net** out, int device, const ha_mlp_
   net->n_dec = decoder->n_linear;
   net->n_pri = prior->n_linear;
   int rc;
-  if ((rc = pack_mlp(net->dec, decoder, "decoder")) != HA_OK || (rc = pack_mlp(net->pri, prior, "prior")) != HA_OK) {
+  if ((rc = pack_mlp(net->dec, decoder, "decoder")) != HA_OK || (rc = pack_mlp(net->pri, prior, "prior")) != HA_OK ||
+      (rc = persist_create(&net->persist, device, decoder)) != HA_OK) {
     ha_humor_net_destroy(net);
     return rc;
   }
@@ -1734,6 +1747,8 @@ extern "C" int ha_humor_net_create(ha_humor_net** out, int device, const ha_mlp_
 extern "C" int ha_humor_net_destroy(ha_humor_net* net) {
   if (!net) return HA_OK;
   DeviceGuard guard(net->device);
+  persist_destroy(net->persist);
+  net->persist = nullptr;
   for (PackedLayer* arr : {net->dec, net->pri})
     for (int i = 0; i < MAXL; ++i) {
       void* ptrs[] = {arr[i].Wf, arr[i].Wb, arr[i].bias, arr[i].gamma, arr[i].beta};
@@ -1741,6 +1756,14 @@ extern "C" int ha_humor_net_destroy(ha_humor_net* net) {
         if (p) (void)hipFree(p);
     }
   delete net;
+  return HA_OK;
+}
+
+extern "C" int ha_humor_persist_status(const ha_humor_net* net, int* available, unsigned int* error_word, int64_t* launches) {
+  HA_REQUIRE(net && available && error_word && launches, "ha_humor_persist_status: null argument");
+  *error_word = persist_error_word(net->persist);
+  *launches = persist_launches(net->persist);
+  *available = persist_usable(net->persist) ? 1 : 0;
   return HA_OK;
 }
 
@@ -1777,6 +1800,20 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
   auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
   auto x_ptr = [&](int t) { return stash + L.xT + (size_t)t * RT * D_INP * 32; };
 
+  if (L.single) {
+    // the whole decoder chain (all S steps: layers, glue, world outputs, the stash the adjoint and the prior read) is ONE launch
+    if (phase == PH_BEGIN) {
+      PersistFwd f;
+      f.B = B; f.S = S;
+      f.past_in0 = past_in0; f.z_seq = z_seq; f.world = world;
+      f.xT = stash + L.xT; f.steps = stash + L.steps; f.per_step = L.per_step; f.off_G = L.off_G;
+      for (int l = 0; l < 4; ++l) f.off_dec[l] = L.off_dec[l];
+      f.t2j = stash + L.t2j;
+      f.ws = stash + L.persist_ws;
+      return persist_forward(net->persist, f, g_rollout_persist >> 1, st);
+    }
+    if (phase == PH_STEP) return HA_OK;
+  }
   if (phase == PH_BEGIN) {
     if (L.acc) HA_CHECK_HIP(hipMemsetAsync(stash + L.steps, 0, (size_t)(S + 1) * L.per_step * sizeof(float), st));
     hipLaunchKernelGGL(transpose_in_kernel, dim3(256), dim3(256), 0, st, z_seq, stash + L.zT, B, S, ZD, ZD, RT);

@@ -1,0 +1,717 @@
+// Persistent, weight-stationary forward of the HuMoR decoder roll-out on gfx950 (humor/models/humor_model.py:785-1017 for
+// B <= 32 sequences): ONE launch for all S steps instead of 5 dependent launches per step.
+//
+// Why: at 32 rows the launch chain is a latency chain (5 dispatches x ~6.5 us per step; the 138 MFLOP of a step are ~1 us of the
+// chip's fp32 matrix rate).  The structure that removes the dispatches without a whole-chip barrier per layer:
+//   * the sequences are independent, so the batch is cut into 8 TEAMS of 4 sequences, one team per XCD (32 CUs, one L2):
+//     a team never talks to another team -- no cross-XCD traffic, no grid barrier;
+//   * the decoder's 2.16 M fp32 weights (8.7 MB) do not fit one CU, but they fit the REGISTER FILES of one XCD: every wave of a
+//     team (32 CUs x 4 SIMDs, one wave per SIMD, 512 VGPRs) keeps its 286-register share of the four layers for the whole launch
+//     (8 x 8.7 MB = 70 MB of the chip's 128 MB of VGPRs) -- per step only activations move;
+//   * 4 rows are the native M of v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products per instruction = 16 k's of one
+//     4-row x 4-column tile): a wave owns 8 (4) output columns of a layer and the WHOLE K, so there is no cross-wave reduction,
+//     only a 16-lane-group reduction of the accumulators;
+//   * a layer's output (4 rows x <=1024 channels) goes to the other 31 CUs of the team as 8-byte {value, tag} granules through
+//     the team's L2: the data is its own flag (tag = 4 step + layer + 1), consumers sweep it with L1-bypassing (sc1) loads until
+//     every tag matches -- one memory round trip per layer, no counters, no fences; GroupNorm + ReLU run on the consumer side
+//     (every CU needs the whole activation as its A operand anyway), the residual composition / heading alignment / frame changes
+//     of the step ("glue") run redundantly on every CU, one wave per sequence.
+// Teams are formed at run time from HW_REG_XCC_ID (a block joins the team of the XCD it landed on), so results never depend on
+// the dispatcher's placement; what the path needs is 32 resident blocks per XCD -- every wait is bounded, a team that does not
+// complete reports through a host-mapped error word and the caller falls back to the launch chain.
+//
+// The kernel fills the same stash as the launch-chain forward (states of all steps, accumulated world transforms, one
+// pre-activation slab per decoder layer and step), so the batched prior and the existing adjoint run unchanged behind it.
+#include "rollout_persist.h"
+
+#include <string.h>
+
+#include <vector>
+
+#include "rot_math.h"
+
+namespace ha {
+
+namespace {
+constexpr int P_DIN = 339, P_DINP = 340, P_XPAD = 352, P_ZD = 48, P_RAW = 216, P_RAWPAD = 224, P_STATE = 348;
+constexpr int P_H0 = 1024, P_H1 = 1024, P_H2 = 512;
+constexpr int TEAM_CUS = 32, NTEAMS = 8, ROWS = 4, NWAVES_TEAM = TEAM_CUS * 4;
+// K chunks (16 k's each) per layer: main part + 3 chunks of latent skip
+constexpr int NC0 = P_XPAD / 16, NC1 = P_H0 / 16, NC2 = P_H1 / 16, NC3 = P_H2 / 16, NCZ = P_ZD / 16;
+// weight registers of a wave: [chunk][column group] per layer
+constexpr int R0 = 0, R1 = R0 + (NC0 + NCZ) * 2, R2 = R1 + (NC1 + NCZ) * 2, R3 = R2 + (NC2 + NCZ), NREG = R3 + (NC3 + NCZ);
+constexpr int L3_WAVES = P_RAW / 4;      // 54 waves own the 216 output columns of the last layer
+// exchange space (bytes): 64-byte header, then per team the four activations as granules [channel][4 rows] x 8 B
+constexpr unsigned XCH_HDR = 256;
+constexpr unsigned ACT_OFF0 = 0, ACT_OFF1 = ACT_OFF0 + P_H0 * 32, ACT_OFF2 = ACT_OFF1 + P_H1 * 32, ACT_OFF3 = ACT_OFF2 + P_H2 * 32;
+constexpr unsigned TEAM_BYTES = ACT_OFF3 + P_RAWPAD * 32;
+constexpr unsigned XCH_BYTES = XCH_HDR + NTEAMS * TEAM_BYTES;
+// LDS (floats)
+constexpr int L_XS0 = 0, L_XS1 = L_XS0 + P_XPAD * 4, L_XS2 = L_XS1 + P_H0 * 4, L_XS3 = L_XS2 + P_H1 * 4, L_ZS = L_XS3 + P_H2 * 4;
+constexpr int L_SX = L_ZS + P_ZD * 4, L_SRAW = L_SX + ROWS * P_XPAD, L_MISC = L_SRAW + ROWS * P_RAWPAD, L_TOTAL = L_MISC + 64;
+constexpr int SPIN_LIMIT = 40000;        // bounded waits (~1 us per spin)
+}  // namespace
+
+size_t persist_ws_floats() { return (XCH_BYTES + 3) / 4; }
+
+struct PersistArgs {
+  int B, S;
+  const float* Wreg;        // [128 waves][NREG][64 lanes]
+  const float* bias[4];     // [1024] [1024] [512] [224]
+  const float* gamma[3];    // GroupNorm affine of the inputs of layers 1..3
+  const float* beta[3];
+  const float* past_in0;
+  const float* z_seq;
+  float* world;
+  float* xT;
+  float* steps;
+  size_t per_step, off_G, off_dec[4];
+  float* t2j;
+  unsigned char* xch;
+  unsigned* err;            // host-mapped error word
+};
+
+struct PersistNet {
+  int device = 0;
+  float* Wreg = nullptr;
+  float* bias[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* gamma[3] = {nullptr, nullptr, nullptr};
+  float* beta[3] = {nullptr, nullptr, nullptr};
+  unsigned* err_host = nullptr;    // hipHostMalloc'ed, mapped
+  unsigned* err_dev = nullptr;
+  bool disabled = false;
+  long long launches = 0;
+};
+
+#ifndef HA_SIMT_EMU
+
+typedef float pvf4 __attribute__((ext_vector_type(4)));
+typedef unsigned puv4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ size_t pq(int c) { return (size_t)(c >> 2) * 128 + (c & 3); }
+
+__device__ __forceinline__ float as_f(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ unsigned as_u(float f) { return __float_as_uint(f); }
+
+// Cross-lane sums, N independent values at a time and stage by stage (all N values advance together: N short dependent chains
+// side by side instead of N long ones back to back).  Within a 16-lane DPP row: v_add with a row_ror operand.  Across rows:
+// v_permlane16_swap / v_permlane32_swap (gfx950) of two copies -- {r0,r0,r2,r2} + {r1,r1,r3,r3} and {lo,lo} + {hi,hi} -- plain
+// VALU instructions instead of ds_bpermute round trips through the LDS crossbar.
+typedef unsigned puv2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ float dpp_ror(float v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float add_xor16(float v) {
+  const puv2 r = __builtin_amdgcn_permlane16_swap(as_u(v), as_u(v), false, false);
+  return as_f(r.x) + as_f(r.y);
+}
+__device__ __forceinline__ float add_xor32(float v) {
+  const puv2 r = __builtin_amdgcn_permlane32_swap(as_u(v), as_u(v), false, false);
+  return as_f(r.x) + as_f(r.y);
+}
+// sum over the lanes of a group (64: the wave, 32: each half-wave), every lane gets its group's sum
+template <int GROUP, int N>
+__device__ __forceinline__ void group_sum_n(float (&v)[N]) {
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x128>(v[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x124>(v[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x122>(v[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x121>(v[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] = add_xor16(v[n]);
+  if (GROUP == 64) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] = add_xor32(v[n]);
+  }
+}
+// accumulator lane (b, j) = 4 b + j: sum over the 16 k-blocks b, every lane gets the sum of its j
+template <int N>
+__device__ __forceinline__ void block_sum_n(float (&v)[N]) {
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x124>(v[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x128>(v[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] = add_xor16(v[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) v[n] = add_xor32(v[n]);
+}
+
+// Sweeps this thread's NQ channels (channel tid + 256 q: 4 granules = 32 bytes each) until every tag matches; the loads bypass
+// the CU's L1 (sc1).  Returns false when the wait ran out (a team member never published).
+template <int NQ>
+__device__ __forceinline__ bool sweep(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, bool active, int tid, float (&x)[NQ][4]) {
+  for (int spins = 0;; ++spins) {
+    unsigned diff = 0;          // (no short-circuit: one straight-line batch of loads and compares)
+    if (active) {
+      puv4 lo[NQ], hi[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        lo[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)(tid + 256 * q) * 32u, 0, 16);
+        hi[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)(tid + 256 * q) * 32u + 16u, 0, 16);
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        diff |= (lo[q].y ^ tag) | (lo[q].w ^ tag) | (hi[q].y ^ tag) | (hi[q].w ^ tag);
+        x[q][0] = as_f(lo[q].x); x[q][1] = as_f(lo[q].z); x[q][2] = as_f(hi[q].x); x[q][3] = as_f(hi[q].z);
+      }
+    }
+    if (__all(diff == 0)) return true;
+    if (spins > SPIN_LIMIT) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// consumer side of a hidden activation: sweep, GroupNorm (two-pass statistics per row and group of GROUP channels) + ReLU, the
+// finished A operand to LDS as [channel][4 rows]
+template <int NQ, int GROUP>
+__device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float (&gam)[NQ], const float (&bet)[NQ],
+                                            float* xs, int tid) {
+  float x[NQ][4];
+  if (!sweep<NQ>(rs, off, tag, true, tid, x)) return false;
+  const float inv_n = 1.0f / (float)GROUP;
+  float mu[NQ * 4], var[NQ * 4];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mu[4 * q + i] = x[q][i];
+  group_sum_n<GROUP>(mu);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      mu[4 * q + i] *= inv_n;
+      const float d = x[q][i] - mu[4 * q + i];
+      var[4 * q + i] = d * d;
+    }
+  group_sum_n<GROUP>(var);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    pvf4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float rstd = rsqrtf(var[4 * q + i] * inv_n + 1e-5f);
+      o[i] = fmaxf((x[q][i] - mu[4 * q + i]) * rstd * gam[q] + bet[q], 0.f);
+    }
+    *reinterpret_cast<pvf4*>(xs + (size_t)(tid + 256 * q) * 4) = o;
+  }
+  return true;
+}
+
+// one layer's share of a wave: all K chunks against the resident weight registers.  The A operands come from LDS in batches of
+// MB chunks, the next batch's reads issued ahead of the current batch's MFMAs (the compiler otherwise waits for every read right
+// before its first use: one LDS round trip per 4 MFMAs); two accumulators per column group break the 2-pass dependent chain.
+constexpr int MB = 16;
+template <int NC_MAIN, int FIRST>
+__device__ __forceinline__ void load_a(const float* xs, const float* zs, int lane, float (&av)[MB]) {
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int c = FIRST + i;
+    if (c < NC_MAIN) av[i] = xs[64 * c + lane];
+    else if (c < NC_MAIN + NCZ) av[i] = zs[64 * (c - NC_MAIN) + lane];
+  }
+}
+template <int NC_MAIN, int NCG, int ROFF, int FIRST>
+__device__ __forceinline__ void mma_batch(const float (&av)[MB], const float (&w)[NREG], pvf4 (&acc)[NCG], pvf4 (&a2)[NCG]) {
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int c = FIRST + i;
+    if (c < NC_MAIN + NCZ) {
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        if (c & 1) a2[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i], w[ROFF + c * NCG + g], a2[g], 0, 0, 0);
+        else acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i], w[ROFF + c * NCG + g], acc[g], 0, 0, 0);
+      }
+    }
+  }
+}
+template <int NC_MAIN, int NCG, int ROFF, int FIRST>
+struct MmaSteps {
+  static __device__ __forceinline__ void run(const float* xs, const float* zs, const float (&w)[NREG], int lane, float (&cur)[MB], pvf4 (&acc)[NCG],
+                                             pvf4 (&a2)[NCG]) {
+    if constexpr (FIRST < NC_MAIN + NCZ) {
+      float nxt[MB];
+      if constexpr (FIRST + MB < NC_MAIN + NCZ) load_a<NC_MAIN, FIRST + MB>(xs, zs, lane, nxt);
+      HA_SCHED_FENCE();
+      mma_batch<NC_MAIN, NCG, ROFF, FIRST>(cur, w, acc, a2);
+      HA_SCHED_FENCE();
+      MmaSteps<NC_MAIN, NCG, ROFF, FIRST + MB>::run(xs, zs, w, lane, nxt, acc, a2);
+    }
+  }
+};
+template <int NC_MAIN, int NCG, int ROFF>
+__device__ __forceinline__ void mma_layer(const float* xs, const float* zs, const float (&w)[NREG], int lane, pvf4 (&acc)[NCG]) {
+  pvf4 a2[NCG];
+#pragma unroll
+  for (int g = 0; g < NCG; ++g) { acc[g] = pvf4{0.f, 0.f, 0.f, 0.f}; a2[g] = pvf4{0.f, 0.f, 0.f, 0.f}; }
+  float first[MB];
+  load_a<NC_MAIN, 0>(xs, zs, lane, first);
+  MmaSteps<NC_MAIN, NCG, ROFF, 0>::run(xs, zs, w, lane, first, acc, a2);
+#pragma unroll
+  for (int g = 0; g < NCG; ++g) acc[g] += a2[g];
+}
+
+// publishes the wave's NCG column groups (columns col0 + 4 g + j) of layer-output `off`: lanes 4 g + j hold column group g.
+// Granules {value, tag} for the team, the plain pre-activation slab [channel quads][32 rows][4] for the adjoint / prior.
+template <int NCG, bool SC1>
+__device__ __forceinline__ void publish(pvf4 (&acc)[NCG], const float (&bias)[NCG], int col0, unsigned char* team_xch, __amdgpu_buffer_rsrc_t rs,
+                                        unsigned off, unsigned tag, float* slab, int row0, int lane, bool member_active) {
+  float sums[4 * NCG], v[4];
+#pragma unroll
+  for (int g = 0; g < NCG; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sums[4 * g + i] = acc[g][i];
+  block_sum_n(sums);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s0 = sums[i] + bias[0];
+    if (NCG == 2) s0 = (lane & 4) ? sums[4 + i] + bias[1] : s0;
+    v[i] = s0;
+  }
+  if (member_active && lane < 4 * NCG) {
+    const int col = col0 + lane;            // lanes 0..3 -> group 0, 4..7 -> group 1: consecutive columns
+    const puv4 lo = {as_u(v[0]), tag, as_u(v[1]), tag}, hi = {as_u(v[2]), tag, as_u(v[3]), tag};
+    if (SC1) {
+      __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off + (unsigned)col * 32u, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off + (unsigned)col * 32u + 16u, 0, 16);
+    } else {
+      puv4* gp = reinterpret_cast<puv4*>(team_xch + off + (size_t)col * 32);
+      gp[0] = lo;
+      gp[1] = hi;
+    }
+    float* sp = slab + pq(col) + (size_t)row0 * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sp[i * 4] = v[i];
+  }
+}
+
+template <bool SC1>
+__global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd_kernel(PersistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs0 = smem + L_XS0;
+  float* xs1 = smem + L_XS1;
+  float* xs2 = smem + L_XS2;
+  float* xs3 = smem + L_XS3;
+  float* zs = smem + L_ZS;
+  float* sX = smem + L_SX;
+  float* sRAW = smem + L_SRAW;
+  volatile int* misc = reinterpret_cast<volatile int*>(smem + L_MISC);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+  // ---- team formation: a block belongs to the XCD it runs on ------------------------------------------------------------
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;       // HW_REG_XCC_ID
+    unsigned* cnt = reinterpret_cast<unsigned*>(a.xch);
+    misc[0] = (int)xcc;
+    misc[1] = (int)atomicAdd(cnt + xcc, 1u);
+    misc[2] = 0;
+  }
+  __syncthreads();
+  // (block-uniform values out of LDS: readfirstlane keeps them -- and the buffer descriptor built from them -- in SGPRs)
+  const int team = __builtin_amdgcn_readfirstlane(misc[0]), m = __builtin_amdgcn_readfirstlane(misc[1]);
+  if (m >= TEAM_CUS) {        // more than 32 blocks on this XCD: another XCD is short of one, its team will time out
+    if (tid == 0) __hip_atomic_store(a.err, 0x100u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  if (a.S == 0) return;       // residency / placement probe
+  const int g = m * 4 + wave;                 // wave of the team
+  const int row0 = team * ROWS;               // the team's sequences
+  unsigned char* team_xch = a.xch + XCH_HDR + (size_t)team * TEAM_BYTES;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(team_xch, 0, TEAM_BYTES, 0x00020000);
+  const bool writer = m == 0;                 // member 0 writes the per-sequence results (world states, state slabs)
+
+  // ---- resident weights -------------------------------------------------------------------------------------------------
+  float w[NREG];
+  {
+    const float* wp = a.Wreg + (size_t)g * NREG * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) w[r] = wp[(size_t)r * 64];
+  }
+  const int j4 = lane & 3;
+  const float b0[2] = {a.bias[0][8 * g + j4], a.bias[0][8 * g + 4 + j4]};
+  const float b1[2] = {a.bias[1][8 * g + j4], a.bias[1][8 * g + 4 + j4]};
+  const float b2[1] = {a.bias[2][4 * g + j4]};
+  const float b3[1] = {g < L3_WAVES ? a.bias[3][4 * g + j4] : 0.f};
+  float gam1[4], bet1[4], gam2[4], bet2[4], gam3[2], bet3[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    gam1[q] = a.gamma[0][tid + 256 * q]; bet1[q] = a.beta[0][tid + 256 * q];
+    gam2[q] = a.gamma[1][tid + 256 * q]; bet2[q] = a.beta[1][tid + 256 * q];
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { gam3[q] = a.gamma[2][tid + 256 * q]; bet3[q] = a.beta[2][tid + 256 * q]; }
+
+  // ---- initial state: x_0 (row-major copy for the glue, [channel][row] copy as the A operand), z_0, world transform ---------
+  for (int e = tid; e < ROWS * P_XPAD; e += 256) {
+    const int i = e / P_XPAD, c = e - i * P_XPAD, r = row0 + i;
+    const float v = (c < P_DIN && r < a.B) ? a.past_in0[(size_t)r * P_DIN + c] : 0.f;
+    sX[e] = v;
+    xs0[c * 4 + i] = v;
+    if (writer && c < P_DINP) a.xT[pq(c) + (size_t)r * 4] = v;
+  }
+  const int zi = tid / P_ZD, zc = tid - zi * P_ZD;          // thread <-> (row, latent channel) for tid < 192
+  const bool zlive = tid < ROWS * P_ZD && row0 + zi < a.B;
+  if (tid < ROWS * P_ZD) zs[zc * 4 + zi] = zlive ? a.z_seq[((size_t)(row0 + zi) * a.S) * P_ZD + zc] : 0.f;
+  // per-sequence state of wave `wave`'s row (identical in every lane)
+  const int myrow = row0 + wave;
+  float G[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, gt[3] = {0.f, 0.f, 0.f}, t2j[3] = {0.f, 0.f, 0.f};
+  if (myrow < a.B) {
+    t2j[0] = -a.past_in0[(size_t)myrow * P_DIN + 207];
+    t2j[1] = -a.past_in0[(size_t)myrow * P_DIN + 208];
+  }
+  if (writer && lane == 0) {
+    float* Gs = a.steps + a.off_G + (size_t)myrow * 12;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Gs[i] = G[i];
+    Gs[9] = Gs[10] = Gs[11] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.t2j[(size_t)myrow * 3 + c] = t2j[c];
+  }
+
+  bool fail = false;
+  for (int t = 0; t < a.S; ++t) {
+    const unsigned tag = 4u * (unsigned)t;
+    float* sp = a.steps + (size_t)t * a.per_step;
+    // latent of the next step: issued now, written to LDS in the glue phase
+    float z_next = 0.f;
+    if (zlive && t + 1 < a.S) z_next = a.z_seq[((size_t)(row0 + zi) * a.S + (t + 1)) * P_ZD + zc];
+    __syncthreads();                                   // xs0 / zs of this step are complete
+    // ---- layer 0: [x_t | z_t] (raw) -> 1024 ---------------------------------------------------------------------------
+    {
+      pvf4 acc[2];
+      mma_layer<NC0, 2, R0>(xs0, zs, w, lane, acc);
+      publish<2, SC1>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, sp + a.off_dec[0], row0, lane, true);
+    }
+    // ---- layer 1 ----------------------------------------------------------------------------------------------------------
+    if (!gather_norm<4, 64>(rs, ACT_OFF0, tag + 1, gam1, bet1, xs1, tid)) fail = true;
+    if (fail) misc[2] = 1;
+    __syncthreads();
+    if (misc[2]) break;
+    {
+      pvf4 acc[2];
+      mma_layer<NC1, 2, R1>(xs1, zs, w, lane, acc);
+      publish<2, SC1>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, sp + a.off_dec[1], row0, lane, true);
+    }
+    // ---- layer 2 ----------------------------------------------------------------------------------------------------------
+    if (!gather_norm<4, 64>(rs, ACT_OFF1, tag + 2, gam2, bet2, xs2, tid)) fail = true;
+    if (fail) misc[2] = 1;
+    __syncthreads();
+    if (misc[2]) break;
+    {
+      pvf4 acc[1];
+      mma_layer<NC2, 1, R2>(xs2, zs, w, lane, acc);
+      publish<1, SC1>(acc, b2, 4 * g, team_xch, rs, ACT_OFF2, tag + 3, sp + a.off_dec[2], row0, lane, true);
+    }
+    // ---- layer 3 (GroupNorm groups of 32) -------------------------------------------------------------------------------
+    if (!gather_norm<2, 32>(rs, ACT_OFF2, tag + 3, gam3, bet3, xs3, tid)) fail = true;
+    if (fail) misc[2] = 1;
+    __syncthreads();
+    if (misc[2]) break;
+    if (g < L3_WAVES) {       // (wave-uniform)
+      pvf4 acc[1];
+      mma_layer<NC3, 1, R3>(xs3, zs, w, lane, acc);
+      publish<1, SC1>(acc, b3, 4 * g, team_xch, rs, ACT_OFF3, tag + 4, sp + a.off_dec[3], row0, lane, true);
+    }
+    // ---- glue: decoder output of the 4 rows -> every CU --------------------------------------------------------------------
+    {
+      float x[1][4];
+      if (!sweep<1>(rs, ACT_OFF3, tag + 4, tid < P_RAW, tid, x)) fail = true;
+      if (tid < P_RAW) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sRAW[i * P_RAWPAD + tid] = x[0][i];
+      }
+    }
+    if (fail) misc[2] = 1;
+    __syncthreads();                                   // also: every wave of this CU is past its layer-3 reads of zs / xs3
+    if (misc[2]) break;
+    if (tid < ROWS * P_ZD) zs[zc * 4 + zi] = z_next;
+    {
+      // one wave per sequence: lanes 0..21 = joints; lanes 0..20 also body rotation b, lane 21 the root rotation
+      const float* X = sX + wave * P_XPAD;
+      const float* RW = sRAW + wave * P_RAWPAD;
+      const bool jl = lane < 22, root = lane == 21;
+      const int aoff = lane < 21 ? 12 + 3 * lane : 6, roff = lane < 21 ? 18 + 9 * lane : 6;
+      float pj[3] = {0.f, 0.f, 0.f}, jv[3] = {0.f, 0.f, 0.f}, pR[9], ptrans[3] = {0.f, 0.f, 0.f}, ptvel[3] = {0.f, 0.f, 0.f}, prvel[3] = {0.f, 0.f, 0.f};
+      float Wm[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { pR[i] = 0.f; Wm[i] = 0.f; }
+      if (jl) {
+        float aa[3], dR[9], Rin[9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          pj[c] = RW[75 + 3 * lane + c] + X[207 + 3 * lane + c];
+          jv[c] = RW[141 + 3 * lane + c] + X[273 + 3 * lane + c];
+          aa[c] = RW[aoff + c];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rin[i] = X[roff + i];
+        rodrigues(aa, dR);
+        mat3_mul(dR, Rin, pR);
+      }
+      if (root) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          ptrans[c] = RW[c] + X[c];
+          ptvel[c] = RW[3 + c] + X[3 + c];
+          prvel[c] = RW[9 + c] + X[15 + c];
+        }
+        W2A wa;
+        w2a_fwd(pR, wa);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Wm[i] = wa.W[i];
+      }
+      const float craw = (lane >= 32 && lane < 41) ? RW[207 + lane - 32] : 0.f;      // contact logits
+      // the root lane's heading alignment and translation to every lane
+      float W[9], ptr[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) W[i] = as_f(__builtin_amdgcn_readlane(as_u(Wm[i]), 21));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ptr[c] = as_f(__builtin_amdgcn_readlane(as_u(ptrans[c]), 21));
+      const float wt[3] = {-ptr[0], -ptr[1], 0.f};
+      const bool live = myrow < a.B;
+      float* WO = (writer && live) ? a.world + ((size_t)myrow * a.S + t) * P_STATE : nullptr;
+      float* XT = writer ? a.xT + (size_t)(t + 1) * P_DINP * 32 + (size_t)myrow * 4 : nullptr;
+      float* Xn = sX + wave * P_XPAD;
+      auto put_x = [&](int c, float v) {
+        Xn[c] = v;
+        xs0[c * 4 + wave] = v;
+        if (XT) XT[pq(c)] = v;
+      };
+      if (jl) {
+        float q[3], o[3];
+        // next input: W (pj + wt + t2j) - t2j ; W jv       world: G^T (pj + t2j) - t2j - gt ; G^T jv
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[c] = pj[c] + wt[c] + t2j[c];
+        mat3_vec(W, q, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put_x(207 + 3 * lane + c, o[c] - t2j[c]);
+        mat3_vec(W, jv, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put_x(273 + 3 * lane + c, o[c]);
+        if (WO) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) q[c] = pj[c] + t2j[c];
+          mat3_tvec(G, q, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) WO[207 + 3 * lane + c] = o[c] - t2j[c] - gt[c];
+          mat3_tvec(G, jv, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) WO[273 + 3 * lane + c] = o[c];
+        }
+        if (!root) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            put_x(18 + 9 * lane + i, pR[i]);
+            if (WO) WO[18 + 9 * lane + i] = pR[i];
+          }
+        }
+      }
+      if (WO && lane >= 32 && lane < 41) WO[339 + lane - 32] = craw;
+      if (XT && lane == 63) XT[pq(P_DIN)] = 0.f;          // pad channel of the state slab
+      // world translation of the predicted root (every lane: it feeds the carried transform)
+      float wtr[3], M[9];
+      mat3_tvec(G, ptr, wtr);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) wtr[c] -= gt[c];
+      if (root) {
+        float q[3], o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[c] = ptrans[c] + wt[c];
+        mat3_vec(W, q, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put_x(c, o[c]);
+        mat3_vec(W, ptvel, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put_x(3 + c, o[c]);
+        mat3_mul(W, pR, M);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) put_x(6 + i, M[i]);
+        mat3_vec(W, prvel, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put_x(15 + c, o[c]);
+        if (WO) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) WO[c] = wtr[c];
+          mat3_tvec(G, ptvel, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) WO[3 + c] = o[c];
+          mat3_tmul(G, pR, M);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) WO[6 + i] = M[i];
+          mat3_tvec(G, prvel, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) WO[15 + c] = o[c];
+        }
+      }
+      // accumulate the world transform: G' = G W, gt' = (-wtrans.x, -wtrans.y, 0)
+      mat3_mul(G, W, M);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) G[i] = M[i];
+      gt[0] = -wtr[0];
+      gt[1] = -wtr[1];
+      gt[2] = 0.f;
+      if (writer && lane == 0) {
+        float* Gs = a.steps + (size_t)(t + 1) * a.per_step + a.off_G + (size_t)myrow * 12;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Gs[i] = G[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Gs[9 + c] = gt[c];
+      }
+    }
+  }
+  if (misc[2] && tid == 0) __hip_atomic_store(a.err, 0x200u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+#endif  // !HA_SIMT_EMU
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+static int p_upload(T** dst, const std::vector<T>& src) {
+  *dst = nullptr;
+  HA_CHECK_HIP(hipMalloc((void**)dst, src.size() * sizeof(T)));
+  HA_CHECK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return HA_OK;
+}
+
+void persist_destroy(PersistNet* p) {
+  if (!p) return;
+#ifndef HA_SIMT_EMU
+  DeviceGuard guard(p->device);
+  if (p->Wreg) (void)hipFree(p->Wreg);
+  for (float* q : p->bias)
+    if (q) (void)hipFree(q);
+  for (float* q : p->gamma)
+    if (q) (void)hipFree(q);
+  for (float* q : p->beta)
+    if (q) (void)hipFree(q);
+  if (p->err_host) (void)hipHostFree(p->err_host);
+#endif
+  delete p;
+}
+
+bool persist_usable(PersistNet* p) {
+  if (!p || p->disabled) return false;
+  if (p->err_host && *reinterpret_cast<volatile unsigned*>(p->err_host) != 0) p->disabled = true;   // sticky: reported by an earlier launch
+  return !p->disabled;
+}
+
+long long persist_launches(PersistNet* p) { return p ? p->launches : 0; }
+
+unsigned persist_error_word(PersistNet* p) { return (p && p->err_host) ? *reinterpret_cast<volatile unsigned*>(p->err_host) : 0u; }
+
+int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
+  *out = nullptr;
+#ifdef HA_SIMT_EMU
+  (void)device; (void)d;
+  return HA_OK;        // the host emulator runs blocks one after another: no persistent teams there
+#else
+  // the shape this path is built for: the default HuMoR decoder [339 + 48] -> 1024 -> 1024 -> 512 -> 216 with the latent skip
+  if (!(d->n_linear == 4 && d->in_dim == P_DIN + P_ZD && d->skip_dim == P_ZD && d->out_dims[0] == P_H0 && d->out_dims[1] == P_H1 &&
+        d->out_dims[2] == P_H2 && d->out_dims[3] == P_RAW))
+    return HA_OK;
+  hipDeviceProp_t prop;
+  HA_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  if (prop.multiProcessorCount != NTEAMS * TEAM_CUS) return HA_OK;
+  PersistNet* p = new PersistNet();
+  p->device = device;
+  const int Kin[4] = {P_DIN + P_ZD, P_H0 + P_ZD, P_H1 + P_ZD, P_H2 + P_ZD}, Cmain[4] = {P_DIN, P_H0, P_H1, P_H2};
+  const int NCm[4] = {NC0, NC1, NC2, NC3}, NCGv[4] = {2, 2, 1, 1}, RO[4] = {R0, R1, R2, R3}, Nout[4] = {P_H0, P_H1, P_H2, P_RAW};
+  std::vector<float> wr((size_t)NWAVES_TEAM * NREG * 64, 0.f);
+  for (int g = 0; g < NWAVES_TEAM; ++g)
+    for (int l = 0; l < 4; ++l)
+      for (int c = 0; c < NCm[l] + NCZ; ++c)
+        for (int cg = 0; cg < NCGv[l]; ++cg)
+          for (int ln = 0; ln < 64; ++ln) {
+            const int b = ln >> 2, j = ln & 3;
+            const int col = (NCGv[l] == 2 ? 8 * g : 4 * g) + 4 * cg + j;
+            int k;
+            if (c < NCm[l]) { k = 16 * c + b; if (k >= Cmain[l]) k = -1; }
+            else k = Cmain[l] + 16 * (c - NCm[l]) + b;
+            float v = 0.f;
+            if (col < Nout[l] && k >= 0) v = d->w[l][(size_t)col * Kin[l] + k];
+            wr[((size_t)g * NREG + RO[l] + c * NCGv[l] + cg) * 64 + ln] = v;
+          }
+  int rc = p_upload(&p->Wreg, wr);
+  const int bpad[4] = {P_H0, P_H1, P_H2, P_RAWPAD};
+  for (int l = 0; l < 4 && rc == HA_OK; ++l) {
+    std::vector<float> bv(bpad[l], 0.f);
+    for (int i = 0; i < Nout[l]; ++i) bv[i] = d->b[l][i];
+    rc = p_upload(&p->bias[l], bv);
+  }
+  for (int l = 1; l < 4 && rc == HA_OK; ++l) {
+    if (!d->gn_gamma[l] || !d->gn_beta[l]) { rc = HA_ERR_INVALID_ARG; set_error("persist_create: GroupNorm affine of layer %d missing", l); break; }
+    std::vector<float> gv(d->gn_gamma[l], d->gn_gamma[l] + Cmain[l]), bv(d->gn_beta[l], d->gn_beta[l] + Cmain[l]);
+    rc = p_upload(&p->gamma[l - 1], gv);
+    if (rc == HA_OK) rc = p_upload(&p->beta[l - 1], bv);
+  }
+  if (rc == HA_OK) {
+    hipError_t e = hipHostMalloc((void**)&p->err_host, 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&p->err_dev, p->err_host, 0);
+    if (e != hipSuccess) { set_error("persist_create: host-mapped error word: %s", hipGetErrorString(e)); rc = HA_ERR_HIP; }
+    else *p->err_host = 0;
+  }
+  if (rc == HA_OK) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_persist_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_persist_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4);
+    if (e != hipSuccess) { set_error("persist_create: LDS attribute: %s", hipGetErrorString(e)); rc = HA_ERR_HIP; }
+  }
+  if (rc == HA_OK) {
+    // placement / residency probe: one launch of the real kernel with zero steps; every XCD must have received exactly 32 blocks
+    unsigned char* xch = nullptr;
+    hipError_t e = hipMalloc((void**)&xch, XCH_HDR);
+    if (e == hipSuccess) e = hipMemset(xch, 0, XCH_HDR);
+    if (e == hipSuccess) {
+      PersistArgs a;
+      memset(&a, 0, sizeof(a));
+      a.xch = xch;
+      a.err = p->err_dev;
+      hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, 0, a);
+      e = hipDeviceSynchronize();
+    }
+    unsigned cnt[NTEAMS] = {0};
+    if (e == hipSuccess) e = hipMemcpy(cnt, xch, sizeof(cnt), hipMemcpyDeviceToHost);
+    if (xch) (void)hipFree(xch);
+    bool even = e == hipSuccess && *p->err_host == 0;
+    for (int i = 0; i < NTEAMS; ++i) even = even && cnt[i] == (unsigned)TEAM_CUS;
+    if (!even) { persist_destroy(p); return HA_OK; }      // not an error: the launch chain serves this device
+  }
+  if (rc != HA_OK) { persist_destroy(p); return rc; }
+  *out = p;
+  return HA_OK;
+#endif
+}
+
+int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t st) {
+#ifdef HA_SIMT_EMU
+  (void)p; (void)f; (void)variant; (void)st;
+  set_error("persistent roll-out: not available on the host emulator");
+  return HA_ERR_INVALID_ARG;
+#else
+  HA_REQUIRE(p && f.B >= 1 && f.B <= NTEAMS * ROWS && f.S >= 1, "persistent roll-out: needs 1 <= B <= 32 sequences");
+  HA_REQUIRE(f.S < (1 << 28), "persistent roll-out: too many steps");
+  HA_CHECK_HIP(hipMemsetAsync(f.ws, 0, XCH_BYTES, st));        // tags, team counters (tag 0 never matches)
+  PersistArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = f.B; a.S = f.S;
+  a.Wreg = p->Wreg;
+  for (int l = 0; l < 4; ++l) a.bias[l] = p->bias[l];
+  for (int l = 0; l < 3; ++l) { a.gamma[l] = p->gamma[l]; a.beta[l] = p->beta[l]; }
+  a.past_in0 = f.past_in0; a.z_seq = f.z_seq; a.world = f.world; a.xT = f.xT; a.steps = f.steps;
+  a.per_step = f.per_step; a.off_G = f.off_G;
+  for (int l = 0; l < 4; ++l) a.off_dec[l] = f.off_dec[l];
+  a.t2j = f.t2j;
+  a.xch = reinterpret_cast<unsigned char*>(f.ws);
+  a.err = p->err_dev;
+  if (variant & 1) hipLaunchKernelGGL(rollout_persist_fwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
+  else hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
+  HA_LAUNCH_CHECK();
+  ++p->launches;
+  return HA_OK;
+#endif
+}
+
+}  // namespace ha

@@ -175,6 +175,13 @@ int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float
                               const float* g_world, const float* g_prior_mu, const float* g_prior_var,
                               float* stash, float* g_past_in0, float* g_z_seq, void* stream);
 
+/* Persistent forward (ha_tune_set "rollout_persist" != 0, B <= 32): state of the weight-stationary one-launch forward of this
+ * network.  *available = 1 when the network / device qualify and no launch has reported a failure; *error_word = the kernel's
+ * host-mapped error word (0 = none; 0x1xx an XCD received more than its 32 blocks, 0x2xx a team member's bounded wait ran out),
+ * meaningful once the stream of the last roll-out has been synchronised; *launches = persistent forwards issued so far for this
+ * network.  After a failure the library uses the launch chain. */
+int ha_humor_persist_status(const ha_humor_net* net, int* available, unsigned int* error_word, int64_t* launches);
+
 /* ------------------------------------------------------------------------------------------------
  * Frozen MLPs on N independent rows (no weight gradients): VPoser v1.0's decoder / encoder as MotionOptimizer.latent2pose /
  * pose2latent call them in every closure (humor/fitting/motion_optimizer.py:1041-1063; Linear + LeakyReLU(0.2), eval-mode

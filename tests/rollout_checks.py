@@ -383,3 +383,46 @@ def check_rot_to_aa_near_pi(lib, device, n=3000, seed=0):
     e = (gr[ok] - gr_ref[ok]).abs().amax(dim=(1, 2)) / sc
     assert e.max().item() < 1e-4, e.max().item()
     return e.max().item()
+
+
+def persist_status(lib, hm, device):
+    """(available, error word, launches) of the persistent forward of `hm`'s network handle on `device` (synchronises first)."""
+    import ctypes as C
+    if device.type == 'cuda':
+        torch.cuda.synchronize(device)
+    h = hm._net_handle(device)
+    av, err, n = C.c_int(), C.c_uint(), C.c_int64()
+    lib.call('ha_humor_persist_status', h.ptr, C.byref(av), C.byref(err), C.byref(n))
+    return av.value, err.value, n.value
+
+
+def check_persistent_vs_chain(lib, device, B, S, seed=0, variant=1, contractive=True):
+    """The one-launch persistent forward (ha_tune_set "rollout_persist") against the launch chain on the same inputs: world states,
+    prior outputs, and -- through the unchanged adjoint reading the persistent kernel's stash -- every gradient."""
+    hm, _ = make_model(lib, device, seed=seed, contractive=contractive)
+    g = torch.Generator().manual_seed(77 + B + S)
+    past, z = canonical_state(B, g).to(device), torch.randn(B, S, 48, generator=g).to(device)
+    gw = torch.randn(B, S, 348, generator=g).to(device)
+    gm, gv = torch.randn(B, S, 48, generator=g).to(device), torch.randn(B, S, 48, generator=g).to(device)
+    res = []
+    n0 = persist_status(lib, hm, device)[2]
+    try:
+        for knob in (0, variant):
+            lib.call('ha_tune_set', b'rollout_persist', knob)
+            p, zz = past.clone().requires_grad_(True), z.clone().requires_grad_(True)
+            out, (pm, pv) = hm.roll_out(p, None, S, z_seq=zz, return_prior=True)
+            w = world_of(out)
+            ((w * gw).sum() + (pm * gm).sum() + (pv * gv).sum()).backward()
+            res.append((w.detach(), pm.detach(), pv.detach(), p.grad.clone(), zz.grad.clone()))
+    finally:
+        lib.call('ha_tune_set', b'rollout_persist', 0)
+    av, err, n1 = persist_status(lib, hm, device)
+    assert err == 0, hex(err)
+    assert av == 1 and n1 == n0 + 1, (av, n0, n1)          # the persistent kernel really ran (no silent fall-back)
+    errs = []
+    for name, a, b, tol in zip(('world', 'prior_mu', 'prior_var', 'g_past', 'g_z'), res[0], res[1], (2e-5, 2e-5, 2e-5, 2e-4, 2e-4)):
+        assert torch.isfinite(b).all(), name
+        e = (a - b).abs().max().item() / max(1.0, a.abs().max().item())
+        errs.append(e)
+        assert e <= tol, (name, e, B, S)
+    return errs

@@ -160,3 +160,37 @@ def test_fused_posterior_encoder_matches_module(gpu_lib, dev):
 def test_posterior_gives_parameter_gradients(gpu_lib, dev):
     """a training-mode infer_step must leave gradients on the encoder / prior weights (module forward), frozen nets run fused."""
     MC.check_posterior_param_grads(gpu_lib, dev, N=9)
+
+
+@pytest.mark.parametrize('variant', [1, 3])
+def test_persistent_forward_matches_launch_chain(gpu_lib, dev, variant):
+    """ha_tune_set("rollout_persist"): ONE persistent launch for the whole decoder chain (register-stationary weights, XCD teams of
+    4 sequences; variant 3 publishes write-through) against the 5-launches-per-step chain -- outputs and gradients."""
+    for B, S in ((32, 59), (5, 7), (1, 3), (32, 1), (17, 20), (4, 119)):
+        print('persistent vs chain', B, S, variant, RC.check_persistent_vs_chain(gpu_lib, dev, B, S, seed=B, variant=variant))
+
+
+def test_persistent_forward_flat_tolerance_vs_oracle(gpu_lib, dev):
+    """The persistent forward at the metric's batch against the oracle / the reference fixture, same flat bars as the launch chain."""
+    gpu_lib.call('ha_tune_set', b'rollout_persist', 1)
+    try:
+        print('persistent 32x59 vs oracle', RC.check_rollout_full_tiles(gpu_lib, dev, 32, 59))
+        print('persistent c4 fixture', RC.check_rollout_long(gpu_lib, dev, 'c4'))
+        RC.check_rollout(gpu_lib, dev, B=4, S=10, seed=4)
+    finally:
+        gpu_lib.call('ha_tune_set', b'rollout_persist', 0)
+
+
+def test_persistent_forward_determinism_and_reuse(gpu_lib, dev):
+    """Back-to-back persistent launches on the same network (fresh stash each): bit-identical results, no stale granules."""
+    hm, _ = RC.make_model(gpu_lib, dev, contractive=True)
+    g = torch.Generator().manual_seed(5)
+    past, z = RC.canonical_state(32, g).to(dev), torch.randn(32, 59, 48, generator=g).to(dev)
+    gpu_lib.call('ha_tune_set', b'rollout_persist', 1)
+    try:
+        outs = [RC.world_of(hm.roll_out(past, None, 59, z_seq=z)) for _ in range(6)]
+    finally:
+        gpu_lib.call('ha_tune_set', b'rollout_persist', 0)
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    assert RC.persist_status(gpu_lib, hm, dev)[1] == 0
