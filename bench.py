@@ -258,9 +258,21 @@ def rollout_c4_ms(dev):
         z.grad = None
         out, (pm, pv) = hm.roll_out(past, None, S, z_seq=z, return_prior=True)
         (out['trans'].sum() + out['joints'].sum() + pm.sum()).backward()
-    tf, tb = time_events(fwd, iters=10, warm=2), time_events(fwd_bwd, iters=10, warm=2)
-    return {'fwd_ms': round(tf, 3), 'fwd_bwd_ms': round(tb, 3), 'steps_per_sec_fwd': round(B_SEQ * S / (tf * 1e-3), 1),
-            'steps_per_sec_fwd_bwd': round(B_SEQ * S / (tb * 1e-3), 1), 'batch': B_SEQ, 'steps': S}
+    from humor_amd import _lib
+    lib = _lib.get_lib()
+    out = {}
+    # default path (forward = ONE persistent launch, weights resident in the XCD teams' register files) and the launch chain beside it
+    for name, knob in (('persistent_forward', 1), ('launch_chain', 0)):
+        lib.call('ha_tune_set', b'rollout_persist', knob)
+        try:
+            tf, tb = time_events(fwd, iters=10, warm=2), time_events(fwd_bwd, iters=10, warm=2)
+        finally:
+            lib.call('ha_tune_set', b'rollout_persist', 1)
+        out[name] = {'fwd_ms': round(tf, 3), 'fwd_bwd_ms': round(tb, 3), 'steps_per_sec_fwd': round(B_SEQ * S / (tf * 1e-3), 1),
+                     'steps_per_sec_fwd_bwd': round(B_SEQ * S / (tb * 1e-3), 1)}
+    res = dict(out['persistent_forward'])
+    res.update(batch=B_SEQ, steps=S, launch_chain=out['launch_chain'])
+    return res
 
 
 def lbfgs_profile(dev, npz, k=5):

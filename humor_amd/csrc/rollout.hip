@@ -58,8 +58,9 @@ int g_gemm_ks = 0;
 int g_rollout_groups = 0;
 // ha_tune_set "rollout_persist": the forward of a roll-out of <= 32 sequences as ONE persistent launch with the decoder resident in
 // the register files of the XCD teams (rollout_persist.hip) instead of 5 dependent launches per step.  0 = launch chain, 1 = on
-// (granules published with plain stores: team = one XCD = one L2), 3 = on, granules published write-through (sc1).
-int g_rollout_persist = 0;
+// (default; granules published with plain stores: team = one XCD = one L2), 3 = on, granules published write-through (sc1).
+// Measured at 32 x 59 (profiles/r03_run1): decoder chain 30.1 -> 15.5 us per step (variant 3: 21.0), forward 1.96 -> 1.09 ms.
+int g_rollout_persist = 1;
 
 struct PackedLayer {
   int Cin = 0, skip = 0, Nout = 0;

@@ -182,6 +182,15 @@ def check_rollout_full_tiles(lib, device, B, S, seed=0):
     drift = (w_ref.detach().double() - w64.detach()).abs().max().item()
     assert drift < 2e-5, drift            # the chain itself is well conditioned
     stable = (per_seq_rel(g_ref[0].numpy(), g64[0].numpy()) < 2e-4) & (per_seq_rel(g_ref[1].numpy(), g64[1].numpy()) < 2e-4)
+    # ... and under 1-ulp perturbations of the inputs (the second half of the generator's criterion: a ReLU unit within rounding
+    # distance of its kink is found by moving the fp32 inputs, not only by changing the precision)
+    for k in range(4):
+        gp = torch.Generator().manual_seed(7 + k)
+        pert = lambda v: (v.detach() * (1.0 + ((torch.rand(v.shape, generator=gp) > 0.5).float() * 2 - 1) * 2.0 ** -23)).requires_grad_(True)
+        pp, zp = pert(past_c), pert(z_c)
+        wp, (pmp, pvp) = H.roll_out(sd, pp, zp)
+        gpt = torch.autograd.grad((wp * gw).sum() + (pmp * gm).sum() + (pvp * gv).sum(), [pp, zp])
+        stable &= (per_seq_rel(gpt[0].numpy(), g_ref[0].numpy()) < 2e-4) & (per_seq_rel(gpt[1].numpy(), g_ref[1].numpy()) < 2e-4)
     past = past_c.detach().to(device).requires_grad_(True)
     z = z_c.detach().to(device).requires_grad_(True)
     out, (pm, pv) = hm.roll_out(past, None, S, z_seq=z, return_prior=True)
@@ -415,7 +424,7 @@ def check_persistent_vs_chain(lib, device, B, S, seed=0, variant=1, contractive=
             ((w * gw).sum() + (pm * gm).sum() + (pv * gv).sum()).backward()
             res.append((w.detach(), pm.detach(), pv.detach(), p.grad.clone(), zz.grad.clone()))
     finally:
-        lib.call('ha_tune_set', b'rollout_persist', 0)
+        lib.call('ha_tune_set', b'rollout_persist', 1)
     av, err, n1 = persist_status(lib, hm, device)
     assert err == 0, hex(err)
     assert av == 1 and n1 == n0 + 1, (av, n0, n1)          # the persistent kernel really ran (no silent fall-back)

@@ -13,33 +13,48 @@ def dev():
     return torch.device('cuda:0')
 
 
+@pytest.fixture(params=[1, 0], ids=['persistent', 'chain'])
+def fwd_path(request, gpu_lib):
+    """Both forwards of a roll-out of <= 32 sequences: the one-launch persistent kernel (default) and the launch chain."""
+    gpu_lib.call('ha_tune_set', b'rollout_persist', request.param)
+    yield request.param
+    gpu_lib.call('ha_tune_set', b'rollout_persist', 1)
+
+
+@pytest.fixture
+def chain_only(gpu_lib):
+    gpu_lib.call('ha_tune_set', b'rollout_persist', 0)
+    yield
+    gpu_lib.call('ha_tune_set', b'rollout_persist', 1)
+
+
 @pytest.mark.parametrize('B,S', [(1, 1), (2, 3), (4, 10), (32, 12), (33, 5), (70, 3), (130, 2)])   # 130 rows: full-K launch policy
-def test_rollout_forward_backward(gpu_lib, dev, B, S):
+def test_rollout_forward_backward(gpu_lib, dev, fwd_path, B, S):
     RC.check_rollout(gpu_lib, dev, B=B, S=S, seed=B)
 
 
-def test_rollout_without_prior(gpu_lib, dev):
+def test_rollout_without_prior(gpu_lib, dev, fwd_path):
     RC.check_rollout(gpu_lib, dev, B=5, S=4, with_prior=False)
 
 
-def test_rollout_golden(gpu_lib, dev):
+def test_rollout_golden(gpu_lib, dev, fwd_path):
     RC.check_rollout_golden(gpu_lib, dev)
 
 
 @pytest.mark.parametrize('name', ['c4', 'c3', 'c5'])
-def test_rollout_baseline_lengths_flat_tolerance(gpu_lib, dev, name):
+def test_rollout_baseline_lengths_flat_tolerance(gpu_lib, dev, fwd_path, name):
     """59 / 89 / 119 steps against the reference's own outputs (tests/golden/rollout_long.npz): flat 1e-4 on every step's
     state and prior output, 1e-3 relative on the gradients -- no conditioning allowance (well-conditioned synthetic prior)."""
     print(name, RC.check_rollout_long(gpu_lib, dev, name))
 
 
 @pytest.mark.parametrize('B,S', [(32, 59), (256, 119)])
-def test_rollout_full_tiles_flat_tolerance(gpu_lib, dev, B, S):
+def test_rollout_full_tiles_flat_tolerance(gpu_lib, dev, fwd_path, B, S):
     """The metric's batch (one FULL 32-row tile, 59 steps) and the C5 batch (eight tiles, 119 steps) at the flat 1e-4 / 1e-3 bars."""
     print(B, S, RC.check_rollout_full_tiles(gpu_lib, dev, B, S))
 
 
-def test_rollout_full_length(gpu_lib, dev):
+def test_rollout_full_length(gpu_lib, dev, fwd_path):
     """BASELINE size (32 sequences x 59 steps): conditioning-aware parity (see check_rollout_conditioned) plus the
     gradient check on an 8-step chain judged against an fp64 oracle.  (The adjoint is amplified like the forward error:
     at 12-16 steps two fp32 implementations already differ by 1-10 % of a gradient whose scale itself varies over three
@@ -48,7 +63,7 @@ def test_rollout_full_length(gpu_lib, dev):
     RC.check_rollout(gpu_lib, dev, B=32, S=8, seed=4, fwd_tol=1e-3, grad_rtol=1e-2, cond_aware=True)
 
 
-def test_rollout_determinism(gpu_lib, dev):
+def test_rollout_determinism(gpu_lib, dev, fwd_path):
     hm, _ = RC.make_model(gpu_lib, dev)
     g = torch.Generator().manual_seed(1)
     past = RC.canonical_state(8, g).to(dev)
@@ -58,7 +73,7 @@ def test_rollout_determinism(gpu_lib, dev):
     assert torch.equal(a, b)
 
 
-def test_rollout_accumulate_policy(gpu_lib, dev):
+def test_rollout_accumulate_policy(gpu_lib, dev, chain_only):
     """ha_tune_set("layer_acc", 1) (fp32-atomic accumulation of the K-split partial tiles, off by default) against the fixed-order
     partial-slab path: same values and gradients up to the summation order of <= 5 partials per element."""
     hm, _ = RC.make_model(gpu_lib, dev, contractive=True)
@@ -170,17 +185,6 @@ def test_persistent_forward_matches_launch_chain(gpu_lib, dev, variant):
         print('persistent vs chain', B, S, variant, RC.check_persistent_vs_chain(gpu_lib, dev, B, S, seed=B, variant=variant))
 
 
-def test_persistent_forward_flat_tolerance_vs_oracle(gpu_lib, dev):
-    """The persistent forward at the metric's batch against the oracle / the reference fixture, same flat bars as the launch chain."""
-    gpu_lib.call('ha_tune_set', b'rollout_persist', 1)
-    try:
-        print('persistent 32x59 vs oracle', RC.check_rollout_full_tiles(gpu_lib, dev, 32, 59))
-        print('persistent c4 fixture', RC.check_rollout_long(gpu_lib, dev, 'c4'))
-        RC.check_rollout(gpu_lib, dev, B=4, S=10, seed=4)
-    finally:
-        gpu_lib.call('ha_tune_set', b'rollout_persist', 0)
-
-
 def test_persistent_forward_determinism_and_reuse(gpu_lib, dev):
     """Back-to-back persistent launches on the same network (fresh stash each): bit-identical results, no stale granules."""
     hm, _ = RC.make_model(gpu_lib, dev, contractive=True)
@@ -190,7 +194,7 @@ def test_persistent_forward_determinism_and_reuse(gpu_lib, dev):
     try:
         outs = [RC.world_of(hm.roll_out(past, None, 59, z_seq=z)) for _ in range(6)]
     finally:
-        gpu_lib.call('ha_tune_set', b'rollout_persist', 0)
+        gpu_lib.call('ha_tune_set', b'rollout_persist', 1)
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
     assert RC.persist_status(gpu_lib, hm, dev)[1] == 0
