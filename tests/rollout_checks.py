@@ -180,24 +180,18 @@ def check_rollout_full_tiles(lib, device, B, S, seed=0):
     w_ref, (pm_r, pv_r) = H.roll_out(sd, past_c, z_c)
     gw, gm, gv = CC.det_weights(w_ref.shape, 0.1), CC.det_weights(pm_r.shape, 0.2), CC.det_weights(pv_r.shape, 0.3)
     g_ref = torch.autograd.grad((w_ref * gw).sum() + (pm_r * gm).sum() + (pv_r * gv).sum(), [past_c, z_c])
-    p64, z64 = past_c.detach().double().requires_grad_(True), z_c.detach().double().requires_grad_(True)
-    w64, (pm64, pv64) = H.roll_out({k: v.double() for k, v in sd.items()}, p64, z64)
-    g64 = torch.autograd.grad((w64 * gw.double()).sum() + (pm64 * gm.double()).sum() + (pv64 * gv.double()).sum(), [p64, z64])
-    drift = (w_ref.detach().double() - w64.detach()).abs().max().item()
+    # Kink flags: which sequences have a ReLU unit within fp32 rounding of its kink is a property of the inputs and weights, and
+    # finding them takes many oracle evaluations (the flagged set grows with the number of 1-ulp perturbations tried and saturates:
+    # 34 -> 56 -> 68 -> 69 sequences of 256 x 119 after fp64 / 4 / 8 / 12 perturbations).  oracle/make_kink_flags.py computes the union
+    # over an fp64 re-evaluation and 24 perturbations once in the build container -> tests/golden/rollout_kink_flags.npz; the oracle
+    # gradient itself is recomputed here.  2 % of the unflagged sequences may still be such cases (they stay under the kink bar).
+    flags = golden('rollout_kink_flags.npz')
+    assert seed == 0 and f'{B}x{S}' in flags.files, 'kink flags exist for the committed cases only (oracle/make_kink_flags.py)'
+    stable = flags[f'{B}x{S}'].astype(bool)
+    with torch.no_grad():
+        w64 = H.roll_out({k: v.double() for k, v in sd.items()}, past_c.detach().double(), z_c.detach().double())[0]
+    drift = (w_ref.detach().double() - w64).abs().max().item()
     assert drift < 2e-5, drift            # the chain itself is well conditioned
-    stable = (per_seq_rel(g_ref[0].numpy(), g64[0].numpy()) < 2e-4) & (per_seq_rel(g_ref[1].numpy(), g64[1].numpy()) < 2e-4)
-    # ... and under 1-ulp perturbations of the inputs (the second half of the generator's criterion: a ReLU unit within rounding
-    # distance of its kink is found by moving the fp32 inputs, not only by changing the precision).  The flagged set grows with the
-    # number of perturbations and saturates: at 256 x 119 the oracle's OWN gradient moves for 34 sequences under fp64, 56 with four
-    # perturbations, 68 with eight, 69 with twelve (~a quarter of the sequences have a ReLU unit within fp32 rounding of its kink
-    # somewhere in 119 steps x 6656 units); eight are used, and 2 % of the unflagged sequences may still be such cases.
-    for k in range(8):
-        gp = torch.Generator().manual_seed(7 + k)
-        pert = lambda v: (v.detach() * (1.0 + ((torch.rand(v.shape, generator=gp) > 0.5).float() * 2 - 1) * 2.0 ** -23)).requires_grad_(True)
-        pp, zp = pert(past_c), pert(z_c)
-        wp, (pmp, pvp) = H.roll_out(sd, pp, zp)
-        gpt = torch.autograd.grad((wp * gw).sum() + (pmp * gm).sum() + (pvp * gv).sum(), [pp, zp])
-        stable &= (per_seq_rel(gpt[0].numpy(), g_ref[0].numpy()) < 2e-4) & (per_seq_rel(gpt[1].numpy(), g_ref[1].numpy()) < 2e-4)
     past = past_c.detach().to(device).requires_grad_(True)
     z = z_c.detach().to(device).requires_grad_(True)
     out, (pm, pv) = hm.roll_out(past, None, S, z_seq=z, return_prior=True)

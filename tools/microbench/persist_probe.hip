@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
+#include "../../humor_amd/csrc/lane_reduce.h"
 typedef float vf4 __attribute__((ext_vector_type(4)));
 typedef unsigned uv2 __attribute__((ext_vector_type(2)));
 
@@ -36,6 +37,29 @@ __global__ void lane_probe(float* out) {
   { const uv2 s = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false); u = __uint_as_float(s.x) + __uint_as_float(s.y); }
   out[192 + l] = u;
 }
+// the reduce-scatter / all-gather sums of lane_reduce.h exactly as the kernel uses them; inputs are small integers (exact sums)
+__global__ void lr_probe(const float* in /* [16][64] */, float* out) {
+  const int l = threadIdx.x;
+  float v[16];
+  for (int n = 0; n < 16; ++n) v[n] = in[n * 64 + l];
+  float a[16];
+  for (int n = 0; n < 16; ++n) a[n] = v[n];
+  ha::lr::wave_sum16(a);
+  for (int n = 0; n < 16; ++n) out[n * 64 + l] = a[n];
+  float b[8];
+  for (int n = 0; n < 8; ++n) b[n] = v[n];
+  ha::lr::half_sum8(b);
+  for (int n = 0; n < 8; ++n) out[1024 + n * 64 + l] = b[n];
+  float c[8], o2[2];
+  for (int n = 0; n < 8; ++n) c[n] = v[n];
+  ha::lr::block_sum8(c, o2);
+  out[1536 + l] = o2[0];
+  out[1600 + l] = o2[1];
+  float d[4];
+  for (int n = 0; n < 4; ++n) d[n] = v[n];
+  out[1664 + l] = ha::lr::block_sum4(d);
+}
+
 __global__ void xcc_census(unsigned* xcc_of_block, unsigned long long* t) {
   extern __shared__ float smem[];
   if (threadIdx.x == 0) {
@@ -87,6 +111,45 @@ int main() {
   printf("2. permlane16_swap all-reduce: %s   permlane32_swap all-reduce: %s\n", b16 ? "FAIL" : "PASS", b32 ? "FAIL" : "PASS");
   printf("3. row_ror 8/4/2/1 row sum: %s   (b, j) block sum: %s\n", brow ? "FAIL" : "PASS", bblk ? "FAIL" : "PASS");
   fails += (b16 != 0) + (b32 != 0) + (brow != 0) + (bblk != 0);
+  // ---- 3b. lane_reduce.h ----
+  {
+    std::vector<float> hin(16 * 64), hout(1728);
+    unsigned rng = 12345u;
+    for (auto& x : hin) { rng = rng * 1664525u + 1013904223u; x = (float)((int)((rng >> 16) % 41) - 20); }
+    float *din, *dout;
+    hipMalloc(&din, hin.size() * 4); hipMalloc(&dout, hout.size() * 4);
+    hipMemcpy(din, hin.data(), hin.size() * 4, hipMemcpyHostToDevice);
+    lr_probe<<<1, 64>>>(din, dout);
+    hipMemcpy(hout.data(), dout, hout.size() * 4, hipMemcpyDeviceToHost);
+    int e16 = 0, e8 = 0, eb8 = 0, eb4 = 0;
+    for (int n = 0; n < 16; ++n) {
+      float tot = 0.f;
+      for (int l = 0; l < 64; ++l) tot += hin[n * 64 + l];
+      for (int l = 0; l < 64; ++l) if (hout[n * 64 + l] != tot) { if (e16 < 4) printf("wave_sum16: value %d lane %d got %g expected %g\n", n, l, hout[n * 64 + l], tot); ++e16; }
+    }
+    for (int n = 0; n < 8; ++n)
+      for (int hh = 0; hh < 2; ++hh) {
+        float tot = 0.f;
+        for (int l = 0; l < 32; ++l) tot += hin[n * 64 + 32 * hh + l];
+        for (int l = 0; l < 32; ++l) if (hout[1024 + n * 64 + 32 * hh + l] != tot) { if (e8 < 4) printf("half_sum8: value %d lane %d got %g expected %g\n", n, 32 * hh + l, hout[1024 + n * 64 + 32 * hh + l], tot); ++e8; }
+      }
+    for (int l = 0; l < 64; ++l) {
+      const int hh = l >> 5, p = (l >> 4) & 1, j = l & 3;
+      for (int e = 0; e < 2; ++e) {        // block_sum8: value 4 h + 2 p + e summed over the lanes with the same j
+        const int n = 4 * hh + 2 * p + e;
+        float tot = 0.f;
+        for (int k = 0; k < 16; ++k) tot += hin[n * 64 + 4 * k + j];
+        const float got = hout[1536 + 64 * e + l];
+        if (got != tot) { if (eb8 < 4) printf("block_sum8: lane %d out[%d] got %g expected %g\n", l, e, got, tot); ++eb8; }
+      }
+      const int n = 2 * hh + p;
+      float tot = 0.f;
+      for (int k = 0; k < 16; ++k) tot += hin[n * 64 + 4 * k + j];
+      if (hout[1664 + l] != tot) { if (eb4 < 4) printf("block_sum4: lane %d got %g expected %g\n", l, hout[1664 + l], tot); ++eb4; }
+    }
+    printf("3b. lane_reduce.h: wave_sum16 %s  half_sum8 %s  block_sum8 %s  block_sum4 %s\n", e16 ? "FAIL" : "PASS", e8 ? "FAIL" : "PASS", eb8 ? "FAIL" : "PASS", eb4 ? "FAIL" : "PASS");
+    fails += (e16 != 0) + (e8 != 0) + (eb8 != 0) + (eb4 != 0);
+  }
   // ---- 4. XCC census ----
   unsigned* xb;
   unsigned long long* tb;
