@@ -26,6 +26,7 @@
 
 #include <string.h>
 
+#include <utility>
 #include <vector>
 
 #include "rot_math.h"
@@ -43,6 +44,7 @@ constexpr int TEAM_CUS = 32, NTEAMS = 8, ROWS = 4, NWAVES_TEAM = TEAM_CUS * 4;
 constexpr int NC0 = P_XPAD / 16, NC1 = P_H0 / 16, NC2 = P_H1 / 16, NC3 = P_H2 / 16, NCZ = P_ZD / 16;
 // weight registers of a wave: [chunk][column group] per layer
 constexpr int R0 = 0, R1 = R0 + (NC0 + NCZ) * 2, R2 = R1 + (NC1 + NCZ) * 2, R3 = R2 + (NC2 + NCZ), NREG = R3 + (NC3 + NCZ);
+constexpr int NWA = 200;                // weight registers kept in AGPRs (the MFMAs' B operand reads them there); the rest in VGPRs
 constexpr int L3_WAVES = P_RAW / 4;      // 54 waves own the 216 output columns of the last layer
 // exchange space (bytes): 64-byte header, then per team the four activations as granules [channel][4 rows] x 8 B
 constexpr unsigned XCH_HDR = 256;
@@ -94,13 +96,13 @@ typedef unsigned puv4 __attribute__((ext_vector_type(4)));
 #ifdef HA_PERSIST_TIMING
 // profiling build only (tools/persist_phase_timing.py): phase timestamps (s_memtime) of one wave for steps PT_T0 .. PT_T0 + 7
 constexpr int PT_T0 = 8, PT_N = 24;
-__device__ unsigned long long g_pts[8][PT_N];
+__device__ unsigned long long g_pts[2][8][PT_N];      // [0]: team 0 member 5 (an ordinary CU), [1]: team 0 member 0 (the writer)
 #define PT(i)                                                                        \
   do {                                                                               \
-    if (pt_on && t >= PT_T0 && t < PT_T0 + 8) g_pts[t - PT_T0][i] = clock64();       \
+    if (pt_on && t >= PT_T0 && t < PT_T0 + 8) g_pts[pt_slot][t - PT_T0][i] = clock64(); \
   } while (0)
-#define PT_ARGS , bool pt_on, int t
-#define PT_PASS , pt_on, t
+#define PT_ARGS , bool pt_on, int pt_slot, int t
+#define PT_PASS , pt_on, pt_slot, t
 #else
 #define PT(i)
 #define PT_ARGS
@@ -192,46 +194,68 @@ __device__ __forceinline__ void load_a(const float* xs, const float* zs, int lan
     else if (c < NC_MAIN + NCZ) av[i] = zs[64 * (c - NC_MAIN) + lane];
   }
 }
-// NACC accumulators per column group, used round-robin: a dependent v_mfma_f32_4x4x1 accumulate has ~64 cycles of latency against
-// 8 cycles of issue (measured: 4 chains -> 14 cycles per MFMA, 2 chains -> 32), so a wave keeps 8 independent chains in flight
-template <int NC_MAIN, int NCG, int ROFF, int FIRST>
-__device__ __forceinline__ void mma_batch(const float (&av)[MB], const float (&w)[NREG], pvf4 (&acc)[NCG][8 / NCG]) {
-  constexpr int NACC = 8 / NCG;
-#pragma unroll
-  for (int i = 0; i < MB; ++i) {
-    const int c = FIRST + i;
-    if (c < NC_MAIN + NCZ) {
-#pragma unroll
-      for (int g = 0; g < NCG; ++g) acc[g][c % NACC] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i], w[ROFF + c * NCG + g], acc[g][c % NACC], 0, 0, 0);
-    }
+// The MFMAs are written as inline asm so that the weight operand can stay in the AGPR half of the wave's 512 registers: the B
+// operand of an MFMA may be an AGPR, but the compiler only reads weights it has first copied to a VGPR (v_accvgpr_read + s_nop + MFMA
+// through ONE temporary: 32 cycles per MFMA measured, against 8 of issue).  NWA weight registers live in AGPRs ("a"), the rest in
+// VGPRs ("v").  8 accumulators (AGPR quads) per wave are used round-robin: a dependent accumulate has ~64 cycles of latency, and
+// the asm statements are volatile so the rotation (distance 8 between two MFMAs on one accumulator) is kept as written.  The
+// compiler's hazard recogniser does not look inside asm: the first MFMA of a chain takes the literal 0 as its C operand (no
+// compiler-written accumulator is read), and mma_layer ends with s_nop 7 before the VALU reads the results.
+template <class F, int... I>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int R, bool FIRST>
+__device__ __forceinline__ void mfma_w(pvf4& acc, float av, const float (&wa)[NWA], const float (&wv)[NREG - NWA]) {
+  if constexpr (R < NWA) {
+    if constexpr (FIRST) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(av), "a"(wa[R]));
+    else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "a"(wa[R]));
+  } else {
+    if constexpr (FIRST) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(av), "v"(wv[R - NWA]));
+    else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(wv[R - NWA]));
   }
 }
 template <int NC_MAIN, int NCG, int ROFF, int FIRST>
+__device__ __forceinline__ void mma_batch(const float (&av)[MB], const float (&wa)[NWA], const float (&wv)[NREG - NWA], pvf4 (&acc)[NCG][8 / NCG]) {
+  constexpr int NACC = 8 / NCG;
+  // (compile-time chunk index: the weight register and the accumulator are template arguments of mfma_w)
+  auto body = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int c = FIRST + i;
+    if constexpr (c < NC_MAIN + NCZ) {
+      if constexpr (NCG == 2) {
+        mfma_w<ROFF + c * 2 + 0, (c < NACC)>(acc[0][c % NACC], av[i], wa, wv);
+        mfma_w<ROFF + c * 2 + 1, (c < NACC)>(acc[1][c % NACC], av[i], wa, wv);
+      } else {
+        mfma_w<ROFF + c, (c < NACC)>(acc[0][c % NACC], av[i], wa, wv);
+      }
+    }
+  };
+  static_for(body, std::make_integer_sequence<int, MB>{});
+}
+template <int NC_MAIN, int NCG, int ROFF, int FIRST>
 struct MmaSteps {
-  static __device__ __forceinline__ void run(const float* xs, const float* zs, const float (&w)[NREG], int lane, float (&cur)[MB],
-                                             pvf4 (&acc)[NCG][8 / NCG]) {
+  static __device__ __forceinline__ void run(const float* xs, const float* zs, const float (&wa)[NWA], const float (&wv)[NREG - NWA], int lane,
+                                             float (&cur)[MB], pvf4 (&acc)[NCG][8 / NCG]) {
     if constexpr (FIRST < NC_MAIN + NCZ) {
       float nxt[MB];
       if constexpr (FIRST + MB < NC_MAIN + NCZ) load_a<NC_MAIN, FIRST + MB>(xs, zs, lane, nxt);
       HA_SCHED_FENCE();
-      mma_batch<NC_MAIN, NCG, ROFF, FIRST>(cur, w, acc);
+      mma_batch<NC_MAIN, NCG, ROFF, FIRST>(cur, wa, wv, acc);
       HA_SCHED_FENCE();
-      MmaSteps<NC_MAIN, NCG, ROFF, FIRST + MB>::run(xs, zs, w, lane, nxt, acc);
+      MmaSteps<NC_MAIN, NCG, ROFF, FIRST + MB>::run(xs, zs, wa, wv, lane, nxt, acc);
     }
   }
 };
 // result: sums[4 g + i] = the lane's partial (its k-block) of column group g, row i
 template <int NC_MAIN, int NCG, int ROFF>
-__device__ __forceinline__ void mma_layer(const float* xs, const float* zs, const float (&w)[NREG], int lane, float (&sums)[4 * NCG]) {
+__device__ __forceinline__ void mma_layer(const float* xs, const float* zs, const float (&wa)[NWA], const float (&wv)[NREG - NWA], int lane,
+                                          float (&sums)[4 * NCG]) {
   constexpr int NACC = 8 / NCG;
+  static_assert(NC_MAIN + NCZ >= NACC, "every accumulator chain starts with a literal-0 MFMA");
   pvf4 acc[NCG][NACC];
-#pragma unroll
-  for (int g = 0; g < NCG; ++g)
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[g][k] = pvf4{0.f, 0.f, 0.f, 0.f};
   float first[MB];
   load_a<NC_MAIN, 0>(xs, zs, lane, first);
-  MmaSteps<NC_MAIN, NCG, ROFF, 0>::run(xs, zs, w, lane, first, acc);
+  MmaSteps<NC_MAIN, NCG, ROFF, 0>::run(xs, zs, wa, wv, lane, first, acc);
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // MFMA results -> VALU reads (hazard the compiler cannot see)
 #pragma unroll
   for (int g = 0; g < NCG; ++g) {
 #pragma unroll
@@ -318,11 +342,13 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   const bool writer = m == 0;                 // member 0 writes the per-sequence results (world states, state slabs)
 
   // ---- resident weights -------------------------------------------------------------------------------------------------
-  float w[NREG];
+  float wa[NWA], wv[NREG - NWA];
   {
     const float* wp = a.Wreg + (size_t)g * NREG * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < NREG; ++r) w[r] = wp[(size_t)r * 64];
+    for (int r = 0; r < NWA; ++r) wa[r] = wp[(size_t)r * 64];
+#pragma unroll
+    for (int r = NWA; r < NREG; ++r) wv[r - NWA] = wp[(size_t)r * 64];
   }
   // bias of the column this lane publishes (publish(): two-group layers lane (h, j) -> column 4 h + j of the wave's eight)
   const int j4 = lane & 3, h4 = 4 * (lane >> 5);
@@ -365,7 +391,8 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   }
 
 #ifdef HA_PERSIST_TIMING
-  const bool pt_on = team == 0 && m == 5 && tid == 0;
+  const bool pt_on = team == 0 && (m == 5 || m == 0) && tid == 0;
+  const int pt_slot = m == 0 ? 1 : 0;
 #endif
   bool fail = false;
   for (int t = 0; t < a.S; ++t) {
@@ -379,7 +406,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     // ---- layer 0: [x_t | z_t] (raw) -> 1024 ---------------------------------------------------------------------------
     {
       float acc[8];
-      mma_layer<NC0, 2, R0>(xs0, zs, w, lane, acc);
+      mma_layer<NC0, 2, R0>(xs0, zs, wa, wv, lane, acc);
       PT(1);
       publish<2, SC1>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, sp + a.off_dec[0], row0, lane);
       PT(2);
@@ -393,7 +420,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     PT(5);
     {
       float acc[8];
-      mma_layer<NC1, 2, R1>(xs1, zs, w, lane, acc);
+      mma_layer<NC1, 2, R1>(xs1, zs, wa, wv, lane, acc);
       PT(6);
       publish<2, SC1>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, sp + a.off_dec[1], row0, lane);
       PT(7);
@@ -407,7 +434,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     PT(10);
     {
       float acc[4];
-      mma_layer<NC2, 1, R2>(xs2, zs, w, lane, acc);
+      mma_layer<NC2, 1, R2>(xs2, zs, wa, wv, lane, acc);
       PT(11);
       publish<1, SC1>(acc, b2, 4 * g, team_xch, rs, ACT_OFF2, tag + 3, sp + a.off_dec[2], row0, lane);
       PT(12);
@@ -421,7 +448,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     PT(15);
     if (g < L3_WAVES) {       // (wave-uniform)
       float acc[4];
-      mma_layer<NC3, 1, R3>(xs3, zs, w, lane, acc);
+      mma_layer<NC3, 1, R3>(xs3, zs, wa, wv, lane, acc);
       PT(16);
       publish<1, SC1>(acc, b3, 4 * g, team_xch, rs, ACT_OFF3, tag + 4, sp + a.off_dec[3], row0, lane);
       PT(17);
@@ -583,9 +610,9 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
 
 #ifdef HA_PERSIST_TIMING
 }  // namespace ha
-extern "C" int ha_debug_persist_timing(unsigned long long* out /* [8][24] */) {
+extern "C" int ha_debug_persist_timing(unsigned long long* out /* [2][8][24] */) {
   HA_CHECK_HIP(hipDeviceSynchronize());
-  HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_pts), sizeof(unsigned long long) * 8 * 24));
+  HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_pts), sizeof(unsigned long long) * 2 * 8 * 24));
   return HA_OK;
 }
 namespace ha {

@@ -435,7 +435,12 @@ def check_persistent_vs_chain(lib, device, B, S, seed=0, variant=1, contractive=
     errs = []
     for name, a, b, tol in zip(('world', 'prior_mu', 'prior_var', 'g_past', 'g_z'), res[0], res[1], (2e-5, 2e-5, 2e-5, 2e-4, 2e-4)):
         assert torch.isfinite(b).all(), name
-        e = (a - b).abs().max().item() / max(1.0, a.abs().max().item())
-        errs.append(e)
-        assert e <= tol, (name, e, B, S)
+        e = (a - b).abs().reshape(B, -1).amax(dim=1) / max(1.0, a.abs().max().item())       # per sequence
+        errs.append(e.max().item())
+        if name.startswith('g_'):
+            # two fp32 evaluations with different summation orders: a sequence with a ReLU unit within rounding of its kink moves by
+            # ~1e-3 (see check_rollout_full_tiles); at most one sequence in ten may, and never beyond the kink bar
+            assert int((e > tol).sum()) <= max(1, B // 10) and e.max().item() <= KINK_RTOL, (name, e.tolist(), B, S)
+        else:
+            assert e.max().item() <= tol, (name, e.max().item(), B, S)
     return errs

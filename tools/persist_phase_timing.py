@@ -20,17 +20,18 @@ with torch.no_grad():
     for _ in range(3):
         hm.roll_out(past, None, S, z_seq=z)
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * (8 * 24))()
+buf = (C.c_ulonglong * (2 * 8 * 24))()
 fn = lib._dll.ha_debug_persist_timing
 fn.restype = C.c_int
 assert fn(buf) == 0
-ts = np.array(list(buf), dtype=np.int64).reshape(8, 24)
+both = np.array(list(buf), dtype=np.int64).reshape(2, 8, 24)
 names = ['top', 'L0 mma', 'L0 publish', 'L1 sweep', 'L1 GN', 'L1 barrier', 'L1 mma', 'L1 publish', 'L2 sweep', 'L2 GN', 'L2 barrier', 'L2 mma',
          'L2 publish', 'L3 sweep', 'L3 GN', 'L3 barrier', 'L3 mma', 'L3 publish', 'raw sweep', 'raw barrier', 'glue']
-d = np.diff(ts[:, :21], axis=1)
-step = ts[1:, 0] - ts[:-1, 0]
-print('ticks per step (s_memtime):', step.tolist(), ' (100 MHz ticks -> x 10 ns)')
-print('%-12s %s' % ('phase', 'ticks to reach it from the previous phase, steps 8..15 | median'))
-for i, n in enumerate(names[1:]):
-    print('%-12s %s | %d' % (n, ' '.join('%5d' % v for v in d[:, i]), int(np.median(d[:, i]))))
-print('sum of medians', int(np.median(d, axis=0).sum()), 'median step', int(np.median(step)))
+for who, ts in (('member 5 (ordinary CU, layer-3 producer)', both[0]), ('member 0 (writer of the per-sequence results)', both[1])):
+    d = np.diff(ts[:, :21], axis=1)
+    step = ts[1:, 0] - ts[:-1, 0]
+    print(who, '-- cycles per step (s_memtime = shader clock):', step.tolist())
+    print('%-12s %s' % ('phase', 'cycles to reach it from the previous phase, steps 8..15 | median'))
+    for i, n in enumerate(names[1:]):
+        print('%-12s %s | %d' % (n, ' '.join('%5d' % v for v in d[:, i]), int(np.median(d[:, i]))))
+    print('sum of medians', int(np.median(d, axis=0).sum()), 'median step', int(np.median(step)))
