@@ -53,7 +53,11 @@ constexpr unsigned TEAM_BYTES = ACT_OFF3 + P_RAWPAD * 32;
 constexpr unsigned XCH_BYTES = XCH_HDR + NTEAMS * TEAM_BYTES;
 // LDS (floats)
 constexpr int L_XS0 = 0, L_XS1 = L_XS0 + P_XPAD * 4, L_XS2 = L_XS1 + P_H0 * 4, L_XS3 = L_XS2 + P_H1 * 4, L_ZS = L_XS3 + P_H2 * 4;
-constexpr int L_SX = L_ZS + P_ZD * 4, L_SRAW = L_SX + ROWS * P_XPAD, L_MISC = L_SRAW + ROWS * P_RAWPAD, L_TOTAL = L_MISC + 64;
+constexpr int L_SX = L_ZS + P_ZD * 4, L_SRAW = L_SX + ROWS * P_XPAD, L_SW = L_SRAW + ROWS * P_RAWPAD, L_SG = L_SW + ROWS * P_XPAD;
+constexpr int L_DUMMY = L_SG + ROWS * 12, L_MISC = L_DUMMY + P_XPAD * 4, L_TOTAL = L_MISC + 64;      // (L_DUMMY: sink of group 1's second store)
+// per-step results of a team (world states, next state slab, accumulated transforms) leave through all 32 CUs, COPY_PER_CU floats each
+constexpr int COPY_WORLD = ROWS * P_STATE, COPY_XT = ROWS * P_DINP, COPY_G = ROWS * 12, COPY_TOTAL = COPY_WORLD + COPY_XT + COPY_G;
+constexpr int COPY_PER_CU = (COPY_TOTAL + TEAM_CUS - 1) / TEAM_CUS;
 constexpr int SPIN_LIMIT = 40000;        // bounded waits (~1 us per spin)
 }  // namespace
 
@@ -306,6 +310,36 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
   }
 }
 
+// rodrigues() of common.h with ONE argument reduction for sine and cosine (the glue is a dependent chain: every instruction counts)
+__device__ __forceinline__ void rodrigues_sc(const float r[3], float R[9]) {
+  const float ux = r[0] + 1e-8f, uy = r[1] + 1e-8f, uz = r[2] + 1e-8f;
+  const float t = sqrtf(ux * ux + uy * uy + uz * uz);
+  const float nx = r[0] / t, ny = r[1] / t, nz = r[2] / t;
+  float s, c;
+  sincosf(t, &s, &c);
+  const float c1 = 1.0f - c;
+  const float nn = nx * nx + ny * ny + nz * nz;
+  R[0] = 1.0f + c1 * (nx * nx - nn);
+  R[1] = -s * nz + c1 * (nx * ny);
+  R[2] = s * ny + c1 * (nx * nz);
+  R[3] = s * nz + c1 * (nx * ny);
+  R[4] = 1.0f + c1 * (ny * ny - nn);
+  R[5] = -s * nx + c1 * (ny * nz);
+  R[6] = -s * ny + c1 * (nx * nz);
+  R[7] = s * nx + c1 * (ny * nz);
+  R[8] = 1.0f + c1 * (nz * nz - nn);
+}
+// w2a_fwd() of rot_math.h (heading alignment, transforms.py:17-42) through rodrigues_sc
+__device__ __forceinline__ void w2a_sc(const float pR[9], float W[9]) {
+  const float rx = -pR[0], ry = -pR[3];
+  const float nrm = sqrtf(rx * rx + ry * ry);
+  const float u = rx / (nrm + 1e-6f);
+  const float angle = acosf(fminf(fmaxf(u, -1.0f), 1.0f));
+  const float sg = -ry / (fabsf(ry) + 1e-6f);
+  const float aa[3] = {0.f, 0.f, sg * angle};
+  rodrigues_sc(aa, W);
+}
+
 template <bool SC1>
 __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd_kernel(PersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -316,6 +350,9 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   float* zs = smem + L_ZS;
   float* sX = smem + L_SX;
   float* sRAW = smem + L_SRAW;
+  float* sW = smem + L_SW;
+  float* sG = smem + L_SG;
+  float* sDummy = smem + L_DUMMY;
   volatile int* misc = reinterpret_cast<volatile int*>(smem + L_MISC);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
@@ -390,6 +427,24 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     for (int c = 0; c < 3; ++c) a.t2j[(size_t)myrow * 3 + c] = t2j[c];
   }
 
+  // The results of step t (world states of the team's sequences, the next state slab, the accumulated transforms) sit in every CU's
+  // LDS after the glue (every CU computes them): CU m writes elements [m, m + 1) x COPY_PER_CU of the team's record, one coalesced
+  // store per thread.  Element order: world [row][348] | state slab quads [quad][row][4] | transforms [row][12].
+  auto copy_out = [&](int t) {
+    if (tid < COPY_PER_CU) {
+      const int e = m * COPY_PER_CU + tid;
+      if (e < COPY_WORLD) {
+        const int i = e / P_STATE, c = e - i * P_STATE;
+        if (row0 + i < a.B) a.world[((size_t)(row0 + i) * a.S + t) * P_STATE + c] = sW[i * P_XPAD + c];
+      } else if (e < COPY_WORLD + COPY_XT) {
+        const int e2 = e - COPY_WORLD, q = e2 >> 4, i = (e2 >> 2) & 3, k = e2 & 3;
+        a.xT[(size_t)(t + 1) * P_DINP * 32 + (size_t)q * 128 + (size_t)(row0 + i) * 4 + k] = sX[i * P_XPAD + 4 * q + k];
+      } else if (e < COPY_TOTAL) {
+        const int e3 = e - COPY_WORLD - COPY_XT;
+        a.steps[(size_t)(t + 1) * a.per_step + a.off_G + (size_t)row0 * 12 + e3] = sG[e3];
+      }
+    }
+  };
 #ifdef HA_PERSIST_TIMING
   const bool pt_on = team == 0 && (m == 5 || m == 0) && tid == 0;
   const int pt_slot = m == 0 ? 1 : 0;
@@ -402,6 +457,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     float z_next = 0.f;
     if (zlive && t + 1 < a.S) z_next = a.z_seq[((size_t)(row0 + zi) * a.S + (t + 1)) * P_ZD + zc];
     __syncthreads();                                   // xs0 / zs of this step are complete
+    if (t > 0) copy_out(t - 1);                        // (stores only: nothing waits for them)
     PT(0);
     // ---- layer 0: [x_t | z_t] (raw) -> 1024 ---------------------------------------------------------------------------
     {
@@ -469,11 +525,16 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     PT(19);
     if (tid < ROWS * P_ZD) zs[zc * 4 + zi] = z_next;
     {
-      // one wave per sequence: lanes 0..21 = joints; lanes 0..20 also body rotation b, lane 21 the root rotation
+      // One wave per sequence, two lane groups running the same instruction stream: group 0 (lanes 0..31) produces the next input
+      // state (frame change by the heading alignment W), group 1 (lanes 32..63) the world-frame output (frame change by the
+      // accumulated G^T).  In a group: lanes 0..21 = joints, lanes 0..20 also body rotation b, lane 21 the root.  Results go to LDS
+      // (next state: row-major for the next glue + [channel][row] as the next A operand; world state: staging); the global copies
+      // are written afterwards by all CUs of the team, one coalesced slice each (copy_out).
+      const int jj = lane & 31, grp = lane >> 5;
       const float* X = sX + wave * P_XPAD;
       const float* RW = sRAW + wave * P_RAWPAD;
-      const bool jl = lane < 22, root = lane == 21;
-      const int aoff = lane < 21 ? 12 + 3 * lane : 6, roff = lane < 21 ? 18 + 9 * lane : 6;
+      const bool jl = jj < 22, root = jj == 21;
+      const int aoff = jj < 21 ? 12 + 3 * jj : 6, roff = jj < 21 ? 18 + 9 * jj : 6;
       float pj[3] = {0.f, 0.f, 0.f}, jv[3] = {0.f, 0.f, 0.f}, pR[9], ptrans[3] = {0.f, 0.f, 0.f}, ptvel[3] = {0.f, 0.f, 0.f}, prvel[3] = {0.f, 0.f, 0.f};
       float Wm[9];
 #pragma unroll
@@ -482,13 +543,13 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
         float aa[3], dR[9], Rin[9];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          pj[c] = RW[75 + 3 * lane + c] + X[207 + 3 * lane + c];
-          jv[c] = RW[141 + 3 * lane + c] + X[273 + 3 * lane + c];
+          pj[c] = RW[75 + 3 * jj + c] + X[207 + 3 * jj + c];
+          jv[c] = RW[141 + 3 * jj + c] + X[273 + 3 * jj + c];
           aa[c] = RW[aoff + c];
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rin[i] = X[roff + i];
-        rodrigues(aa, dR);
+        rodrigues_sc(aa, dR);
         mat3_mul(dR, Rin, pR);
       }
       if (root) {
@@ -498,111 +559,87 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
           ptvel[c] = RW[3 + c] + X[3 + c];
           prvel[c] = RW[9 + c] + X[15 + c];
         }
-        W2A wa;
-        w2a_fwd(pR, wa);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Wm[i] = wa.W[i];
       }
+      if (lane == 21) w2a_sc(pR, Wm);
       const float craw = (lane >= 32 && lane < 41) ? RW[207 + lane - 32] : 0.f;      // contact logits
-      // the root lane's heading alignment and translation to every lane
+      // the root's heading alignment and translation to every lane
       float W[9], ptr[3];
 #pragma unroll
       for (int i = 0; i < 9; ++i) W[i] = as_f(__builtin_amdgcn_readlane(as_u(Wm[i]), 21));
 #pragma unroll
       for (int c = 0; c < 3; ++c) ptr[c] = as_f(__builtin_amdgcn_readlane(as_u(ptrans[c]), 21));
-      const float wt[3] = {-ptr[0], -ptr[1], 0.f};
-      const bool live = myrow < a.B;
-      float* WO = (writer && live) ? a.world + ((size_t)myrow * a.S + t) * P_STATE : nullptr;
-      float* XT = writer ? a.xT + (size_t)(t + 1) * P_DINP * 32 + (size_t)myrow * 4 : nullptr;
-      float* Xn = sX + wave * P_XPAD;
-      auto put_x = [&](int c, float v) {
-        Xn[c] = v;
-        xs0[c * 4 + wave] = v;
-        if (XT) XT[pq(c)] = v;
+      // group 0: y = W (p + wt + t2j) - t2j ; W v        group 1: y = G^T (p + t2j) - t2j - gt ; G^T v
+      float M[9], add[3], sub[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) M[3 * i + k] = grp ? G[3 * k + i] : W[3 * i + k];
+      add[0] = grp ? 0.f : -ptr[0];
+      add[1] = grp ? 0.f : -ptr[1];
+      add[2] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sub[c] = grp ? gt[c] : 0.f;
+      float* Wn = sW + wave * P_XPAD;
+      // group 0 -> next state (row-major + [channel][row]), group 1 -> world staging (+ a sink): two unconditional stores per value
+      float* dst1 = grp ? Wn : sX + wave * P_XPAD;
+      float* dst2 = (grp ? sDummy : xs0) + wave;
+      auto put = [&](int c, float v) {
+        dst1[c] = v;
+        dst2[c * 4] = v;
       };
       if (jl) {
         float q[3], o[3];
-        // next input: W (pj + wt + t2j) - t2j ; W jv       world: G^T (pj + t2j) - t2j - gt ; G^T jv
 #pragma unroll
-        for (int c = 0; c < 3; ++c) q[c] = pj[c] + wt[c] + t2j[c];
-        mat3_vec(W, q, o);
+        for (int c = 0; c < 3; ++c) q[c] = pj[c] + add[c] + t2j[c];
+        mat3_vec(M, q, o);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) put_x(207 + 3 * lane + c, o[c] - t2j[c]);
-        mat3_vec(W, jv, o);
+        for (int c = 0; c < 3; ++c) put(207 + 3 * jj + c, o[c] - t2j[c] - sub[c]);
+        mat3_vec(M, jv, o);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) put_x(273 + 3 * lane + c, o[c]);
-        if (WO) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) q[c] = pj[c] + t2j[c];
-          mat3_tvec(G, q, o);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) WO[207 + 3 * lane + c] = o[c] - t2j[c] - gt[c];
-          mat3_tvec(G, jv, o);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) WO[273 + 3 * lane + c] = o[c];
-        }
+        for (int c = 0; c < 3; ++c) put(273 + 3 * jj + c, o[c]);
         if (!root) {
 #pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            put_x(18 + 9 * lane + i, pR[i]);
-            if (WO) WO[18 + 9 * lane + i] = pR[i];
-          }
+          for (int i = 0; i < 9; ++i) put(18 + 9 * jj + i, pR[i]);
+        } else {
+          // root: trans' = M (ptrans + add) - sub ; tvel' = M ptvel ; R' = M pR ; rvel' = M prvel
+          float Rm[9];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) q[c] = ptrans[c] + add[c];
+          mat3_vec(M, q, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) put(c, o[c] - sub[c]);
+          mat3_vec(M, ptvel, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) put(3 + c, o[c]);
+          mat3_mul(M, pR, Rm);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) put(6 + i, Rm[i]);
+          mat3_vec(M, prvel, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) put(15 + c, o[c]);
         }
       }
-      if (WO && lane >= 32 && lane < 41) WO[339 + lane - 32] = craw;
-      if (XT && lane == 63) XT[pq(P_DIN)] = 0.f;          // pad channel of the state slab
-      // world translation of the predicted root (every lane: it feeds the carried transform)
-      float wtr[3], M[9];
+      if (lane >= 32 && lane < 41) Wn[339 + lane - 32] = craw;
+      // accumulate the world transform (every lane, identical): wtrans = G^T ptrans - gt ; G' = G W ; gt' = (-wtrans.x, -wtrans.y, 0)
+      float wtr[3], GW[9];
       mat3_tvec(G, ptr, wtr);
+      mat3_mul(G, W, GW);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) wtr[c] -= gt[c];
-      if (root) {
-        float q[3], o[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) q[c] = ptrans[c] + wt[c];
-        mat3_vec(W, q, o);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) put_x(c, o[c]);
-        mat3_vec(W, ptvel, o);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) put_x(3 + c, o[c]);
-        mat3_mul(W, pR, M);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) put_x(6 + i, M[i]);
-        mat3_vec(W, prvel, o);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) put_x(15 + c, o[c]);
-        if (WO) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) WO[c] = wtr[c];
-          mat3_tvec(G, ptvel, o);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) WO[3 + c] = o[c];
-          mat3_tmul(G, pR, M);
-#pragma unroll
-          for (int i = 0; i < 9; ++i) WO[6 + i] = M[i];
-          mat3_tvec(G, prvel, o);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) WO[15 + c] = o[c];
-        }
-      }
-      // accumulate the world transform: G' = G W, gt' = (-wtrans.x, -wtrans.y, 0)
-      mat3_mul(G, W, M);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) G[i] = M[i];
-      gt[0] = -wtr[0];
-      gt[1] = -wtr[1];
+      for (int i = 0; i < 9; ++i) G[i] = GW[i];
+      gt[0] = -(wtr[0] - gt[0]);
+      gt[1] = -(wtr[1] - gt[1]);
       gt[2] = 0.f;
-      if (writer && lane == 0) {
-        float* Gs = a.steps + (size_t)(t + 1) * a.per_step + a.off_G + (size_t)myrow * 12;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Gs[i] = G[i];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Gs[9 + c] = gt[c];
+      if (lane == 0) {
+        pvf4* gs = reinterpret_cast<pvf4*>(sG + wave * 12);
+        gs[0] = pvf4{GW[0], GW[1], GW[2], GW[3]};
+        gs[1] = pvf4{GW[4], GW[5], GW[6], GW[7]};
+        gs[2] = pvf4{GW[8], gt[0], gt[1], gt[2]};
       }
     }
     PT(20);
   }
+  __syncthreads();
+  if (!misc[2]) copy_out(a.S - 1);
   if (misc[2] && tid == 0) __hip_atomic_store(a.err, 0x200u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
