@@ -61,6 +61,9 @@ int g_rollout_groups = 0;
 // (default; granules published with plain stores: team = one XCD = one L2), 3 = on, granules published write-through (sc1).
 // Measured at 32 x 59 (profiles/r03_run1): decoder chain 30.1 -> 15.5 us per step (variant 3: 21.0), forward 1.96 -> 1.09 ms.
 int g_rollout_persist = 1;
+// ha_tune_set "rollout_persist_bwd": 1 (default) = behind a persistent forward the adjoint is ONE persistent launch too (reverse scan,
+// transposed weights resident, rollout_persist.hip); 0 = the launch-chain adjoint reads the persistent forward's stash.
+int g_rollout_persist_bwd = 1;
 
 struct PackedLayer {
   int Cin = 0, skip = 0, Nout = 0;
@@ -1491,6 +1494,8 @@ struct StashLayout {
   // persistent kernel; the adjoint reads it like a one-split partial slab
   bool single = false;
   size_t persist_ws = 0;         // exchange space of the persistent kernel
+  size_t off_gn[3] = {0, 0, 0}, off_gl = 0;   // single: per step GroupNorm statistics [16][32][2] x 3, glue record [32][32]
+  size_t dz_part = 0;            // single: partial dL/dz products of the persistent adjoint [S][31][32][48]
   size_t bwd_set = 0;            // acc: floats per step of the adjoint scratch (bwd_dec[] are offsets of step 0's set); else 0
   size_t bwd_begin = 0, bwd_floats = 0;
   int rd_f(int i) const { return (acc || single) ? 1 : nsf_dec[i]; }     // partial slabs a consumer of decoder layer i's output reads
@@ -1526,6 +1531,10 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, b
   L.off_G = ptake(RT * 32 * 12);
   for (int i = 0; i < net->n_dec; ++i) L.off_dec[i] = ptake((size_t)L.rd_f(i) * RT * net->dec[i].Nout_pad * 32);
   for (int i = 0; i + 1 < net->n_dec; ++i) L.off_hsum[i] = L.hsum ? ptake(RT * net->dec[i].Nout_pad * 32) : 0;
+  if (L.single) {
+    for (int i = 0; i < 3; ++i) L.off_gn[i] = ptake(16 * 32 * 2);
+    L.off_gl = ptake(32 * 32);
+  }
   L.per_step = p;
   L.steps = take(p * (size_t)(S + 1));
   size_t widest = 0;
@@ -1552,7 +1561,10 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, b
   }
   if (L.finish)
     L.fin[0] = take(RT * 1280 * 32);     // widest operand: K <= 1280 (checked at pack time)
-  if (L.single) L.persist_ws = take(persist_ws_floats());
+  if (L.single) {
+    L.persist_ws = take(persist_ws_floats());
+    L.dz_part = take((size_t)S * persist_dz_slots() * 32 * ZD);
+  }
   L.total = o;
 }
 
@@ -1763,7 +1775,7 @@ extern "C" int ha_humor_net_destroy(ha_humor_net* net) {
 extern "C" int ha_humor_persist_status(const ha_humor_net* net, int* available, unsigned int* error_word, int64_t* launches) {
   HA_REQUIRE(net && available && error_word && launches, "ha_humor_persist_status: null argument");
   *error_word = persist_error_word(net->persist);
-  *launches = persist_launches(net->persist);
+  *launches = persist_launches(net->persist) + (persist_launches_bwd(net->persist) << 32);
   *available = persist_usable(net->persist) ? 1 : 0;
   return HA_OK;
 }
@@ -1809,6 +1821,8 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
       f.past_in0 = past_in0; f.z_seq = z_seq; f.world = world;
       f.xT = stash + L.xT; f.steps = stash + L.steps; f.per_step = L.per_step; f.off_G = L.off_G;
       for (int l = 0; l < 4; ++l) f.off_dec[l] = L.off_dec[l];
+      for (int l = 0; l < 3; ++l) f.off_gn[l] = L.off_gn[l];
+      f.off_gl = L.off_gl;
       f.t2j = stash + L.t2j;
       f.ws = stash + L.persist_ws;
       return persist_forward(net->persist, f, g_rollout_persist >> 1, st);
@@ -2000,6 +2014,25 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
     }
   };
 
+  const bool persist_bwd = L.single && g_rollout_persist_bwd != 0;
+  if (persist_bwd) {
+    if (phase == PH_BEGIN) {
+      PersistBwd f;
+      f.B = B; f.S = S;
+      f.g_world = g_world;
+      f.gx_pri = with_prior ? stash + L.gx_pri : nullptr; f.gxp_pad = gxp_pad;
+      f.xT = stash + L.xT; f.steps = stash + L.steps; f.per_step = L.per_step; f.off_G = L.off_G;
+      for (int l = 0; l < 4; ++l) f.off_dec[l] = L.off_dec[l];
+      for (int l = 0; l < 3; ++l) f.off_gn[l] = L.off_gn[l];
+      f.off_gl = L.off_gl;
+      f.t2j = stash + L.t2j;
+      f.g_past0 = g_past_in0; f.g_z = g_z_seq;
+      f.dz_part = stash + L.dz_part;
+      f.ws = stash + L.persist_ws;
+      return persist_backward(net->persist, f, g_rollout_persist >> 1, st);
+    }
+    return HA_OK;
+  }
   if (phase == PH_BEGIN) return HA_OK;
   if (phase == PH_STEP) {
     GlueParams g;

@@ -16,19 +16,40 @@ struct PersistFwd {
   float* xT = nullptr;               // [(S+1)][340][32]   input states of all steps (quad-interleaved 32-row tile)
   float* steps = nullptr;            // per-step region base
   size_t per_step = 0, off_G = 0, off_dec[4] = {0, 0, 0, 0};
+  size_t off_gn[3] = {0, 0, 0}, off_gl = 0;   // per step: GroupNorm statistics of the hidden activations; glue record (for the persistent adjoint)
   float* t2j = nullptr;              // [32][3]
   float* ws = nullptr;               // persist_ws_floats() floats of exchange space (zeroed by persist_forward before the launch)
 };
 
+// The adjoint of the same roll-out: reads the forward's stash (states, decoder pre-activations, GroupNorm statistics, glue
+// records, accumulated transforms) and the prior's dL/dx slabs, writes dL/dpast_in0 and dL/dz.
+struct PersistBwd {
+  int B = 0, S = 0;
+  const float* g_world = nullptr;    // [B][S][348] or null
+  const float* gx_pri = nullptr;     // [S][gxp_pad][32] or null
+  int gxp_pad = 0;
+  const float* xT = nullptr;
+  const float* steps = nullptr;
+  size_t per_step = 0, off_G = 0, off_dec[4] = {0, 0, 0, 0}, off_gn[3] = {0, 0, 0}, off_gl = 0;
+  const float* t2j = nullptr;
+  float* g_past0 = nullptr;          // [B][339]
+  float* g_z = nullptr;              // [B][S][48]
+  float* dz_part = nullptr;          // [S][persist_dz_slots()][32][48]
+  float* ws = nullptr;
+};
+
 size_t persist_ws_floats();
+int persist_dz_slots();      // partial dL/dz products per (step, sequence) written by the persistent adjoint
 // *out stays null (and HA_OK is returned) when the network or the device does not have the shape this path is built for
 int persist_create(PersistNet** out, int device, const ha_mlp_desc* decoder);
 void persist_destroy(PersistNet* p);
 // false after a launch has reported a failure (a team that never completed): the caller then uses the launch chain
 bool persist_usable(PersistNet* p);
 int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t st);
+int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_t st);
 // error word of the most recent launches (0 = none); valid after the stream has been synchronised
 unsigned persist_error_word(PersistNet* p);
 long long persist_launches(PersistNet* p);
+long long persist_launches_bwd(PersistNet* p);
 
 }  // namespace ha

@@ -49,19 +49,44 @@ constexpr int L3_WAVES = P_RAW / 4;      // 54 waves own the 216 output columns 
 // exchange space (bytes): 64-byte header, then per team the four activations as granules [channel][4 rows] x 8 B
 constexpr unsigned XCH_HDR = 256;
 constexpr unsigned ACT_OFF0 = 0, ACT_OFF1 = ACT_OFF0 + P_H0 * 32, ACT_OFF2 = ACT_OFF1 + P_H1 * 32, ACT_OFF3 = ACT_OFF2 + P_H2 * 32;
-constexpr unsigned TEAM_BYTES = ACT_OFF3 + P_RAWPAD * 32;
+constexpr unsigned TEAM_BYTES = ACT_OFF3 + P_XPAD * 32;       // (the adjoint's last buffer, dL/dx through layer 0, is the widest: 352 channels)
 constexpr unsigned XCH_BYTES = XCH_HDR + NTEAMS * TEAM_BYTES;
 // LDS (floats)
 constexpr int L_XS0 = 0, L_XS1 = L_XS0 + P_XPAD * 4, L_XS2 = L_XS1 + P_H0 * 4, L_XS3 = L_XS2 + P_H1 * 4, L_ZS = L_XS3 + P_H2 * 4;
 constexpr int L_SX = L_ZS + P_ZD * 4, L_SRAW = L_SX + ROWS * P_XPAD, L_SW = L_SRAW + ROWS * P_RAWPAD, L_SG = L_SW + ROWS * P_XPAD;
-constexpr int L_DUMMY = L_SG + ROWS * 12, L_MISC = L_DUMMY + P_XPAD * 4, L_TOTAL = L_MISC + 64;      // (L_DUMMY: sink of group 1's second store)
+constexpr int L_SGL = L_SG + ROWS * 12 + 16, L_DUMMY = L_SGL + ROWS * 32, L_MISC = L_DUMMY + P_XPAD * 4, L_TOTAL = L_MISC + 64;      // (L_DUMMY: sink of group 1's second store)
 // per-step results of a team (world states, next state slab, accumulated transforms) leave through all 32 CUs, COPY_PER_CU floats each
-constexpr int COPY_WORLD = ROWS * P_STATE, COPY_XT = ROWS * P_DINP, COPY_G = ROWS * 12, COPY_TOTAL = COPY_WORLD + COPY_XT + COPY_G;
+constexpr int COPY_WORLD = ROWS * P_STATE, COPY_XT = ROWS * P_DINP, COPY_G = ROWS * 12, COPY_GL = ROWS * 32;
+constexpr int COPY_TOTAL = COPY_WORLD + COPY_XT + COPY_G + COPY_GL;
 constexpr int COPY_PER_CU = (COPY_TOTAL + TEAM_CUS - 1) / TEAM_CUS;
 constexpr int SPIN_LIMIT = 40000;        // bounded waits (~1 us per spin)
+
+// ---- persistent adjoint: transposed layers, K chunks = forward output channels / 16 ---------------------------------------------
+constexpr int BC3 = P_RAWPAD / 16, BC2 = P_H2 / 16, BC1 = P_H1 / 16, BC0 = P_H0 / 16;
+// weight registers of a wave: main products (dL/d activation), then its share of the dL/dz products
+constexpr int BR3 = 0, BR2 = BR3 + BC3, BR1 = BR2 + BC2 * 2, BR0 = BR1 + BC1 * 2;
+constexpr int DZ0_CH = 8, DZ1_CH = 8, DZ2_CH = 4, DZ3_CH = 2;             // chunks per dL/dz task (12 column groups x K splits)
+constexpr int DZ0_WAVES = 12 * (BC0 / DZ0_CH), DZ1_WAVES = 12 * (BC1 / DZ1_CH), DZ2_WAVES = 12 * (BC2 / DZ2_CH), DZ3_WAVES = 12 * (BC3 / DZ3_CH);
+constexpr int BRZ0 = BR0 + BC0, BRZ1 = BRZ0 + DZ0_CH, BRZ2 = BRZ1 + DZ1_CH, BRZ3 = BRZ2 + DZ2_CH, NREG_B_ALL = BRZ3 + DZ3_CH;
+constexpr int NREG_B = BRZ0, NDZ = NREG_B_ALL - NREG_B;       // registers: the main products; LDS: the wave's dL/dz weights [NDZ][64 lanes]
+constexpr int NWA_B = 200;
+constexpr int L0T_WAVES = P_XPAD / 4 - 3;      // 85 waves own the 340 columns of dL/dx through layer 0
+// partial dL/dz slots per (step, sequence): K splits of the four layers, summed in this order by dz_reduce_kernel
+constexpr int DZ_S0 = 0, DZ_S1 = DZ_S0 + BC0 / DZ0_CH, DZ_S2 = DZ_S1 + BC1 / DZ1_CH, DZ_S3 = DZ_S2 + BC2 / DZ2_CH, DZ_SLOTS = DZ_S3 + BC3 / DZ3_CH;
+// exchange space of the adjoint (granules [channel][4 rows] x 8 B per team; same region as the forward's)
+constexpr unsigned GA_OFF3 = 0, GA_OFF2 = GA_OFF3 + P_H2 * 32, GA_OFF1 = GA_OFF2 + P_H1 * 32, GX_OFF0 = GA_OFF1 + P_H0 * 32;
+static_assert(GX_OFF0 + P_XPAD * 32 <= TEAM_BYTES, "the adjoint's exchange buffers fit the forward's region");
+// LDS of the adjoint (floats): per-step inputs double-buffered (prefetched one step ahead), operands, adjoint states
+constexpr int PF_X = 0, PF_RAW = PF_X + ROWS * P_XPAD, PF_GW = PF_RAW + ROWS * P_RAWPAD, PF_GL = PF_GW + ROWS * P_XPAD, PF_G = PF_GL + ROWS * 32;
+constexpr int PF_GXP = PF_G + 64, PF_SIZE = PF_GXP + ROWS * P_XPAD;
+constexpr int LB_PF = 0, LB_D3 = LB_PF + 2 * PF_SIZE, LB_D2 = LB_D3 + P_RAWPAD * 4, LB_D1 = LB_D2 + P_H2 * 4, LB_D0 = LB_D1 + P_H1 * 4;
+constexpr int LB_GXN = LB_D0 + P_H0 * 4, LB_GXD = LB_GXN + ROWS * P_XPAD, LB_CARRY = LB_GXD + ROWS * P_XPAD, LB_MISC = LB_CARRY + 80;
+constexpr int LB_GB = LB_MISC + 64, LB_WZ = LB_GB + 2 * (P_H0 + P_H1 + P_H2);      // GroupNorm affine: gamma | beta of the three activations
+constexpr int LB_TOTAL = LB_WZ + 4 * NDZ * 64;                                      // dL/dz weights of the CU's four waves
 }  // namespace
 
 size_t persist_ws_floats() { return (XCH_BYTES + 3) / 4; }
+int persist_dz_slots() { return DZ_SLOTS; }
 
 struct PersistArgs {
   int B, S;
@@ -75,6 +100,7 @@ struct PersistArgs {
   float* xT;
   float* steps;
   size_t per_step, off_G, off_dec[4];
+  size_t off_gn[3], off_gl;  // per step: GroupNorm statistics [16 groups][32 rows][2] of the three hidden activations; glue record [32 rows][32]
   float* t2j;
   unsigned char* xch;
   unsigned* err;            // host-mapped error word
@@ -83,13 +109,14 @@ struct PersistArgs {
 struct PersistNet {
   int device = 0;
   float* Wreg = nullptr;
+  float* Wreg_b = nullptr;          // transposed layers for the adjoint
   float* bias[4] = {nullptr, nullptr, nullptr, nullptr};
   float* gamma[3] = {nullptr, nullptr, nullptr};
   float* beta[3] = {nullptr, nullptr, nullptr};
   unsigned* err_host = nullptr;    // hipHostMalloc'ed, mapped
   unsigned* err_dev = nullptr;
   bool disabled = false;
-  long long launches = 0;
+  long long launches = 0, launches_bwd = 0;
 };
 
 #ifndef HA_SIMT_EMU
@@ -145,9 +172,10 @@ __device__ __forceinline__ bool sweep(__amdgpu_buffer_rsrc_t rs, unsigned off, u
 
 // consumer side of a hidden activation: sweep, GroupNorm (two-pass statistics per row and group of GROUP channels) + ReLU, the
 // finished A operand to LDS as [channel][4 rows]
+// stats (or null): the (mean, rstd) of every (group, row) go to stats[group][32 rows][2] for the adjoint (one CU of the team writes)
 template <int NQ, int GROUP, int PTI = 0>
 __device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float (&gam)[NQ], const float (&bet)[NQ],
-                                            float* xs, int tid PT_ARGS) {
+                                            float* xs, int tid, float* stats, int row0 PT_ARGS) {
   float x[NQ][4];
   if (!sweep<NQ>(rs, off, tag, true, tid, x)) return false;
   PT(PTI);
@@ -174,13 +202,20 @@ __device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned 
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     pvf4 o;
+    float rs4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       // (v_rsq_f32 itself: the argument is >= 1e-5, so rsqrtf's denormal pre-scaling never applies and the result is the same)
-      const float rstd = __builtin_amdgcn_rsqf(var[4 * q + i] * inv_n + 1e-5f);
-      o[i] = fmaxf((x[q][i] - mu[4 * q + i]) * rstd * gam[q] + bet[q], 0.f);
+      rs4[i] = __builtin_amdgcn_rsqf(var[4 * q + i] * inv_n + 1e-5f);
+      o[i] = fmaxf((x[q][i] - mu[4 * q + i]) * rs4[i] * gam[q] + bet[q], 0.f);
     }
     *reinterpret_cast<pvf4*>(xs + (size_t)(tid + 256 * q) * 4) = o;
+    if (stats && (tid & (GROUP - 1)) == 0) {        // one lane per group: its channel tid + 256 q lies in group (tid + 256 q) / GROUP
+      const int grp = (tid + 256 * q) / GROUP;
+      pvf4* sp = reinterpret_cast<pvf4*>(stats + ((size_t)grp * 32 + row0) * 2);
+      sp[0] = pvf4{mu[4 * q], rs4[0], mu[4 * q + 1], rs4[1]};
+      sp[1] = pvf4{mu[4 * q + 2], rs4[2], mu[4 * q + 3], rs4[3]};
+    }
   }
   return true;
 }
@@ -189,13 +224,13 @@ __device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned 
 // MB chunks, the next batch's reads issued ahead of the current batch's MFMAs (the compiler otherwise waits for every read right
 // before its first use: one LDS round trip per 4 MFMAs); two accumulators per column group break the 2-pass dependent chain.
 constexpr int MB = 16;
-template <int NC_MAIN, int FIRST>
+template <int NC_MAIN, int NZ, int FIRST>
 __device__ __forceinline__ void load_a(const float* xs, const float* zs, int lane, float (&av)[MB]) {
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
     const int c = FIRST + i;
     if (c < NC_MAIN) av[i] = xs[64 * c + lane];
-    else if (c < NC_MAIN + NCZ) av[i] = zs[64 * (c - NC_MAIN) + lane];
+    else if (c < NC_MAIN + NZ) av[i] = zs[64 * (c - NC_MAIN) + lane];
   }
 }
 // The MFMAs are written as inline asm so that the weight operand can stay in the AGPR half of the wave's 512 registers: the B
@@ -207,8 +242,9 @@ __device__ __forceinline__ void load_a(const float* xs, const float* zs, int lan
 // compiler-written accumulator is read), and mma_layer ends with s_nop 7 before the VALU reads the results.
 template <class F, int... I>
 __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int R, bool FIRST>
-__device__ __forceinline__ void mfma_w(pvf4& acc, float av, const float (&wa)[NWA], const float (&wv)[NREG - NWA]) {
+template <int R, bool FIRST, int NWAS, int NWVS>
+__device__ __forceinline__ void mfma_w(pvf4& acc, float av, const float (&wa)[NWAS], const float (&wv)[NWVS]) {
+  constexpr int NWA = NWAS;
   if constexpr (R < NWA) {
     if constexpr (FIRST) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(av), "a"(wa[R]));
     else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "a"(wa[R]));
@@ -217,9 +253,10 @@ __device__ __forceinline__ void mfma_w(pvf4& acc, float av, const float (&wa)[NW
     else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(wv[R - NWA]));
   }
 }
-template <int NC_MAIN, int NCG, int ROFF, int FIRST>
-__device__ __forceinline__ void mma_batch(const float (&av)[MB], const float (&wa)[NWA], const float (&wv)[NREG - NWA], pvf4 (&acc)[NCG][8 / NCG]) {
+template <int NC_MAIN, int NZ, int NCG, int ROFF, int FIRST, int NWAS, int NWVS>
+__device__ __forceinline__ void mma_batch(const float (&av)[MB], const float (&wa)[NWAS], const float (&wv)[NWVS], pvf4 (&acc)[NCG][8 / NCG]) {
   constexpr int NACC = 8 / NCG;
+  constexpr int NCZ = NZ;
   // (compile-time chunk index: the weight register and the accumulator are template arguments of mfma_w)
   auto body = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -235,37 +272,36 @@ __device__ __forceinline__ void mma_batch(const float (&av)[MB], const float (&w
   };
   static_for(body, std::make_integer_sequence<int, MB>{});
 }
-template <int NC_MAIN, int NCG, int ROFF, int FIRST>
+template <int NC_MAIN, int NZ, int NCG, int ROFF, int FIRST, int NWAS, int NWVS>
 struct MmaSteps {
-  static __device__ __forceinline__ void run(const float* xs, const float* zs, const float (&wa)[NWA], const float (&wv)[NREG - NWA], int lane,
+  static __device__ __forceinline__ void run(const float* xs, const float* zs, const float (&wa)[NWAS], const float (&wv)[NWVS], int lane,
                                              float (&cur)[MB], pvf4 (&acc)[NCG][8 / NCG]) {
-    if constexpr (FIRST < NC_MAIN + NCZ) {
+    if constexpr (FIRST < NC_MAIN + NZ) {
       float nxt[MB];
-      if constexpr (FIRST + MB < NC_MAIN + NCZ) load_a<NC_MAIN, FIRST + MB>(xs, zs, lane, nxt);
+      if constexpr (FIRST + MB < NC_MAIN + NZ) load_a<NC_MAIN, NZ, FIRST + MB>(xs, zs, lane, nxt);
       HA_SCHED_FENCE();
-      mma_batch<NC_MAIN, NCG, ROFF, FIRST>(cur, wa, wv, acc);
+      mma_batch<NC_MAIN, NZ, NCG, ROFF, FIRST>(cur, wa, wv, acc);
       HA_SCHED_FENCE();
-      MmaSteps<NC_MAIN, NCG, ROFF, FIRST + MB>::run(xs, zs, wa, wv, lane, nxt, acc);
+      MmaSteps<NC_MAIN, NZ, NCG, ROFF, FIRST + MB, NWAS, NWVS>::run(xs, zs, wa, wv, lane, nxt, acc);
     }
   }
 };
 // result: sums[4 g + i] = the lane's partial (its k-block) of column group g, row i
-template <int NC_MAIN, int NCG, int ROFF>
-__device__ __forceinline__ void mma_layer(const float* xs, const float* zs, const float (&wa)[NWA], const float (&wv)[NREG - NWA], int lane,
+// (NC_MAIN chunks from xs, then NZ chunks from zs; when fewer chunks than chains exist only the first NC_MAIN + NZ chains are used)
+template <int NC_MAIN, int NZ, int NCG, int ROFF, int NWAS, int NWVS>
+__device__ __forceinline__ void mma_layer(const float* xs, const float* zs, const float (&wa)[NWAS], const float (&wv)[NWVS], int lane,
                                           float (&sums)[4 * NCG]) {
-  constexpr int NACC = 8 / NCG;
-  static_assert(NC_MAIN + NCZ >= NACC, "every accumulator chain starts with a literal-0 MFMA");
-  pvf4 acc[NCG][NACC];
+  constexpr int NACC = (8 / NCG) < (NC_MAIN + NZ) ? (8 / NCG) : (NC_MAIN + NZ);
+  static_assert(NCG == 1 || NC_MAIN + NZ >= 4, "two column groups: four chains each");
+  pvf4 acc[NCG][8 / NCG];
   float first[MB];
-  load_a<NC_MAIN, 0>(xs, zs, lane, first);
-  MmaSteps<NC_MAIN, NCG, ROFF, 0>::run(xs, zs, wa, wv, lane, first, acc);
+  load_a<NC_MAIN, NZ, 0>(xs, zs, lane, first);
+  MmaSteps<NC_MAIN, NZ, NCG, ROFF, 0, NWAS, NWVS>::run(xs, zs, wa, wv, lane, first, acc);
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // MFMA results -> VALU reads (hazard the compiler cannot see)
 #pragma unroll
   for (int g = 0; g < NCG; ++g) {
 #pragma unroll
-    for (int st = NACC / 2; st >= 1; st /= 2)
-#pragma unroll
-      for (int k = 0; k < st; ++k) acc[g][k] += acc[g][k + st];
+    for (int k = 1; k < NACC; ++k) acc[g][0] += acc[g][k];
 #pragma unroll
     for (int i = 0; i < 4; ++i) sums[4 * g + i] = acc[g][0][i];
   }
@@ -291,9 +327,11 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
       const unsigned goff = off + (unsigned)col * 32u + (unsigned)p * 16u;
       if (SC1) __builtin_amdgcn_raw_buffer_store_b128(gr, rs, goff, 0, 16);
       else *reinterpret_cast<puv4*>(team_xch + goff) = gr;
-      float* sp = slab + pq(col) + (size_t)(row0 + 2 * p) * 4;
-      sp[0] = v0;
-      sp[4] = v1;
+      if (slab) {
+        float* sp = slab + pq(col) + (size_t)(row0 + 2 * p) * 4;
+        sp[0] = v0;
+        sp[4] = v1;
+      }
     }
   } else {
     const float t = lr::block_sum4(sums);
@@ -305,7 +343,7 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
       const unsigned goff = off + (unsigned)col * 32u + (unsigned)row * 8u;
       if (SC1) __builtin_amdgcn_raw_buffer_store_b64(gr, rs, goff, 0, 16);
       else *reinterpret_cast<puv2*>(team_xch + goff) = gr;
-      slab[pq(col) + (size_t)(row0 + row) * 4] = v0;
+      if (slab) slab[pq(col) + (size_t)(row0 + row) * 4] = v0;
     }
   }
 }
@@ -329,8 +367,8 @@ __device__ __forceinline__ void rodrigues_sc(const float r[3], float R[9]) {
   R[7] = s * nx + c1 * (ny * nz);
   R[8] = 1.0f + c1 * (nz * nz - nn);
 }
-// w2a_fwd() of rot_math.h (heading alignment, transforms.py:17-42) through rodrigues_sc
-__device__ __forceinline__ void w2a_sc(const float pR[9], float W[9]) {
+// w2a_fwd() of rot_math.h (heading alignment, transforms.py:17-42) through rodrigues_sc; returns the heading angle
+__device__ __forceinline__ float w2a_sc(const float pR[9], float W[9]) {
   const float rx = -pR[0], ry = -pR[3];
   const float nrm = sqrtf(rx * rx + ry * ry);
   const float u = rx / (nrm + 1e-6f);
@@ -338,6 +376,7 @@ __device__ __forceinline__ void w2a_sc(const float pR[9], float W[9]) {
   const float sg = -ry / (fabsf(ry) + 1e-6f);
   const float aa[3] = {0.f, 0.f, sg * angle};
   rodrigues_sc(aa, W);
+  return angle;
 }
 
 template <bool SC1>
@@ -352,6 +391,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   float* sRAW = smem + L_SRAW;
   float* sW = smem + L_SW;
   float* sG = smem + L_SG;
+  float* sGL = smem + L_SGL;
   float* sDummy = smem + L_DUMMY;
   volatile int* misc = reinterpret_cast<volatile int*>(smem + L_MISC);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -429,7 +469,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
 
   // The results of step t (world states of the team's sequences, the next state slab, the accumulated transforms) sit in every CU's
   // LDS after the glue (every CU computes them): CU m writes elements [m, m + 1) x COPY_PER_CU of the team's record, one coalesced
-  // store per thread.  Element order: world [row][348] | state slab quads [quad][row][4] | transforms [row][12].
+  // store per thread.  Element order: world [row][348] | state slab quads [quad][row][4] | transforms [row][12] | glue record [row][32].
   auto copy_out = [&](int t) {
     if (tid < COPY_PER_CU) {
       const int e = m * COPY_PER_CU + tid;
@@ -439,9 +479,12 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       } else if (e < COPY_WORLD + COPY_XT) {
         const int e2 = e - COPY_WORLD, q = e2 >> 4, i = (e2 >> 2) & 3, k = e2 & 3;
         a.xT[(size_t)(t + 1) * P_DINP * 32 + (size_t)q * 128 + (size_t)(row0 + i) * 4 + k] = sX[i * P_XPAD + 4 * q + k];
-      } else if (e < COPY_TOTAL) {
+      } else if (e < COPY_WORLD + COPY_XT + COPY_G) {
         const int e3 = e - COPY_WORLD - COPY_XT;
         a.steps[(size_t)(t + 1) * a.per_step + a.off_G + (size_t)row0 * 12 + e3] = sG[e3];
+      } else if (e < COPY_TOTAL) {
+        const int e4 = e - COPY_WORLD - COPY_XT - COPY_G;
+        a.steps[(size_t)t * a.per_step + a.off_gl + (size_t)row0 * 32 + e4] = sGL[e4];
       }
     }
   };
@@ -462,13 +505,13 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     // ---- layer 0: [x_t | z_t] (raw) -> 1024 ---------------------------------------------------------------------------
     {
       float acc[8];
-      mma_layer<NC0, 2, R0>(xs0, zs, wa, wv, lane, acc);
+      mma_layer<NC0, NCZ, 2, R0>(xs0, zs, wa, wv, lane, acc);
       PT(1);
       publish<2, SC1>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, sp + a.off_dec[0], row0, lane);
       PT(2);
     }
     // ---- layer 1 ----------------------------------------------------------------------------------------------------------
-    if (!gather_norm<4, 64, 3>(rs, ACT_OFF0, tag + 1, gam1, bet1, xs1, tid PT_PASS)) fail = true;
+    if (!gather_norm<4, 64, 3>(rs, ACT_OFF0, tag + 1, gam1, bet1, xs1, tid, m == 1 ? sp + a.off_gn[0] : nullptr, row0 PT_PASS)) fail = true;
     PT(4);
     if (fail) misc[2] = 1;
     __syncthreads();
@@ -476,13 +519,13 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     PT(5);
     {
       float acc[8];
-      mma_layer<NC1, 2, R1>(xs1, zs, wa, wv, lane, acc);
+      mma_layer<NC1, NCZ, 2, R1>(xs1, zs, wa, wv, lane, acc);
       PT(6);
       publish<2, SC1>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, sp + a.off_dec[1], row0, lane);
       PT(7);
     }
     // ---- layer 2 ----------------------------------------------------------------------------------------------------------
-    if (!gather_norm<4, 64, 8>(rs, ACT_OFF1, tag + 2, gam2, bet2, xs2, tid PT_PASS)) fail = true;
+    if (!gather_norm<4, 64, 8>(rs, ACT_OFF1, tag + 2, gam2, bet2, xs2, tid, m == 2 ? sp + a.off_gn[1] : nullptr, row0 PT_PASS)) fail = true;
     PT(9);
     if (fail) misc[2] = 1;
     __syncthreads();
@@ -490,13 +533,13 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     PT(10);
     {
       float acc[4];
-      mma_layer<NC2, 1, R2>(xs2, zs, wa, wv, lane, acc);
+      mma_layer<NC2, NCZ, 1, R2>(xs2, zs, wa, wv, lane, acc);
       PT(11);
       publish<1, SC1>(acc, b2, 4 * g, team_xch, rs, ACT_OFF2, tag + 3, sp + a.off_dec[2], row0, lane);
       PT(12);
     }
     // ---- layer 3 (GroupNorm groups of 32) -------------------------------------------------------------------------------
-    if (!gather_norm<2, 32, 13>(rs, ACT_OFF2, tag + 3, gam3, bet3, xs3, tid PT_PASS)) fail = true;
+    if (!gather_norm<2, 32, 13>(rs, ACT_OFF2, tag + 3, gam3, bet3, xs3, tid, m == 3 ? sp + a.off_gn[2] : nullptr, row0 PT_PASS)) fail = true;
     PT(14);
     if (fail) misc[2] = 1;
     __syncthreads();
@@ -504,7 +547,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     PT(15);
     if (g < L3_WAVES) {       // (wave-uniform)
       float acc[4];
-      mma_layer<NC3, 1, R3>(xs3, zs, wa, wv, lane, acc);
+      mma_layer<NC3, NCZ, 1, R3>(xs3, zs, wa, wv, lane, acc);
       PT(16);
       publish<1, SC1>(acc, b3, 4 * g, team_xch, rs, ACT_OFF3, tag + 4, sp + a.off_dec[3], row0, lane);
       PT(17);
@@ -539,8 +582,11 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float Wm[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) { pR[i] = 0.f; Wm[i] = 0.f; }
+      float dR[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) dR[i] = 0.f;
       if (jl) {
-        float aa[3], dR[9], Rin[9];
+        float aa[3], Rin[9];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           pj[c] = RW[75 + 3 * jj + c] + X[207 + 3 * jj + c];
@@ -560,7 +606,14 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
           prvel[c] = RW[9 + c] + X[15 + c];
         }
       }
-      if (lane == 21) w2a_sc(pR, Wm);
+      if (lane == 21) {
+        const float angle = w2a_sc(pR, Wm);
+        // record for the adjoint of this step: heading alignment W, predicted root rotation pR = dR Rin, dR, heading angle
+        float* gl = sGL + wave * 32;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { gl[i] = Wm[i]; gl[9 + i] = pR[i]; gl[18 + i] = dR[i]; }
+        gl[27] = angle;
+      }
       const float craw = (lane >= 32 && lane < 41) ? RW[207 + lane - 32] : 0.f;      // contact logits
       // the root's heading alignment and translation to every lane
       float W[9], ptr[3];
@@ -643,6 +696,569 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   if (misc[2] && tid == 0) __hip_atomic_store(a.err, 0x200u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+
+// a (x) b accumulated into M (3x3): M[i][k] += a_i b_k
+__device__ __forceinline__ void outer_acc3(float M[9], const float a[3], const float b[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) M[i * 3 + k] = fmaf(a[i], b[k], M[i * 3 + k]);
+}
+// a dL/dz task: CH chunks of the activation adjoint against the wave's LDS-resident latent-column weights
+template <int CH>
+__device__ __forceinline__ void dz_mma(const float* xs, const float* wl, int lane, float (&acc)[4]) {
+  pvf4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < CH; i += 2) {
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * i + lane], wl[64 * i + lane], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * (i + 1) + lane], wl[64 * (i + 1) + lane], c1, 0, 0, 0);
+  }
+  c0 += c1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = c0[i];
+}
+// one K-split partial of dL/dz (columns 4 cg .. 4 cg + 3 of the latent, the team's 4 rows) -> part[t][slot][row][48]
+__device__ __forceinline__ void dz_store(const float (&acc)[4], float* part, int t, int slot, int cg, int row0, int lane) {
+  const float v = lr::block_sum4(acc);
+  if ((lane & 12) == 0) {
+    const int row = 2 * (lane >> 5) + ((lane >> 4) & 1), j = lane & 3;
+    part[(((size_t)t * DZ_SLOTS + slot) * 32 + row0 + row) * P_ZD + 4 * cg + j] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent adjoint: the reverse scan over the S steps as ONE launch, same teams / exchange as the forward.
+// Per step t (S-1 .. 0) and team: total adjoint of x_{t+1} (own direct part + prior part + the layer-0 input gradient of step t+1
+// from the team) -> glue adjoint (one wave per sequence) -> dL/d(decoder output) -> four transposed layer products with the
+// GroupNorm/ReLU adjoints on the consumer side (statistics from the forward's stash), dL/dz as K-split partial products.
+// ---------------------------------------------------------------------------------------------------
+struct PersistBwdArgs {
+  int B, S;
+  const float* Wreg;        // [128 waves][NREG_B][64 lanes]
+  const float* gamma[3];
+  const float* beta[3];
+  const float* g_world;     // [B][S][348] or null
+  const float* gx_pri;      // [S][gxp_pad][32] or null: dL/dx_t through the prior, all steps
+  int gxp_pad;
+  const float* xT;
+  const float* steps;
+  size_t per_step, off_G, off_dec[4], off_gn[3], off_gl;
+  const float* t2j;
+  float* g_past0;           // [B][339]
+  float* dz_part;           // [S][DZ_SLOTS][32][48]
+  unsigned char* xch;
+  unsigned* err;
+};
+
+// R = rodrigues(r) and gr = dL/dr for gR = dL/dR, sharing the norm, the direction and ONE sine/cosine evaluation
+// (rodrigues() / rodrigues_bwd() of common.h fused)
+__device__ __forceinline__ void rod_fwd_bwd(const float r[3], const float gR[9], float R[9], float gr[3]) {
+  const float ux = r[0] + 1e-8f, uy = r[1] + 1e-8f, uz = r[2] + 1e-8f;
+  const float t = sqrtf(ux * ux + uy * uy + uz * uz);
+  const float it = 1.0f / t;
+  const float nx = r[0] / t, ny = r[1] / t, nz = r[2] / t;
+  float s, c;
+  sincosf(t, &s, &c);
+  const float c1 = 1.0f - c;
+  const float nn = nx * nx + ny * ny + nz * nz;
+  R[0] = 1.0f + c1 * (nx * nx - nn);
+  R[1] = -s * nz + c1 * (nx * ny);
+  R[2] = s * ny + c1 * (nx * nz);
+  R[3] = s * nz + c1 * (nx * ny);
+  R[4] = 1.0f + c1 * (ny * ny - nn);
+  R[5] = -s * nx + c1 * (ny * nz);
+  R[6] = -s * ny + c1 * (nx * nz);
+  R[7] = s * nx + c1 * (ny * nz);
+  R[8] = 1.0f + c1 * (nz * nz - nn);
+  const float gK_dot = -nz * gR[1] + ny * gR[2] + nz * gR[3] - nx * gR[5] - ny * gR[6] + nx * gR[7];
+  const float tr = gR[0] + gR[4] + gR[8];
+  const float nGn = nx * (gR[0] * nx + gR[1] * ny + gR[2] * nz) + ny * (gR[3] * nx + gR[4] * ny + gR[5] * nz) +
+                    nz * (gR[6] * nx + gR[7] * ny + gR[8] * nz);
+  const float gK2_dot = nGn - nn * tr;
+  const float gt = c * gK_dot + s * gK2_dot;
+  const float sx = (gR[0] + gR[0]) * nx + (gR[1] + gR[3]) * ny + (gR[2] + gR[6]) * nz;
+  const float sy = (gR[3] + gR[1]) * nx + (gR[4] + gR[4]) * ny + (gR[5] + gR[7]) * nz;
+  const float sz = (gR[6] + gR[2]) * nx + (gR[7] + gR[5]) * ny + (gR[8] + gR[8]) * nz;
+  const float gnx = s * (gR[7] - gR[5]) + c1 * (sx - 2.0f * tr * nx);
+  const float gny = s * (gR[2] - gR[6]) + c1 * (sy - 2.0f * tr * ny);
+  const float gnz = s * (gR[3] - gR[1]) + c1 * (sz - 2.0f * tr * nz);
+  const float gn_r = gnx * r[0] + gny * r[1] + gnz * r[2];
+  const float k = (gt - gn_r * it * it) * it;
+  gr[0] = gnx * it + k * ux;
+  gr[1] = gny * it + k * uy;
+  gr[2] = gnz * it + k * uz;
+}
+
+// consumer side of an activation adjoint: sweep dL/da (a = ReLU(GroupNorm(h))), the forward's h and statistics, GroupNorm/ReLU
+// adjoint (gn_apply mode 3 of the launch chain: dh = rstd (dxh - mean(dxh) - xh mean(dxh xh))), dh to LDS as [channel][4 rows]
+template <int NQ, int GROUP>
+__device__ __forceinline__ bool gather_norm_bwd(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float* gam_lds, const float* bet_lds,
+                                                const float* hslab, const float* stats, int row0, float* ds, int tid) {
+  // forward pre-activations and statistics of this thread's channels -> normalised activation xh (kept with rstd across the sweep)
+  float xh[NQ][4], rstd[NQ][4];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int c = tid + 256 * q;
+    const float* hp = hslab + pq(c) + (size_t)row0 * 4;
+    float h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = hp[i * 4];
+    const pvf4* sp = reinterpret_cast<const pvf4*>(stats + ((size_t)(c / GROUP) * 32 + row0) * 2);
+    const pvf4 s0 = sp[0], s1 = sp[1];
+    rstd[q][0] = s0.y; rstd[q][1] = s0.w; rstd[q][2] = s1.y; rstd[q][3] = s1.w;
+    xh[q][0] = (h[0] - s0.x) * s0.y; xh[q][1] = (h[1] - s0.z) * s0.w; xh[q][2] = (h[2] - s1.x) * s1.y; xh[q][3] = (h[3] - s1.z) * s1.w;
+  }
+  float ga[NQ][4];
+  if (!sweep<NQ>(rs, off, tag, true, tid, ga)) return false;
+  const float inv_n = 1.0f / (float)GROUP;
+  float dxh[NQ * 4], m2[NQ * 4];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float gam = gam_lds[tid + 256 * q], bet = bet_lds[tid + 256 * q];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float y = xh[q][i] * gam + bet;
+      dxh[4 * q + i] = (y > 0.f ? ga[q][i] : 0.f) * gam;
+      m2[4 * q + i] = dxh[4 * q + i] * xh[q][i];
+    }
+  }
+  float m1[NQ * 4];
+#pragma unroll
+  for (int k = 0; k < NQ * 4; ++k) m1[k] = dxh[k];
+  if constexpr (GROUP == 64) { lr::wave_sum16(m1); lr::wave_sum16(m2); }
+  else { lr::half_sum8(m1); lr::half_sum8(m2); }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    pvf4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = rstd[q][i] * (dxh[4 * q + i] - m1[4 * q + i] * inv_n - xh[q][i] * (m2[4 * q + i] * inv_n));
+    *reinterpret_cast<pvf4*>(ds + (size_t)(tid + 256 * q) * 4) = o;
+  }
+  return true;
+}
+
+template <bool SC1>
+__global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd_kernel(PersistBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sD3 = smem + LB_D3;
+  float* sD2 = smem + LB_D2;
+  float* sD1 = smem + LB_D1;
+  float* sD0 = smem + LB_D0;
+  float* sGXN = smem + LB_GXN;
+  float* sGXD = smem + LB_GXD;
+  float* sCarry = smem + LB_CARRY;
+  volatile int* misc = reinterpret_cast<volatile int*>(smem + LB_MISC);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    unsigned* cnt = reinterpret_cast<unsigned*>(a.xch);
+    misc[0] = (int)xcc;
+    misc[1] = (int)atomicAdd(cnt + xcc, 1u);
+    misc[2] = 0;
+  }
+  __syncthreads();
+  const int team = __builtin_amdgcn_readfirstlane(misc[0]), m = __builtin_amdgcn_readfirstlane(misc[1]);
+  if (m >= TEAM_CUS) {
+    if (tid == 0) __hip_atomic_store(a.err, 0x300u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  const int g = m * 4 + wave;
+  const int row0 = team * ROWS;
+  unsigned char* team_xch = a.xch + XCH_HDR + (size_t)team * TEAM_BYTES;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(team_xch, 0, TEAM_BYTES, 0x00020000);
+
+  // ---- resident transposed weights ------------------------------------------------------------------------------------------
+  float wa[NWA_B], wv[NREG_B - NWA_B];
+  float* sWz = smem + LB_WZ + wave * NDZ * 64;
+  {
+    const float* wp = a.Wreg + (size_t)g * NREG_B_ALL * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < NWA_B; ++r) wa[r] = wp[(size_t)r * 64];
+#pragma unroll
+    for (int r = NWA_B; r < NREG_B; ++r) wv[r - NWA_B] = wp[(size_t)r * 64];
+#pragma unroll
+    for (int r = 0; r < NDZ; ++r) sWz[r * 64 + lane] = wp[(size_t)(NREG_B + r) * 64];
+  }
+  // GroupNorm affine of the three hidden activations in LDS (register budget: 292 weight registers per wave)
+  float* sGam1 = smem + LB_GB;
+  float* sBet1 = sGam1 + P_H0;
+  float* sGam2 = sBet1 + P_H0;
+  float* sBet2 = sGam2 + P_H1;
+  float* sGam3 = sBet2 + P_H1;
+  float* sBet3 = sGam3 + P_H2;
+  for (int c = tid; c < P_H0; c += 256) { sGam1[c] = a.gamma[0][c]; sBet1[c] = a.beta[0][c]; sGam2[c] = a.gamma[1][c]; sBet2[c] = a.beta[1][c]; }
+  for (int c = tid; c < P_H2; c += 256) { sGam3[c] = a.gamma[2][c]; sBet3[c] = a.beta[2][c]; }
+
+  // ---- per-step inputs: (channel quad, row) per thread, 16-byte loads, one step ahead ---------------------------------------
+  // x_t (state slab), decoder output (slab 3), dL/dworld_t, glue record, accumulated transform, dL/dx_{t+1} through the prior
+  const int pq_q = tid >> 2, pq_i = tid & 3;                  // first pass: quads 0..63; second pass: quads 64..127
+  // two halves, each live in four 16-byte registers only while one sweep spins: A = state, decoder output, glue record, transform
+  // (issued before the dL/dx sweep at the top of a step); B = dL/dworld and the prior part (issued before the first layer sweep)
+  pvf4 pf[4];
+  const pvf4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto prefetch_a_issue = [&](int tp) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pf[k] = zero4;
+    const int r = row0 + pq_i;
+    if (tp >= 0) {
+      const float* sp = a.steps + (size_t)tp * a.per_step;
+      const float* xs = a.xT + (size_t)tp * P_DINP * 32 + (size_t)r * 4;
+      pf[0] = *reinterpret_cast<const pvf4*>(xs + (size_t)pq_q * 128);
+      if (pq_q + 64 < P_DINP / 4) pf[1] = *reinterpret_cast<const pvf4*>(xs + (size_t)(pq_q + 64) * 128);
+      if (pq_q < P_RAW / 4) pf[2] = *reinterpret_cast<const pvf4*>(sp + a.off_dec[3] + (size_t)pq_q * 128 + (size_t)r * 4);
+      if (pq_q < 8) pf[3] = *reinterpret_cast<const pvf4*>(sp + a.off_gl + (size_t)r * 32 + 4 * pq_q);
+      else if (pq_q < 11) pf[3] = *reinterpret_cast<const pvf4*>(sp + a.off_G + (size_t)r * 12 + 4 * (pq_q - 8));
+    }
+  };
+  auto prefetch_a_store = [&](int tp) {
+    float* b = smem + LB_PF + (tp & 1) * PF_SIZE;
+    *reinterpret_cast<pvf4*>(b + PF_X + pq_i * P_XPAD + 4 * pq_q) = pf[0];
+    if (pq_q + 64 < P_XPAD / 4) *reinterpret_cast<pvf4*>(b + PF_X + pq_i * P_XPAD + 4 * (pq_q + 64)) = pf[1];
+    if (pq_q < P_RAWPAD / 4) *reinterpret_cast<pvf4*>(b + PF_RAW + pq_i * P_RAWPAD + 4 * pq_q) = pf[2];
+    if (pq_q < 8) *reinterpret_cast<pvf4*>(b + PF_GL + pq_i * 32 + 4 * pq_q) = pf[3];
+    else if (pq_q < 11) *reinterpret_cast<pvf4*>(b + PF_G + pq_i * 12 + 4 * (pq_q - 8)) = pf[3];
+  };
+  auto prefetch_b_issue = [&](int tp) {        // tp >= -1; the prior part belongs to step tp + 1
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pf[k] = zero4;
+    const int r = row0 + pq_i;
+    if (tp >= 0 && a.g_world && r < a.B) {
+      const float* gw = a.g_world + ((size_t)r * a.S + tp) * P_STATE;
+      pf[0] = *reinterpret_cast<const pvf4*>(gw + 4 * pq_q);
+      if (pq_q + 64 < P_STATE / 4) pf[1] = *reinterpret_cast<const pvf4*>(gw + 4 * (pq_q + 64));
+    }
+    if (a.gx_pri && tp + 1 < a.S) {
+      const float* gp = a.gx_pri + (size_t)(tp + 1) * a.gxp_pad * 32 + (size_t)r * 4;
+      pf[2] = *reinterpret_cast<const pvf4*>(gp + (size_t)pq_q * 128);
+      if (pq_q + 64 < P_DINP / 4) pf[3] = *reinterpret_cast<const pvf4*>(gp + (size_t)(pq_q + 64) * 128);
+    }
+  };
+  auto prefetch_b_store = [&](int tp) {
+    float* b = smem + LB_PF + (tp & 1) * PF_SIZE;
+    *reinterpret_cast<pvf4*>(b + PF_GW + pq_i * P_XPAD + 4 * pq_q) = pf[0];
+    if (pq_q + 64 < P_XPAD / 4) *reinterpret_cast<pvf4*>(b + PF_GW + pq_i * P_XPAD + 4 * (pq_q + 64)) = pf[1];
+    *reinterpret_cast<pvf4*>(b + PF_GXP + pq_i * P_XPAD + 4 * pq_q) = pf[2];
+    if (pq_q + 64 < P_XPAD / 4) *reinterpret_cast<pvf4*>(b + PF_GXP + pq_i * P_XPAD + 4 * (pq_q + 64)) = pf[3];
+  };
+
+  // per-sequence carried adjoints of wave `wave`'s row (identical in every lane): dL/dG', dL/dgt', dL/dt2j so far
+  // (kept in LDS between the steps, sCarry[row][16]: dL/dG' 9 | dL/dgt' 3 | dL/dt2j 3 -- and the row's t2j at [row][64 + ..])
+  const int myrow = row0 + wave;
+  if (lane < 16) sCarry[wave * 16 + lane] = 0.f;
+  for (int e = tid; e < ROWS * P_XPAD; e += 256) { sGXD[e] = 0.f; sGXN[e] = 0.f; }
+
+  prefetch_a_issue(a.S - 1);
+  prefetch_a_store(a.S - 1);
+  prefetch_b_issue(a.S - 1);
+  prefetch_b_store(a.S - 1);
+
+  bool fail = false;
+  for (int t = a.S - 1; t >= 0; --t) {
+    const unsigned tag = 4u * (unsigned)(a.S - 1 - t);
+    const float* sp = a.steps + (size_t)t * a.per_step;
+    const float* cur = smem + LB_PF + (t & 1) * PF_SIZE;
+    // ---- total adjoint of x_{t+1}: own direct part + prior part + the team's layer-0 input gradient of step t+1 ----------------
+    prefetch_a_issue(t - 1);
+    __syncthreads();                                   // the prefetched buffer of this step and sGXD of step t+1 are complete
+    {
+      float gx[2][4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gx[q][i] = 0.f;
+      if (t < a.S - 1 && !sweep<2>(rs, GX_OFF0, tag, true, tid, gx)) fail = true;     // (352 channels = 2 x 176: all threads sweep)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = tid + 256 * q;
+        if (c < P_XPAD) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sGXN[i * P_XPAD + c] = sGXD[i * P_XPAD + c] + cur[PF_GXP + i * P_XPAD + c] + gx[q][i];
+        }
+      }
+    }
+    prefetch_a_store(t - 1);
+    if (fail) misc[2] = 1;
+    __syncthreads();
+    if (misc[2]) break;
+    // ---- glue adjoint: one wave per sequence ------------------------------------------------------------------------------
+    {
+      const float* X = cur + PF_X + wave * P_XPAD;
+      const float* RW = cur + PF_RAW + wave * P_RAWPAD;
+      const float* GWp = cur + PF_GW + wave * P_XPAD;
+      const float* GL = cur + PF_GL + wave * 32;
+      const float* Gp = cur + PF_G + wave * 12;
+      const float* GXN = sGXN + wave * P_XPAD;
+      float* GXD = sGXD + wave * P_XPAD;
+      float W[9], G[9], gt[3], gGn[9], ggtn[3], t2j[3];
+      float* carry = sCarry + wave * 16;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { W[i] = GL[i]; G[i] = Gp[i]; gGn[i] = carry[i]; }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { gt[c] = Gp[9 + c]; ggtn[c] = carry[9 + c]; t2j[c] = a.t2j[(size_t)myrow * 3 + c]; }
+      // vector tasks, lanes 0..26: joints (position + velocity), root translation / velocity, root angular velocity, the three
+      // columns of the predicted root rotation (velocity-type: frame change only)
+      const int v = lane;
+      const bool has_pos = v <= 22, has_t2j = v < 22, active = v <= 26;
+      // channel offsets: position (raw, x), velocity (raw, x), adjoints (world / next) use the x offsets
+      int rp = 0, xp = 0, rv = 0, xv = 0;
+      if (v < 22) { rp = 75 + 3 * v; xp = 207 + 3 * v; rv = 141 + 3 * v; xv = 273 + 3 * v; }
+      else if (v == 22) { rp = 0; xp = 0; rv = 3; xv = 3; }
+      else if (v == 23) { rv = 9; xv = 15; }
+      float pos[3] = {0.f, 0.f, 0.f}, vel[3] = {0.f, 0.f, 0.f}, gwp[3] = {0.f, 0.f, 0.f}, gwv[3] = {0.f, 0.f, 0.f}, gxp[3] = {0.f, 0.f, 0.f}, gxv[3] = {0.f, 0.f, 0.f};
+      if (active) {
+        if (v <= 23) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            vel[c] = RW[rv + c] + X[xv + c];
+            gwv[c] = GWp[xv + c];
+            gxv[c] = GXN[xv + c];
+            if (has_pos) {
+              pos[c] = RW[rp + c] + X[xp + c];
+              gwp[c] = GWp[xp + c];
+              gxp[c] = GXN[xp + c];
+            }
+          }
+          if (v == 22) { gwp[0] -= ggtn[0]; gwp[1] -= ggtn[1]; }          // carried gt' = (-wtrans.x, -wtrans.y, 0)
+        } else {
+          const int k = v - 24;                                             // column k of pR (rows at stride 3)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            vel[c] = GL[9 + 3 * c + k];
+            gwv[c] = GWp[6 + 3 * c + k];
+            gxv[c] = GXN[6 + 3 * c + k];
+          }
+        }
+      }
+      const float ptx = as_f(__builtin_amdgcn_readlane(as_u(pos[0]), 22)), pty = as_f(__builtin_amdgcn_readlane(as_u(pos[1]), 22));
+      const float wt[3] = {-ptx, -pty, 0.f};
+      const float tj[3] = {has_t2j ? t2j[0] : 0.f, has_t2j ? t2j[1] : 0.f, has_t2j ? t2j[2] : 0.f};
+      float gW[9], gG[9], ggt[3] = {0.f, 0.f, 0.f}, gwt[3] = {0.f, 0.f, 0.f}, gt2[3] = {0.f, 0.f, 0.f};
+      float gpos[3] = {0.f, 0.f, 0.f}, gvel[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { gW[i] = 0.f; gG[i] = 0.f; }
+      if (active) {
+        float o[3], q[3];
+        if (has_pos) {
+          // world: G^T (p + tj) - tj - gt
+#pragma unroll
+          for (int c = 0; c < 3; ++c) q[c] = pos[c] + tj[c];
+          mat3_vec(G, gwp, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { gpos[c] += o[c]; if (has_t2j) gt2[c] += o[c] - gwp[c]; ggt[c] -= gwp[c]; }
+          outer_acc3(gG, q, gwp);
+          // next input: W (p + wt + tj) - tj
+#pragma unroll
+          for (int c = 0; c < 3; ++c) q[c] = pos[c] + wt[c] + tj[c];
+          mat3_tvec(W, gxp, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { gpos[c] += o[c]; gwt[c] += o[c]; if (has_t2j) gt2[c] += o[c] - gxp[c]; }
+          outer_acc3(gW, gxp, q);
+        }
+        // velocity-type: world G^T v, next input W v
+        mat3_vec(G, gwv, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gvel[c] += o[c];
+        outer_acc3(gG, vel, gwv);
+        mat3_tvec(W, gxv, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gvel[c] += o[c];
+        outer_acc3(gW, gxv, vel);
+      }
+      // sums over the lanes: dL/dW (9), dL/dG (9), dL/dgt (3), dL/dwt (3), dL/dt2j (3)
+      float r1[16], r2[16];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { r1[i] = gW[i]; r2[i] = gG[i]; }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { r1[9 + c] = ggt[c]; r1[12 + c] = gwt[c]; r2[9 + c] = gt2[c]; }
+      r1[15] = 0.f;
+#pragma unroll
+      for (int k = 12; k < 16; ++k) r2[k] = 0.f;
+      lr::wave_sum16(r1);
+      lr::wave_sum16(r2);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { gW[i] = r1[i]; gG[i] = r2[i]; }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { ggt[c] = r1[9 + c]; gwt[c] = r1[12 + c]; gt2[c] = r2[9 + c]; }
+      // carried: G' = G W : dL/dG += dL/dG' W^T ; dL/dW += G^T dL/dG'
+      {
+        float M[9];
+        mat3_mult(gGn, W, M);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gG[i] += M[i];
+        mat3_tmul(G, gGn, M);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gW[i] += M[i];
+      }
+      // heading alignment W = world2aligned(pR): dL/dpR[0], dL/dpR[3]
+      float g0, g3;
+      {
+        W2A wa2;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wa2.W[i] = W[i];
+        wa2.rx = -GL[9];
+        wa2.ry = -GL[12];
+        wa2.nrm = sqrtf(wa2.rx * wa2.rx + wa2.ry * wa2.ry);
+        wa2.u = wa2.rx / (wa2.nrm + 1e-6f);
+        wa2.xp = fminf(fmaxf(wa2.u, -1.0f), 1.0f);
+        wa2.angle = GL[27];
+        wa2.s = -wa2.ry / (fabsf(wa2.ry) + 1e-6f);
+        wa2.az = wa2.s * wa2.angle;
+        w2a_bwd(wa2, gW, g0, g3);
+      }
+      // root translation: wt = (-ptrans.x, -ptrans.y, 0)
+      if (v == 22) { gpos[0] -= gwt[0]; gpos[1] -= gwt[1]; }
+      // carry to step t-1
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) carry[i] = gG[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { carry[9 + c] = ggt[c]; carry[12 + c] += gt2[c]; }
+      }
+      // outputs of the vector tasks: dL/d(decoder output) (A operand of the transposed last layer, [channel][row]) and the direct
+      // part of dL/dx_t
+      if (v <= 23) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          sD3[(rv + c) * 4 + wave] = gvel[c];
+          GXD[xv + c] = gvel[c];
+          if (has_pos) {
+            sD3[(rp + c) * 4 + wave] = gpos[c];
+            GXD[xp + c] = gpos[c];
+          }
+        }
+      }
+      // rotation adjoints, lanes 32..52 = body rotations, lane 53 = the root: p = dR Rin
+      float gcol[3][3];                                // dL/dpR columns from lanes 24..26
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gcol[k][c] = as_f(__builtin_amdgcn_readlane(as_u(gvel[c]), 24 + k));
+      if (lane >= 32 && lane <= 53) {
+        const bool rt = lane == 53;
+        const int b = lane - 32;
+        const int ao = rt ? 6 : 12 + 3 * b, ro = rt ? 6 : 18 + 9 * b;
+        float gp[9], Rin[9], aa[3], gd[9], dRm[9], gRin[9], gaa[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          Rin[i] = X[ro + i];
+          gp[i] = rt ? gcol[i % 3][i / 3] : GWp[ro + i] + GXN[ro + i];
+        }
+        if (rt) { gp[0] += g0; gp[3] += g3; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) aa[c] = RW[ao + c];
+        mat3_mult(gp, Rin, gd);            // dL/ddR = dL/dp Rin^T
+        rod_fwd_bwd(aa, gd, dRm, gaa);
+        mat3_tmul(dRm, gp, gRin);          // dL/dRin = dR^T dL/dp
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sD3[(ao + c) * 4 + wave] = gaa[c];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) GXD[ro + i] = gRin[i];
+      }
+      // contact logits pass straight through; padding channels of the operand stay zero
+      if (lane >= 54 && lane < 63) sD3[(207 + lane - 54) * 4 + wave] = GWp[339 + lane - 54];
+      if (lane == 63) {
+#pragma unroll
+        for (int c = P_RAW; c < P_RAWPAD; ++c) sD3[c * 4 + wave] = 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- transposed layer 3: dL/d(decoder output) [216] -> dL/da3 [512] (+ dz) ------------------------------------------------
+    {
+      float acc[4];
+      mma_layer<BC3, 0, 1, BR3>(sD3, sD3, wa, wv, lane, acc);
+      publish<1, SC1>(acc, 0.f, 4 * g, team_xch, rs, GA_OFF3, tag + 1, nullptr, row0, lane);
+      if (g < DZ3_WAVES) {
+        float accz[4];
+        dz_mma<DZ3_CH>(sD3 + 64 * DZ3_CH * (g % (BC3 / DZ3_CH)), sWz + (BRZ3 - BRZ0) * 64, lane, accz);
+        dz_store(accz, a.dz_part, t, DZ_S3 + g % (BC3 / DZ3_CH), g / (BC3 / DZ3_CH), row0, lane);
+      }
+    }
+    // ---- layer 2 ------------------------------------------------------------------------------------------------------------
+    prefetch_b_issue(t - 1);
+    if (!gather_norm_bwd<2, 32>(rs, GA_OFF3, tag + 1, sGam3, sBet3, sp + a.off_dec[2], sp + a.off_gn[2], row0, sD2, tid)) fail = true;
+    prefetch_b_store(t - 1);
+    if (fail) misc[2] = 1;
+    __syncthreads();
+    if (misc[2]) break;
+    {
+      float acc[8];
+      mma_layer<BC2, 0, 2, BR2>(sD2, sD2, wa, wv, lane, acc);
+      publish<2, SC1>(acc, 0.f, 8 * g, team_xch, rs, GA_OFF2, tag + 2, nullptr, row0, lane);
+      if (g < DZ2_WAVES) {
+        float accz[4];
+        dz_mma<DZ2_CH>(sD2 + 64 * DZ2_CH * (g % (BC2 / DZ2_CH)), sWz + (BRZ2 - BRZ0) * 64, lane, accz);
+        dz_store(accz, a.dz_part, t, DZ_S2 + g % (BC2 / DZ2_CH), g / (BC2 / DZ2_CH), row0, lane);
+      }
+    }
+    // ---- layer 1 ------------------------------------------------------------------------------------------------------------
+    if (!gather_norm_bwd<4, 64>(rs, GA_OFF2, tag + 2, sGam2, sBet2, sp + a.off_dec[1], sp + a.off_gn[1], row0, sD1, tid)) fail = true;
+    if (fail) misc[2] = 1;
+    __syncthreads();
+    if (misc[2]) break;
+    {
+      float acc[8];
+      mma_layer<BC1, 0, 2, BR1>(sD1, sD1, wa, wv, lane, acc);
+      publish<2, SC1>(acc, 0.f, 8 * g, team_xch, rs, GA_OFF1, tag + 3, nullptr, row0, lane);
+      if (g < DZ1_WAVES) {
+        float accz[4];
+        dz_mma<DZ1_CH>(sD1 + 64 * DZ1_CH * (g % (BC1 / DZ1_CH)), sWz + (BRZ1 - BRZ0) * 64, lane, accz);
+        dz_store(accz, a.dz_part, t, DZ_S1 + g % (BC1 / DZ1_CH), g / (BC1 / DZ1_CH), row0, lane);
+      }
+    }
+    // ---- layer 0 ------------------------------------------------------------------------------------------------------------
+    if (!gather_norm_bwd<4, 64>(rs, GA_OFF1, tag + 3, sGam1, sBet1, sp + a.off_dec[0], sp + a.off_gn[0], row0, sD0, tid)) fail = true;
+    if (fail) misc[2] = 1;
+    __syncthreads();
+    if (misc[2]) break;
+    {
+      float acc[4];
+      if (g < L0T_WAVES) mma_layer<BC0, 0, 1, BR0>(sD0, sD0, wa, wv, lane, acc);
+      else { acc[0] = acc[1] = acc[2] = acc[3] = 0.f; }
+      if (g < P_XPAD / 4) publish<1, SC1>(acc, 0.f, 4 * g, team_xch, rs, GX_OFF0, tag + 4, nullptr, row0, lane);     // (waves 85..87: the zero padding)
+      if (g < DZ0_WAVES) {
+        float accz[4];
+        dz_mma<DZ0_CH>(sD0 + 64 * DZ0_CH * (g % (BC0 / DZ0_CH)), sWz, lane, accz);
+        dz_store(accz, a.dz_part, t, DZ_S0 + g % (BC0 / DZ0_CH), g / (BC0 / DZ0_CH), row0, lane);
+      }
+    }
+  }
+  // ---- dL/dpast_in0 = total adjoint of x_0 (the t2j = -(x0[207], x0[208], 0) dependence included) -------------------------------
+  __syncthreads();
+  if (!misc[2]) {
+    float gx[2][4];
+    const float* cur = smem + LB_PF + 1 * PF_SIZE;          // buffer of "step -1": only its prior part (step 0) is populated
+    if (!sweep<2>(rs, GX_OFF0, 4u * (unsigned)a.S, true, tid, gx)) misc[2] = 1;
+    __syncthreads();
+    if (!misc[2] && m == 0) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = tid + 256 * q;
+        if (c < P_DIN) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float vsum = sGXD[i * P_XPAD + c] + cur[PF_GXP + i * P_XPAD + c] + gx[q][i];
+            if (c == 207) vsum -= sCarry[i * 16 + 12];
+            if (c == 208) vsum -= sCarry[i * 16 + 13];
+            if (row0 + i < a.B) a.g_past0[(size_t)(row0 + i) * P_DIN + c] = vsum;
+          }
+        }
+      }
+    }
+  }
+  if (misc[2] && tid == 0) __hip_atomic_store(a.err, 0x400u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// g_z[b][t][c] = sum of the DZ_SLOTS partial products, fixed order
+__global__ void dz_reduce_kernel(const float* __restrict__ part, float* __restrict__ g_z, int B, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * S * P_ZD) return;
+  const int c = i % P_ZD, t = (i / P_ZD) % S, b = i / (P_ZD * S);
+  float v = 0.f;
+  for (int sl = 0; sl < DZ_SLOTS; ++sl) v += part[(((size_t)t * DZ_SLOTS + sl) * 32 + b) * P_ZD + c];
+  g_z[i] = v;
+}
+
 #endif  // !HA_SIMT_EMU
 
 #ifdef HA_PERSIST_TIMING
@@ -671,6 +1287,7 @@ void persist_destroy(PersistNet* p) {
 #ifndef HA_SIMT_EMU
   DeviceGuard guard(p->device);
   if (p->Wreg) (void)hipFree(p->Wreg);
+  if (p->Wreg_b) (void)hipFree(p->Wreg_b);
   for (float* q : p->bias)
     if (q) (void)hipFree(q);
   for (float* q : p->gamma)
@@ -689,6 +1306,7 @@ bool persist_usable(PersistNet* p) {
 }
 
 long long persist_launches(PersistNet* p) { return p ? p->launches : 0; }
+long long persist_launches_bwd(PersistNet* p) { return p ? p->launches_bwd : 0; }
 
 unsigned persist_error_word(PersistNet* p) { return (p && p->err_host) ? *reinterpret_cast<volatile unsigned*>(p->err_host) : 0u; }
 
@@ -725,6 +1343,32 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
             wr[((size_t)g * NREG + RO[l] + c * NCGv[l] + cg) * 64 + ln] = v;
           }
   int rc = p_upload(&p->Wreg, wr);
+  if (rc == HA_OK) {
+    // adjoint: B operand lane (b, j) of chunk c = W_l[forward output 16 c + b][forward input column]
+    std::vector<float> wb((size_t)NWAVES_TEAM * NREG_B_ALL * 64, 0.f);
+    auto W = [&](int l, int k, int col) -> float { return (k < Nout[l] && col < Kin[l]) ? d->w[l][(size_t)k * Kin[l] + col] : 0.f; };
+    for (int g = 0; g < NWAVES_TEAM; ++g)
+      for (int ln = 0; ln < 64; ++ln) {
+        const int b = ln >> 2, j = ln & 3;
+        float* dst = wb.data() + (size_t)g * NREG_B_ALL * 64 + ln;
+        auto put = [&](int reg, float v) { dst[(size_t)reg * 64] = v; };
+        for (int c = 0; c < BC3; ++c) put(BR3 + c, 4 * g + j < P_H2 ? W(3, 16 * c + b, 4 * g + j) : 0.f);
+        for (int c = 0; c < BC2; ++c)
+          for (int cg = 0; cg < 2; ++cg) put(BR2 + c * 2 + cg, W(2, 16 * c + b, 8 * g + 4 * cg + j));
+        for (int c = 0; c < BC1; ++c)
+          for (int cg = 0; cg < 2; ++cg) put(BR1 + c * 2 + cg, W(1, 16 * c + b, 8 * g + 4 * cg + j));
+        for (int c = 0; c < BC0; ++c) put(BR0 + c, (g < L0T_WAVES && 4 * g + j < P_DIN) ? W(0, 16 * c + b, 4 * g + j) : 0.f);
+        if (g < DZ0_WAVES)
+          for (int i = 0; i < DZ0_CH; ++i) put(BRZ0 + i, W(0, 16 * ((g % (BC0 / DZ0_CH)) * DZ0_CH + i) + b, P_DIN + 4 * (g / (BC0 / DZ0_CH)) + j));
+        if (g < DZ1_WAVES)
+          for (int i = 0; i < DZ1_CH; ++i) put(BRZ1 + i, W(1, 16 * ((g % (BC1 / DZ1_CH)) * DZ1_CH + i) + b, P_H0 + 4 * (g / (BC1 / DZ1_CH)) + j));
+        if (g < DZ2_WAVES)
+          for (int i = 0; i < DZ2_CH; ++i) put(BRZ2 + i, W(2, 16 * ((g % (BC2 / DZ2_CH)) * DZ2_CH + i) + b, P_H1 + 4 * (g / (BC2 / DZ2_CH)) + j));
+        if (g < DZ3_WAVES)
+          for (int i = 0; i < DZ3_CH; ++i) put(BRZ3 + i, W(3, 16 * ((g % (BC3 / DZ3_CH)) * DZ3_CH + i) + b, P_H2 + 4 * (g / (BC3 / DZ3_CH)) + j));
+      }
+    rc = p_upload(&p->Wreg_b, wb);
+  }
   const int bpad[4] = {P_H0, P_H1, P_H2, P_RAWPAD};
   for (int l = 0; l < 4 && rc == HA_OK; ++l) {
     std::vector<float> bv(bpad[l], 0.f);
@@ -746,6 +1390,8 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
   if (rc == HA_OK) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_persist_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_persist_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_persist_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_TOTAL * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_persist_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_TOTAL * 4);
     if (e != hipSuccess) { set_error("persist_create: LDS attribute: %s", hipGetErrorString(e)); rc = HA_ERR_HIP; }
   }
   if (rc == HA_OK) {
@@ -792,6 +1438,8 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
   a.past_in0 = f.past_in0; a.z_seq = f.z_seq; a.world = f.world; a.xT = f.xT; a.steps = f.steps;
   a.per_step = f.per_step; a.off_G = f.off_G;
   for (int l = 0; l < 4; ++l) a.off_dec[l] = f.off_dec[l];
+  for (int l = 0; l < 3; ++l) a.off_gn[l] = f.off_gn[l];
+  a.off_gl = f.off_gl;
   a.t2j = f.t2j;
   a.xch = reinterpret_cast<unsigned char*>(f.ws);
   a.err = p->err_dev;
@@ -799,6 +1447,38 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
   else hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
   HA_LAUNCH_CHECK();
   ++p->launches;
+  return HA_OK;
+#endif
+}
+
+int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_t st) {
+#ifdef HA_SIMT_EMU
+  (void)p; (void)f; (void)variant; (void)st;
+  set_error("persistent roll-out: not available on the host emulator");
+  return HA_ERR_INVALID_ARG;
+#else
+  HA_REQUIRE(p && f.B >= 1 && f.B <= NTEAMS * ROWS && f.S >= 1, "persistent roll-out adjoint: needs 1 <= B <= 32 sequences");
+  HA_CHECK_HIP(hipMemsetAsync(f.ws, 0, XCH_BYTES, st));
+  PersistBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = f.B; a.S = f.S;
+  a.Wreg = p->Wreg_b;
+  for (int l = 0; l < 3; ++l) { a.gamma[l] = p->gamma[l]; a.beta[l] = p->beta[l]; }
+  a.g_world = f.g_world; a.gx_pri = f.gx_pri; a.gxp_pad = f.gxp_pad;
+  a.xT = f.xT; a.steps = f.steps; a.per_step = f.per_step; a.off_G = f.off_G;
+  for (int l = 0; l < 4; ++l) a.off_dec[l] = f.off_dec[l];
+  for (int l = 0; l < 3; ++l) a.off_gn[l] = f.off_gn[l];
+  a.off_gl = f.off_gl;
+  a.t2j = f.t2j; a.g_past0 = f.g_past0; a.dz_part = f.dz_part;
+  a.xch = reinterpret_cast<unsigned char*>(f.ws);
+  a.err = p->err_dev;
+  if (variant & 1) hipLaunchKernelGGL(rollout_persist_bwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), LB_TOTAL * 4, st, a);
+  else hipLaunchKernelGGL(rollout_persist_bwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), LB_TOTAL * 4, st, a);
+  HA_LAUNCH_CHECK();
+  const int n = f.B * f.S * P_ZD;
+  hipLaunchKernelGGL(dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)f.dz_part, f.g_z, f.B, f.S);
+  HA_LAUNCH_CHECK();
+  ++p->launches_bwd;
   return HA_OK;
 #endif
 }

@@ -179,7 +179,7 @@ int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float
  * network.  *available = 1 when the network / device qualify and no launch has reported a failure; *error_word = the kernel's
  * host-mapped error word (0 = none; 0x1xx an XCD received more than its 32 blocks, 0x2xx a team member's bounded wait ran out),
  * meaningful once the stream of the last roll-out has been synchronised; *launches = persistent forwards issued so far for this
- * network.  After a failure the library uses the launch chain. */
+ * network in the low 32 bits, persistent adjoints in the high 32 bits.  After a failure the library uses the launch chain. */
 int ha_humor_persist_status(const ha_humor_net* net, int* available, unsigned int* error_word, int64_t* launches);
 
 /* ------------------------------------------------------------------------------------------------

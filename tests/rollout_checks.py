@@ -410,8 +410,9 @@ def persist_status(lib, hm, device):
 
 
 def check_persistent_vs_chain(lib, device, B, S, seed=0, variant=1, contractive=True):
-    """The one-launch persistent forward (ha_tune_set "rollout_persist") against the launch chain on the same inputs: world states,
-    prior outputs, and -- through the unchanged adjoint reading the persistent kernel's stash -- every gradient."""
+    """The one-launch persistent forward and adjoint (ha_tune_set "rollout_persist" / "rollout_persist_bwd") against the launch chain on
+    the same inputs: world states, prior outputs and every gradient, for (i) persistent forward + launch-chain adjoint reading its
+    stash and (ii) persistent forward + persistent adjoint."""
     hm, _ = make_model(lib, device, seed=seed, contractive=contractive)
     g = torch.Generator().manual_seed(77 + B + S)
     past, z = canonical_state(B, g).to(device), torch.randn(B, S, 48, generator=g).to(device)
@@ -420,8 +421,9 @@ def check_persistent_vs_chain(lib, device, B, S, seed=0, variant=1, contractive=
     res = []
     n0 = persist_status(lib, hm, device)[2]
     try:
-        for knob in (0, variant):
+        for knob, bwd in ((0, 0), (variant, 0), (variant, 1)):
             lib.call('ha_tune_set', b'rollout_persist', knob)
+            lib.call('ha_tune_set', b'rollout_persist_bwd', bwd)
             p, zz = past.clone().requires_grad_(True), z.clone().requires_grad_(True)
             out, (pm, pv) = hm.roll_out(p, None, S, z_seq=zz, return_prior=True)
             w = world_of(out)
@@ -429,18 +431,21 @@ def check_persistent_vs_chain(lib, device, B, S, seed=0, variant=1, contractive=
             res.append((w.detach(), pm.detach(), pv.detach(), p.grad.clone(), zz.grad.clone()))
     finally:
         lib.call('ha_tune_set', b'rollout_persist', 1)
+        lib.call('ha_tune_set', b'rollout_persist_bwd', 1)
     av, err, n1 = persist_status(lib, hm, device)
     assert err == 0, hex(err)
-    assert av == 1 and n1 == n0 + 1, (av, n0, n1)          # the persistent kernel really ran (no silent fall-back)
+    # the persistent kernels really ran (no silent fall-back): two forwards (low word), one adjoint (high word)
+    assert av == 1 and (n1 & 0xffffffff) == (n0 & 0xffffffff) + 2 and (n1 >> 32) == (n0 >> 32) + 1, (av, n0, n1)
     errs = []
-    for name, a, b, tol in zip(('world', 'prior_mu', 'prior_var', 'g_past', 'g_z'), res[0], res[1], (2e-5, 2e-5, 2e-5, 2e-4, 2e-4)):
-        assert torch.isfinite(b).all(), name
-        e = (a - b).abs().reshape(B, -1).amax(dim=1) / max(1.0, a.abs().max().item())       # per sequence
-        errs.append(e.max().item())
-        if name.startswith('g_'):
-            # two fp32 evaluations with different summation orders: a sequence with a ReLU unit within rounding of its kink moves by
-            # ~1e-3 (see check_rollout_full_tiles); at most one sequence in ten may, and never beyond the kink bar
-            assert int((e > tol).sum()) <= max(1, B // 10) and e.max().item() <= KINK_RTOL, (name, e.tolist(), B, S)
-        else:
-            assert e.max().item() <= tol, (name, e.max().item(), B, S)
+    for k in (1, 2):
+        for name, a, b, tol in zip(('world', 'prior_mu', 'prior_var', 'g_past', 'g_z'), res[0], res[k], (2e-5, 2e-5, 2e-5, 2e-4, 2e-4)):
+            assert torch.isfinite(b).all(), (name, k)
+            e = (a - b).abs().reshape(B, -1).amax(dim=1) / max(1.0, a.abs().max().item())       # per sequence
+            errs.append(e.max().item())
+            if name.startswith('g_'):
+                # two fp32 evaluations with different summation orders: a sequence with a ReLU unit within rounding of its kink moves
+                # by ~1e-3 (see check_rollout_full_tiles); at most one sequence in ten may, and never beyond the kink bar
+                assert int((e > tol).sum()) <= max(1, B // 10) and e.max().item() <= KINK_RTOL, (name, k, e.tolist(), B, S)
+            else:
+                assert e.max().item() <= tol, (name, k, e.max().item(), B, S)
     return errs

@@ -13,12 +13,15 @@ def dev():
     return torch.device('cuda:0')
 
 
-@pytest.fixture(params=[1, 0], ids=['persistent', 'chain'])
+@pytest.fixture(params=[(1, 1), (1, 0), (0, 0)], ids=['persistent', 'persistent_fwd_chain_bwd', 'chain'])
 def fwd_path(request, gpu_lib):
-    """Both forwards of a roll-out of <= 32 sequences: the one-launch persistent kernel (default) and the launch chain."""
-    gpu_lib.call('ha_tune_set', b'rollout_persist', request.param)
+    """The paths of a roll-out of <= 32 sequences: one persistent launch per direction (default), persistent forward with the
+    launch-chain adjoint, and the launch chain in both directions."""
+    gpu_lib.call('ha_tune_set', b'rollout_persist', request.param[0])
+    gpu_lib.call('ha_tune_set', b'rollout_persist_bwd', request.param[1])
     yield request.param
     gpu_lib.call('ha_tune_set', b'rollout_persist', 1)
+    gpu_lib.call('ha_tune_set', b'rollout_persist_bwd', 1)
 
 
 @pytest.fixture

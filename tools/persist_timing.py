@@ -44,11 +44,13 @@ for B, S in ((32, 59), (4, 59), (32, 119)):
         past.grad = None; z.grad = None
         out, (pm, pv) = hm.roll_out(past, None, S, z_seq=z, return_prior=True)
         (out['trans'].sum() + out['joints'].sum() + pm.sum()).backward()
-    for knob in (0, 1, 3):
+    for knob, bwd in ((0, 0), (1, 0), (1, 1), (3, 1)):
         lib.call('ha_tune_set', b'rollout_persist', knob)
+        lib.call('ha_tune_set', b'rollout_persist_bwd', bwd)
         r = {'fwd_ms': round(ev(fwd), 4), 'fwd_noprior_ms': round(ev(fwd_noprior), 4), 'fwd_bwd_ms': round(ev(fb), 4)}
         r['us_per_step_decoder_chain'] = round(1e3 * r['fwd_noprior_ms'] / S, 2)
-        res[f'{B}x{S} persist={knob}'] = r
-        print(B, S, knob, r, flush=True)
-lib.call('ha_tune_set', b'rollout_persist', 0)
+        res[f'{B}x{S} persist={knob} bwd={bwd}'] = r
+        print(B, S, knob, bwd, r, flush=True)
+lib.call('ha_tune_set', b'rollout_persist', 1)
+lib.call('ha_tune_set', b'rollout_persist_bwd', 1)
 print(json.dumps(res))
