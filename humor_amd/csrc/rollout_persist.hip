@@ -148,21 +148,23 @@ __device__ __forceinline__ unsigned as_u(float f) { return __float_as_uint(f); }
 // Sweeps this thread's NQ channels (channel tid + 256 q: 4 granules = 32 bytes each) until every tag matches; the loads bypass
 // the CU's L1 (sc1).  Returns false when the wait ran out (a team member never published).
 template <int NQ>
-__device__ __forceinline__ bool sweep(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, bool active, int tid, float (&x)[NQ][4]) {
+__device__ __forceinline__ bool sweep(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, int nch, int tid, float (&x)[NQ][4]) {
   for (int spins = 0;; ++spins) {
     unsigned diff = 0;          // (no short-circuit: one straight-line batch of loads and compares)
-    if (active) {
-      puv4 lo[NQ], hi[NQ];
+    puv4 lo[NQ], hi[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
+    for (int q = 0; q < NQ; ++q) {
+      lo[q] = puv4{0u, tag, 0u, tag};
+      hi[q] = lo[q];
+      if (tid + 256 * q < nch) {          // channels beyond the activation's width: nothing to wait for
         lo[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)(tid + 256 * q) * 32u, 0, 16);
         hi[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)(tid + 256 * q) * 32u + 16u, 0, 16);
       }
+    }
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        diff |= (lo[q].y ^ tag) | (lo[q].w ^ tag) | (hi[q].y ^ tag) | (hi[q].w ^ tag);
-        x[q][0] = as_f(lo[q].x); x[q][1] = as_f(lo[q].z); x[q][2] = as_f(hi[q].x); x[q][3] = as_f(hi[q].z);
-      }
+    for (int q = 0; q < NQ; ++q) {
+      diff |= (lo[q].y ^ tag) | (lo[q].w ^ tag) | (hi[q].y ^ tag) | (hi[q].w ^ tag);
+      x[q][0] = as_f(lo[q].x); x[q][1] = as_f(lo[q].z); x[q][2] = as_f(hi[q].x); x[q][3] = as_f(hi[q].z);
     }
     if (__all(diff == 0)) return true;
     if (spins > SPIN_LIMIT) return false;
@@ -177,7 +179,7 @@ template <int NQ, int GROUP, int PTI = 0>
 __device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float (&gam)[NQ], const float (&bet)[NQ],
                                             float* xs, int tid, float* stats, int row0 PT_ARGS) {
   float x[NQ][4];
-  if (!sweep<NQ>(rs, off, tag, true, tid, x)) return false;
+  if (!sweep<NQ>(rs, off, tag, NQ * 256, tid, x)) return false;
   PT(PTI);
   // two-pass statistics of the lane's NQ x 4 (channel quarter, row) values over their groups: all sums of a pass in one
   // reduce-scatter / all-gather (lane_reduce.h)
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     // ---- glue: decoder output of the 4 rows -> every CU --------------------------------------------------------------------
     {
       float x[1][4];
-      if (!sweep<1>(rs, ACT_OFF3, tag + 4, tid < P_RAW, tid, x)) fail = true;
+      if (!sweep<1>(rs, ACT_OFF3, tag + 4, P_RAW, tid, x)) fail = true;
       if (tid < P_RAW) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) sRAW[i * P_RAWPAD + tid] = x[0][i];
@@ -809,7 +811,7 @@ __device__ __forceinline__ bool gather_norm_bwd(__amdgpu_buffer_rsrc_t rs, unsig
     xh[q][0] = (h[0] - s0.x) * s0.y; xh[q][1] = (h[1] - s0.z) * s0.w; xh[q][2] = (h[2] - s1.x) * s1.y; xh[q][3] = (h[3] - s1.z) * s1.w;
   }
   float ga[NQ][4];
-  if (!sweep<NQ>(rs, off, tag, true, tid, ga)) return false;
+  if (!sweep<NQ>(rs, off, tag, NQ * 256, tid, ga)) return false;
   const float inv_n = 1.0f / (float)GROUP;
   float dxh[NQ * 4], m2[NQ * 4];
 #pragma unroll
@@ -967,7 +969,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int i = 0; i < 4; ++i) gx[q][i] = 0.f;
-      if (t < a.S - 1 && !sweep<2>(rs, GX_OFF0, tag, true, tid, gx)) fail = true;     // (352 channels = 2 x 176: all threads sweep)
+      if (t < a.S - 1 && !sweep<2>(rs, GX_OFF0, tag, P_XPAD, tid, gx)) fail = true;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int c = tid + 256 * q;
@@ -1228,7 +1230,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
   if (!misc[2]) {
     float gx[2][4];
     const float* cur = smem + LB_PF + 1 * PF_SIZE;          // buffer of "step -1": only its prior part (step 0) is populated
-    if (!sweep<2>(rs, GX_OFF0, 4u * (unsigned)a.S, true, tid, gx)) misc[2] = 1;
+    if (!sweep<2>(rs, GX_OFF0, 4u * (unsigned)a.S, P_XPAD, tid, gx)) misc[2] = 1;
     __syncthreads();
     if (!misc[2] && m == 0) {
 #pragma unroll
