@@ -1780,6 +1780,20 @@ extern "C" int ha_humor_persist_status(const ha_humor_net* net, int* available, 
   return HA_OK;
 }
 
+#ifdef HA_PERSIST_DEBUG
+// debugging build only (tools/build_variant.sh pdebug -DHA_PERSIST_DEBUG): stash offsets (floats) of the regions the persistent
+// kernels exchange, so that a script can read them back: [xT, steps, per_step, off_G, off_dec0..3, off_gn0..2, off_gl, dz_part, single]
+extern "C" int ha_debug_persist_layout(const ha_humor_net* net, int B, int S, int64_t* out) {
+  StashLayout L;
+  make_layout(net, B, S, L);
+  int64_t v[] = {(int64_t)L.xT, (int64_t)L.steps, (int64_t)L.per_step, (int64_t)L.off_G, (int64_t)L.off_dec[0], (int64_t)L.off_dec[1], (int64_t)L.off_dec[2],
+                 (int64_t)L.off_dec[3], (int64_t)L.off_gn[0], (int64_t)L.off_gn[1], (int64_t)L.off_gn[2], (int64_t)L.off_gl, (int64_t)L.dz_part, L.single ? 1 : 0,
+                 (int64_t)L.persist_ws};
+  for (int i = 0; i < 15; ++i) out[i] = v[i];
+  return HA_OK;
+}
+#endif
+
 #ifdef HA_LAYER_TIMING
 extern "C" int ha_debug_layer_timing(unsigned long long* out /* [64][10] */, unsigned int* launches) {
   HA_CHECK_HIP(hipDeviceSynchronize());

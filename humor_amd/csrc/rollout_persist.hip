@@ -65,10 +65,12 @@ constexpr int SPIN_LIMIT = 40000;        // bounded waits (~1 us per spin)
 constexpr int BC3 = P_RAWPAD / 16, BC2 = P_H2 / 16, BC1 = P_H1 / 16, BC0 = P_H0 / 16;
 // weight registers of a wave: main products (dL/d activation), then its share of the dL/dz products
 constexpr int BR3 = 0, BR2 = BR3 + BC3, BR1 = BR2 + BC2 * 2, BR0 = BR1 + BC1 * 2;
+constexpr int BC0_LDS = 20, BC0_REG = BC0 - BC0_LDS;      // layer 0: the last BC0_LDS chunks' weights live in LDS (register budget)
 constexpr int DZ0_CH = 8, DZ1_CH = 8, DZ2_CH = 4, DZ3_CH = 2;             // chunks per dL/dz task (12 column groups x K splits)
 constexpr int DZ0_WAVES = 12 * (BC0 / DZ0_CH), DZ1_WAVES = 12 * (BC1 / DZ1_CH), DZ2_WAVES = 12 * (BC2 / DZ2_CH), DZ3_WAVES = 12 * (BC3 / DZ3_CH);
-constexpr int BRZ0 = BR0 + BC0, BRZ1 = BRZ0 + DZ0_CH, BRZ2 = BRZ1 + DZ1_CH, BRZ3 = BRZ2 + DZ2_CH, NREG_B_ALL = BRZ3 + DZ3_CH;
+constexpr int BRZ0 = BR0 + BC0_REG, BRZ1 = BRZ0 + DZ0_CH, BRZ2 = BRZ1 + DZ1_CH, BRZ3 = BRZ2 + DZ2_CH, NREG_B_ALL = BRZ3 + DZ3_CH;
 constexpr int NREG_B = BRZ0, NDZ = NREG_B_ALL - NREG_B;       // registers: the main products; LDS: the wave's dL/dz weights [NDZ][64 lanes]
+constexpr int NLW = NDZ + BC0_LDS;                            // LDS-resident weight vectors per wave: dL/dz tasks, then layer 0's tail
 constexpr int NWA_B = 200;
 constexpr int L0T_WAVES = P_XPAD / 4 - 3;      // 85 waves own the 340 columns of dL/dx through layer 0
 // partial dL/dz slots per (step, sequence): K splits of the four layers, summed in this order by dz_reduce_kernel
@@ -79,10 +81,11 @@ static_assert(GX_OFF0 + P_XPAD * 32 <= TEAM_BYTES, "the adjoint's exchange buffe
 // LDS of the adjoint (floats): per-step inputs double-buffered (prefetched one step ahead), operands, adjoint states
 constexpr int PF_X = 0, PF_RAW = PF_X + ROWS * P_XPAD, PF_GW = PF_RAW + ROWS * P_RAWPAD, PF_GL = PF_GW + ROWS * P_XPAD, PF_G = PF_GL + ROWS * 32;
 constexpr int PF_GXP = PF_G + 64, PF_SIZE = PF_GXP + ROWS * P_XPAD;
-constexpr int LB_PF = 0, LB_D3 = LB_PF + 2 * PF_SIZE, LB_D2 = LB_D3 + P_RAWPAD * 4, LB_D1 = LB_D2 + P_H2 * 4, LB_D0 = LB_D1 + P_H1 * 4;
+constexpr int LB_PF = 0, LB_D3 = LB_PF + 2 * PF_SIZE, LB_D1 = LB_D3 + P_RAWPAD * 4, LB_D0 = LB_D1 + P_H1 * 4;
+constexpr int LB_D2 = LB_D0;       // (dh2 and dh0 live two phases apart: same space)
 constexpr int LB_GXN = LB_D0 + P_H0 * 4, LB_GXD = LB_GXN + ROWS * P_XPAD, LB_CARRY = LB_GXD + ROWS * P_XPAD, LB_MISC = LB_CARRY + 80;
 constexpr int LB_GB = LB_MISC + 64, LB_WZ = LB_GB + 2 * (P_H0 + P_H1 + P_H2);      // GroupNorm affine: gamma | beta of the three activations
-constexpr int LB_TOTAL = LB_WZ + 4 * NDZ * 64;                                      // dL/dz weights of the CU's four waves
+constexpr int LB_TOTAL = LB_WZ + 4 * NLW * 64;                                      // LDS-resident weights of the CU's four waves
 }  // namespace
 
 size_t persist_ws_floats() { return (XCH_BYTES + 3) / 4; }
@@ -251,8 +254,10 @@ __device__ __forceinline__ void mfma_w(pvf4& acc, float av, const float (&wa)[NW
     if constexpr (FIRST) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(av), "a"(wa[R]));
     else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "a"(wa[R]));
   } else {
-    if constexpr (FIRST) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(av), "v"(wv[R - NWA]));
-    else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(wv[R - NWA]));
+    // (a VGPR-class weight may be parked in an AGPR by the register allocator and copied back right in front of the asm: that copy
+    // is a VALU write the MFMA must not read within two wait states, and the hazard recogniser does not look inside the asm)
+    if constexpr (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(av), "v"(wv[R - NWA]));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(wv[R - NWA]));
   }
 }
 template <int NC_MAIN, int NZ, int NCG, int ROFF, int FIRST, int NWAS, int NWVS>
@@ -299,7 +304,14 @@ __device__ __forceinline__ void mma_layer(const float* xs, const float* zs, cons
   float first[MB];
   load_a<NC_MAIN, NZ, 0>(xs, zs, lane, first);
   MmaSteps<NC_MAIN, NZ, NCG, ROFF, 0, NWAS, NWVS>::run(xs, zs, wa, wv, lane, first, acc);
-  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // MFMA results -> VALU reads (hazard the compiler cannot see)
+  // MFMA results -> VALU reads: a hazard the compiler cannot see (the MFMAs are opaque asm to it).  The wait is tied to every
+  // accumulator ("+a"), otherwise the scheduler may place an accumulator read between the last MFMA and a free-standing s_nop.
+  if constexpr (NCG == 2)
+    asm volatile("s_nop 7" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]));
+  else if constexpr (NACC == 8)
+    asm volatile("s_nop 7" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[0][4]), "+a"(acc[0][5]), "+a"(acc[0][6]), "+a"(acc[0][7]));
+  else
+    static_assert(NCG == 2 || NACC == 8, "accumulator fence");
 #pragma unroll
   for (int g = 0; g < NCG; ++g) {
 #pragma unroll
@@ -709,13 +721,18 @@ __device__ __forceinline__ void outer_acc3(float M[9], const float a[3], const f
 // a dL/dz task: CH chunks of the activation adjoint against the wave's LDS-resident latent-column weights
 template <int CH>
 __device__ __forceinline__ void dz_mma(const float* xs, const float* wl, int lane, float (&acc)[4]) {
-  pvf4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+  pvf4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
 #pragma unroll
   for (int i = 0; i < CH; i += 2) {
-    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * i + lane], wl[64 * i + lane], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * (i + 1) + lane], wl[64 * (i + 1) + lane], c1, 0, 0, 0);
+    if ((i & 2) == 0) {
+      c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * i + lane], wl[64 * i + lane], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * (i + 1) + lane], wl[64 * (i + 1) + lane], c1, 0, 0, 0);
+    } else {
+      c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * i + lane], wl[64 * i + lane], c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * (i + 1) + lane], wl[64 * (i + 1) + lane], c3, 0, 0, 0);
+    }
   }
-  c0 += c1;
+  c0 = (c0 + c1) + (c2 + c3);
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = c0[i];
 }
@@ -872,15 +889,15 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
 
   // ---- resident transposed weights ------------------------------------------------------------------------------------------
   float wa[NWA_B], wv[NREG_B - NWA_B];
-  float* sWz = smem + LB_WZ + wave * NDZ * 64;
+  float* sWz = smem + LB_WZ + wave * NLW * 64;
   {
-    const float* wp = a.Wreg + (size_t)g * NREG_B_ALL * 64 + lane;
+    const float* wp = a.Wreg + (size_t)g * (NREG_B_ALL + BC0_LDS) * 64 + lane;
 #pragma unroll
     for (int r = 0; r < NWA_B; ++r) wa[r] = wp[(size_t)r * 64];
 #pragma unroll
     for (int r = NWA_B; r < NREG_B; ++r) wv[r - NWA_B] = wp[(size_t)r * 64];
 #pragma unroll
-    for (int r = 0; r < NDZ; ++r) sWz[r * 64 + lane] = wp[(size_t)(NREG_B + r) * 64];
+    for (int r = 0; r < NLW; ++r) sWz[r * 64 + lane] = wp[(size_t)(NREG_B + r) * 64];
   }
   // GroupNorm affine of the three hidden activations in LDS (register budget: 292 weight registers per wave)
   float* sGam1 = smem + LB_GB;
@@ -992,12 +1009,14 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       const float* Gp = cur + PF_G + wave * 12;
       const float* GXN = sGXN + wave * P_XPAD;
       float* GXD = sGXD + wave * P_XPAD;
+      // (per-sequence values are wave-uniform: readfirstlane moves them to scalar registers -- the vector file holds the weights)
+      auto uni = [](float v) { return as_f(__builtin_amdgcn_readfirstlane(as_u(v))); };
       float W[9], G[9], gt[3], gGn[9], ggtn[3], t2j[3];
       float* carry = sCarry + wave * 16;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) { W[i] = GL[i]; G[i] = Gp[i]; gGn[i] = carry[i]; }
+      for (int i = 0; i < 9; ++i) { W[i] = uni(GL[i]); G[i] = uni(Gp[i]); gGn[i] = uni(carry[i]); }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { gt[c] = Gp[9 + c]; ggtn[c] = carry[9 + c]; t2j[c] = a.t2j[(size_t)myrow * 3 + c]; }
+      for (int c = 0; c < 3; ++c) { gt[c] = uni(Gp[9 + c]); ggtn[c] = uni(carry[9 + c]); t2j[c] = uni(a.t2j[(size_t)myrow * 3 + c]); }
       // vector tasks, lanes 0..26: joints (position + velocity), root translation / velocity, root angular velocity, the three
       // columns of the predicted root rotation (velocity-type: frame change only)
       const int v = lane;
@@ -1215,8 +1234,13 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     if (misc[2]) break;
     {
       float acc[4];
-      if (g < L0T_WAVES) mma_layer<BC0, 0, 1, BR0>(sD0, sD0, wa, wv, lane, acc);
-      else { acc[0] = acc[1] = acc[2] = acc[3] = 0.f; }
+      if (g < L0T_WAVES) {
+        float tail[4];
+        mma_layer<BC0_REG, 0, 1, BR0>(sD0, sD0, wa, wv, lane, acc);
+        dz_mma<BC0_LDS>(sD0 + 64 * BC0_REG, sWz + NDZ * 64, lane, tail);        // the LDS-resident tail of K
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += tail[i];
+      } else { acc[0] = acc[1] = acc[2] = acc[3] = 0.f; }
       if (g < P_XPAD / 4) publish<1, SC1>(acc, 0.f, 4 * g, team_xch, rs, GX_OFF0, tag + 4, nullptr, row0, lane);     // (waves 85..87: the zero padding)
       if (g < DZ0_WAVES) {
         float accz[4];
@@ -1347,19 +1371,20 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
   int rc = p_upload(&p->Wreg, wr);
   if (rc == HA_OK) {
     // adjoint: B operand lane (b, j) of chunk c = W_l[forward output 16 c + b][forward input column]
-    std::vector<float> wb((size_t)NWAVES_TEAM * NREG_B_ALL * 64, 0.f);
+    std::vector<float> wb((size_t)NWAVES_TEAM * (NREG_B_ALL + BC0_LDS) * 64, 0.f);
     auto W = [&](int l, int k, int col) -> float { return (k < Nout[l] && col < Kin[l]) ? d->w[l][(size_t)k * Kin[l] + col] : 0.f; };
     for (int g = 0; g < NWAVES_TEAM; ++g)
       for (int ln = 0; ln < 64; ++ln) {
         const int b = ln >> 2, j = ln & 3;
-        float* dst = wb.data() + (size_t)g * NREG_B_ALL * 64 + ln;
+        float* dst = wb.data() + (size_t)g * (NREG_B_ALL + BC0_LDS) * 64 + ln;
         auto put = [&](int reg, float v) { dst[(size_t)reg * 64] = v; };
         for (int c = 0; c < BC3; ++c) put(BR3 + c, 4 * g + j < P_H2 ? W(3, 16 * c + b, 4 * g + j) : 0.f);
         for (int c = 0; c < BC2; ++c)
           for (int cg = 0; cg < 2; ++cg) put(BR2 + c * 2 + cg, W(2, 16 * c + b, 8 * g + 4 * cg + j));
         for (int c = 0; c < BC1; ++c)
           for (int cg = 0; cg < 2; ++cg) put(BR1 + c * 2 + cg, W(1, 16 * c + b, 8 * g + 4 * cg + j));
-        for (int c = 0; c < BC0; ++c) put(BR0 + c, (g < L0T_WAVES && 4 * g + j < P_DIN) ? W(0, 16 * c + b, 4 * g + j) : 0.f);
+        for (int c = 0; c < BC0; ++c)
+          put(c < BC0_REG ? BR0 + c : NREG_B_ALL + (c - BC0_REG), (g < L0T_WAVES && 4 * g + j < P_DIN) ? W(0, 16 * c + b, 4 * g + j) : 0.f);
         if (g < DZ0_WAVES)
           for (int i = 0; i < DZ0_CH; ++i) put(BRZ0 + i, W(0, 16 * ((g % (BC0 / DZ0_CH)) * DZ0_CH + i) + b, P_DIN + 4 * (g / (BC0 / DZ0_CH)) + j));
         if (g < DZ1_WAVES)
