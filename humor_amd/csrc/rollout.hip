@@ -1503,6 +1503,10 @@ struct StashLayout {
   size_t total = 0;
 };
 
+// row groups of the call being served on this host thread (for_each_group): side-by-side groups run on their own streams, and two
+// persistent launches cannot share the chip (each needs one block on every CU), so the one-launch path serves single-group calls only
+static thread_local int tl_groups = 1;
+
 static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, bool allow_acc = true) {
   L.RT = ceil_div(B, 32);
   const size_t RT = L.RT;
@@ -1517,7 +1521,7 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, b
   for (int i = 0; i < net->n_dec; ++i) { L.nsf_dec[i] = ceil_div(net->dec[i].nslices_f, L.spb); L.nsb_dec[i] = ceil_div(net->dec[i].nslices_b, L.spb); }
   // GroupNorm prologues once per activation in gn_finish_kernel (see there and the policy note above)
   L.finish = (L.RT >= 2 && g_layer_finish != 0) || g_layer_finish == 2;     // 0: never, 2: always (A/B runs)
-  L.single = allow_acc && !L.finish && B <= 32 && g_rollout_persist != 0 && persist_usable(net->persist);
+  L.single = allow_acc && !L.finish && B <= 32 && tl_groups == 1 && g_rollout_persist != 0 && persist_usable(net->persist);
   L.acc = allow_acc && !L.finish && !L.single && g_layer_acc != 0;
   L.hsum = !L.finish && !L.acc && !L.single && g_layer_hsum != 0;
   size_t o = 0;
@@ -1809,7 +1813,10 @@ extern "C" int ha_humor_rollout_workspace(const ha_humor_net* net, int B, int S,
   // whole batch (sampling roll-out: one chain; its slabs never accumulate) or the row groups of forward / backward side by side
   int ng, rpg;
   group_plan(B, ng, rpg);
-  const size_t whole = group_stash_floats(net, B, S), grouped = ng > 1 ? (size_t)ng * group_stash_floats(net, rpg, S) : 0;
+  const size_t whole = group_stash_floats(net, B, S);
+  tl_groups = ng;
+  const size_t grouped = ng > 1 ? (size_t)ng * group_stash_floats(net, rpg, S) : 0;
+  tl_groups = 1;
   *stash_floats = (int64_t)(whole > grouped ? whole : grouped);
   return HA_OK;
 }
@@ -2114,6 +2121,7 @@ template <typename F>
 static int for_each_group(int device, int B, int S, bool reverse, hipStream_t st, F&& fn) {
   int ng, rpg;
   group_plan(B, ng, rpg);
+  struct GroupScope { int prev; explicit GroupScope(int n) : prev(tl_groups) { tl_groups = n; } ~GroupScope() { tl_groups = prev; } } scope(ng);
   SidePool* P = nullptr;
   if (ng > 1) {
     int rc = side_pool(device, &P);
@@ -2147,10 +2155,18 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
   HA_REQUIRE(net && past_in0 && z_seq && world && stash, "ha_humor_rollout_forward: null argument");
   HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_forward: B and S must be >= 1");
   HA_REQUIRE((prior_mu == nullptr) == (prior_var == nullptr), "ha_humor_rollout_forward: prior_mu and prior_var go together");
+  if (persist_take_failure(net->persist)) {
+    set_error("ha_humor_rollout_forward: an earlier persistent roll-out launch on this network failed (error word 0x%x: its bounded waits ran out -- was "
+              "another kernel holding part of the GPU?); the results of that call are invalid.  This network now uses the launch chain.",
+              persist_error_word(net->persist));
+    return HA_ERR_HIP;
+  }
   DeviceGuard guard(net->device);
   int ng, rpg;
   group_plan(B, ng, rpg);
+  tl_groups = ng;
   const size_t gs = ng > 1 ? group_stash_floats(net, rpg, S) : 0;
+  tl_groups = 1;
   return for_each_group(net->device, B, S, false, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
     const size_t r = (size_t)r0;
     return rollout_forward_impl(net, rows, S, past_in0 + r * D_IN, z_seq + r * S * ZD, world + r * S * D_STATE,
@@ -2165,10 +2181,17 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
   HA_REQUIRE(net && stash && g_past_in0 && g_z_seq, "ha_humor_rollout_backward: null argument");
   HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_backward: B and S must be >= 1");
   (void)z_seq;
+  if (persist_take_failure(net->persist)) {
+    set_error("ha_humor_rollout_backward: an earlier persistent roll-out launch on this network failed (error word 0x%x); its results are invalid.  "
+              "This network now uses the launch chain.", persist_error_word(net->persist));
+    return HA_ERR_HIP;
+  }
   DeviceGuard guard(net->device);
   int ng, rpg;
   group_plan(B, ng, rpg);
+  tl_groups = ng;
   const size_t gs = ng > 1 ? group_stash_floats(net, rpg, S) : 0;
+  tl_groups = 1;
   return for_each_group(net->device, B, S, true, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
     const size_t r = (size_t)r0;
     return rollout_backward_impl(net, rows, S, g_world ? g_world + r * S * D_STATE : nullptr,

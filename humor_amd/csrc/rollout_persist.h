@@ -45,6 +45,8 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* decoder);
 void persist_destroy(PersistNet* p);
 // false after a launch has reported a failure (a team that never completed): the caller then uses the launch chain
 bool persist_usable(PersistNet* p);
+// true exactly once after a persistent launch has reported a failure (the caller returns an error: earlier results are invalid)
+bool persist_take_failure(PersistNet* p);
 int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t st);
 int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_t st);
 // error word of the most recent launches (0 = none); valid after the stream has been synchronised

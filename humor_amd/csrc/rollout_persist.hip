@@ -119,6 +119,7 @@ struct PersistNet {
   unsigned* err_host = nullptr;    // hipHostMalloc'ed, mapped
   unsigned* err_dev = nullptr;
   bool disabled = false;
+  bool reported = false;            // the failure has been returned to a caller once
   long long launches = 0, launches_bwd = 0;
 };
 
@@ -1333,6 +1334,16 @@ bool persist_usable(PersistNet* p) {
 
 long long persist_launches(PersistNet* p) { return p ? p->launches : 0; }
 long long persist_launches_bwd(PersistNet* p) { return p ? p->launches_bwd : 0; }
+
+// A persistent launch runs asynchronously: a failure (its bounded waits ran out, e.g. because another process's kernel held part of
+// the chip) is only known to the host later.  The first entry point called after that returns an error ONCE -- the results of the
+// failed call are invalid and the caller must know -- and from then on the launch chain serves this network.
+bool persist_take_failure(PersistNet* p) {
+  if (!p || p->reported || !p->err_host || *reinterpret_cast<volatile unsigned*>(p->err_host) == 0) return false;
+  p->reported = true;
+  p->disabled = true;
+  return true;
+}
 
 unsigned persist_error_word(PersistNet* p) { return (p && p->err_host) ? *reinterpret_cast<volatile unsigned*>(p->err_host) : 0u; }
 
