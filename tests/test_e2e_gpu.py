@@ -123,7 +123,11 @@ def test_sharded_run_is_identical_on_all_ranks(gpu_lib, dev, smplh_npz, tmp_path
     import torch.multiprocessing as mp
     out = str(tmp_path / 'final_rank%d.pt')
     port = 31000 + (os.getpid() % 2000)
-    mp.spawn(_sharded_run_worker, args=(2, port, smplh_npz, out), nprocs=2, join=True)
+    os.environ['HUMOR_AMD_ROLLOUT_PERSIST'] = '0'          # two processes on ONE GPU (see humor_amd/_lib.py)
+    try:
+        mp.spawn(_sharded_run_worker, args=(2, port, smplh_npz, out), nprocs=2, join=True)
+    finally:
+        del os.environ['HUMOR_AMD_ROLLOUT_PERSIST']
     r0, r1 = torch.load(out % 0), torch.load(out % 1)
     assert set(r0) == set(r1) and 'latent_motion' in r0 and r0['floor_plane'].shape == (4, 4)
     for k in r0:
@@ -179,7 +183,7 @@ def test_bench_starts_n_ranks_itself(gpu_lib):
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, HUMOR_AMD_BENCH_BACKEND='gloo', HUMOR_AMD_BENCH_ONE_GPU='1')
+    env = dict(os.environ, HUMOR_AMD_BENCH_BACKEND='gloo', HUMOR_AMD_BENCH_ONE_GPU='1', HUMOR_AMD_ROLLOUT_PERSIST='0')
     env.pop('WORLD_SIZE', None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
                        env=env, capture_output=True, text=True, timeout=900)

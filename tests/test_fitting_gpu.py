@@ -115,7 +115,11 @@ def test_sharded_stage3_closure_on_gpu(gpu_lib, dev, smplh_npz, tmp_path):
     from oracle import closure_cases as CC
     out = str(tmp_path / 'sharded3.pt')
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_sharded_gpu_worker, args=(2, port, smplh_npz, out), nprocs=2, join=True)
+    os.environ['HUMOR_AMD_ROLLOUT_PERSIST'] = '0'          # two processes on ONE GPU (see humor_amd/_lib.py)
+    try:
+        mp.spawn(_sharded_gpu_worker, args=(2, port, smplh_npz, out), nprocs=2, join=True)
+    finally:
+        del os.environ['HUMOR_AMD_ROLLOUT_PERSIST']
     sharded = torch.load(out)
     B, T = 6, 10
     case = CC.make_case('rgb', B, T, seed=2)
