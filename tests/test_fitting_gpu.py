@@ -124,7 +124,11 @@ def test_sharded_stage3_closure_on_gpu(gpu_lib, dev, smplh_npz, tmp_path):
     B, T = 6, 10
     case = CC.make_case('rgb', B, T, seed=2)
     opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
-    res = FC.eval_stage(opt, case, 2, dev)
+    gpu_lib.call('ha_tune_set', b'rollout_persist', 0)      # the same roll-out path as the two workers: this test is about the sharding
+    try:
+        res = FC.eval_stage(opt, case, 2, dev)
+    finally:
+        gpu_lib.call('ha_tune_set', b'rollout_persist', 1)
     assert abs(res['loss'].item() - sharded['loss']) <= 1e-5 * abs(res['loss'].item())
     for k, v in res.items():
         if k != 'loss':
