@@ -188,30 +188,35 @@ def time_events(fn, iters, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
-def skin_roofline(dev, npz, N=B_SEQ * T_SEQ, traffic=PMC_TRAFFIC_BYTES):
+def skin_roofline(dev, npz, N=B_SEQ * T_SEQ, traffic=PMC_TRAFFIC_BYTES, rotate=1):
     """The streaming LBS kernel alone (ha_lbs_skin) at N frames: algorithmic bytes / event-timed launch duration.
-    Launched on torch's current stream, so the HIP events bracket exactly these launches.  N = 1920 is the metric's batch
-    (32 x 60; its 159 MB operands partly live in the 256 MiB Infinity Cache), N = 30720 (C5) is cache-free."""
+    Launched on torch's current stream, so the HIP events bracket exactly these launches.
+    rotate = number of operand sets the launches cycle through.  At the metric's batch (N = 1920) one set is 159 MB read + 159 MB
+    written: back-to-back launches on ONE set are partly served by the 256 MiB Infinity Cache (not an HBM figure); cycling through
+    enough sets that > 256 MiB lie between two uses of a line makes every launch stream from / to HBM.  N = 30720 (C5) is
+    cache-free with one set."""
     from humor_amd import _lib
     from humor_amd.body_model import BodyModel
     lib = _lib.get_lib()
     h = BodyModel(npz, num_betas=16)._handle_for(dev)
-    vposed = torch.randn(N * V * 3 + 4, device=dev)
-    A = torch.randn(N, J, 12, device=dev)
-    transl = torch.randn(N, 3, device=dev)
-    verts = torch.empty(N, V, 3, device=dev)
-    st = _lib.stream_ptr(verts)
+    sets = [(torch.randn(N * V * 3 + 4, device=dev), torch.randn(N, J, 12, device=dev), torch.randn(N, 3, device=dev),
+             torch.empty(N, V, 3, device=dev)) for _ in range(rotate)]
+    st = _lib.stream_ptr(sets[0][3])
+    state = {'i': 0}
 
     def launch():
+        vposed, A, transl, verts = sets[state['i'] % rotate]
+        state['i'] += 1
         lib.call('ha_lbs_skin', h.ptr, N, _lib.ptr(vposed), _lib.ptr(A), _lib.ptr(transl), _lib.ptr(verts), st)
     # cache-free sizes: the first ~20 back-to-back launches ride a power-management transient (0.93 ms, then a hump up to 1.3 ms, then
     # a steady ~0.98 ms; tools/skin_jitter.py, profiles/r02_run20_skin_jitter.txt) -- the sustained figure is the one reported
-    ms = time_events(launch, iters=50 if N <= 4096 else 30, warm=5 if N <= 4096 else 30)
+    small = N <= 4096
+    ms = time_events(launch, iters=(48 if rotate > 1 else 50) if small else 30, warm=(6 if rotate > 1 else 5) if small else 30)
     nbytes = SKIN_BYTES_PER_FRAME * N
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {'kernel': 'lbs_skin (ha_lbs_skin)', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': PMC_TRAFFIC_SOURCE,
-            'avg_launch_us': round(ms * 1e3, 2),
+            'avg_launch_us': round(ms * 1e3, 2), 'operand_sets': rotate,
             'bytes_per_launch': nbytes, 'frames_per_launch': N}
 
 
@@ -610,7 +615,10 @@ def run(args):
 
     if rank == 0:
         gpu_eval = fc.snapshot() if world == 1 and not args.no_cpu_baseline else None      # for the parity field (untimed)
-        roof = skin_roofline(dev, npz)          # first among the side measurements: same chip state as in earlier rounds
+        # the roofline kernel at the metric's batch, HBM figure: launches rotate over 4 operand sets (1.27 GB: > 256 MiB of other
+        # lines between two uses of any line); the single-set (Infinity-Cache-assisted) figure of rounds 1-2 is kept beside it
+        roof = skin_roofline(dev, npz, rotate=4)
+        roof['cache_warm_single_set'] = {k: v for k, v in skin_roofline(dev, npz, rotate=1).items() if k in ('achieved', 'frac', 'avg_launch_us')}
         ms_dense, ms_dense_fb = dense_smpl_ms(dev, npz)
         res = {
             'metric': 'fitting closure evaluations/s (stage-3 objective fwd+bwd), batch=32 seq=60 per GPU',
@@ -650,9 +658,9 @@ def run(args):
             res['roofline_c5'] = skin_roofline(dev, npz, N=256 * 120, traffic=PMC_TRAFFIC_BYTES_C5)
             res['roofline_c5']['note'] = ('cache-free size (5.2 GB per launch); at this size the kernel\'s own copy-only mode reaches 5.77 TB/s '
                                           'and a torch device copy 4.94 TB/s (profiles/r02_pmc_lbs/SUMMARY.txt)')
-            res['roofline']['note'] = ('the metric\'s batch (32 x 60): 159 MB operands, partly served by the 256 MiB Infinity Cache; 5 warm-up + 50 timed '
-                                       'launches as in round 1 (a series of 80 back-to-back launches settles 15-25 % lower: the gather\'s LDS replays push '
-                                       'the package into its power limit, profiles/experiments/README.md); see roofline_c5 for the cache-free, sustained figure')
+            res['roofline']['note'] = ('the metric\'s batch (32 x 60) on 4 rotating operand sets = streamed from / to HBM; cache_warm_single_set = the '
+                                       'same launches on ONE 159 + 159 MB set (partly served by the 256 MiB Infinity Cache: the figure of rounds 1-2); '
+                                       'roofline_c5 = the cache-free C5 size, sustained')
             # BASELINE config C5 (batch 256 x 120 frames): LBS GB/s, pose-blend and decoder/prior MLP fp32-MFMA utilisation
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import bench_c5

@@ -128,6 +128,7 @@ struct PersistNet {
 typedef float pvf4 __attribute__((ext_vector_type(4)));
 typedef unsigned puv4 __attribute__((ext_vector_type(4)));
 
+struct PersistBwdArgs;
 #ifdef HA_PERSIST_TIMING
 // profiling build only (tools/persist_phase_timing.py): phase timestamps (s_memtime) of one wave for steps PT_T0 .. PT_T0 + 7
 constexpr int PT_T0 = 8, PT_N = 24;
@@ -138,10 +139,20 @@ __device__ unsigned long long g_pts[2][8][PT_N];      // [0]: team 0 member 5 (a
   } while (0)
 #define PT_ARGS , bool pt_on, int pt_slot, int t
 #define PT_PASS , pt_on, pt_slot, t
+__device__ unsigned long long g_ptb[8][PT_N];         // adjoint: team 0 member 5, steps S-1-PT_T0 downwards
+#define PTB(i)                                                                                       \
+  do {                                                                                               \
+    if (ptb_on && (a.S - 1 - t) >= PT_T0 && (a.S - 1 - t) < PT_T0 + 8) g_ptb[a.S - 1 - t - PT_T0][i] = clock64(); \
+  } while (0)
+#define PTB_ARGS , bool ptb_on, int t, const PersistBwdArgs& a
+#define PTB_PASS , ptb_on, t, a
 #else
 #define PT(i)
 #define PT_ARGS
 #define PT_PASS
+#define PTB(i)
+#define PTB_ARGS
+#define PTB_PASS
 #endif
 
 __device__ __forceinline__ size_t pq(int c) { return (size_t)(c >> 2) * 128 + (c & 3); }
@@ -719,23 +730,23 @@ __device__ __forceinline__ void outer_acc3(float M[9], const float a[3], const f
 #pragma unroll
     for (int k = 0; k < 3; ++k) M[i * 3 + k] = fmaf(a[i], b[k], M[i * 3 + k]);
 }
-// a dL/dz task: CH chunks of the activation adjoint against the wave's LDS-resident latent-column weights
+// a dL/dz task (or layer 0's LDS-resident K tail): CH chunks of the activation adjoint against LDS-resident weight vectors.  All
+// operands are read first, then the MFMAs run on min(CH, 8) independent accumulators.
 template <int CH>
 __device__ __forceinline__ void dz_mma(const float* xs, const float* wl, int lane, float (&acc)[4]) {
-  pvf4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+  constexpr int NCH = CH < 8 ? CH : 8;
+  float av[CH], bv[CH];
 #pragma unroll
-  for (int i = 0; i < CH; i += 2) {
-    if ((i & 2) == 0) {
-      c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * i + lane], wl[64 * i + lane], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * (i + 1) + lane], wl[64 * (i + 1) + lane], c1, 0, 0, 0);
-    } else {
-      c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * i + lane], wl[64 * i + lane], c2, 0, 0, 0);
-      c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs[64 * (i + 1) + lane], wl[64 * (i + 1) + lane], c3, 0, 0, 0);
-    }
-  }
-  c0 = (c0 + c1) + (c2 + c3);
+  for (int i = 0; i < CH; ++i) { av[i] = xs[64 * i + lane]; bv[i] = wl[64 * i + lane]; }
+  pvf4 c[NCH];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = c0[i];
+  for (int k = 0; k < NCH; ++k) c[k] = pvf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < CH; ++i) c[i % NCH] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i], bv[i], c[i % NCH], 0, 0, 0);
+#pragma unroll
+  for (int k = 1; k < NCH; ++k) c[0] += c[k];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = c[0][i];
 }
 // one K-split partial of dL/dz (columns 4 cg .. 4 cg + 3 of the latent, the team's 4 rows) -> part[t][slot][row][48]
 __device__ __forceinline__ void dz_store(const float (&acc)[4], float* part, int t, int slot, int cg, int row0, int lane) {
@@ -809,27 +820,67 @@ __device__ __forceinline__ void rod_fwd_bwd(const float r[3], const float gR[9],
   gr[2] = gnz * it + k * uz;
 }
 
+// w2a_bwd() of rot_math.h with the rotation adjoint through rod_fwd_bwd (one sine/cosine evaluation)
+__device__ __forceinline__ void w2a_bwd_sc(const W2A& o, const float gW[9], float& g_p0, float& g_p3) {
+  const float aa[3] = {0.f, 0.f, o.az};
+  float gaa[3], Runused[9];
+  rod_fwd_bwd(aa, gW, Runused, gaa);
+  const float g_az = gaa[2];
+  const float g_s = o.angle * g_az;
+  const float g_angle = o.s * g_az;
+  const float g_xp = -g_angle / sqrtf(1.0f - o.xp * o.xp);
+  const float g_u = (o.u >= -1.0f && o.u <= 1.0f) ? g_xp : 0.f;
+  const float d = o.nrm + 1e-6f;
+  float g_rx = g_u / d;
+  float g_ry = 0.f;
+  const float g_nrm = -g_u * o.rx / (d * d);
+  if (o.nrm > 0.f) {
+    g_rx += g_nrm * o.rx / o.nrm;
+    g_ry += g_nrm * o.ry / o.nrm;
+  }
+  const float ar = fabsf(o.ry), da = ar + 1e-6f;
+  const float sgn = o.ry > 0.f ? 1.f : (o.ry < 0.f ? -1.f : 0.f);
+  const float ds = -(da - o.ry * sgn) / (da * da);
+  g_ry += g_s * ds;
+  g_p0 = -g_rx;
+  g_p3 = -g_ry;
+}
+
 // consumer side of an activation adjoint: sweep dL/da (a = ReLU(GroupNorm(h))), the forward's h and statistics, GroupNorm/ReLU
-// adjoint (gn_apply mode 3 of the launch chain: dh = rstd (dxh - mean(dxh) - xh mean(dxh xh))), dh to LDS as [channel][4 rows]
+// adjoint (gn_apply mode 3 of the launch chain: dh = rstd (dxh - mean(dxh) - xh mean(dxh xh))), dh to LDS as [channel][4 rows].
+// The forward's pre-activations and statistics come from HBM / the Infinity Cache (~2 us): they are requested one phase early
+// (gnb_issue, before the previous layer's MFMAs) so that the sweep's loads do not queue behind them.
+template <int NQ>
+struct GnbRegs {
+  float h[NQ][4];
+  pvf4 s0[NQ], s1[NQ];        // (mean, rstd) of rows 0-1 and 2-3 of the channel's group
+};
 template <int NQ, int GROUP>
-__device__ __forceinline__ bool gather_norm_bwd(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float* gam_lds, const float* bet_lds,
-                                                const float* hslab, const float* stats, int row0, float* ds, int tid) {
-  // forward pre-activations and statistics of this thread's channels -> normalised activation xh (kept with rstd across the sweep)
-  float xh[NQ][4], rstd[NQ][4];
+__device__ __forceinline__ void gnb_issue(const float* hslab, const float* stats, int row0, int tid, GnbRegs<NQ>& r) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int c = tid + 256 * q;
     const float* hp = hslab + pq(c) + (size_t)row0 * 4;
-    float h[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h[i] = hp[i * 4];
+    for (int i = 0; i < 4; ++i) r.h[q][i] = hp[i * 4];
     const pvf4* sp = reinterpret_cast<const pvf4*>(stats + ((size_t)(c / GROUP) * 32 + row0) * 2);
-    const pvf4 s0 = sp[0], s1 = sp[1];
-    rstd[q][0] = s0.y; rstd[q][1] = s0.w; rstd[q][2] = s1.y; rstd[q][3] = s1.w;
-    xh[q][0] = (h[0] - s0.x) * s0.y; xh[q][1] = (h[1] - s0.z) * s0.w; xh[q][2] = (h[2] - s1.x) * s1.y; xh[q][3] = (h[3] - s1.z) * s1.w;
+    r.s0[q] = sp[0];
+    r.s1[q] = sp[1];
+  }
+}
+template <int NQ, int GROUP, int PTI = 0>
+__device__ __forceinline__ bool gather_norm_bwd(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float* gam_lds, const float* bet_lds,
+                                                const GnbRegs<NQ>& r, float* ds, int tid PTB_ARGS) {
+  float xh[NQ][4], rstd[NQ][4];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    rstd[q][0] = r.s0[q].y; rstd[q][1] = r.s0[q].w; rstd[q][2] = r.s1[q].y; rstd[q][3] = r.s1[q].w;
+    xh[q][0] = (r.h[q][0] - r.s0[q].x) * r.s0[q].y; xh[q][1] = (r.h[q][1] - r.s0[q].z) * r.s0[q].w;
+    xh[q][2] = (r.h[q][2] - r.s1[q].x) * r.s1[q].y; xh[q][3] = (r.h[q][3] - r.s1[q].z) * r.s1[q].w;
   }
   float ga[NQ][4];
   if (!sweep<NQ>(rs, off, tag, NQ * 256, tid, ga)) return false;
+  PTB(PTI);
   const float inv_n = 1.0f / (float)GROUP;
   float dxh[NQ * 4], m2[NQ * 4];
 #pragma unroll
@@ -973,6 +1024,9 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
   prefetch_b_issue(a.S - 1);
   prefetch_b_store(a.S - 1);
 
+#ifdef HA_PERSIST_TIMING
+  const bool ptb_on = team == 0 && m == 5 && tid == 0;
+#endif
   bool fail = false;
   for (int t = a.S - 1; t >= 0; --t) {
     const unsigned tag = 4u * (unsigned)(a.S - 1 - t);
@@ -981,6 +1035,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     // ---- total adjoint of x_{t+1}: own direct part + prior part + the team's layer-0 input gradient of step t+1 ----------------
     prefetch_a_issue(t - 1);
     __syncthreads();                                   // the prefetched buffer of this step and sGXD of step t+1 are complete
+    PTB(0);
     {
       float gx[2][4];
 #pragma unroll
@@ -997,10 +1052,12 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
         }
       }
     }
+    PTB(1);
     prefetch_a_store(t - 1);
     if (fail) misc[2] = 1;
     __syncthreads();
     if (misc[2]) break;
+    PTB(2);
     // ---- glue adjoint: one wave per sequence ------------------------------------------------------------------------------
     {
       const float* X = cur + PF_X + wave * P_XPAD;
@@ -1126,7 +1183,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
         wa2.angle = GL[27];
         wa2.s = -wa2.ry / (fabsf(wa2.ry) + 1e-6f);
         wa2.az = wa2.s * wa2.angle;
-        w2a_bwd(wa2, gW, g0, g3);
+        w2a_bwd_sc(wa2, gW, g0, g3);
       }
       // root translation: wt = (-ptrans.x, -ptrans.y, 0)
       if (v == 22) { gpos[0] -= gwt[0]; gpos[1] -= gwt[1]; }
@@ -1184,11 +1241,16 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
         for (int c = P_RAW; c < P_RAWPAD; ++c) sD3[c * 4 + wave] = 0.f;
       }
     }
+    PTB(3);
     __syncthreads();
+    PTB(4);
     // ---- transposed layer 3: dL/d(decoder output) [216] -> dL/da3 [512] (+ dz) ------------------------------------------------
+    GnbRegs<2> gr2;
+    gnb_issue<2, 32>(sp + a.off_dec[2], sp + a.off_gn[2], row0, tid, gr2);
     {
       float acc[4];
       mma_layer<BC3, 0, 1, BR3>(sD3, sD3, wa, wv, lane, acc);
+      PTB(5);
       publish<1, SC1>(acc, 0.f, 4 * g, team_xch, rs, GA_OFF3, tag + 1, nullptr, row0, lane);
       if (g < DZ3_WAVES) {
         float accz[4];
@@ -1197,15 +1259,21 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       }
     }
     // ---- layer 2 ------------------------------------------------------------------------------------------------------------
+    PTB(6);
     prefetch_b_issue(t - 1);
-    if (!gather_norm_bwd<2, 32>(rs, GA_OFF3, tag + 1, sGam3, sBet3, sp + a.off_dec[2], sp + a.off_gn[2], row0, sD2, tid)) fail = true;
+    if (!gather_norm_bwd<2, 32, 7>(rs, GA_OFF3, tag + 1, sGam3, sBet3, gr2, sD2, tid PTB_PASS)) fail = true;
     prefetch_b_store(t - 1);
+    PTB(8);
     if (fail) misc[2] = 1;
     __syncthreads();
     if (misc[2]) break;
+    PTB(9);
+    GnbRegs<4> gr1;
+    gnb_issue<4, 64>(sp + a.off_dec[1], sp + a.off_gn[1], row0, tid, gr1);
     {
       float acc[8];
       mma_layer<BC2, 0, 2, BR2>(sD2, sD2, wa, wv, lane, acc);
+      PTB(10);
       publish<2, SC1>(acc, 0.f, 8 * g, team_xch, rs, GA_OFF2, tag + 2, nullptr, row0, lane);
       if (g < DZ2_WAVES) {
         float accz[4];
@@ -1214,13 +1282,19 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       }
     }
     // ---- layer 1 ------------------------------------------------------------------------------------------------------------
-    if (!gather_norm_bwd<4, 64>(rs, GA_OFF2, tag + 2, sGam2, sBet2, sp + a.off_dec[1], sp + a.off_gn[1], row0, sD1, tid)) fail = true;
+    PTB(11);
+    if (!gather_norm_bwd<4, 64, 12>(rs, GA_OFF2, tag + 2, sGam2, sBet2, gr1, sD1, tid PTB_PASS)) fail = true;
+    PTB(13);
     if (fail) misc[2] = 1;
     __syncthreads();
     if (misc[2]) break;
+    PTB(14);
+    GnbRegs<4> gr0;
+    gnb_issue<4, 64>(sp + a.off_dec[0], sp + a.off_gn[0], row0, tid, gr0);
     {
       float acc[8];
       mma_layer<BC1, 0, 2, BR1>(sD1, sD1, wa, wv, lane, acc);
+      PTB(15);
       publish<2, SC1>(acc, 0.f, 8 * g, team_xch, rs, GA_OFF1, tag + 3, nullptr, row0, lane);
       if (g < DZ1_WAVES) {
         float accz[4];
@@ -1229,10 +1303,13 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       }
     }
     // ---- layer 0 ------------------------------------------------------------------------------------------------------------
-    if (!gather_norm_bwd<4, 64>(rs, GA_OFF1, tag + 3, sGam1, sBet1, sp + a.off_dec[0], sp + a.off_gn[0], row0, sD0, tid)) fail = true;
+    PTB(16);
+    if (!gather_norm_bwd<4, 64, 17>(rs, GA_OFF1, tag + 3, sGam1, sBet1, gr0, sD0, tid PTB_PASS)) fail = true;
+    PTB(18);
     if (fail) misc[2] = 1;
     __syncthreads();
     if (misc[2]) break;
+    PTB(19);
     {
       float acc[4];
       if (g < L0T_WAVES) {
@@ -1242,6 +1319,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] += tail[i];
       } else { acc[0] = acc[1] = acc[2] = acc[3] = 0.f; }
+      PTB(20);
       if (g < P_XPAD / 4) publish<1, SC1>(acc, 0.f, 4 * g, team_xch, rs, GX_OFF0, tag + 4, nullptr, row0, lane);     // (waves 85..87: the zero padding)
       if (g < DZ0_WAVES) {
         float accz[4];
@@ -1249,6 +1327,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
         dz_store(accz, a.dz_part, t, DZ_S0 + g % (BC0 / DZ0_CH), g / (BC0 / DZ0_CH), row0, lane);
       }
     }
+    PTB(21);
   }
   // ---- dL/dpast_in0 = total adjoint of x_0 (the t2j = -(x0[207], x0[208], 0) dependence included) -------------------------------
   __syncthreads();
@@ -1293,6 +1372,11 @@ __global__ void dz_reduce_kernel(const float* __restrict__ part, float* __restri
 extern "C" int ha_debug_persist_timing(unsigned long long* out /* [2][8][24] */) {
   HA_CHECK_HIP(hipDeviceSynchronize());
   HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_pts), sizeof(unsigned long long) * 2 * 8 * 24));
+  return HA_OK;
+}
+extern "C" int ha_debug_persist_timing_bwd(unsigned long long* out /* [8][24] */) {
+  HA_CHECK_HIP(hipDeviceSynchronize());
+  HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_ptb), sizeof(unsigned long long) * 8 * 24));
   return HA_OK;
 }
 namespace ha {

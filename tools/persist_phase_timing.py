@@ -35,3 +35,25 @@ for who, ts in (('member 5 (ordinary CU, layer-3 producer)', both[0]), ('member 
     for i, n in enumerate(names[1:]):
         print('%-12s %s | %d' % (n, ' '.join('%5d' % v for v in d[:, i]), int(np.median(d[:, i]))))
     print('sum of medians', int(np.median(d, axis=0).sum()), 'median step', int(np.median(step)))
+
+# ---- adjoint ----------------------------------------------------------------------------------------------------------------
+pz = past.clone().requires_grad_(True)
+zz = z.clone().requires_grad_(True)
+for _ in range(3):
+    pz.grad = None; zz.grad = None
+    out, (pm, pv) = hm.roll_out(pz, None, S, z_seq=zz, return_prior=True)
+    (out['trans'].sum() + out['joints'].sum() + out['root_orient'].sum() + pm.sum()).backward()
+torch.cuda.synchronize()
+bufb = (C.c_ulonglong * (8 * 24))()
+fb = lib._dll.ha_debug_persist_timing_bwd
+fb.restype = C.c_int
+assert fb(bufb) == 0
+tb = np.array(list(bufb), dtype=np.int64).reshape(8, 24)
+bn = ['top', 'dx sweep', 'barrier', 'glue adj', 'barrier', 'L3T mma', 'L3T pub+dz', 'L2 sweep', 'L2 GN adj', 'L2 barrier', 'L2T mma', 'L2T pub+dz',
+      'L1 sweep', 'L1 GN adj', 'L1 barrier', 'L1T mma', 'L1T pub+dz', 'L0 sweep', 'L0 GN adj', 'L0 barrier', 'L0T mma', 'L0T pub+dz']
+d = np.diff(tb[:, :22], axis=1)
+step = tb[1:, 0] - tb[:-1, 0]
+print('adjoint, member 5 -- cycles per step:', step.tolist())
+for i, n in enumerate(bn[1:]):
+    print('%-12s %s | %d' % (n, ' '.join('%5d' % v for v in d[:, i]), int(np.median(d[:, i]))))
+print('sum of medians', int(np.median(d, axis=0).sum()), 'median step', int(np.median(step)))
