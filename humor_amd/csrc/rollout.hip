@@ -1495,6 +1495,7 @@ struct StashLayout {
   bool single = false;
   size_t persist_ws = 0;         // exchange space of the persistent kernel
   size_t off_gn[3] = {0, 0, 0}, off_gl = 0;   // single: per step GroupNorm statistics [16][32][2] x 3, glue record [32][32]
+  size_t off_ht[3] = {0, 0, 0};               // single: per step the hidden pre-activations again, team layout [8][channel][4 rows]
   size_t dz_part = 0;            // single: partial dL/dz products of the persistent adjoint [S][31][32][48]
   size_t bwd_set = 0;            // acc: floats per step of the adjoint scratch (bwd_dec[] are offsets of step 0's set); else 0
   size_t bwd_begin = 0, bwd_floats = 0;
@@ -1538,6 +1539,7 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, b
   if (L.single) {
     for (int i = 0; i < 3; ++i) L.off_gn[i] = ptake(16 * 32 * 2);
     L.off_gl = ptake(32 * 32);
+    for (int i = 0; i < 3; ++i) L.off_ht[i] = ptake(32 * (size_t)net->dec[i].Nout);
   }
   L.per_step = p;
   L.steps = take(p * (size_t)(S + 1));
@@ -1842,7 +1844,7 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
       f.past_in0 = past_in0; f.z_seq = z_seq; f.world = world;
       f.xT = stash + L.xT; f.steps = stash + L.steps; f.per_step = L.per_step; f.off_G = L.off_G;
       for (int l = 0; l < 4; ++l) f.off_dec[l] = L.off_dec[l];
-      for (int l = 0; l < 3; ++l) f.off_gn[l] = L.off_gn[l];
+      for (int l = 0; l < 3; ++l) { f.off_gn[l] = L.off_gn[l]; f.off_ht[l] = L.off_ht[l]; }
       f.off_gl = L.off_gl;
       f.t2j = stash + L.t2j;
       f.ws = stash + L.persist_ws;
@@ -2044,7 +2046,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
       f.gx_pri = with_prior ? stash + L.gx_pri : nullptr; f.gxp_pad = gxp_pad;
       f.xT = stash + L.xT; f.steps = stash + L.steps; f.per_step = L.per_step; f.off_G = L.off_G;
       for (int l = 0; l < 4; ++l) f.off_dec[l] = L.off_dec[l];
-      for (int l = 0; l < 3; ++l) f.off_gn[l] = L.off_gn[l];
+      for (int l = 0; l < 3; ++l) { f.off_gn[l] = L.off_gn[l]; f.off_ht[l] = L.off_ht[l]; }
       f.off_gl = L.off_gl;
       f.t2j = stash + L.t2j;
       f.g_past0 = g_past_in0; f.g_z = g_z_seq;

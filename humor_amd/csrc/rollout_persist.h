@@ -17,6 +17,7 @@ struct PersistFwd {
   float* steps = nullptr;            // per-step region base
   size_t per_step = 0, off_G = 0, off_dec[4] = {0, 0, 0, 0};
   size_t off_gn[3] = {0, 0, 0}, off_gl = 0;   // per step: GroupNorm statistics of the hidden activations; glue record (for the persistent adjoint)
+  size_t off_ht[3] = {0, 0, 0};               // per step: the hidden pre-activations in team layout [8][channel][4 rows]
   float* t2j = nullptr;              // [32][3]
   float* ws = nullptr;               // persist_ws_floats() floats of exchange space (zeroed by persist_forward before the launch)
 };
@@ -30,7 +31,7 @@ struct PersistBwd {
   int gxp_pad = 0;
   const float* xT = nullptr;
   const float* steps = nullptr;
-  size_t per_step = 0, off_G = 0, off_dec[4] = {0, 0, 0, 0}, off_gn[3] = {0, 0, 0}, off_gl = 0;
+  size_t per_step = 0, off_G = 0, off_dec[4] = {0, 0, 0, 0}, off_gn[3] = {0, 0, 0}, off_gl = 0, off_ht[3] = {0, 0, 0};
   const float* t2j = nullptr;
   float* g_past0 = nullptr;          // [B][339]
   float* g_z = nullptr;              // [B][S][48]

@@ -104,6 +104,7 @@ struct PersistArgs {
   float* steps;
   size_t per_step, off_G, off_dec[4];
   size_t off_gn[3], off_gl;  // per step: GroupNorm statistics [16 groups][32 rows][2] of the three hidden activations; glue record [32 rows][32]
+  size_t off_ht[3];          // per step: the hidden pre-activations again, team layout [8 teams][channel][4 rows]
   float* t2j;
   unsigned char* xch;
   unsigned* err;            // host-mapped error word
@@ -338,9 +339,11 @@ __device__ __forceinline__ void mma_layer(const float* xs, const float* zs, cons
 //   NCG = 2: column group h, rows 2 p and 2 p + 1  -> ONE 16-byte store of two {value, tag} granules,
 //   NCG = 1: row 2 h + p                            -> ONE 8-byte granule;
 // the same lanes write the plain pre-activation slab [channel quads][32 rows][4] for the adjoint / prior.
+// ht (or null): a second copy of the pre-activations in the team's own layout [channel][4 rows] (16 contiguous bytes per channel: the
+// persistent adjoint reads its h with one coalesced 16-byte load per channel instead of four scattered 4-byte loads from the slab)
 template <int NCG, bool SC1>
 __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias_lane, int col0, unsigned char* team_xch, __amdgpu_buffer_rsrc_t rs,
-                                        unsigned off, unsigned tag, float* slab, int row0, int lane) {
+                                        unsigned off, unsigned tag, float* slab, int row0, int lane, float* ht = nullptr) {
   const int h = lane >> 5, p = (lane >> 4) & 1, j = lane & 3;
   const bool storer = (lane & 12) == 0;
   if constexpr (NCG == 2) {
@@ -358,6 +361,10 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
         sp[0] = v0;
         sp[4] = v1;
       }
+      if (ht) {
+        typedef float pvf2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<pvf2*>(ht + (size_t)col * 4 + 2 * p) = pvf2{v0, v1};
+      }
     }
   } else {
     const float t = lr::block_sum4(sums);
@@ -370,6 +377,7 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
       if (SC1) __builtin_amdgcn_raw_buffer_store_b64(gr, rs, goff, 0, 16);
       else *reinterpret_cast<puv2*>(team_xch + goff) = gr;
       if (slab) slab[pq(col) + (size_t)(row0 + row) * 4] = v0;
+      if (ht) ht[(size_t)col * 4 + row] = v0;
     }
   }
 }
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float acc[8];
       mma_layer<NC0, NCZ, 2, R0>(xs0, zs, wa, wv, lane, acc);
       PT(1);
-      publish<2, SC1>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, sp + a.off_dec[0], row0, lane);
+      publish<2, SC1>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, sp + a.off_dec[0], row0, lane, sp + a.off_ht[0] + (size_t)team * P_H0 * 4);
       PT(2);
     }
     // ---- layer 1 ----------------------------------------------------------------------------------------------------------
@@ -547,7 +555,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float acc[8];
       mma_layer<NC1, NCZ, 2, R1>(xs1, zs, wa, wv, lane, acc);
       PT(6);
-      publish<2, SC1>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, sp + a.off_dec[1], row0, lane);
+      publish<2, SC1>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, sp + a.off_dec[1], row0, lane, sp + a.off_ht[1] + (size_t)team * P_H1 * 4);
       PT(7);
     }
     // ---- layer 2 ----------------------------------------------------------------------------------------------------------
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float acc[4];
       mma_layer<NC2, NCZ, 1, R2>(xs2, zs, wa, wv, lane, acc);
       PT(11);
-      publish<1, SC1>(acc, b2, 4 * g, team_xch, rs, ACT_OFF2, tag + 3, sp + a.off_dec[2], row0, lane);
+      publish<1, SC1>(acc, b2, 4 * g, team_xch, rs, ACT_OFF2, tag + 3, sp + a.off_dec[2], row0, lane, sp + a.off_ht[2] + (size_t)team * P_H2 * 4);
       PT(12);
     }
     // ---- layer 3 (GroupNorm groups of 32) -------------------------------------------------------------------------------
@@ -773,7 +781,7 @@ struct PersistBwdArgs {
   int gxp_pad;
   const float* xT;
   const float* steps;
-  size_t per_step, off_G, off_dec[4], off_gn[3], off_gl;
+  size_t per_step, off_G, off_dec[4], off_gn[3], off_gl, off_ht[3];
   const float* t2j;
   float* g_past0;           // [B][339]
   float* dz_part;           // [S][DZ_SLOTS][32][48]
@@ -787,7 +795,7 @@ __device__ __forceinline__ void rod_fwd_bwd(const float r[3], const float gR[9],
   const float ux = r[0] + 1e-8f, uy = r[1] + 1e-8f, uz = r[2] + 1e-8f;
   const float t = sqrtf(ux * ux + uy * uy + uz * uz);
   const float it = 1.0f / t;
-  const float nx = r[0] / t, ny = r[1] / t, nz = r[2] / t;
+  const float nx = r[0] * it, ny = r[1] * it, nz = r[2] * it;      // (one reciprocal: the adjoint is a dependent chain)
   float s, c;
   sincosf(t, &s, &c);
   const float c1 = 1.0f - c;
@@ -828,19 +836,20 @@ __device__ __forceinline__ void w2a_bwd_sc(const W2A& o, const float gW[9], floa
   const float g_az = gaa[2];
   const float g_s = o.angle * g_az;
   const float g_angle = o.s * g_az;
-  const float g_xp = -g_angle / sqrtf(1.0f - o.xp * o.xp);
+  const float g_xp = -g_angle * __builtin_amdgcn_rsqf(1.0f - o.xp * o.xp);
   const float g_u = (o.u >= -1.0f && o.u <= 1.0f) ? g_xp : 0.f;
-  const float d = o.nrm + 1e-6f;
-  float g_rx = g_u / d;
+  const float id = 1.0f / (o.nrm + 1e-6f);
+  float g_rx = g_u * id;
   float g_ry = 0.f;
-  const float g_nrm = -g_u * o.rx / (d * d);
+  const float g_nrm = -g_u * o.rx * (id * id);
   if (o.nrm > 0.f) {
-    g_rx += g_nrm * o.rx / o.nrm;
-    g_ry += g_nrm * o.ry / o.nrm;
+    const float inr = 1.0f / o.nrm;
+    g_rx += g_nrm * o.rx * inr;
+    g_ry += g_nrm * o.ry * inr;
   }
-  const float ar = fabsf(o.ry), da = ar + 1e-6f;
+  const float ar = fabsf(o.ry), da = ar + 1e-6f, ida = 1.0f / da;
   const float sgn = o.ry > 0.f ? 1.f : (o.ry < 0.f ? -1.f : 0.f);
-  const float ds = -(da - o.ry * sgn) / (da * da);
+  const float ds = -(da - o.ry * sgn) * (ida * ida);
   g_ry += g_s * ds;
   g_p0 = -g_rx;
   g_p3 = -g_ry;
@@ -852,17 +861,16 @@ __device__ __forceinline__ void w2a_bwd_sc(const W2A& o, const float gW[9], floa
 // (gnb_issue, before the previous layer's MFMAs) so that the sweep's loads do not queue behind them.
 template <int NQ>
 struct GnbRegs {
-  float h[NQ][4];
+  pvf4 h[NQ];                 // the channel's four rows
   pvf4 s0[NQ], s1[NQ];        // (mean, rstd) of rows 0-1 and 2-3 of the channel's group
 };
+// ht: the team's copy of the pre-activations, [channel][4 rows]
 template <int NQ, int GROUP>
-__device__ __forceinline__ void gnb_issue(const float* hslab, const float* stats, int row0, int tid, GnbRegs<NQ>& r) {
+__device__ __forceinline__ void gnb_issue(const float* ht, const float* stats, int row0, int tid, GnbRegs<NQ>& r) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int c = tid + 256 * q;
-    const float* hp = hslab + pq(c) + (size_t)row0 * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r.h[q][i] = hp[i * 4];
+    r.h[q] = *reinterpret_cast<const pvf4*>(ht + (size_t)c * 4);
     const pvf4* sp = reinterpret_cast<const pvf4*>(stats + ((size_t)(c / GROUP) * 32 + row0) * 2);
     r.s0[q] = sp[0];
     r.s1[q] = sp[1];
@@ -1246,7 +1254,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     PTB(4);
     // ---- transposed layer 3: dL/d(decoder output) [216] -> dL/da3 [512] (+ dz) ------------------------------------------------
     GnbRegs<2> gr2;
-    gnb_issue<2, 32>(sp + a.off_dec[2], sp + a.off_gn[2], row0, tid, gr2);
+    gnb_issue<2, 32>(sp + a.off_ht[2] + (size_t)team * P_H2 * 4, sp + a.off_gn[2], row0, tid, gr2);
     {
       float acc[4];
       mma_layer<BC3, 0, 1, BR3>(sD3, sD3, wa, wv, lane, acc);
@@ -1269,7 +1277,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     if (misc[2]) break;
     PTB(9);
     GnbRegs<4> gr1;
-    gnb_issue<4, 64>(sp + a.off_dec[1], sp + a.off_gn[1], row0, tid, gr1);
+    gnb_issue<4, 64>(sp + a.off_ht[1] + (size_t)team * P_H1 * 4, sp + a.off_gn[1], row0, tid, gr1);
     {
       float acc[8];
       mma_layer<BC2, 0, 2, BR2>(sD2, sD2, wa, wv, lane, acc);
@@ -1290,7 +1298,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     if (misc[2]) break;
     PTB(14);
     GnbRegs<4> gr0;
-    gnb_issue<4, 64>(sp + a.off_dec[0], sp + a.off_gn[0], row0, tid, gr0);
+    gnb_issue<4, 64>(sp + a.off_ht[0] + (size_t)team * P_H0 * 4, sp + a.off_gn[0], row0, tid, gr0);
     {
       float acc[8];
       mma_layer<BC1, 0, 2, BR1>(sD1, sD1, wa, wv, lane, acc);
@@ -1560,7 +1568,7 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
   a.past_in0 = f.past_in0; a.z_seq = f.z_seq; a.world = f.world; a.xT = f.xT; a.steps = f.steps;
   a.per_step = f.per_step; a.off_G = f.off_G;
   for (int l = 0; l < 4; ++l) a.off_dec[l] = f.off_dec[l];
-  for (int l = 0; l < 3; ++l) a.off_gn[l] = f.off_gn[l];
+  for (int l = 0; l < 3; ++l) { a.off_gn[l] = f.off_gn[l]; a.off_ht[l] = f.off_ht[l]; }
   a.off_gl = f.off_gl;
   a.t2j = f.t2j;
   a.xch = reinterpret_cast<unsigned char*>(f.ws);
@@ -1589,7 +1597,7 @@ int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_
   a.g_world = f.g_world; a.gx_pri = f.gx_pri; a.gxp_pad = f.gxp_pad;
   a.xT = f.xT; a.steps = f.steps; a.per_step = f.per_step; a.off_G = f.off_G;
   for (int l = 0; l < 4; ++l) a.off_dec[l] = f.off_dec[l];
-  for (int l = 0; l < 3; ++l) a.off_gn[l] = f.off_gn[l];
+  for (int l = 0; l < 3; ++l) { a.off_gn[l] = f.off_gn[l]; a.off_ht[l] = f.off_ht[l]; }
   a.off_gl = f.off_gl;
   a.t2j = f.t2j; a.g_past0 = f.g_past0; a.dz_part = f.dz_part;
   a.xch = reinterpret_cast<unsigned char*>(f.ws);
