@@ -65,7 +65,7 @@ constexpr int SPIN_LIMIT = 40000;        // bounded waits (~1 us per spin)
 constexpr int BC3 = P_RAWPAD / 16, BC2 = P_H2 / 16, BC1 = P_H1 / 16, BC0 = P_H0 / 16;
 // weight registers of a wave: main products (dL/d activation), then its share of the dL/dz products
 constexpr int BR3 = 0, BR2 = BR3 + BC3, BR1 = BR2 + BC2 * 2, BR0 = BR1 + BC1 * 2;
-constexpr int BC0_LDS = 20, BC0_REG = BC0 - BC0_LDS;      // layer 0: the last BC0_LDS chunks' weights live in LDS (register budget)
+constexpr int BC0_LDS = 24, BC0_REG = BC0 - BC0_LDS;      // layer 0: the last BC0_LDS chunks' weights live in LDS (register budget)
 constexpr int DZ0_CH = 8, DZ1_CH = 8, DZ2_CH = 4, DZ3_CH = 2;             // chunks per dL/dz task (12 column groups x K splits)
 constexpr int DZ0_WAVES = 12 * (BC0 / DZ0_CH), DZ1_WAVES = 12 * (BC1 / DZ1_CH), DZ2_WAVES = 12 * (BC2 / DZ2_CH), DZ3_WAVES = 12 * (BC3 / DZ3_CH);
 constexpr int BRZ0 = BR0 + BC0_REG, BRZ1 = BRZ0 + DZ0_CH, BRZ2 = BRZ1 + DZ1_CH, BRZ3 = BRZ2 + DZ2_CH, NREG_B_ALL = BRZ3 + DZ3_CH;
