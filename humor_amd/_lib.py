@@ -61,6 +61,13 @@ class RolloutPostArgs(C.Structure):
         'g_world', 'g_trans0', 'g_root0', 'g_pose0', 'g_joints0', 'g_c2p_R', 'g_c2p_t', 'partial')]
 
 
+class RigidImageArgs(C.Structure):
+    """ha_rigid_image_args (include/humor_amd.h)."""
+    _fields_ = [('N', C.c_int), ('J', C.c_int), ('V', C.c_int)] + [(n, C.c_void_p) for n in (
+        'joints', 'verts', 'root', 'trans', 'root2', 'trans2', 'joints2', 'verts2', 'g_joints2', 'g_verts2',
+        'g_joints', 'g_verts', 'g_root', 'g_trans', 'g_root2', 'g_trans2')]
+
+
 _SIGS = {
     'ha_last_error': (C.c_char_p, []),
     'ha_abi_version': (C.c_int, []),
@@ -99,6 +106,8 @@ _SIGS = {
     'ha_fit_pre_backward': (C.c_int, [C.POINTER(FitPreArgs), C.c_void_p]),
     'ha_rollout_post_forward': (C.c_int, [C.POINTER(RolloutPostArgs), C.c_void_p]),
     'ha_rollout_post_backward': (C.c_int, [C.POINTER(RolloutPostArgs), C.c_void_p]),
+    'ha_rigid_image_forward': (C.c_int, [C.POINTER(RigidImageArgs), C.c_void_p]),
+    'ha_rigid_image_backward': (C.c_int, [C.POINTER(RigidImageArgs), C.c_void_p]),
     'ha_lbfgs_coeffs': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ha_lbfgs_gram': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ha_lbfgs_gram_workspace': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int64)]),

@@ -25,6 +25,13 @@ namespace ha {
 
 void set_error(const char* fmt, ...);
 
+// LDS written by some lanes of a wavefront is read by other lanes of the SAME wavefront: no s_barrier needed, only the ordering
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // returnless hardware fp32 add at the L2 / memory side (global_atomic_add_f32; no compare-and-swap loop)
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
 #ifdef HA_SIMT_EMU

@@ -88,6 +88,7 @@ static void free_set(VertexSet& s) {
   if (s.Pd_k) (void)hipFree(s.Pd_k);
   if (s.w) (void)hipFree(s.w);
   if (s.idx) (void)hipFree(s.idx);
+  if (s.Wc) (void)hipFree(s.Wc);
   if (s.ids) (void)hipFree(s.ids);
   s = VertexSet();
 }
@@ -104,6 +105,7 @@ static int build_set(ha_smpl_model* m, int slot, const int32_t* ids, int n) {
   std::vector<float> pdk((size_t)s.nchunks * 3 * kChunk * Kp, 0.0f);   // coefficient-major copy for the adjoint
   std::vector<float> w((size_t)s.nchunks * nnz * kChunk, 0.0f);
   std::vector<int32_t> ix((size_t)s.nchunks * nnz * kChunk, 0);
+  std::vector<float> wc((size_t)s.nchunks * kChunk * kMaxJoints, 0.0f);   // [chunk][vertex][joint], dense (the adjoint's dL/dA sum)
   for (int i = 0; i < n; ++i) {
     const int v = ids ? ids[i] : i;
     const int ch = i / kChunk, ln = i % kChunk;
@@ -117,6 +119,7 @@ static int build_set(ha_smpl_model* m, int slot, const int32_t* ids, int n) {
     for (int q = 0; q < nnz; ++q) {
       w[((size_t)ch * nnz + q) * kChunk + ln] = m->h_w[(size_t)v * nnz + q];
       ix[((size_t)ch * nnz + q) * kChunk + ln] = m->h_idx[(size_t)v * nnz + q];
+      wc[((size_t)ch * kChunk + ln) * kMaxJoints + m->h_idx[(size_t)v * nnz + q]] += m->h_w[(size_t)v * nnz + q];
     }
   }
   int rc;
@@ -124,6 +127,7 @@ static int build_set(ha_smpl_model* m, int slot, const int32_t* ids, int n) {
   if ((rc = upload(&s.Pd_k, pdk)) != HA_OK) return rc;
   if ((rc = upload(&s.w, w)) != HA_OK) return rc;
   if ((rc = upload(&s.idx, ix)) != HA_OK) return rc;
+  if ((rc = upload(&s.Wc, wc)) != HA_OK) return rc;
   if (ids) {
     std::vector<int32_t> idv(ids, ids + n);
     if ((rc = upload(&s.ids, idv)) != HA_OK) return rc;
@@ -172,7 +176,7 @@ extern "C" int ha_smpl_model_create(ha_smpl_model** out, int device, int V, int 
   if (cidx.empty()) cidx.push_back(0);
 
   // pre-contracted joint regressor (double accumulation, rounded once)
-  std::vector<float> Jt((size_t)J * 3), Js((size_t)J * 3 * (NB > 0 ? NB : 1), 0.0f);
+  std::vector<float> Jt((size_t)J * 3), Js((size_t)(NB > 0 ? NB : 1) * 3 * kMaxJoints, 0.0f);   // Js: [NB][3][64], lane = joint
   for (int j = 0; j < J; ++j)
     for (int c = 0; c < 3; ++c) {
       double acc = 0.0;
@@ -182,7 +186,7 @@ extern "C" int ha_smpl_model_create(ha_smpl_model** out, int device, int V, int 
         double a2 = 0.0;
         for (int v = 0; v < V; ++v)
           a2 += (double)J_regressor[(size_t)j * V + v] * (double)shapedirs[((size_t)v * 3 + c) * NB + l];
-        Js[((size_t)j * 3 + c) * NB + l] = (float)a2;
+        Js[((size_t)l * 3 + c) * kMaxJoints + j] = (float)a2;
       }
     }
 
@@ -306,13 +310,24 @@ extern "C" int ha_smpl_model_define_subset(ha_smpl_model* m, int slot, const int
 // ===================================================================================================
 namespace ha {
 
+#ifdef HA_SMPL_TIMING
+// profiling build only (tools/smpl_phase_timing.py): phase timestamps of wave 0 of block 0
+__device__ unsigned long long g_smpl_pt[2][16];
+#define SPT(k, i)                                                         \
+  do {                                                                    \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_smpl_pt[k][i] = clock64(); \
+  } while (0)
+#else
+#define SPT(k, i)
+#endif
+
 struct FrameParams {
   // model
   const float* Jt; const float* Js; const int32_t* parents; const int32_t* jdepth;
   const int32_t* child_start; const int32_t* child_idx;
   int J, NB, Kfull, Kfull_pad, kf4, depth;   // kf4: Kfull_pad rounded to 4 floats (LDS stride)
   // vertex set
-  const float* Pd_v; const float* Pd_k; int Kp; const float* w; const int32_t* idx;
+  const float* Pd_v; const float* Pd_k; int Kp; const float* w; const int32_t* idx; const float* Wc;
   int nverts, nchunks, nnz;
   // problem
   int N, n_active, Kc;
@@ -328,6 +343,19 @@ struct FrameParams {
 };
 
 constexpr int FW = 4;  // waves (= frames) per block
+
+// 12 floats at a 16-byte aligned LDS address as three 16-byte accesses
+__device__ __forceinline__ void lds_ld12(const float* src, float o[12]) {
+  const float4* q = reinterpret_cast<const float4*>(src);
+  const float4 a = q[0], b = q[1], c = q[2];
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; o[8] = c.x; o[9] = c.y; o[10] = c.z; o[11] = c.w;
+}
+__device__ __forceinline__ void lds_st12(float* dst, const float v[12]) {
+  float4* q = reinterpret_cast<float4*>(dst);
+  q[0] = make_float4(v[0], v[1], v[2], v[3]);
+  q[1] = make_float4(v[4], v[5], v[6], v[7]);
+  q[2] = make_float4(v[8], v[9], v[10], v[11]);
+}
 
 // Per-joint forward state kept in registers by lane j.
 struct JointState {
@@ -356,12 +384,27 @@ __device__ __forceinline__ void joint_forward(const FrameParams& p, int f, int l
       const float rr[3] = {r[0], r[1], r[2]};
       rodrigues(rr, s.R);
     }
+    // (a block's critical path is a chain of load latencies, not bandwidth: 8 shape coefficients x 3 joint-minor rows of Js in
+    // flight per trip)
+    const float* js = p.Js + j;
+    const float* be = p.betas + (size_t)f * p.NB;
+    float a0 = p.Jt[j * 3], a1 = p.Jt[j * 3 + 1], a2 = p.Jt[j * 3 + 2];
+    int l = 0;
+    for (; l + 8 <= p.NB; l += 8) {
+      float b[8], x[8], y[8], z[8];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float acc = p.Jt[j * 3 + c];
-      for (int l = 0; l < p.NB; ++l) acc = fmaf(p.betas[(size_t)f * p.NB + l], p.Js[(j * 3 + c) * p.NB + l], acc);
-      s.Jr[c] = acc;
+      for (int u = 0; u < 8; ++u) {
+        b[u] = be[l + u];
+        x[u] = js[((l + u) * 3 + 0) * kMaxJoints]; y[u] = js[((l + u) * 3 + 1) * kMaxJoints]; z[u] = js[((l + u) * 3 + 2) * kMaxJoints];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a0 = fmaf(b[u], x[u], a0); a1 = fmaf(b[u], y[u], a1); a2 = fmaf(b[u], z[u], a2); }
     }
+    for (; l < p.NB; ++l) {
+      const float b = be[l];
+      a0 = fmaf(b, js[(l * 3 + 0) * kMaxJoints], a0); a1 = fmaf(b, js[(l * 3 + 1) * kMaxJoints], a1); a2 = fmaf(b, js[(l * 3 + 2) * kMaxJoints], a2);
+    }
+    s.Jr[0] = a0; s.Jr[1] = a1; s.Jr[2] = a2;
   }
   // coefficient vector: betas | 1 | pose feature (prefix of length Kc is what the kernels iterate over)
   for (int i = lane; i < p.NB; i += 64) coeff[i] = p.betas[(size_t)f * p.NB + i];
@@ -380,30 +423,27 @@ __device__ __forceinline__ void joint_forward(const FrameParams& p, int f, int l
     const float pj = __shfl(s.Jr[c], psrc);
     s.t[c] = s.parent < 0 ? s.Jr[c] : s.Jr[c] - pj;
   }
-  // chain by level
+  // chain by level (Gs is the wave's own: ordering inside the wavefront is all that is needed)
   if (isj && s.parent < 0) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) s.G[i] = s.R[i];
 #pragma unroll
     for (int c = 0; c < 3; ++c) s.G[9 + c] = s.t[c];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) Gs[j * 12 + i] = s.G[i];
+    lds_st12(Gs + j * 12, s.G);
   }
-  __syncthreads();
+  wave_sync();
   for (int lvl = 1; lvl <= p.depth; ++lvl) {
     if (isj && s.depth == lvl) {
       float Gp[12];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Gp[i] = Gs[s.parent * 12 + i];
+      lds_ld12(Gs + s.parent * 12, Gp);
       mat3_mul(Gp, s.R, s.G);
       float tt[3];
       mat3_vec(Gp, s.t, tt);
 #pragma unroll
       for (int c = 0; c < 3; ++c) s.G[9 + c] = tt[c] + Gp[9 + c];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Gs[j * 12 + i] = s.G[i];
+      lds_st12(Gs + j * 12, s.G);
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -432,10 +472,72 @@ __device__ __forceinline__ void blend_vertex(const FrameParams& p, int chunk, in
   vp[0] = ax; vp[1] = ay; vp[2] = az;
 }
 
-__device__ __forceinline__ void blend_transform(const FrameParams& p, int chunk, int lane, const float* As, float T[12]) {
+// The same sum for the FW frames of a block at once: every wave streams a quarter of the coefficient range of Pd_v and applies it
+// to all FW coefficient vectors (coeff of frame g at smem + g * per_wave), so the block reads the chunk's slice of Pd once instead
+// of once per frame (the 1920-frame closure call moved 0.7 GB through the L2s per direction for a 170 KB matrix).  The partial
+// sums meet in `vps` [FW][192]: in round r wave w adds its partial of frame (w + r) % FW -- a fixed order per frame.
+__device__ __forceinline__ void blend_vertex_block(const FrameParams& p, int chunk, int wave, int lane, const float* smem, int per_wave,
+                                                   float* vps, float vp[3]) {
+  const float* pd = p.Pd_v + (size_t)chunk * p.Kfull * 192 + lane;
+  const int kq = (p.Kc + FW - 1) / FW, k0 = wave * kq, k1 = k0 + kq < p.Kc ? k0 + kq : p.Kc;
+  float acc[FW][3];
+#pragma unroll
+  for (int g = 0; g < FW; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.f;
+#pragma unroll 13
+  for (int k = k0; k < k1; ++k) {
+    const float* q = pd + (size_t)k * 192;
+    const float x = q[0], y = q[64], z = q[128];
+#pragma unroll
+    for (int g = 0; g < FW; ++g) {
+      const float c = smem[g * per_wave + k];
+      acc[g][0] = fmaf(c, x, acc[g][0]);
+      acc[g][1] = fmaf(c, y, acc[g][1]);
+      acc[g][2] = fmaf(c, z, acc[g][2]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < FW; ++r) {
+    const int gs = (wave + r) % FW;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < FW; ++g)
+      if (g == gs) { a0 = acc[g][0]; a1 = acc[g][1]; a2 = acc[g][2]; }
+    float* dst = vps + gs * 192 + lane;
+    if (r == 0) { dst[0] = a0; dst[64] = a1; dst[128] = a2; }
+    else { dst[0] += a0; dst[64] += a1; dst[128] += a2; }
+    __syncthreads();
+  }
+  vp[0] = vps[wave * 192 + lane]; vp[1] = vps[wave * 192 + 64 + lane]; vp[2] = vps[wave * 192 + 128 + lane];
+}
+
+// the lane's skinning entries of `chunk` (up to kSkinReg of them in registers, loaded together)
+constexpr int kSkinReg = 4;
+struct SkinEntries {
+  float w[kSkinReg];
+  int j[kSkinReg];
+};
+__device__ __forceinline__ void load_skin(const FrameParams& p, int chunk, int lane, SkinEntries& e) {
+#pragma unroll
+  for (int q = 0; q < kSkinReg; ++q) {
+    const bool on = q < p.nnz;
+    const int qq = on ? q : 0;           // (clamped, not branched: the loads of all entries go out together)
+    const float wv = p.w[((size_t)chunk * p.nnz + qq) * 64 + lane];
+    const int jv = p.idx[((size_t)chunk * p.nnz + qq) * 64 + lane];
+    e.w[q] = on ? wv : 0.f;
+    e.j[q] = on ? jv : 0;
+  }
+}
+
+__device__ __forceinline__ void blend_transform(const FrameParams& p, int chunk, int lane, const SkinEntries& e, const float* As, float T[12]) {
 #pragma unroll
   for (int i = 0; i < 12; ++i) T[i] = 0.f;
-  for (int q = 0; q < p.nnz; ++q) {
+#pragma unroll
+  for (int q = 0; q < kSkinReg; ++q) {
+    const float* a = As + e.j[q] * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = fmaf(e.w[q], a[i], T[i]);
+  }
+  for (int q = kSkinReg; q < p.nnz; ++q) {
     const float wq = p.w[((size_t)chunk * p.nnz + q) * 64 + lane];
     const int jq = p.idx[((size_t)chunk * p.nnz + q) * 64 + lane];
     const float* a = As + jq * 12;
@@ -454,8 +556,10 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_fwd_kernel(FrameParams p) 
   const bool valid = f < p.N;
   if (!valid) f = p.N - 1;
 
+  SPT(0, 0);
   JointState s;
   joint_forward(p, f, lane, coeff, Gs, s);
+  SPT(0, 1);
 
   float tl[3] = {0.f, 0.f, 0.f};
   if (p.transl) { tl[0] = p.transl[(size_t)f * 3]; tl[1] = p.transl[(size_t)f * 3 + 1]; tl[2] = p.transl[(size_t)f * 3 + 2]; }
@@ -499,8 +603,12 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_fwd_kernel(FrameParams p) 
   if (p.verts) {
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
       float vp[3], T[12];
-      blend_vertex(p, chunk, lane, coeff, vp);
-      blend_transform(p, chunk, lane, Gs, T);
+      SkinEntries sk;
+      load_skin(p, chunk, lane, sk);
+      SPT(0, 2);
+      blend_vertex_block(p, chunk, wave, lane, smem, per_wave, smem + FW * per_wave, vp);
+      SPT(0, 3);
+      blend_transform(p, chunk, lane, sk, Gs, T);
       const int v = chunk * 64 + lane;
       if (valid && v < p.nverts) {
         float o[3];
@@ -512,33 +620,47 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_fwd_kernel(FrameParams p) 
       }
     }
   }
+  SPT(0, 4);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // backward
-// LDS per wave: coeff[Kfull_pad] | Gs[J*12] | As[J*12] | gA[J*12] | msg[J*16] | gvp[192] | gco[Kfull_pad]
+// LDS per wave: coeff[Kfull_pad] | Gs[J*12] | As[J*12] | msg[max(J*16, 64*12)] | gvp[192] | gco[Kfull_pad]; then the block's v_posed
+// exchange [FW][192]
 // ---------------------------------------------------------------------------------------------------
 constexpr int kMaxKM = 8;  // Kfull_pad <= 512 -> at most 8 coefficient gradients per lane
+
+// message area: 16 floats per joint in the reverse chain, 12 per vertex of a chunk in the vertex phase
+__host__ __device__ inline int bwd_msg_floats(int J) { return J * 16 > kChunk * 12 ? J * 16 : kChunk * 12; }
+__host__ __device__ inline int bwd_wave_floats(int kf4, int J) { return 2 * kf4 + J * 24 + bwd_msg_floats(J) + 192; }
 
 __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int J = p.J;
-  const int per_wave = 2 * p.kf4 + J * (12 * 3 + 16) + 192;
+  const int per_wave = bwd_wave_floats(p.kf4, J);
   float* coeff = smem + wave * per_wave;
   float* Gs = coeff + p.kf4;
   float* As = Gs + J * 12;
-  float* gA = As + J * 12;
-  float* msg = gA + J * 12;
-  float* gvp = msg + J * 16;
+  float* msg = As + J * 12;
+  float* gvp = msg + bwd_msg_floats(J);
   float* gco = gvp + 192;
   int f = blockIdx.x * FW + wave;
   const bool valid = f < p.N;
   if (!valid) f = p.N - 1;
   const bool isj = lane < J;
 
+  // children of the lane's joint for the reverse chain, loaded before anything waits on them
+  constexpr int kChildReg = 5;
+  int ch_reg[kChildReg], ch_c0 = 0, ch_c1 = 0;
+  if (isj) { ch_c0 = p.child_start[lane]; ch_c1 = p.child_start[lane + 1]; }
+#pragma unroll
+  for (int u = 0; u < kChildReg; ++u) ch_reg[u] = ch_c0 + u < ch_c1 ? p.child_idx[ch_c0 + u] : -1;
+
+  SPT(1, 0);
   JointState s;
   joint_forward(p, f, lane, coeff, Gs, s);
+  SPT(1, 1);
   if (isj) {
     float gj[3];
     mat3_vec(s.G, s.Jr, gj);
@@ -546,81 +668,129 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
     for (int i = 0; i < 9; ++i) As[lane * 12 + i] = s.G[i];
 #pragma unroll
     for (int c = 0; c < 3; ++c) As[lane * 12 + 9 + c] = s.G[9 + c] - gj[c];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) gA[lane * 12 + i] = 0.f;
   }
-  __syncthreads();
+  __syncthreads();      // (also: every wave's coefficient vector is complete before the block-wide blend reads it)
 
   // ---- vertex phase ------------------------------------------------------------------------------
   float gco_reg[kMaxKM];
 #pragma unroll
   for (int m = 0; m < kMaxKM; ++m) gco_reg[m] = 0.f;
+  const int off_gvp = p.kf4 + J * 24 + bwd_msg_floats(J), off_gco = off_gvp + 192;
+  float gco_blk[FW][kMaxKM];      // this wave's rows of the chunk, every frame of the block
+#pragma unroll
+  for (int g = 0; g < FW; ++g)
+#pragma unroll
+    for (int m = 0; m < kMaxKM; ++m) gco_blk[g][m] = 0.f;
   float gtl[3] = {0.f, 0.f, 0.f};   // transl gradient partial (vertices of this lane, then joints)
+  float gAr[12];                    // dL/dA of the lane's joint
+#pragma unroll
+  for (int i = 0; i < 12; ++i) gAr[i] = 0.f;
   if (p.g_verts) {
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
       float vp[3], T[12];
-      blend_vertex(p, chunk, lane, coeff, vp);
-      blend_transform(p, chunk, lane, As, T);
+      SkinEntries sk;
+      load_skin(p, chunk, lane, sk);
       const int v = chunk * 64 + lane;
       float g[3] = {0.f, 0.f, 0.f};
       if (v < p.nverts) {
         const float* src = p.g_verts + ((size_t)f * p.nverts + v) * 3;
         g[0] = src[0]; g[1] = src[1]; g[2] = src[2];
       }
+      SPT(1, 2);
+      blend_vertex_block(p, chunk, wave, lane, smem, per_wave, smem + FW * per_wave, vp);
+      SPT(1, 3);
+      blend_transform(p, chunk, lane, sk, As, T);
       gtl[0] += g[0]; gtl[1] += g[1]; gtl[2] += g[2];
       float gv[3];
       mat3_tvec(T, g, gv);          // dL/dv_posed = T_R^T g
       gvp[lane] = gv[0]; gvp[64 + lane] = gv[1]; gvp[128 + lane] = gv[2];
-      // dL/dA_j += w * [g (x) v_posed | g]
-      for (int q = 0; q < p.nnz; ++q) {
-        const float wq = p.w[((size_t)chunk * p.nnz + q) * 64 + lane];
-        const int jq = p.idx[((size_t)chunk * p.nnz + q) * 64 + lane];
-        if (wq != 0.f) {
-          float* dst = gA + jq * 12;
+      // dL/dA_j += sum_v w_vj [g (x) v_posed | g]: every lane posts the 12-vector of its vertex, then lane j adds up the chunk's
+      // vertices against the dense weight column of its joint (one coalesced 256-byte row of Wc and three broadcast LDS reads per
+      // vertex; a fixed order, where LDS float atomics took a third of the kernel)
+      {
+        float u[12];
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const float wg = wq * g[a];
-            atomicAdd(dst + a * 3 + 0, wg * vp[0]);
-            atomicAdd(dst + a * 3 + 1, wg * vp[1]);
-            atomicAdd(dst + a * 3 + 2, wg * vp[2]);
-            atomicAdd(dst + 9 + a, wg);
-          }
+        for (int a = 0; a < 3; ++a) {
+          u[a * 3 + 0] = g[a] * vp[0]; u[a * 3 + 1] = g[a] * vp[1]; u[a * 3 + 2] = g[a] * vp[2];
+          u[9 + a] = g[a];
+        }
+        lds_st12(msg + lane * 12, u);      // (the message area is idle until the reverse chain)
+        wave_sync();
+        const float* wc = p.Wc + (size_t)chunk * kChunk * kMaxJoints + lane;
+#pragma unroll 8
+        for (int vv = 0; vv < kChunk; ++vv) {
+          const float wv = wc[vv * kMaxJoints];
+          float uv[12];
+          lds_ld12(msg + vv * 12, uv);
+#pragma unroll
+          for (int i = 0; i < 12; ++i) gAr[i] = fmaf(wv, uv[i], gAr[i]);
         }
       }
       __syncthreads();
-      // dL/dcoeff[k] += sum_{v,c} gvp[c][v] * Pd[k][c][v]   (lane = k; the coefficient-major copy makes every load a
-      // coalesced 256-byte row segment -- each lane streaming its own 768-byte row of Pd_v cost 64 cache lines per load)
-      // (register m = 4 r + e of lane l holds coefficient k = 256 r + 4 l + e: one 16-byte load per row and range)
+      SPT(1, 4);
+      // dL/dcoeff[g][k] += sum_{v,c} gvp[g][c][v] * Pd[k][c][v] for the FW frames g of the block: lane = 4 coefficients per 256-range
+      // (register m = 4 r + e of lane l holds k = 256 r + 4 l + e: one 16-byte load per row and range of the coefficient-major copy),
+      // wave w takes the rows i = 48 w .. 48 w + 47 of the chunk's 192 and applies each to all FW frames, so the block reads the
+      // chunk's slice of Pd_k once; the per-wave partials are added per frame after the chunk loop
       {
         const float* base = p.Pd_k + (size_t)chunk * 192 * p.Kp + 4 * lane;
+        const int i0 = wave * (192 / FW);
         if (p.Kc <= 256) {
-#pragma unroll 8
-          for (int i = 0; i < 192; ++i) {
-            const float gi = gvp[i];
+#pragma unroll 12
+          for (int i = i0; i < i0 + 192 / FW; ++i) {
             const float4 a = *reinterpret_cast<const float4*>(base + (size_t)i * p.Kp);
-            gco_reg[0] = fmaf(a.x, gi, gco_reg[0]); gco_reg[1] = fmaf(a.y, gi, gco_reg[1]);
-            gco_reg[2] = fmaf(a.z, gi, gco_reg[2]); gco_reg[3] = fmaf(a.w, gi, gco_reg[3]);
+#pragma unroll
+            for (int g = 0; g < FW; ++g) {
+              const float gi = smem[g * per_wave + off_gvp + i];
+              gco_blk[g][0] = fmaf(a.x, gi, gco_blk[g][0]); gco_blk[g][1] = fmaf(a.y, gi, gco_blk[g][1]);
+              gco_blk[g][2] = fmaf(a.z, gi, gco_blk[g][2]); gco_blk[g][3] = fmaf(a.w, gi, gco_blk[g][3]);
+            }
           }
         } else {
-#pragma unroll 4
-          for (int i = 0; i < 192; ++i) {
-            const float gi = gvp[i];
+#pragma unroll 6
+          for (int i = i0; i < i0 + 192 / FW; ++i) {
             const float4 a = *reinterpret_cast<const float4*>(base + (size_t)i * p.Kp);
             const float4 b = *reinterpret_cast<const float4*>(base + (size_t)i * p.Kp + 256);
-            gco_reg[0] = fmaf(a.x, gi, gco_reg[0]); gco_reg[1] = fmaf(a.y, gi, gco_reg[1]);
-            gco_reg[2] = fmaf(a.z, gi, gco_reg[2]); gco_reg[3] = fmaf(a.w, gi, gco_reg[3]);
-            gco_reg[4] = fmaf(b.x, gi, gco_reg[4]); gco_reg[5] = fmaf(b.y, gi, gco_reg[5]);
-            gco_reg[6] = fmaf(b.z, gi, gco_reg[6]); gco_reg[7] = fmaf(b.w, gi, gco_reg[7]);
+#pragma unroll
+            for (int g = 0; g < FW; ++g) {
+              const float gi = smem[g * per_wave + off_gvp + i];
+              gco_blk[g][0] = fmaf(a.x, gi, gco_blk[g][0]); gco_blk[g][1] = fmaf(a.y, gi, gco_blk[g][1]);
+              gco_blk[g][2] = fmaf(a.z, gi, gco_blk[g][2]); gco_blk[g][3] = fmaf(a.w, gi, gco_blk[g][3]);
+              gco_blk[g][4] = fmaf(b.x, gi, gco_blk[g][4]); gco_blk[g][5] = fmaf(b.y, gi, gco_blk[g][5]);
+              gco_blk[g][6] = fmaf(b.z, gi, gco_blk[g][6]); gco_blk[g][7] = fmaf(b.w, gi, gco_blk[g][7]);
+            }
           }
         }
       }
       __syncthreads();
     }
+    SPT(1, 5);
+    // per frame: the FW partials in a fixed order (round r: wave w adds its partial of frame (w + r) % FW into that frame's gco)
+#pragma unroll
+    for (int r = 0; r < FW; ++r) {
+      const int gs = (wave + r) % FW;
+      float* dst = smem + gs * per_wave + off_gco;
+#pragma unroll
+      for (int m = 0; m < kMaxKM; ++m) {
+        const int k = 256 * (m >> 2) + 4 * lane + (m & 3);
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < FW; ++g)
+          if (g == gs) v = gco_blk[g][m];
+        if (k < p.Kfull_pad) dst[k] = r == 0 ? v : dst[k] + v;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < kMaxKM; ++m) {
+      const int k = 256 * (m >> 2) + 4 * lane + (m & 3);
+      if (k < p.Kfull_pad) gco_reg[m] = gco[k];
+    }
   }
   if (p.gA_in) {
     if (isj) {
 #pragma unroll
-      for (int i = 0; i < 12; ++i) gA[lane * 12 + i] = p.gA_in[((size_t)f * J + lane) * 12 + i];
+      for (int i = 0; i < 12; ++i) gAr[i] = p.gA_in[((size_t)f * J + lane) * 12 + i];
     }
 #pragma unroll
     for (int m = 0; m < kMaxKM; ++m) {
@@ -640,6 +810,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
   }
   __syncthreads();
 
+  SPT(1, 6);
   // ---- chain backward ----------------------------------------------------------------------------
   // gG = dL/dG_j (world transform): from A_j = [G.R | G.t - G.R Jr] and posed joint = G.t
   float gG[12], gJr[3] = {0.f, 0.f, 0.f};
@@ -648,7 +819,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
   if (isj) {
     float gAj[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) gAj[i] = gA[lane * 12 + i];
+    for (int i = 0; i < 12; ++i) gAj[i] = gAr[i];
     float gjt[3] = {0.f, 0.f, 0.f};
     if (p.g_joints) {
 #pragma unroll
@@ -672,9 +843,8 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
   for (int lvl = p.depth; lvl >= 1; --lvl) {
     if (isj && s.depth == lvl) {
       // own gG is final here: emit the message to the parent and the local gradients
-      float Gp[9];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Gp[i] = Gs[s.parent * 12 + i];
+      float Gp[12];
+      lds_ld12(Gs + s.parent * 12, Gp);
       float m9[9];
       mat3_mult(gG, s.R, m9);                       // gG.R * R^T
 #pragma unroll
@@ -684,23 +854,26 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
       mat3_tmul(Gp, gG, gR);                        // gR = Gp.R^T gG.R
       const float ggt[3] = {gG[9], gG[10], gG[11]};
       mat3_tvec(Gp, ggt, gt);                       // gt = Gp.R^T gG.t
-#pragma unroll
-      for (int i = 0; i < 9; ++i) msg[lane * 16 + i] = m9[i];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { msg[lane * 16 + 9 + c] = gG[9 + c]; msg[lane * 16 + 12 + c] = gt[c]; }
+      float4* mq = reinterpret_cast<float4*>(msg + lane * 16);
+      mq[0] = make_float4(m9[0], m9[1], m9[2], m9[3]);
+      mq[1] = make_float4(m9[4], m9[5], m9[6], m9[7]);
+      mq[2] = make_float4(m9[8], gG[9], gG[10], gG[11]);
+      mq[3] = make_float4(gt[0], gt[1], gt[2], 0.f);
     }
-    __syncthreads();
+    wave_sync();        // the wave's own messages; a parent's slot is not one its children read, so one ordering point per level
     if (isj && s.depth == lvl - 1) {
-      const int c0 = p.child_start[lane], c1 = p.child_start[lane + 1];
-      for (int ci = c0; ci < c1; ++ci) {
-        const int ch = p.child_idx[ci];
+      auto take = [&](int ch) {
+        const float4* mq = reinterpret_cast<const float4*>(msg + ch * 16);
+        const float4 a = mq[0], b = mq[1], c = mq[2], d = mq[3];
+        gG[0] += a.x; gG[1] += a.y; gG[2] += a.z; gG[3] += a.w; gG[4] += b.x; gG[5] += b.y; gG[6] += b.z; gG[7] += b.w;
+        gG[8] += c.x; gG[9] += c.y; gG[10] += c.z; gG[11] += c.w;
+        gJr[0] -= d.x; gJr[1] -= d.y; gJr[2] -= d.z;
+      };
 #pragma unroll
-        for (int i = 0; i < 12; ++i) gG[i] += msg[ch * 16 + i];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gJr[c] -= msg[ch * 16 + 12 + c];
-      }
+      for (int u = 0; u < kChildReg; ++u)
+        if (ch_reg[u] >= 0) take(ch_reg[u]);
+      for (int ci = ch_c0 + kChildReg; ci < ch_c1; ++ci) take(p.child_idx[ci]);
     }
-    __syncthreads();
   }
   if (isj && s.parent < 0) {
 #pragma unroll
@@ -713,6 +886,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
     for (int c = 0; c < 3; ++c) gJr[c] += gt[c];
   }
 
+  SPT(1, 7);
   // ---- pose gradient -------------------------------------------------------------------------------
   if (isj && valid && p.g_pose) {
     float gr[3] = {0.f, 0.f, 0.f};
@@ -728,21 +902,33 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
 #pragma unroll
     for (int c = 0; c < 3; ++c) p.g_pose[((size_t)f * J + lane) * 3 + c] = gr[c];
   }
+  SPT(1, 8);
   // ---- betas gradient: coefficient part + rest-joint part ------------------------------------------
   if (p.g_betas) {
-    if (isj) {
+    // rest-joint part: sum over joints (lanes) of gJr . Js[joint][:, l]; 8 shape coefficients per trip, fixed butterfly order
+    const float* js = p.Js + (isj ? lane : 0);
+    for (int l0 = 0; l0 < p.NB; l0 += 8) {
+      float part[8];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) msg[lane * 16 + c] = gJr[c];   // all message reads are behind the last barrier
-    }
-    __syncthreads();
-    for (int l = lane; l < p.NB; l += 64) {
-      float acc = gco[l];
-      for (int j = 0; j < J; ++j)
+      for (int u = 0; u < 8; ++u) {
+        const int l = l0 + u;
+        part[u] = 0.f;
+        if (isj && l < p.NB)
+          part[u] = fmaf(gJr[0], js[(l * 3 + 0) * kMaxJoints], fmaf(gJr[1], js[(l * 3 + 1) * kMaxJoints], gJr[2] * js[(l * 3 + 2) * kMaxJoints]));
+      }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc = fmaf(msg[j * 16 + c], p.Js[(j * 3 + c) * p.NB + l], acc);
-      if (valid) p.g_betas[(size_t)f * p.NB + l] = acc;
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part[u] += __shfl_xor(part[u], off);
+      }
+      float mine = part[0];
+#pragma unroll
+      for (int u = 1; u < 8; ++u)
+        if (lane == u) mine = part[u];
+      if (lane < 8 && l0 + lane < p.NB && valid) p.g_betas[(size_t)f * p.NB + l0 + lane] = gco[l0 + lane] + mine;
     }
   }
+  SPT(1, 9);
   // ---- transl gradient: wave reduction -------------------------------------------------------------
   if (p.g_transl) {
 #pragma unroll
@@ -753,6 +939,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
       if (lane == 0 && valid) p.g_transl[(size_t)f * 3 + c] = vsum;
     }
   }
+  SPT(1, 10);
 }
 
 // ===================================================================================================
@@ -1191,7 +1378,7 @@ static void fill_model(FrameParams& p, const ha_smpl_model* m, int slot) {
   p.child_start = m->child_start; p.child_idx = m->child_idx;
   p.J = m->J; p.NB = m->NB; p.Kfull = m->Kfull; p.Kfull_pad = m->Kfull_pad; p.kf4 = (m->Kfull_pad + 3) & ~3; p.depth = m->depth;
   const VertexSet& s = m->sets[slot];
-  p.Pd_v = s.Pd_v; p.Pd_k = s.Pd_k; p.Kp = ceil_div(m->Kfull, 128) * 128; p.w = s.w; p.idx = s.idx;
+  p.Pd_v = s.Pd_v; p.Pd_k = s.Pd_k; p.Kp = ceil_div(m->Kfull, 128) * 128; p.w = s.w; p.idx = s.idx; p.Wc = s.Wc;
   p.nverts = s.n; p.nchunks = s.nchunks; p.nnz = m->nnz;
 }
 
@@ -1267,7 +1454,7 @@ extern "C" int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_ac
   p.N = N; p.n_active = n_active; p.Kc = m->NB + 1 + (n_active - 1) * 9;
   p.pose = pose; p.betas = betas; p.transl = transl;
   p.joints = joints; p.A_out = A_out;
-  const size_t lds = (size_t)FW * (((m->Kfull_pad + 3) & ~3) + m->J * 12) * sizeof(float);
+  const size_t lds = ((size_t)FW * (((m->Kfull_pad + 3) & ~3) + m->J * 12) + FW * 192) * sizeof(float);   // + the block's v_posed exchange
   const int blocks = ceil_div(N, FW);
   if (algo == 1) {
     p.verts = verts;
@@ -1308,7 +1495,7 @@ extern "C" int ha_smpl_backward(const ha_smpl_model* m, int slot, int N, int n_a
   p.pose = pose; p.betas = betas;
   p.g_verts = g_verts; p.g_joints = g_joints;
   p.g_pose = g_pose; p.g_betas = g_betas; p.g_transl = g_transl;
-  const size_t lds = (size_t)FW * (2 * ((m->Kfull_pad + 3) & ~3) + m->J * (12 * 3 + 16) + 192) * sizeof(float);
+  const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + FW * 192) * sizeof(float);
   hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
@@ -1359,8 +1546,16 @@ extern "C" int ha_smpl_backward_dense(const ha_smpl_model* m, int N, int n_activ
   p.g_pose = g_pose; p.g_betas = g_betas; p.g_transl = g_transl;
   p.gA_in = ws + P.off_gA; p.gco_part = ws + P.off_gco; p.gco_ks = P.KS; p.gco_rows = N; p.gco_ld = P.ld;
   p.gtl_part = ws + P.off_gtl; p.gtl_np = P.np;
-  const size_t lds = (size_t)FW * (2 * ((m->Kfull_pad + 3) & ~3) + m->J * (12 * 3 + 16) + 192) * sizeof(float);
+  const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + FW * 192) * sizeof(float);
   hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, st, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
+
+#ifdef HA_SMPL_TIMING
+extern "C" int ha_debug_smpl_timing(unsigned long long* out /* [2][16] */) {
+  HA_CHECK_HIP(hipDeviceSynchronize());
+  HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_smpl_pt), sizeof(unsigned long long) * 2 * 16));
+  return HA_OK;
+}
+#endif

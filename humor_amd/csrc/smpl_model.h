@@ -24,6 +24,8 @@ struct VertexSet {
   // skinning weights / joint indices, general form: [nchunks][nnz][64]
   float* w = nullptr;
   int32_t* idx = nullptr;
+  // the same weights dense per chunk: [nchunks][64 vertices][64 joints] (adjoint: dL/dA_j = sum_v Wc[v][j] * [g (x) v_posed | g])
+  float* Wc = nullptr;
   int32_t* ids = nullptr;   // [n] vertex ids (device); nullptr for slot 0
 };
 
@@ -39,7 +41,7 @@ struct ha_smpl_model {
   int depth = 0;      // max tree depth (root = 0)
   // joint constants (device)
   float* Jt = nullptr;        // [J,3]   J_regressor @ v_template
-  float* Js = nullptr;        // [J,3,NB] J_regressor @ shapedirs
+  float* Js = nullptr;        // [NB,3,64] J_regressor @ shapedirs, joint-minor (lane = joint reads are coalesced)
   int32_t* parents = nullptr; // [J], parents[0] = -1
   int32_t* jdepth = nullptr;  // [J]
   int32_t* child_start = nullptr;  // [J+1] CSR of children (deterministic parent-side accumulation in backward)

@@ -144,6 +144,45 @@ class RolloutPost(torch.autograd.Function):
         return None, gw, gt0, gr0, gp0, gj0, gR, gt
 
 
+class RigidImage(torch.autograd.Function):
+    """(joints [N,J,3], verts [N,V,3], root [N,3], trans [N,3], root2 [N,3], trans2 [N,3]) -> (joints2, verts2): the SMPL output of
+    the same pose and shape under the root pose (root2, trans2), as the rigid image of the evaluation made with (root, trans):
+    ha_rigid_image_forward / _backward (include/humor_amd.h), one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, lib, joints, verts, root, trans, root2, trans2):
+        joints, verts, root, trans, root2, trans2 = (x.detach().contiguous().float() for x in (joints, verts, root, trans, root2, trans2))
+        N, J, V = joints.shape[0], joints.shape[1], verts.shape[1]
+        joints2, verts2 = torch.empty_like(joints), torch.empty_like(verts)
+        a = _lib.RigidImageArgs()
+        a.N, a.J, a.V = N, J, V
+        for k, v in dict(joints=joints, verts=verts, root=root, trans=trans, root2=root2, trans2=trans2, joints2=joints2, verts2=verts2).items():
+            if v.numel():
+                setattr(a, k, v.data_ptr())
+        lib.call('ha_rigid_image_forward', C.byref(a), _lib.stream_ptr(joints))
+        ctx.lib = lib
+        ctx.save_for_backward(joints, verts, root, trans, root2, trans2)
+        ctx.set_materialize_grads(False)
+        return joints2, verts2
+
+    @staticmethod
+    def backward(ctx, g_joints2, g_verts2):
+        joints, verts, root, trans, root2, trans2 = ctx.saved_tensors
+        N, J, V = joints.shape[0], joints.shape[1], verts.shape[1]
+        c = lambda x: None if x is None else x.contiguous().float()
+        g_joints2, g_verts2 = c(g_joints2), c(g_verts2)
+        out = dict(g_joints=torch.empty_like(joints), g_verts=torch.empty_like(verts), g_root=torch.empty_like(root),
+                   g_trans=torch.empty_like(trans), g_root2=torch.empty_like(root2), g_trans2=torch.empty_like(trans2))
+        a = _lib.RigidImageArgs()
+        a.N, a.J, a.V = N, J, V
+        for k, v in dict(joints=joints, verts=verts, root=root, trans=trans, root2=root2, trans2=trans2, g_joints2=g_joints2,
+                         g_verts2=g_verts2, **out).items():
+            if v is not None and v.numel():
+                setattr(a, k, v.data_ptr())
+        ctx.lib.call('ha_rigid_image_backward', C.byref(a), _lib.stream_ptr(joints))
+        return (None, out['g_joints'], out['g_verts'], out['g_root'], out['g_trans'], out['g_root2'], out['g_trans2'])
+
+
 class FitPre(torch.autograd.Function):
     """(floor [B,3], trans0 [B,3], root0 [B,3], pose0 [B,63], jcam [B,22,3], trans_vel [B,3], joints_vel [B,22,3], root_orient_vel [B,3])
     -> (past_in [B,339], trans_p [B,3], root_p [B,3], joints_p [B,22,3], c2p_R [B,3,3], c2p_t [B,3], root_height [B,1]):

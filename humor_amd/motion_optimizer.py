@@ -35,7 +35,8 @@ class MotionOptimizer():
                  motion_prior=None, init_motion_prior=None, optim_floor=False, camera_matrix=None, robust_loss_type='none',
                  robust_tuning_const=4.6851, joint2d_sigma=100, stage3_tune_init_state=True, stage3_tune_init_num_frames=15,
                  stage3_tune_init_freeze_start=30, stage3_tune_init_freeze_end=50, stage3_contact_refine_only=False,
-                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs='auto', fused_loss=True, lbfgs='fused', fused_post=True, fused_pre=True, fused_vposer=True):
+                 use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs='auto', fused_loss=True, lbfgs='fused', fused_post=True, fused_pre=True, fused_vposer=True,
+                 rigid_cam_body=True):
         B, T = batch_size, seq_len
         self.device = device
         self.batch_size, self.seq_len = B, T
@@ -68,6 +69,9 @@ class MotionOptimizer():
         self.lbfgs_impl = lbfgs
         self.fused_post = bool(fused_post)
         self.fused_pre = bool(fused_pre)
+        # stage 3 evaluates the body model on the same pose and shape under two root trajectories (prior frame, camera frame):
+        # the second evaluation as the rigid image of the first (ha_rigid_image_*) instead of a second SMPL forward + backward
+        self.rigid_cam_body = bool(rigid_cam_body)
         # VPoser decode (+ 6-D -> R -> axis-angle) / encode through ha_mlp_* instead of the module's ATen ops (humor_amd/mlp.py)
         self.fused_vposer = bool(fused_vposer)
         self._vposer_handle = None
@@ -546,6 +550,30 @@ class MotionOptimizer():
         loss, stats = self.fitting_loss.smpl_fit(obs_local, pred, self.seq_len, halo=halo)
         return self.fitting_loss.add_next_side(loss, 'smpl', pred, halo), stats
 
+    def smpl_results_moved(self, pred, trans, root_orient, new_trans, new_root_orient):
+        '''
+        The smpl_results() dictionary of the same pose_body / betas under another root trajectory: `pred` was evaluated with
+        (trans, root_orient) [B,T,3]; every joint and vertex moves rigidly about the root joint (csrc/rigid.hip).
+        '''
+        from . import _lib as _libmod
+        from .fit_kernels import RigidImage
+        lib = self.fit_bm._lib
+        B, T, _ = trans.size()
+        jtr = pred['jtr']
+        verts = pred['points3d'] if self.dense_smpl else pred['verts3d']
+        f3 = lambda x: x.reshape(B * T, 3)
+        j2, v2 = RigidImage.apply(lib if lib is not None else _libmod.get_lib(), jtr.reshape(B * T, -1, 3), verts.reshape(B * T, -1, 3),
+                                  f3(root_orient), f3(trans), f3(new_root_orient), f3(new_trans))
+        joints, verts = j2.reshape(B, T, -1, 3), v2.reshape(B, T, -1, 3)
+        nj = len(SMPL_JOINTS)
+        out = {'joints3d': joints[:, :, :nj], 'joints3d_extra': joints[:, :, nj:], 'faces': pred['faces'], 'jtr': joints}
+        if self.dense_smpl:
+            out['points3d'] = verts
+            out['verts3d'] = verts.index_select(2, self._keypt_idx(verts.device))
+        else:
+            out['verts3d'] = verts
+        return out
+
     def _pre_stage3_eager(self, latent_pose, trans, root_orient, betas, floor, trans_vel, joints_vel, root_orient_vel):
         from . import _lib as _libmod
         from .fit_kernels import FitPre
@@ -604,7 +632,10 @@ class MotionOptimizer():
             pred['contacts'], pred['contacts_conf'] = rr['contacts'], rr['contacts_conf']
         cam_pred = pred
         if self.optim_floor:
-            cam_pred, _ = self.smpl_results(cam_rr['trans'], cam_rr['root_orient'], rr['pose_body'], betas)
+            if self.rigid_cam_body and (trans.is_cuda or (lib is not None and lib.emulator)):
+                cam_pred = self.smpl_results_moved(pred, rr['trans'], rr['root_orient'], cam_rr['trans'], cam_rr['root_orient'])
+            else:
+                cam_pred, _ = self.smpl_results(cam_rr['trans'], cam_rr['root_orient'], rr['pose_body'], betas)
             cam_pred.update(betas=betas, floor_plane=floor)
             if pose_prior_on:
                 cam_pred['latent_pose'] = cur_latent_pose

@@ -318,6 +318,26 @@ int ha_rollout_post_forward(const ha_rollout_post_args* args, void* stream);
 int ha_rollout_post_backward(const ha_rollout_post_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The SMPL body of a frame under a second root pose (replaces the second BodyModel evaluation of a stage-3 closure,
+ * humor/fitting/motion_optimizer.py:584 -- same pose_body and betas as :573, camera-frame root instead of the prior-frame one).
+ * Every SMPL output point is R (x - J0) + J0 + t with x independent of the root (humor/body_model/body_model.py:146-153), so
+ *     X' = Q (X - p) + p - t + t',   Q = rodrigues(root2) rodrigues(root)^T,   p = joints[:, 0]  (= J0 + t).
+ *   inputs  joints [N,J,3] / verts [N,V,3] (V may be 0) of the first evaluation, root / trans [N,3] it was made with,
+ *           root2 / trans2 [N,3] the second root pose (axis-angle)
+ *   outputs joints2 [N,J,3], verts2 [N,V,3]
+ * Backward: g_joints2 / g_verts2 may be NULL (= zero); g_joints, g_verts, g_root, g_trans, g_root2, g_trans2 are fully written.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ha_rigid_image_args {
+  int N, J, V;
+  const float* joints; const float* verts; const float* root; const float* trans; const float* root2; const float* trans2;
+  float* joints2; float* verts2;
+  const float* g_joints2; const float* g_verts2;
+  float* g_joints; float* g_verts; float* g_root; float* g_trans; float* g_root2; float* g_trans2;
+} ha_rigid_image_args;
+int ha_rigid_image_forward(const ha_rigid_image_args* args, void* stream);
+int ha_rigid_image_backward(const ha_rigid_image_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Chamfer distance (replaces humor/utils/chamfer_distance/chamfer_distance.cu: ChamferDistanceKernelLauncher :140-157 and
  * ChamferDistanceGradKernelLauncher :189-208, i.e. chamfer_distance.py's cd.forward_cuda / cd.backward_cuda).
  *   xyz1 [b,n,3], xyz2 [b,m,3];  dist1[b,n] / idx1[b,n]: squared distance to, and index of, the nearest point of xyz2 for every

@@ -211,3 +211,48 @@ def check_fit_pre(lib, device, npz, B=3, seed=0):
         worst = max(worst, e)
         assert e < 2e-4, (k, e, q.abs().max().item())
     return worst
+
+
+def check_rigid_image(lib, device, npz, N=5, seed=0, dense=False):
+    """ha_rigid_image (the SMPL output under a second root pose as the rigid image of the first evaluation) against evaluating the
+    body model twice: both outputs and the gradients w.r.t. pose, shape and both root poses."""
+    from humor_amd.body_model import BodyModel
+    from humor_amd.fit_kernels import RigidImage
+    from humor_amd.tables import KEYPT_VERTS
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: sc * torch.randn(*s, generator=g)
+    base = dict(trans=torch.cat([r(N, 2, sc=0.5), 1.0 + r(N, 1, sc=0.3)], 1), root=r(N, 3, sc=0.8), pose=r(N, 63, sc=0.3), betas=r(N, 16, sc=0.5),
+                trans2=torch.cat([r(N, 2, sc=0.3), 4.0 + r(N, 1, sc=0.3)], 1), root2=torch.tensor([np.pi, 0.0, 0.0]) + r(N, 3, sc=0.4))
+    bm = BodyModel(npz, num_betas=16, batch_size=N, use_vtx_selector=True, vertex_subset=None if dense else KEYPT_VERTS, _lib_override=lib)
+    smpl = lambda tr, ro, x: bm(pose_body=x['pose'], pose_hand=None, betas=x['betas'], root_orient=ro, trans=tr)
+
+    def leaves():
+        return {k: v.clone().to(device).requires_grad_(True) for k, v in base.items()}
+
+    def moved(x):
+        b = smpl(x['trans'], x['root'], x)
+        j2, v2 = RigidImage.apply(lib, b.Jtr, b.v, x['root'], x['trans'], x['root2'], x['trans2'])
+        return b.Jtr, b.v, j2, v2
+
+    def twice(x):
+        b, b2 = smpl(x['trans'], x['root'], x), smpl(x['trans2'], x['root2'], x)
+        return b.Jtr, b.v, b2.Jtr, b2.v
+
+    xa, xb = leaves(), leaves()
+    oa, ob = moved(xa), twice(xb)
+    la = lb = 0.0
+    for i, (a, b_) in enumerate(zip(oa, ob)):
+        assert a.shape == b_.shape, (i, a.shape, b_.shape)
+        e = (a.detach() - b_.detach()).abs().max().item()
+        assert e < 1e-5, (i, e)
+        wgt = CC.det_weights(a.shape, 0.3 * (i + 1)).to(device)
+        la, lb = la + (a * wgt).sum(), lb + (b_ * wgt).sum()
+    ks = list(base.keys())
+    ga = torch.autograd.grad(la, [xa[k] for k in ks])
+    gb = torch.autograd.grad(lb, [xb[k] for k in ks])
+    worst = 0.0
+    for k, p, q in zip(ks, ga, gb):
+        e = (p - q).abs().max().item() / max(1.0, q.abs().max().item())
+        worst = max(worst, e)
+        assert e < 1e-4, (k, e, q.abs().max().item())
+    return worst

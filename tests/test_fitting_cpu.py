@@ -174,6 +174,12 @@ def test_emu_fit_pre_kernel_equals_op_chain(emu_lib, smplh_npz):
     print('fit pre: worst relative gradient difference', FL.check_fit_pre(emu_lib, CPU, smplh_npz, B=2, seed=1))
 
 
+def test_emu_rigid_image_equals_second_smpl_evaluation(emu_lib, smplh_npz):
+    """ha_rigid_image on the SIMT emulator against a second body-model evaluation under the second root pose."""
+    import fitloss_checks as FL
+    print('rigid image: worst relative gradient difference', FL.check_rigid_image(emu_lib, CPU, smplh_npz, N=3, seed=2))
+
+
 def test_emu_lbfgs_kernels_long_history(emu_lib):
     """Gram pass, pair installation + coefficient kernel and the scalars kernel on the SIMT emulator with 90 stored pairs in rotated
     slots (lanes own two rows of the recurrences) against the float64 two-loop recursion."""

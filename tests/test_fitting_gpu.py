@@ -218,6 +218,27 @@ def test_rollout_post_kernel_equals_op_chain(gpu_lib, dev, smplh_npz):
             assert e < 1e-4, (k, e)
 
 
+def test_rigid_image_equals_second_smpl_evaluation(gpu_lib, dev, smplh_npz):
+    """The camera-frame body as the rigid image of the prior-frame one (ha_rigid_image_*) against a second SMPL evaluation: stand-alone
+    (key-vertex subset and every vertex) and through the stage-3 objective."""
+    import fitloss_checks as FL
+    from oracle import closure_cases as CC
+    for N, dense in ((7, False), (1920, False), (64, True)):
+        print('rigid image', N, dense, FL.check_rigid_image(gpu_lib, dev, smplh_npz, N=N, seed=N, dense=dense))
+    B, T = 4, 12
+    case = CC.make_case('rgb', B, T, seed=7)
+    res = []
+    for rigid in (True, False):
+        opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
+        opt.rigid_cam_body = rigid
+        res.append(FC.eval_stage(opt, case, 2, dev))
+    assert abs(res[0]['loss'].item() - res[1]['loss'].item()) <= 1e-5 * abs(res[1]['loss'].item())
+    for k in res[0]:
+        if k != 'loss':
+            e = (res[0][k] - res[1][k]).abs().max().item() / max(1.0, res[1][k].abs().max().item())
+            assert e < 2e-4, (k, e)
+
+
 def test_fit_pre_kernel_equals_op_chain(gpu_lib, dev, smplh_npz):
     """Fused stage-3 set-up against the op chain it replaces, stand-alone and through the stage-3 objective."""
     import fitloss_checks as FL
