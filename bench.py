@@ -40,13 +40,14 @@ V, J = 6890, 52
 # algorithmic HBM bytes per frame of the LBS skinning kernel = read v_posed (V*12) + A (J*48), write verts (V*12)
 SKIN_BYTES_PER_FRAME = V * 12 * 2 + J * 48
 # HBM traffic of one ha_lbs_skin launch at N=1920 from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
-# tools/skin_once.py via tools/pmc_lbs.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM', WRITE_SIZE as reported, KiB;
-# both calibrated in the same passes on a device copy of exactly 155,025 KiB): 2 * 88692.8 + 155148.1 KiB.
-# Offline measurement (counters cannot be read inside bench.py); see profiles/r01_run6_pmc_lbs/SUMMARY.txt.
-PMC_TRAFFIC_BYTES = int((2 * 88696.2 + 155175.2) * 1024)
+# tools/skin_once.py via tools/pmc_lbs.sh, launches cycling over 4 operand sets like the timed launches here; FETCH_SIZE doubled
+# per MI355X_MICROARCH.md 'HBM', WRITE_SIZE as reported, KiB; both calibrated in the same passes on a device copy of exactly
+# 155,025 KiB, which reads back as 2 x 77,524 and 155,025).  Offline measurement (counters cannot be read inside bench.py).
+PMC_TRAFFIC_BYTES = int((2 * 88692.2 + 155025.2) * 1024)
 # the same passes at the C5 size (N = 30720 frames, operands >> the 256 MiB Infinity Cache): profiles/r02_pmc_lbs/SUMMARY.txt
 PMC_TRAFFIC_BYTES_C5 = int((2 * 1345686.9 + 2480400.8) * 1024)
-PMC_TRAFFIC_SOURCE = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r02_pmc_lbs (re-run on the shipped kernel; FETCH x2 gfx950 correction)'
+PMC_TRAFFIC_SOURCE = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over 4 rotating operand sets, profiles/r03_pmc_lbs (FETCH x2 gfx950 correction; '
+                      'LDS bank-conflict cycles are 1.4 % of the LDS-active cycles in the same passes)')
 
 
 def parse():

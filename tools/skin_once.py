@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Launches the LBS skinning kernel a few times (for rocprofv3 --pmc runs).  usage: skin_once.py <variant> [N]"""
+"""Launches the LBS skinning kernel a few times (for rocprofv3 --pmc runs), cycling over `sets` operand sets so that no launch
+finds its operands in the 256 MiB Infinity Cache.  usage: skin_once.py <variant> [N] [sets]"""
 import os
 import sys
 import tempfile
@@ -17,12 +18,12 @@ dev = torch.device('cuda:0')
 lib = _lib.get_lib()
 npz = synth.write_smplh_npz(os.path.join(tempfile.mkdtemp(), 'm.npz'))
 h = BodyModel(npz, num_betas=16)._handle_for(dev)
-vp = torch.randn(N * V * 3 + 4, device=dev)
-A = torch.randn(N, J, 12, device=dev)
-tr = torch.randn(N, 3, device=dev)
-out = torch.empty(N, V, 3, device=dev)
+R = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+sets = [(torch.randn(N * V * 3 + 4, device=dev), torch.randn(N, J, 12, device=dev), torch.randn(N, 3, device=dev),
+         torch.empty(N, V, 3, device=dev)) for _ in range(R)]
 lib.call('ha_tune_set', b'skin_variant', var)
-for _ in range(5):
+for i in range(5 if R == 1 else 3 * R):
+    vp, A, tr, out = sets[i % R]
     lib.call('ha_lbs_skin', h.ptr, N, _lib.ptr(vp), _lib.ptr(A), _lib.ptr(tr), _lib.ptr(out), _lib.stream_ptr(out))
 # calibration launches for the PMC byte counters: a plain device copy of exactly the v_posed byte count
 src = torch.randn(N * V * 3, device=dev)
