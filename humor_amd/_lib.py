@@ -89,6 +89,8 @@ _SIGS = {
     'ha_rotmat_to_aa_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ha_rot6d_to_rotmat_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ha_rot6d_to_rotmat_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_rot9d_to_rotmat_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ha_rot9d_to_rotmat_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ha_humor_net_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(MlpDesc), C.POINTER(MlpDesc)]),
     'ha_humor_net_destroy': (C.c_int, [C.c_void_p]),
     'ha_humor_rollout_workspace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),

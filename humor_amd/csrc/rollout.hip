@@ -23,7 +23,16 @@
 
 namespace ha {
 
-constexpr int D_IN = 339, D_RAW = 216, D_STATE = 348, ZD = 48, NJT = 22, NBODY = 21;
+constexpr int D_IN = 339, D_STATE = 348, ZD = 48, NJT = 22, NBODY = 21;
+// Decoder output ("raw") layout for an output rotation representation of ROTW floats per joint (3: axis-angle, 6: 6-D, 9: 9-D;
+// humor_model.py:100-140 output_dim_list): trans 3 | trans_vel 3 | root_orient ROTW | root_orient_vel 3 | pose_body 21 x ROTW |
+// joints 66 | joints_vel 66 | contacts 9
+template <int ROTW>
+struct RawLayout {
+  static constexpr int ROOT = 6, RVEL = 6 + ROTW, BODY = 9 + ROTW, JNT = 9 + 22 * ROTW, JVEL = JNT + 66, CONT = JVEL + 66, D = CONT + 9;
+};
+constexpr int D_RAW = RawLayout<3>::D;       // 216: the fitting configuration
+constexpr int D_RAW_MAX = RawLayout<9>::D;   // 348
 constexpr int D_INP = 340;       // D_IN rounded up to a channel quad (the pad channel of a state slab is kept at zero)
 constexpr int SLICE = 64;        // channels per wave K-slice
 constexpr int MAXL = 8;
@@ -82,6 +91,7 @@ struct PackedLayer {
 struct ha_humor_net {
   int device = 0;
   int n_dec = 0, n_pri = 0;
+  int rotw = 3;                            // floats per joint of the decoder's output rotation representation (3 aa, 6 6-D, 9 9-D)
   ha::PackedLayer dec[ha::MAXL], pri[ha::MAXL];
   ha::PersistNet* persist = nullptr;      // register-stationary decoder for the persistent forward (null: shape / device not eligible)
 };
@@ -703,14 +713,28 @@ struct PredState {
   float pj[3], jv[3];       // joint position / velocity (lane j < 22)
   float dB[9], Bin[9], pB[9];   // body rotation j-1 (lanes 1..21): delta, input, product
   float ptrans[3], ptvel[3], prvel[3], dR[9], Rin[9], pR[9];   // lane 0
-  float raw_aa_b[3], raw_aa_r[3];
+  float raw_aa_b[9], raw_aa_r[9];   // raw rotation outputs (ROTW of them used)
 };
+
+// residual rotation from the decoder's raw output (humor_model.py:476-484 convert_to_rotmat(out_val, rep=out_rot_rep)) and its adjoint
+template <int ROTW>
+__device__ __forceinline__ void delta_rot(const float* raw, float R[9]) {
+  if constexpr (ROTW == 3) rodrigues(raw, R);
+  else if constexpr (ROTW == 6) rot6d_to_rotmat(raw, R);
+  else rot9d_to_rotmat(raw, R);
+}
+template <int ROTW>
+__device__ __forceinline__ void delta_rot_bwd(const float* raw, const float gR[9], float* graw) {
+  if constexpr (ROTW == 3) rodrigues_bwd(raw, gR, graw);
+  else if constexpr (ROTW == 6) rot6d_to_rotmat_bwd(raw, gR, graw);
+  else rot9d_to_rotmat_bwd(raw, gR, graw);
+}
 
 // LDS staging of one row's vectors: every lane issues its (independent) loads back-to-back, one barrier, then the
 // per-joint math reads LDS.  (The kernels are pure latency: a runtime slab loop per element would serialise ~100 L2/HBM
 // round trips per lane.)
-constexpr int S_X = 0, S_RAW = 352, S_GXN = 576, S_GW = 928, S_TOTAL = 1280;
-constexpr int S_SH = 1280, S_RED = 1296, S_TOTAL_BWD = 1328;   // + W(9) ptr(3) of the root | the joint wave's sums (27)
+constexpr int S_X = 0, S_RAW = 352, S_GXN = 704, S_GW = 1056, S_TOTAL = 1408;      // (the raw area holds up to D_RAW_MAX channels)
+constexpr int S_SH = 1408, S_RED = 1424, S_TOTAL_BWD = 1456;   // + W(9) ptr(3) of the root | the joint wave's sums (27)
 
 template <int NQ, int NT = 64>   // NQ = ceil(channel quads / NT): thread l stages quads l, l + NT, ... (16-byte loads)
 __device__ __forceinline__ void stage_slabs(float* dst, const float* base, int nsplit, int RT, int C, int nch, int rt, int rr,
@@ -748,30 +772,37 @@ __device__ __forceinline__ void stage_slabs(float* dst, const float* base, int n
   }
 }
 
+template <int ROTW>
 __device__ __forceinline__ void predict_joints(const float* sX, const float* sRAW, int j, PredState& s) {
+  using RL = RawLayout<ROTW>;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    s.pj[c] = sRAW[75 + 3 * j + c] + sX[207 + 3 * j + c];
-    s.jv[c] = sRAW[141 + 3 * j + c] + sX[273 + 3 * j + c];
+    s.pj[c] = sRAW[RL::JNT + 3 * j + c] + sX[207 + 3 * j + c];
+    s.jv[c] = sRAW[RL::JVEL + 3 * j + c] + sX[273 + 3 * j + c];
   }
 }
+template <int ROTW>
 __device__ __forceinline__ void predict_body(const float* sX, const float* sRAW, int bidx, PredState& s) {
+  using RL = RawLayout<ROTW>;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) s.raw_aa_b[c] = sRAW[12 + 3 * bidx + c];
-  rodrigues(s.raw_aa_b, s.dB);
+  for (int c = 0; c < ROTW; ++c) s.raw_aa_b[c] = sRAW[RL::BODY + ROTW * bidx + c];
+  delta_rot<ROTW>(s.raw_aa_b, s.dB);
 #pragma unroll
   for (int i = 0; i < 9; ++i) s.Bin[i] = sX[18 + 9 * bidx + i];
   mat3_mul(s.dB, s.Bin, s.pB);
 }
+template <int ROTW>
 __device__ __forceinline__ void predict_root(const float* sX, const float* sRAW, PredState& s) {
+  using RL = RawLayout<ROTW>;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     s.ptrans[c] = sRAW[c] + sX[c];
     s.ptvel[c] = sRAW[3 + c] + sX[3 + c];
-    s.raw_aa_r[c] = sRAW[6 + c];
-    s.prvel[c] = sRAW[9 + c] + sX[15 + c];
+    s.prvel[c] = sRAW[RL::RVEL + c] + sX[15 + c];
   }
-  rodrigues(s.raw_aa_r, s.dR);
+#pragma unroll
+  for (int c = 0; c < ROTW; ++c) s.raw_aa_r[c] = sRAW[RL::ROOT + c];
+  delta_rot<ROTW>(s.raw_aa_r, s.dR);
 #pragma unroll
   for (int i = 0; i < 9; ++i) s.Rin[i] = sX[6 + i];
   mat3_mul(s.dR, s.Rin, s.pR);
@@ -779,7 +810,9 @@ __device__ __forceinline__ void predict_root(const float* sX, const float* sRAW,
 
 // Forward glue of step t.  Three waves per sequence (the same split as glue_bwd_kernel): wave 0 the root (lane 0), wave 1
 // the joints, wave 2 the body rotations, contact logits and the prior outputs.
+template <int ROTW>
 __global__ __launch_bounds__(192) void glue_fwd_kernel(GlueParams p) {
+  using RL = RawLayout<ROTW>;
   const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rt = r >> 5, rr = r & 31;
   const bool valid = r < p.B;
@@ -793,7 +826,7 @@ __global__ __launch_bounds__(192) void glue_fwd_kernel(GlueParams p) {
   float* sRAW = smem + S_RAW;
   float* sSH = smem + S_SH;
   stage_slabs<1, 192>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, tid, false);
-  stage_slabs<1, 192>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, tid, false);
+  stage_slabs<1, 192>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, RL::D, rt, rr, tid, false);
   if (tid == 0) XN[qoff(D_IN)] = 0.f;      // pad channel of the next state slab
   float G[9], gt[3], t2j[3];
 #pragma unroll
@@ -812,7 +845,7 @@ __global__ __launch_bounds__(192) void glue_fwd_kernel(GlueParams p) {
   if (wave == 0) {
     // heading alignment from the predicted root orientation
     if (lane == 0) {
-      predict_root(sX, sRAW, s);
+      predict_root<ROTW>(sX, sRAW, s);
       W2A wa;
       w2a_fwd(s.pR, wa);
 #pragma unroll
@@ -821,10 +854,10 @@ __global__ __launch_bounds__(192) void glue_fwd_kernel(GlueParams p) {
       for (int c = 0; c < 3; ++c) sSH[9 + c] = s.ptrans[c];
     }
   } else if (wave == 1) {
-    if (lane < NJT) predict_joints(sX, sRAW, lane, s);
+    if (lane < NJT) predict_joints<ROTW>(sX, sRAW, lane, s);
   } else {
     if (lane >= 1 && lane < NJT) {
-      predict_body(sX, sRAW, lane - 1, s);
+      predict_body<ROTW>(sX, sRAW, lane - 1, s);
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         XN[qoff(18 + 9 * (lane - 1) + i)] = s.pB[i];
@@ -833,7 +866,7 @@ __global__ __launch_bounds__(192) void glue_fwd_kernel(GlueParams p) {
     }
     if (lane >= 32 && lane < 32 + 9) {
       const int c = lane - 32;
-      WO[339 + c] = sRAW[207 + c];
+      WO[339 + c] = sRAW[RL::CONT + c];
     }
     if (p.prior_mu && lane < ZD) {
       const float mu = slab_sum(p.pri_out, p.pri_nsplit, p.RT, p.pri_pad, rt, lane, rr);
@@ -933,7 +966,9 @@ __device__ __forceinline__ void outer_acc(float M[9], const float a[3], const fl
 // body rotations, wave 3 the latent / prior / contact adjoints -- and meet at two barriers (W from the root's forward
 // recomputation; the joint wave's reduced shared adjoints back to the root).
 
+template <int ROTW>
 __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
+  using RL = RawLayout<ROTW>;
   const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rt = r >> 5, rr = r & 31;
   if (r >= p.B) return;
@@ -957,7 +992,7 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
   }
   if (!final_collect) {
     stage_slabs<1, 256>(sX, p.xT, 1, p.RT, D_INP, D_IN, rt, rr, tid, false);
-    stage_slabs<1, 256>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, D_RAW, rt, rr, tid, false);
+    stage_slabs<1, 256>(sRAW, p.dec_out, p.dec_nsplit, p.RT, p.dec_pad, RL::D, rt, rr, tid, false);
     const float* GWp = p.g_world ? p.g_world + ((size_t)r * p.S + p.t) * D_STATE : nullptr;
     for (int c = tid; c < D_STATE; c += 256) sGW[c] = GWp ? GWp[c] : 0.f;
   }
@@ -1012,7 +1047,7 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
   // ---- phase 1 (before W is known) ---------------------------------------------------------------------
   if (wave == 0) {
     if (lane == 0) {
-      predict_root(sX, sRAW, s);
+      predict_root<ROTW>(sX, sRAW, s);
       w2a_fwd(s.pR, wa);
 #pragma unroll
       for (int i = 0; i < 9; ++i) sSH[i] = wa.W[i];
@@ -1020,20 +1055,20 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
       for (int c = 0; c < 3; ++c) sSH[9 + c] = s.ptrans[c];
     }
   } else if (wave == 1) {
-    if (lane < NJT) predict_joints(sX, sRAW, lane, s);
+    if (lane < NJT) predict_joints<ROTW>(sX, sRAW, lane, s);
   } else if (wave == 2) {
     // body rotation: pB = dB * Bin goes unchanged to both outputs (no dependence on W or G)
     if (lane >= 1 && lane < NJT) {
       const int bidx = lane - 1;
-      predict_body(sX, sRAW, bidx, s);
-      float gpB[9], gdB[9], gBin[9], gaa[3];
+      predict_body<ROTW>(sX, sRAW, bidx, s);
+      float gpB[9], gdB[9], gBin[9], gaa[ROTW];
 #pragma unroll
       for (int i = 0; i < 9; ++i) gpB[i] = gw(18 + 9 * bidx + i) + GXN(18 + 9 * bidx + i);
       mat3_mult(gpB, s.Bin, gdB);      // gdB = gpB * Bin^T
       mat3_tmul(s.dB, gpB, gBin);      // gBin = dB^T * gpB
-      rodrigues_bwd(s.raw_aa_b, gdB, gaa);
+      delta_rot_bwd<ROTW>(s.raw_aa_b, gdB, gaa);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) GD[qoff(12 + 3 * bidx + c)] = gaa[c];
+      for (int c = 0; c < ROTW; ++c) GD[qoff(RL::BODY + ROTW * bidx + c)] = gaa[c];
 #pragma unroll
       for (int i = 0; i < 9; ++i) GX[qoff(18 + 9 * bidx + i)] = gBin[i];
     }
@@ -1044,8 +1079,8 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
       for (int i = 0; i < p.dz_n; ++i) v += slab_sum(p.dz_src[i], p.dz_nsplit[i], p.RT, p.dz_pad[i], rt, p.dz_off[i] + lane, rr);
       p.g_z[((size_t)r * p.S + (p.t + 1)) * ZD + lane] = v;
     }
-    if (lane >= 32 && lane < 32 + 9) GD[qoff(207 + lane - 32)] = gw(339 + lane - 32);
-    for (int c = D_RAW + lane; c < p.dec_pad; c += 64) GD[qoff(c)] = 0.f;
+    if (lane >= 32 && lane < 32 + 9) GD[qoff(RL::CONT + lane - 32)] = gw(339 + lane - 32);
+    for (int c = RL::D + lane; c < p.dec_pad; c += 64) GD[qoff(c)] = 0.f;
     if (p.g_pri_out) {
       float* GP = p.g_pri_out + (size_t)rt * p.pri_pad * 32 + (size_t)rr * 4;
       if (lane < ZD) {
@@ -1105,9 +1140,9 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
     // residual composition: pj = raw + x
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      GD[qoff(75 + 3 * j + c)] = gpj[c];
+      GD[qoff(RL::JNT + 3 * j + c)] = gpj[c];
       GX[qoff(207 + 3 * j + c)] = gpj[c];
-      GD[qoff(141 + 3 * j + c)] = gjv[c];
+      GD[qoff(RL::JVEL + 3 * j + c)] = gjv[c];
       GX[qoff(273 + 3 * j + c)] = gjv[c];
     }
     }
@@ -1211,17 +1246,18 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
     gpR[0] += g0;
     gpR[3] += g3;
     // pR = dR * Rin
-    float gdR[9], gRin[9], gaa[3];
+    float gdR[9], gRin[9], gaa[ROTW];
     mat3_mult(gpR, s.Rin, gdR);
     mat3_tmul(s.dR, gpR, gRin);
-    rodrigues_bwd(s.raw_aa_r, gdR, gaa);
+    delta_rot_bwd<ROTW>(s.raw_aa_r, gdR, gaa);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       GD[qoff(c)] = gptrans[c];        GX[qoff(c)] = gptrans[c];
       GD[qoff(3 + c)] = gptvel[c];   GX[qoff(3 + c)] = gptvel[c];
-      GD[qoff(6 + c)] = gaa[c];
-      GD[qoff(9 + c)] = gprvel[c];   GX[qoff(15 + c)] = gprvel[c];
+      GD[qoff(RL::RVEL + c)] = gprvel[c];   GX[qoff(15 + c)] = gprvel[c];
     }
+#pragma unroll
+    for (int c = 0; c < ROTW; ++c) GD[qoff(RL::ROOT + c)] = gaa[c];
 #pragma unroll
     for (int i = 0; i < 9; ++i) GX[qoff(6 + i)] = gRin[i];
     // carry to step t-1
@@ -1230,6 +1266,19 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) { carry[9 + c] = ggt[c]; carry[12 + c] = g_t2j_acc[c] + gt2[c]; }
   }
+}
+
+static inline void launch_glue_fwd(int rotw, int rows, hipStream_t st, const GlueParams& g) {
+  const size_t lds = S_TOTAL_BWD * sizeof(float);
+  if (rotw == 3) hipLaunchKernelGGL(glue_fwd_kernel<3>, dim3(rows), dim3(192), lds, st, g);
+  else if (rotw == 6) hipLaunchKernelGGL(glue_fwd_kernel<6>, dim3(rows), dim3(192), lds, st, g);
+  else hipLaunchKernelGGL(glue_fwd_kernel<9>, dim3(rows), dim3(192), lds, st, g);
+}
+static inline void launch_glue_bwd(int rotw, int rows, hipStream_t st, const GlueParams& g) {
+  const size_t lds = S_TOTAL_BWD * sizeof(float);
+  if (rotw == 3) hipLaunchKernelGGL(glue_bwd_kernel<3>, dim3(rows), dim3(256), lds, st, g);
+  else if (rotw == 6) hipLaunchKernelGGL(glue_bwd_kernel<6>, dim3(rows), dim3(256), lds, st, g);
+  else hipLaunchKernelGGL(glue_bwd_kernel<9>, dim3(rows), dim3(256), lds, st, g);
 }
 
 // z_t = mu + eps * sqrt(var) (or mu when eps is null) from the prior output slabs of step t; writes the transposed
@@ -1380,6 +1429,26 @@ __global__ void rot6d_bwd_kernel(int n, const float* __restrict__ x, const float
   rot6d_to_rotmat_bwd(v, g, o);
 #pragma unroll
   for (int k = 0; k < 6; ++k) gx[(size_t)i * 6 + k] = o[k];
+}
+__global__ void rot9d_fwd_kernel(int n, const float* __restrict__ x, float* __restrict__ R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v[9], M[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) v[k] = x[(size_t)i * 9 + k];
+  rot9d_to_rotmat(v, M);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = M[k];
+}
+__global__ void rot9d_bwd_kernel(int n, const float* __restrict__ x, const float* __restrict__ gR, float* __restrict__ gx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v[9], g[9], o[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { v[k] = x[(size_t)i * 9 + k]; g[k] = gR[(size_t)i * 9 + k]; }
+  rot9d_to_rotmat_bwd(v, g, o);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) gx[(size_t)i * 9 + k] = o[k];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1742,8 +1811,11 @@ using namespace ha;
 
 extern "C" int ha_humor_net_create(ha_humor_net** out, int device, const ha_mlp_desc* decoder, const ha_mlp_desc* prior) {
   HA_REQUIRE(out && decoder && prior, "ha_humor_net_create: null argument");
-  HA_REQUIRE(decoder->in_dim == D_IN + ZD && decoder->skip_dim == ZD && decoder->out_dims[decoder->n_linear - 1] == D_RAW,
-             "ha_humor_net_create: decoder must map [339+48] -> 216 with a 48-d latent skip (got in=%d skip=%d)", decoder->in_dim, decoder->skip_dim);
+  const int raw = decoder->out_dims[decoder->n_linear - 1];
+  const int rotw = raw == RawLayout<3>::D ? 3 : raw == RawLayout<6>::D ? 6 : raw == RawLayout<9>::D ? 9 : 0;
+  HA_REQUIRE(decoder->in_dim == D_IN + ZD && decoder->skip_dim == ZD && rotw != 0,
+             "ha_humor_net_create: decoder must map [339+48] -> 216 / 282 / 348 (out_rot_rep aa / 6d / 9d) with a 48-d latent skip "
+             "(got in=%d skip=%d out=%d)", decoder->in_dim, decoder->skip_dim, raw);
   HA_REQUIRE(prior->in_dim == D_IN && prior->skip_dim == 0 && prior->out_dims[prior->n_linear - 1] == 2 * ZD,
              "ha_humor_net_create: prior must map 339 -> 96");
   HA_REQUIRE(prior->n_linear <= 2 * decoder->n_linear, "ha_humor_net_create: the prior may be at most twice as deep as the decoder");
@@ -1753,6 +1825,7 @@ extern "C" int ha_humor_net_create(ha_humor_net** out, int device, const ha_mlp_
   net->device = device;
   net->n_dec = decoder->n_linear;
   net->n_pri = prior->n_linear;
+  net->rotw = rotw;
   int rc;
   if ((rc = pack_mlp(net->dec, decoder, "decoder")) != HA_OK || (rc = pack_mlp(net->pri, prior, "prior")) != HA_OK ||
       (rc = persist_create(&net->persist, device, decoder)) != HA_OK) {
@@ -1892,7 +1965,7 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
     g.Gs_next = step_ptr(t + 1) + L.off_G;
     g.t2j = stash + L.t2j;
     g.world = world;
-    hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(192), S_TOTAL_BWD * sizeof(float), st, g);
+    launch_glue_fwd(net->rotw, rows, st, g);
     HA_LAUNCH_CHECK();
     return HA_OK;
   }
@@ -1970,7 +2043,7 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
     g.t2j = stash + L.t2j;
     g.world = world;
     g.prior_mu = prior_mu; g.prior_var = prior_var;
-    hipLaunchKernelGGL(glue_fwd_kernel, dim3(rows), dim3(192), S_TOTAL_BWD * sizeof(float), st, g);
+    launch_glue_fwd(net->rotw, rows, st, g);
     HA_LAUNCH_CHECK();
   }
   return HA_OK;
@@ -2060,7 +2133,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
   if (phase == PH_STEP) {
     GlueParams g;
     fill_glue(g, t);
-    hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(256), S_TOTAL_BWD * sizeof(float), st, g);
+    launch_glue_bwd(net->rotw, rows, st, g);
     HA_LAUNCH_CHECK();
     float* sp = step_ptr(t);
     for (int l = nd - 1; l >= 0; --l) {
@@ -2084,7 +2157,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
   }
   GlueParams g;
   fill_glue(g, -1);
-  hipLaunchKernelGGL(glue_bwd_kernel, dim3(rows), dim3(256), S_TOTAL_BWD * sizeof(float), st, g);
+  launch_glue_bwd(net->rotw, rows, st, g);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -2235,6 +2308,14 @@ extern "C" int ha_rot6d_to_rotmat_fwd(int n, const float* x, float* R, void* str
 extern "C" int ha_rot6d_to_rotmat_bwd(int n, const float* x, const float* gR, float* gx, void* stream) {
   HA_REQUIRE(x && gR && gx, "ha_rot6d_to_rotmat_bwd: null argument");
   HA_ROT_ENTRY("ha_rot6d_to_rotmat_bwd", rot6d_bwd_kernel, x, gR, gx);
+}
+extern "C" int ha_rot9d_to_rotmat_fwd(int n, const float* x, float* R, void* stream) {
+  HA_REQUIRE(x && R, "ha_rot9d_to_rotmat_fwd: null argument");
+  HA_ROT_ENTRY("ha_rot9d_to_rotmat_fwd", rot9d_fwd_kernel, x, R);
+}
+extern "C" int ha_rot9d_to_rotmat_bwd(int n, const float* x, const float* gR, float* gx, void* stream) {
+  HA_REQUIRE(x && gR && gx, "ha_rot9d_to_rotmat_bwd: null argument");
+  HA_ROT_ENTRY("ha_rot9d_to_rotmat_bwd", rot9d_bwd_kernel, x, gR, gx);
 }
 
 // ---------------------------------------------------------------------------------------------------

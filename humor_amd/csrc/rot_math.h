@@ -229,4 +229,121 @@ HA_HD void rot6d_to_rotmat_bwd(const float x[6], const float gR[9], float gx[6])
   gx[1] = ga2[0]; gx[3] = ga2[1]; gx[5] = ga2[2];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 9-D rotation representation -> rotation matrix (Levinson et al.), restating rot9d_to_rotmat (humor/utils/transforms.py:222-241):
+// M = U S V^T (singular values in descending order), R = U diag(1, 1, det(U V^T)) V^T -- the rotation closest to M.
+// SVD of the 3x3 by one-sided (Hestenes) Jacobi rotations applied to the columns of M: accurate to fp32 rounding relative to
+// every column pair (the eigen-decomposition of M^T M would square the condition number).
+// ---------------------------------------------------------------------------------------------------
+struct Svd3 {
+  float U[9], V[9], s[3], d;     // M = U diag(s) V^T, s descending; d = det(U V^T) = +-1
+};
+
+HA_HD void svd3(const float M[9], Svd3& o) {
+  float b[3][3], v[3][3];          // b[k] = column k of M V, v[k] = column k of V
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { b[k][i] = M[i * 3 + k]; v[k][i] = i == k ? 1.f : 0.f; }
+  for (int sweep = 0; sweep < 6; ++sweep) {
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+      const float al = b[p][0] * b[p][0] + b[p][1] * b[p][1] + b[p][2] * b[p][2];
+      const float be = b[q][0] * b[q][0] + b[q][1] * b[q][1] + b[q][2] * b[q][2];
+      const float ga = b[p][0] * b[q][0] + b[p][1] * b[q][1] + b[p][2] * b[q][2];
+      if (ga * ga > 1e-30f && ga * ga > 1e-16f * al * be) {
+        const float zeta = (be - al) / (2.0f * ga);
+        const float t = (zeta >= 0.f ? 1.0f : -1.0f) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+        const float c = 1.0f / sqrtf(1.0f + t * t), sn = c * t;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float bp = b[p][i], bq = b[q][i], vp = v[p][i], vq = v[q][i];
+          b[p][i] = c * bp - sn * bq; b[q][i] = sn * bp + c * bq;
+          v[p][i] = c * vp - sn * vq; v[q][i] = sn * vp + c * vq;
+        }
+      }
+    }
+  }
+  float n[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) n[k] = sqrtf(b[k][0] * b[k][0] + b[k][1] * b[k][1] + b[k][2] * b[k][2]);
+  // descending order (three compare-exchanges)
+  auto cswap = [&](int x, int y) {
+    if (n[x] < n[y]) {
+      const float tn = n[x]; n[x] = n[y]; n[y] = tn;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float tb = b[x][i]; b[x][i] = b[y][i]; b[y][i] = tb;
+        const float tv = v[x][i]; v[x][i] = v[y][i]; v[y][i] = tv;
+      }
+    }
+  };
+  cswap(0, 1); cswap(1, 2); cswap(0, 1);
+  float u[3][3];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float inv = 1.0f / (n[k] > 1e-30f ? n[k] : 1e-30f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u[k][i] = b[k][i] * inv;
+  }
+  const float cx[3] = {u[0][1] * u[1][2] - u[0][2] * u[1][1], u[0][2] * u[1][0] - u[0][0] * u[1][2], u[0][0] * u[1][1] - u[0][1] * u[1][0]};
+  if (n[2] > 1e-6f * n[0] && n[2] > 1e-30f) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u[2][i] = b[2][i] / n[2];
+  } else {            // rank-deficient: any unit vector completing the basis (R does not depend on its sign)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u[2][i] = cx[i];
+  }
+  const float detU = cx[0] * u[2][0] + cx[1] * u[2][1] + cx[2] * u[2][2];
+  const float vx[3] = {v[0][1] * v[1][2] - v[0][2] * v[1][1], v[0][2] * v[1][0] - v[0][0] * v[1][2], v[0][0] * v[1][1] - v[0][1] * v[1][0]};
+  const float detV = vx[0] * v[2][0] + vx[1] * v[2][1] + vx[2] * v[2][2];
+  o.d = detU * detV >= 0.f ? 1.0f : -1.0f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    o.s[k] = n[k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o.U[i * 3 + k] = u[k][i]; o.V[i * 3 + k] = v[k][i]; }
+  }
+}
+
+HA_HD void rot9d_to_rotmat(const float x[9], float R[9]) {
+  Svd3 f;
+  svd3(x, f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      R[i * 3 + j] = f.U[i * 3] * f.V[j * 3] + f.U[i * 3 + 1] * f.V[j * 3 + 1] + f.d * f.U[i * 3 + 2] * f.V[j * 3 + 2];
+}
+
+// dL/dM given dL/dR.  With A = U^T dM V the differential is dR = U Y V^T, Y_kk = 0 and for k < l, e = d_k d_l:
+//   Y_kl = (A_kl - e A_lk) / (s_k + e s_l),   Y_lk = -e Y_kl
+// (e = +1: the smooth polar-factor derivative, finite also for equal singular values -- where the autograd of torch.svd, which the
+// reference differentiates through, divides by s_k^2 - s_l^2; e = -1 only for pairs with the flipped third direction).
+HA_HD void rot9d_to_rotmat_bwd(const float x[9], const float gR[9], float gx[9]) {
+  Svd3 f;
+  svd3(x, f);
+  float T[9], Gt[9];
+  mat3_tmul(f.U, gR, T);           // U^T gR
+  mat3_mul(T, f.V, Gt);            // U^T gR V
+  const float dd[3] = {1.0f, 1.0f, f.d};
+  float gA[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) gA[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int l = k + 1; l < 3; ++l) {
+      const float e = dd[k] * dd[l];
+      float den = f.s[k] + e * f.s[l];
+      den = fabsf(den) > 1e-20f ? den : 1e-20f;
+      const float h = (Gt[k * 3 + l] - e * Gt[l * 3 + k]) / den;
+      gA[k * 3 + l] = h;
+      gA[l * 3 + k] = -e * h;
+    }
+  mat3_mul(f.U, gA, T);            // U gA
+  mat3_mult(T, f.V, gx);           // U gA V^T
+}
+
 }  // namespace ha

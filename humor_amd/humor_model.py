@@ -7,8 +7,9 @@ reference checkpoint loads with ``load_state_dict``), the attributes the optimis
 ``infer_global_seq`` / ``prior`` / ``posterior`` / ``decode`` / ``sample_step`` / ``split_output`` / ``prepare_input``.
 
 The roll-out kernels implement the configuration the fitting pipeline uses (in_rot_rep='mat', out_rot_rep='aa',
-steps_in=1, 'smpl+joints(+contacts)', output_delta=True).  Other configurations raise NotImplementedError instead of
-silently running somewhere else.
+steps_in=1, 'smpl+joints(+contacts)', output_delta=True) and its output-rotation variants out_rot_rep='6d' / '9d'
+(humor_model.py:476-484; these take the launch-chain kernels, the persistent roll-out is built for the 216-wide decoder).
+Other configurations raise NotImplementedError instead of silently running somewhere else.
 """
 import ctypes as C
 
@@ -273,23 +274,42 @@ class HumorModel(nn.Module):
         B = x_past.size(0)
         return self.infer_step(x_past.reshape(B, -1), x_t.reshape(B, -1))
 
+    def _delta_rotmat(self, raw):
+        """Residual rotations from the decoder's raw output [N, rot_dim] -> [N,3,3] in plain PyTorch (convert_to_rotmat of the
+        out_rot_rep, humor/utils/transforms.py:60-73): Rodrigues, 6-D Gram-Schmidt (:201-220) or the SVD projection (:222-241)."""
+        from .frames import _rodrigues_torch
+        if self.out_rot_rep == 'aa':
+            return _rodrigues_torch(raw)
+        if self.out_rot_rep == '6d':
+            x = raw.reshape(-1, 3, 2)
+            a1, a2 = x[:, :, 0], x[:, :, 1]
+            b1 = torch.nn.functional.normalize(a1)
+            b2 = torch.nn.functional.normalize(a2 - (b1 * a2).sum(1, keepdim=True) * b1)
+            return torch.stack((b1, b2, torch.cross(b1, b2, dim=1)), dim=-1)
+        x = raw.reshape(-1, 3, 3)
+        u, _, vh = torch.linalg.svd(x)
+        s_p = torch.eye(3, dtype=x.dtype, device=x.device).expand_as(x).clone()
+        s_p[:, 2, 2] = torch.det(torch.matmul(u, vh))
+        return torch.matmul(torch.matmul(u, s_p), vh)
+
     def decode(self, z, past_in):
         """One decoder evaluation + residual composition in plain PyTorch (humor_model.py:445-498): the canonical-frame state after
         one step, [B, 339 (+9 contact logits)].  Off the hot path: roll_out runs the same arithmetic in the HIP kernels."""
-        from .frames import _rodrigues_torch
         B = z.size(0)
         past_in = past_in.reshape(B, -1)
         raw = self.decoder(torch.cat([past_in, z], dim=1))
-        if not (self.output_delta and self.in_rot_rep == 'mat' and self.out_rot_rep == 'aa'):
-            raise NotImplementedError("decode implements output_delta=True, in_rot_rep='mat', out_rot_rep='aa'")
-        dR = _rodrigues_torch(raw[:, 6:9])
+        if not (self.output_delta and self.in_rot_rep == 'mat'):
+            raise NotImplementedError("decode implements output_delta=True, in_rot_rep='mat'")
+        w = self.output_rot_dim
+        o_root, o_rvel, o_body, o_j = 6, 6 + w, 9 + w, 9 + 22 * w
+        dR = self._delta_rotmat(raw[:, o_root:o_root + w])
         R_root = torch.matmul(dR, past_in[:, 6:15].reshape(B, 3, 3)).reshape(B, 9)
-        dB = _rodrigues_torch(raw[:, 12:75].reshape(B * NUM_BODY_JOINTS, 3)).reshape(B, NUM_BODY_JOINTS, 3, 3)
+        dB = self._delta_rotmat(raw[:, o_body:o_body + NUM_BODY_JOINTS * w].reshape(B * NUM_BODY_JOINTS, w)).reshape(B, NUM_BODY_JOINTS, 3, 3)
         R_body = torch.matmul(dB, past_in[:, 18:207].reshape(B, NUM_BODY_JOINTS, 3, 3)).reshape(B, NUM_BODY_JOINTS * 9)
-        out = torch.cat([raw[:, 0:3] + past_in[:, 0:3], raw[:, 3:6] + past_in[:, 3:6], R_root, raw[:, 9:12] + past_in[:, 15:18], R_body,
-                         raw[:, 75:141] + past_in[:, 207:273], raw[:, 141:207] + past_in[:, 273:339]], dim=1)
+        out = torch.cat([raw[:, 0:3] + past_in[:, 0:3], raw[:, 3:6] + past_in[:, 3:6], R_root, raw[:, o_rvel:o_rvel + 3] + past_in[:, 15:18], R_body,
+                         raw[:, o_j:o_j + 66] + past_in[:, 207:273], raw[:, o_j + 66:o_j + 132] + past_in[:, 273:339]], dim=1)
         if self.pred_contacts:
-            out = torch.cat([out, raw[:, 207:216]], dim=1)
+            out = torch.cat([out, raw[:, o_j + 132:o_j + 141]], dim=1)
         return out
 
     def sample_step(self, past_in, t_in=None, use_mean=False, z=None, return_prior=False, return_z=False):
@@ -338,14 +358,14 @@ class HumorModel(nn.Module):
     # roll-out (hot path)
     # ------------------------------------------------------------------------------------------------
     def _check_rollout_config(self):
-        if not (self.in_rot_rep == 'mat' and self.out_rot_rep == 'aa' and self.steps_in == 1 and self.output_delta
-                and self.input_data_dim == 339):
-            raise NotImplementedError("humor_amd roll-out kernels implement in_rot_rep='mat', out_rot_rep='aa', steps_in=1, "
-                                      "output_delta=True, 'smpl+joints(+contacts)' (the fitting configuration)")
+        if not (self.in_rot_rep == 'mat' and self.steps_in == 1 and self.output_delta and self.input_data_dim == 339):
+            raise NotImplementedError("humor_amd roll-out kernels implement in_rot_rep='mat', out_rot_rep 'aa' / '6d' / '9d', steps_in=1, "
+                                      "output_delta=True, 'smpl+joints(+contacts)' (the fitting configuration and its output "
+                                      "rotation variants)")
         if not self.use_conditional_prior:
             raise NotImplementedError('roll-out kernels expect the conditional prior network')
         if not self.pred_contacts:
-            raise NotImplementedError("roll-out kernels expect the contact head (model_data_config='smpl+joints+contacts': 216 decoder outputs)")
+            raise NotImplementedError("roll-out kernels expect the contact head (model_data_config='smpl+joints+contacts': 216 / 282 / 348 decoder outputs)")
 
     def _net_handle(self, device):
         lib = self._lib if self._lib is not None else _lib.get_lib()

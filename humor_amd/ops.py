@@ -76,6 +76,30 @@ class _Rot6d(torch.autograd.Function):
         return g, None
 
 
+class _Rot9d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lib):
+        x = x.contiguous().float()
+        R = torch.empty(x.shape[0], 9, dtype=torch.float32, device=x.device)
+        lib.call('ha_rot9d_to_rotmat_fwd', x.shape[0], _lib.ptr(x), _lib.ptr(R), _lib.stream_ptr(x))
+        ctx.lib = lib
+        ctx.save_for_backward(x)
+        return R.view(-1, 3, 3)
+
+    @staticmethod
+    def backward(ctx, gR):
+        x, = ctx.saved_tensors
+        gR = gR.contiguous().float().view(-1, 9)
+        g = torch.empty_like(x)
+        ctx.lib.call('ha_rot9d_to_rotmat_bwd', x.shape[0], _lib.ptr(x), _lib.ptr(gR), _lib.ptr(g), _lib.stream_ptr(x))
+        return g, None
+
+
+def rot9d_to_rotmat(x, _lib_override=None):
+    """[N,9] -> [N,3,3], the rotation closest to each 3x3 (SVD projection): humor/utils/transforms.py:222-241."""
+    return _Rot9d.apply(x.reshape(-1, 9), _lib_for(x, _lib_override))
+
+
 def rot6d_to_rotmat(x, _lib_override=None):
     """[N,6] (or anything viewable as [-1,3,2]) -> [N,3,3]: humor/utils/transforms.py:201-220."""
     return _Rot6d.apply(x.reshape(-1, 6), _lib_for(x, _lib_override))

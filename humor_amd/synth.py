@@ -200,6 +200,27 @@ def contractive_state_dict(seed=0):
     return humor_state_dict(seed=seed, **CONTRACTIVE)
 
 
+def rotrep_state_dict(out_rot_rep, seed=0, yaw_rate=0.1):
+    """contractive_state_dict for a model with out_rot_rep '6d' or '9d' (decoder output 282 / 348 wide, humor_model.py:100-140):
+    the same scaled-down weights, and the bias of every rotation output set to the representation of the identity (body joints) or
+    of a steady turn about z (root) -- what a trained residual decoder emits -- so that the per-step deltas stay small."""
+    w = {'6d': 6, '9d': 9}[out_rot_rep]
+    sd = humor_state_dict(seed=seed, out_dim=150 + 22 * w, weight_scale=CONTRACTIVE['weight_scale'], out_scale=CONTRACTIVE['out_scale'])
+    last = max(int(k.split('.')[2]) for k in sd if k.startswith('decoder.net.'))
+    bias = sd[f'decoder.net.{last}.bias']
+    c, sn = math.cos(yaw_rate), math.sin(yaw_rate)
+
+    def rep(R):        # R row-major 3x3 -> the representation whose conversion returns R
+        if w == 9:
+            return torch.tensor(R, dtype=torch.float32).reshape(9)
+        return torch.tensor([R[0][0], R[0][1], R[1][0], R[1][1], R[2][0], R[2][1]], dtype=torch.float32)   # [3][2]: first two columns
+    eye = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]
+    bias[6:6 + w] += rep([[c, -sn, 0.0], [sn, c, 0.0], [0.0, 0.0, 1.0]])
+    for j in range(21):
+        bias[9 + w + j * w:9 + w + (j + 1) * w] += rep(eye)
+    return sd
+
+
 # --------------------------------------------------------------------------------------------------
 # VPoser stand-in and init-state GMM
 # --------------------------------------------------------------------------------------------------

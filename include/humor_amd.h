@@ -119,6 +119,11 @@ int ha_rotmat_to_aa_bwd(int n, const float* R, const float* g_aa, float* gR, voi
  * HumorModel(out_rot_rep='6d') end in it): x [n,6] viewed as [3,2] (columns a1, a2) -> R [n,9] = [b1 | b2 | b1 x b2]. */
 int ha_rot6d_to_rotmat_fwd(int n, const float* x /*[n,6]*/, float* R /*[n,9]*/, void* stream);
 int ha_rot6d_to_rotmat_bwd(int n, const float* x, const float* gR /*[n,9]*/, float* gx /*[n,6]*/, void* stream);
+/* 9-D representation -> rotation matrix (humor/utils/transforms.py:222-241 rot9d_to_rotmat: U diag(1, 1, det(U V^T)) V^T of the SVD
+ * of the 3x3; HumorModel(out_rot_rep='9d'), humor/models/humor_model.py:476-484).  The backward pass is the derivative of that
+ * projection itself (finite for equal singular values, where the autograd of torch.svd is not). */
+int ha_rot9d_to_rotmat_fwd(int n, const float* x /*[n,9]*/, float* R /*[n,9]*/, void* stream);
+int ha_rot9d_to_rotmat_bwd(int n, const float* x, const float* gR /*[n,9]*/, float* gx /*[n,9]*/, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HuMoR CVAE roll-out (replaces HumorModel.roll_out / sample_step / prior / decode / MLP.forward /

@@ -16,6 +16,7 @@ conditional prior, output_delta=True, canonicalize_input=False):
 Unlike the reference (dicts of [B,1,D] tensors) the state is kept as flat vectors:
   past_in [B,339] = trans 0:3 | trans_vel 3:6 | root R 6:15 | root_vel 15:18 | body R 18:207 | joints 207:273 | joints_vel 273:339
   dec_raw [B,216] = trans 0:3 | trans_vel 3:6 | root aa 6:9 | root_vel 9:12 | body aa 12:75 | joints 75:141 | joints_vel 141:207 | contacts 207:216
+          (out_rot_rep '6d' / '9d': 6 / 9 floats per rotation instead of 3 -> 282 / 348 wide, same order)
   state   [B,348] = past_in layout + contacts 339:348
 
 Pinned against the unmodified reference (imported with oracle/ref_loader.py) by tests/test_oracle.py and
@@ -113,16 +114,42 @@ def mlp_forward(x, lin, gn, skip=None):
 # ---------------------------------------------------------------------------------------------
 # one roll-out step
 # ---------------------------------------------------------------------------------------------
+def rot6d_to_rotmat(x):
+    """[N,6] -> [N,3,3], restating rot6d_to_rotmat (humor/utils/transforms.py:201-220; cross along the last axis, see the header)."""
+    x = x.reshape(-1, 3, 2)
+    a1, a2 = x[:, :, 0], x[:, :, 1]
+    b1 = F.normalize(a1)
+    b2 = F.normalize(a2 - torch.einsum('bi,bi->b', b1, a2).unsqueeze(-1) * b1)
+    return torch.stack((b1, b2, torch.cross(b1, b2, dim=1)), dim=-1)
+
+
+def rot9d_to_rotmat(x):
+    """[N,9] -> [N,3,3], restating rot9d_to_rotmat (humor/utils/transforms.py:222-241): U diag(1, 1, det(U V^T)) V^T of the SVD."""
+    x = x.reshape(-1, 3, 3)
+    u, s, v = torch.svd(x)
+    v_T = v.transpose(-2, -1)
+    s_p = torch.eye(3).to(x).reshape((1, 3, 3)).expand_as(x).clone()
+    s_p[:, 2, 2] = torch.det(torch.matmul(u, v_T))
+    return torch.matmul(torch.matmul(u, s_p), v_T)
+
+
+RAW_WIDTH = {216: 3, 282: 6, 348: 9}     # decoder output width -> floats per joint of out_rot_rep ('aa', '6d', '9d')
+
+
 def decode_compose(past_in, raw):
-    """decoder residual composition (humor_model.py:460-494): vectors add, rotations left-multiply."""
+    """decoder residual composition (humor_model.py:460-494): vectors add, rotations left-multiply.  The output rotation
+    representation follows from the raw width: 216 'aa' (Rodrigues), 282 '6d', 348 '9d' (convert_to_rotmat, transforms.py:60-73)."""
     B = past_in.shape[0]
-    dR = batch_rodrigues(raw[:, 6:9]).reshape(B, 3, 3)
+    w = RAW_WIDTH[raw.shape[1]]
+    conv = {3: batch_rodrigues, 6: rot6d_to_rotmat, 9: rot9d_to_rotmat}[w]
+    o_rvel, o_body, o_j = 6 + w, 9 + w, 9 + 22 * w
+    dR = conv(raw[:, 6:6 + w]).reshape(B, 3, 3)
     R_root = torch.matmul(dR, past_in[:, 6:15].reshape(B, 3, 3)).reshape(B, 9)
-    dB = batch_rodrigues(raw[:, 12:75].reshape(-1, 3)).reshape(B, NBODY, 3, 3)
+    dB = conv(raw[:, o_body:o_body + NBODY * w].reshape(-1, w)).reshape(B, NBODY, 3, 3)
     R_body = torch.matmul(dB, past_in[:, 18:207].reshape(B, NBODY, 3, 3)).reshape(B, NBODY * 9)
     return torch.cat([raw[:, 0:3] + past_in[:, 0:3], raw[:, 3:6] + past_in[:, 3:6], R_root,
-                      raw[:, 9:12] + past_in[:, 15:18], R_body, raw[:, 75:141] + past_in[:, 207:273],
-                      raw[:, 141:207] + past_in[:, 273:339], raw[:, 207:216]], dim=1)
+                      raw[:, o_rvel:o_rvel + 3] + past_in[:, 15:18], R_body, raw[:, o_j:o_j + 66] + past_in[:, 207:273],
+                      raw[:, o_j + 66:o_j + 132] + past_in[:, 273:339], raw[:, o_j + 132:o_j + 141]], dim=1)
 
 
 def _rot_pts(Rm, pts):        # Rm [B,3,3], pts [B,K,3] -> [B,K,3]  (R @ p per point)

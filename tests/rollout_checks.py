@@ -228,6 +228,68 @@ def check_rollout_golden(lib, device):
     assert np.abs(aa_root.detach().cpu().numpy().reshape(gd['aa_root'].shape) - gd['aa_root']).max() < FWD_TOL
 
 
+def check_rollout_rotrep_short(lib, device, rep, B=2, S=2):
+    """The first S steps of B sequences of the rotation-representation fixture (emulator-sized): forward against the reference's
+    outputs, gradients against the restated oracle's autograd on the same inputs."""
+    gd = golden('rollout_rotrep.npz')
+    p = 'r' + rep + '_'
+    sd = synth.rotrep_state_dict(rep, seed=int(gd['weight_seed']))
+    hm = HumorModel(in_rot_rep='mat', out_rot_rep=rep, latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1, _lib_override=lib)
+    hm.load_state_dict(sd)
+    hm = hm.to(device).eval()
+    pc = torch.tensor(gd[p + 'past0'][:B]).requires_grad_(True)
+    zc = torch.tensor(gd[p + 'z'][:B, :S]).requires_grad_(True)
+    past, z = pc.detach().clone().to(device).requires_grad_(True), zc.detach().clone().to(device).requires_grad_(True)
+    out, (pm, pv) = hm.roll_out(past, None, S, z_seq=z, return_prior=True)
+    world = world_of(out)
+    assert np.abs(world.detach().cpu().numpy() - gd[p + 'world'][:B, :S]).max() < FWD_TOL
+    assert np.abs(pm.detach().cpu().numpy() - gd[p + 'prior_mu'][:B, :S]).max() < FWD_TOL
+    t = lambda k: torch.tensor(gd[p + k][:B, :S])
+    g0, gz = torch.autograd.grad((world * t('gw').to(device)).sum() + (pm * t('gm').to(device)).sum() + (pv * t('gv').to(device)).sum(), [past, z])
+    wo, (pmo, pvo) = H.roll_out(sd, pc, zc)
+    r0, rz = torch.autograd.grad((wo * t('gw')).sum() + (pmo * t('gm')).sum() + (pvo * t('gv')).sum(), [pc, zc])
+    e0 = (g0.cpu() - r0).abs().max().item() / max(1.0, r0.abs().max().item())
+    ez = (gz.cpu() - rz).abs().max().item() / max(1.0, rz.abs().max().item())
+    assert e0 < GRAD_RTOL and ez < GRAD_RTOL, (e0, ez)
+    return e0, ez
+
+
+def check_rollout_rotrep_golden(lib, device, rep):
+    """HumorModel(out_rot_rep='6d' | '9d') roll-out (the launch-chain kernels with the 6-D / SVD residual-rotation glue) against the
+    reference-generated fixture (oracle/make_golden_rotrep.py), and the model's plain-PyTorch single step (decode) against the
+    oracle's on the first step."""
+    gd = golden('rollout_rotrep.npz')
+    p = 'r' + rep + '_'
+    sd = synth.rotrep_state_dict(rep, seed=int(gd['weight_seed']))
+    hm = HumorModel(in_rot_rep='mat', out_rot_rep=rep, latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1, _lib_override=lib)
+    hm.load_state_dict(sd)
+    hm = hm.to(device).eval()
+    past = torch.tensor(gd[p + 'past0']).to(device).requires_grad_(True)
+    z = torch.tensor(gd[p + 'z']).to(device).requires_grad_(True)
+    out, (pm, pv) = hm.roll_out(past, None, z.shape[1], z_seq=z, return_prior=True)
+    world = world_of(out)
+    ew = np.abs(world.detach().cpu().numpy() - gd[p + 'world']).max()
+    assert ew < FWD_TOL, ew
+    assert np.abs(pm.detach().cpu().numpy() - gd[p + 'prior_mu']).max() < FWD_TOL
+    assert np.abs(pv.detach().cpu().numpy() - gd[p + 'prior_var']).max() < FWD_TOL
+    t = lambda k: torch.tensor(gd[p + k]).to(device)
+    loss = (world * t('gw')).sum() + (pm * t('gm')).sum() + (pv * t('gv')).sum()
+    g0, gz = torch.autograd.grad(loss, [past, z])
+    e0 = np.abs(g0.cpu().numpy() - gd[p + 'g_past0']).max() / max(1.0, np.abs(gd[p + 'g_past0']).max())
+    ez = np.abs(gz.cpu().numpy() - gd[p + 'g_z']).max() / max(1.0, np.abs(gd[p + 'g_z']).max())
+    assert e0 < GRAD_RTOL and ez < GRAD_RTOL, (e0, ez)
+    # single step in plain PyTorch (HumorModel.decode) against the oracle's residual composition
+    with torch.no_grad():
+        pc, zc = torch.tensor(gd[p + 'past0']), torch.tensor(gd[p + 'z'])[:, 0]
+        hc = HumorModel(in_rot_rep='mat', out_rot_rep=rep, latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1, _lib_override=lib)
+        hc.load_state_dict(sd)
+        hc.eval()
+        dec_lin, dec_gn = H.mlp_params(sd, 'decoder')
+        raw = H.mlp_forward(torch.cat([pc, zc], 1), dec_lin, dec_gn, skip=zc)
+        assert (hc.decode(zc, pc) - H.decode_compose(pc, raw)).abs().max().item() < 1e-5
+    return ew, e0, ez
+
+
 def check_rotations_golden(lib, device):
     gd = golden('rotations.npz')
     aa = torch.tensor(gd['aa']).to(device).requires_grad_(True)
@@ -372,6 +434,62 @@ def check_rot6d(lib, device, n=2000, seed=0):
     assert eg[well].max().item() < 1e-4, eg[well].max().item()
     assert (eg <= 1e-4 * cond * cond).all()
     return R_ref
+
+
+def rot9d_reference_formula(x):
+    """rot9d_to_rotmat as humor/utils/transforms.py:222-241 writes it (torch.svd; the live test in test_oracle.py pins it bit for bit)."""
+    B = x.size(0)
+    x = x.reshape((B, 3, 3))
+    u, s, v = torch.svd(x)
+    v_T = v.transpose(-2, -1)
+    s_p = torch.eye(3).to(x).reshape((1, 3, 3)).expand_as(x).clone()
+    s_p[:, 2, 2] = torch.det(torch.matmul(u, v_T))
+    return torch.matmul(torch.matmul(u, s_p), v_T).reshape((B, 9))
+
+
+def check_rot9d(lib, device, n=2000, seed=0):
+    """rot9d_to_rotmat kernel (Jacobi SVD projection + its adjoint) against the reference formula evaluated by PyTorch (torch.svd and
+    its autograd) in float64: perturbed rotations (what a residual decoder emits), generic matrices of both determinant signs,
+    the identity.  torch.svd's autograd divides by s_k^2 - s_l^2, so gradients are compared on rows with separated singular values."""
+    g = torch.Generator().manual_seed(seed)
+    n3 = n // 3
+    Rr = L.batch_rodrigues(1.5 * torch.randn(n3, 3, generator=g)).reshape(n3, 9)
+    xc = torch.cat([Rr + 0.2 * torch.randn(n3, 9, generator=g), torch.randn(n - n3, 9, generator=g)], 0)
+    xc[0] = torch.eye(3).reshape(9)
+    xd = xc.double().requires_grad_(True)
+    x = xc.clone().to(device).requires_grad_(True)
+    R_ref = rot9d_reference_formula(xd)
+    Rm = ops.rot9d_to_rotmat(x, _lib_override=lib).reshape(n, 9)
+    sv = torch.linalg.svdvals(xc.double().reshape(n, 3, 3))
+    det = torch.det(xc.double().reshape(n, 3, 3))
+    # conditioning of the projection: 1 / (s_2 + s_3) for det > 0, 1 / (s_2 - s_3) for det < 0
+    gap = torch.where(det > 0, sv[:, 1] + sv[:, 2], sv[:, 1] - sv[:, 2]) / sv[:, 0]
+    e = (Rm.detach().cpu().double() - R_ref.detach()).abs().amax(dim=1)
+    assert (e <= 2e-6 / gap.clamp(min=1e-6)).all(), (e * gap).max().item()
+    ortho = (torch.matmul(Rm.detach().cpu().reshape(n, 3, 3), Rm.detach().cpu().reshape(n, 3, 3).transpose(1, 2)) - torch.eye(3)).abs().max().item()
+    assert ortho < 1e-5, ortho
+    assert (torch.det(Rm.detach().cpu().reshape(n, 3, 3)) > 0.999).all()
+    gR = torch.randn(n, 9, generator=g)
+    ga = torch.autograd.grad((Rm * gR.to(device)).sum(), x)[0].cpu().double()
+    ga_ref = torch.autograd.grad((R_ref * gR.double()).sum(), xd)[0]
+    sep = torch.minimum(sv[:, 0] - sv[:, 1], sv[:, 1] - sv[:, 2]) / sv[:, 0]
+    well = (sep > 0.05) & (gap > 0.05)
+    assert well.sum().item() > n // 4
+    eg = (ga - ga_ref).abs().amax(dim=1) / ga_ref.abs().amax(dim=1).clamp(min=1.0)
+    assert eg[well].max().item() < 1e-4, eg[well].max().item()
+    # rows with (nearly) equal singular values: finite and equal to a central finite difference of the projection itself
+    idx = [0] + torch.nonzero(~well).flatten()[:8].tolist()
+    eps = 1e-4
+    for i in idx:
+        if gap[i] < 0.05:
+            continue
+        fd = torch.zeros(9, dtype=torch.float64)
+        for k in range(9):
+            xp, xm = xc[i].double().clone(), xc[i].double().clone()
+            xp[k] += eps; xm[k] -= eps
+            fd[k] = ((rot9d_reference_formula(xp[None]) - rot9d_reference_formula(xm[None]))[0] * gR[i].double()).sum() / (2 * eps)
+        assert (ga[i] - fd).abs().max().item() < 2e-3 * max(1.0, fd.abs().max().item()), (i, ga[i], fd)
+    return eg[well].max().item()
 
 
 def check_rot_to_aa_near_pi(lib, device, n=3000, seed=0):

@@ -306,6 +306,36 @@ def test_rot6d_formula_matches_reference_live():
     assert torch.equal(ours, R.transforms.rot6d_to_rotmat(x))
 
 
+@pytest.mark.parametrize('rep', ['6d', '9d'])
+def test_oracle_rollout_rotation_representations_match_the_golden_fixture(rep):
+    """The restated roll-out with the 6-D / 9-D residual rotations against the reference-generated rollout_rotrep.npz."""
+    from conftest import golden
+    from humor_amd import synth
+    from oracle import humor_restated as H
+    gd = golden('rollout_rotrep.npz')
+    p = 'r' + rep + '_'
+    sd = synth.rotrep_state_dict(rep, seed=int(gd['weight_seed']))
+    past = torch.tensor(gd[p + 'past0']).requires_grad_(True)
+    z = torch.tensor(gd[p + 'z']).requires_grad_(True)
+    world, (pm, pv) = H.roll_out(sd, past, z)
+    assert np.abs(world.detach().numpy() - gd[p + 'world']).max() < 2e-5
+    assert np.abs(pm.detach().numpy() - gd[p + 'prior_mu']).max() < 2e-5
+    t = lambda k: torch.tensor(gd[p + k])
+    g0, gz = torch.autograd.grad((world * t('gw')).sum() + (pm * t('gm')).sum() + (pv * t('gv')).sum(), [past, z])
+    assert np.abs(g0.numpy() - gd[p + 'g_past0']).max() < 3e-4 * max(1.0, np.abs(gd[p + 'g_past0']).max())
+    assert np.abs(gz.numpy() - gd[p + 'g_z']).max() < 3e-4 * max(1.0, np.abs(gd[p + 'g_z']).max())
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason='reference tree only exists in the build container')
+def test_rot9d_formula_matches_reference_live():
+    """The formula tests/rollout_checks.check_rot9d holds the kernel to is the reference's rot9d_to_rotmat (transforms.py:222-241), bit for bit."""
+    import rollout_checks as RC
+    R = ref_loader.load()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(64, 9, generator=g)
+    assert torch.equal(RC.rot9d_reference_formula(x), R.transforms.rot9d_to_rotmat(x))
+
+
 @pytest.mark.skipif(not ref_loader.available(), reason='reference tree only exists in the build container')
 def test_infer_global_seq_and_velocities_match_reference_live():
     """SURVEY 8(a) a15, directly: HumorModel.infer_global_seq (all T-1 frame pairs canonicalised and pushed through prior + posterior

@@ -12,6 +12,7 @@ def test_emu_rotation_kernels(emu_lib):
     RC.check_rot_random(emu_lib, CPU, n=512)
     RC.check_rotations_golden(emu_lib, CPU)
     RC.check_rot6d(emu_lib, CPU, n=300)
+    RC.check_rot9d(emu_lib, CPU, n=300)
     RC.check_rot_to_aa_near_pi(emu_lib, CPU, n=900)
 
 
@@ -39,6 +40,14 @@ def test_emu_prior_gemm_two_row_tiles_per_wave(emu_lib):
         RC.check_rollout(emu_lib, CPU, B=2, S=3)
     finally:
         emu_lib.call('ha_tune_set', b'gemm_rm', 0)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize('rep', ['6d', '9d'])
+def test_emu_rollout_output_rotation_representations(emu_lib, rep):
+    # glue_fwd / glue_bwd instantiated for 6 / 9 floats per rotation (Gram-Schmidt / Jacobi-SVD residual rotations and their adjoints)
+    # (two sequences x two steps of the reference-generated fixture; the full 4 x 12 fixture is the GPU tier's, 24 min per case here)
+    print(rep, RC.check_rollout_rotrep_short(emu_lib, CPU, rep))
 
 
 def test_rollout_refuses_cpu():

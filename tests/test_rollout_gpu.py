@@ -44,6 +44,12 @@ def test_rollout_golden(gpu_lib, dev, fwd_path):
     RC.check_rollout_golden(gpu_lib, dev)
 
 
+@pytest.mark.parametrize('rep', ['6d', '9d'])
+def test_rollout_output_rotation_representations(gpu_lib, dev, rep):
+    """HumorModel(out_rot_rep='6d' / '9d') (humor_model.py:476-484) against the reference-generated fixture: flat 1e-4 / 1e-3 bars."""
+    print(rep, RC.check_rollout_rotrep_golden(gpu_lib, dev, rep))
+
+
 @pytest.mark.parametrize('name', ['c4', 'c3', 'c5'])
 def test_rollout_baseline_lengths_flat_tolerance(gpu_lib, dev, fwd_path, name):
     """59 / 89 / 119 steps against the reference's own outputs (tests/golden/rollout_long.npz): flat 1e-4 on every step's
@@ -125,6 +131,7 @@ def test_rotation_kernels(gpu_lib, dev):
     RC.check_rot_random(gpu_lib, dev, n=100000)
     RC.check_rotations_golden(gpu_lib, dev)
     RC.check_rot6d(gpu_lib, dev, n=50000)
+    print('rot9d gradient: worst relative error', RC.check_rot9d(gpu_lib, dev, n=30000))
     print('R->aa gradient near pi: worst relative error', RC.check_rot_to_aa_near_pi(gpu_lib, dev, n=50000))
 
 
