@@ -68,6 +68,12 @@ class RigidImageArgs(C.Structure):
         'g_joints', 'g_verts', 'g_root', 'g_trans', 'g_root2', 'g_trans2')]
 
 
+class GmmArgs(C.Structure):
+    """ha_gmm_args (include/humor_amd.h)."""
+    _fields_ = ([('B', C.c_int), ('K', C.c_int), ('D', C.c_int), ('nseg', C.c_int), ('seg', C.c_void_p * 4), ('seg_width', C.c_int * 4),
+                 ('seg_stride', C.c_int * 4)] + [(n, C.c_void_p) for n in ('means', 'Linv', 'LinvT', 'cst', 'lp', 'gpart', 'nll', 'g_x')])
+
+
 _SIGS = {
     'ha_last_error': (C.c_char_p, []),
     'ha_abi_version': (C.c_int, []),
@@ -108,6 +114,7 @@ _SIGS = {
     'ha_fit_pre_backward': (C.c_int, [C.POINTER(FitPreArgs), C.c_void_p]),
     'ha_rollout_post_forward': (C.c_int, [C.POINTER(RolloutPostArgs), C.c_void_p]),
     'ha_rollout_post_backward': (C.c_int, [C.POINTER(RolloutPostArgs), C.c_void_p]),
+    'ha_gmm_nll': (C.c_int, [C.POINTER(GmmArgs), C.c_void_p]),
     'ha_rigid_image_forward': (C.c_int, [C.POINTER(RigidImageArgs), C.c_void_p]),
     'ha_rigid_image_backward': (C.c_int, [C.POINTER(RigidImageArgs), C.c_void_p]),
     'ha_lbfgs_coeffs': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

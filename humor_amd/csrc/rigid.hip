@@ -59,7 +59,8 @@ __global__ void rigid_image_fwd_kernel(ha_rigid_image_args a) {
 }
 
 __global__ void rigid_image_bwd_kernel(ha_rigid_image_args a) {
-  __shared__ float red[4][RG_NRED];
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [4][RG_NRED] (dynamic LDS only: the host emulator tier has no static LDS)
+  float (*red)[RG_NRED] = reinterpret_cast<float (*)[RG_NRED]>(smem);
   const int f = blockIdx.x;
   RigidFrame r;
   rigid_frame(a, f, r);
@@ -148,7 +149,7 @@ extern "C" int ha_rigid_image_backward(const ha_rigid_image_args* args, void* st
   HA_REQUIRE(a.joints && a.root && a.trans && a.root2 && a.trans2, "ha_rigid_image_backward: forward tensors missing");
   HA_REQUIRE(a.g_joints && a.g_root && a.g_trans && a.g_root2 && a.g_trans2, "ha_rigid_image_backward: null gradient output");
   HA_REQUIRE(a.V == 0 || (a.verts && a.g_verts), "ha_rigid_image_backward: vertex tensors missing");
-  hipLaunchKernelGGL(rigid_image_bwd_kernel, dim3(a.N), dim3(rigid_threads(a)), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(rigid_image_bwd_kernel, dim3(a.N), dim3(rigid_threads(a)), 4 * RG_NRED * sizeof(float), (hipStream_t)stream, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

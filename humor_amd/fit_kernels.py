@@ -183,6 +183,52 @@ class RigidImage(torch.autograd.Function):
         return (None, out['g_joints'], out['g_verts'], out['g_root'], out['g_trans'], out['g_root2'], out['g_trans2'])
 
 
+class GmmNll(torch.autograd.Function):
+    """(segments [B, ...] whose per-sequence sizes add up to the mixture's dimension) -> -sum_b log p(x_b) under the Gaussian mixture
+    `gmm` (fitting_loss._GMM): ha_gmm_nll (include/humor_amd.h), value and gradient in two launches + one row sum.  A segment that is a
+    view with contiguous rows (frame 0 of a [B,T,J,3] tensor) is read in place."""
+
+    @staticmethod
+    def forward(ctx, lib, gmm, *segs):
+        B, dev = segs[0].shape[0], segs[0].device
+        rows = []
+        for s in segs:
+            s = s.detach()
+            w = s[0].numel()
+            if s.dtype == torch.float32 and s[0].is_contiguous():
+                rows.append((s, w, s.stride(0) if B > 1 else w))         # row b starts at data_ptr + b * stride(0)
+            else:
+                s = s.reshape(B, -1).contiguous().float()
+                rows.append((s, w, w))
+        K, D = gmm.means.shape
+        new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        lp, gpart, nll, g_x = new(B, K), new(B, K, D), new(B), new(B, D)
+        a = _lib.GmmArgs()
+        a.B, a.K, a.D, a.nseg = B, K, D, len(rows)
+        for i, (s, w, st) in enumerate(rows):
+            a.seg[i], a.seg_width[i], a.seg_stride[i] = s.data_ptr(), w, st
+        t = gmm.device_tables(dev)
+        for k, v in dict(means=t['means'], Linv=t['Linv'], LinvT=t['LinvT'], cst=t['const'], lp=lp, gpart=gpart, nll=nll, g_x=g_x).items():
+            setattr(a, k, v.data_ptr())
+        lib.call('ha_gmm_nll', C.byref(a), _lib.stream_ptr(rows[0][0]))
+        ctx.shapes = [tuple(s.shape) for s in segs]
+        ctx.save_for_backward(g_x)
+        return nll.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        g_x, = ctx.saved_tensors
+        gx = g_x * g
+        out, o = [], 0
+        for sh in ctx.shapes:
+            w = 1
+            for d in sh[1:]:
+                w *= d
+            out.append(gx[:, o:o + w].reshape(sh))
+            o += w
+        return (None, None) + tuple(out)
+
+
 class FitPre(torch.autograd.Function):
     """(floor [B,3], trans0 [B,3], root0 [B,3], pose0 [B,63], jcam [B,22,3], trans_vel [B,3], joints_vel [B,22,3], root_orient_vel [B,3])
     -> (past_in [B,339], trans_p [B,3], root_p [B,3], joints_p [B,22,3], c2p_R [B,3,3], c2p_t [B,3], root_height [B,1]):

@@ -81,6 +81,15 @@ class _GMM:
         self.const = (torch.log(weights / weights.sum()) - torch.log(torch.diagonal(L, dim1=-2, dim2=-1)).sum(-1)
                       - 0.5 * means.shape[-1] * math.log(2 * math.pi))                    # [K]
 
+    def device_tables(self, device):
+        """contiguous fp32 tables for ha_gmm_nll on `device` (the factors and their transposes), built once"""
+        key = str(device)
+        t = getattr(self, '_tables', None)
+        if t is None or t[0] != key:
+            f = lambda v: v.detach().to(device=device, dtype=torch.float32).contiguous()
+            t = self._tables = (key, dict(means=f(self.means), Linv=f(self.Linv), LinvT=f(self.Linv.transpose(1, 2)), const=f(self.const)))
+        return t[1]
+
     def log_prob(self, x):
         diff = x.unsqueeze(1) - self.means.unsqueeze(0)                                  # [B,K,D]
         y = torch.einsum('kij,bkj->bki', self.Linv, diff)
@@ -575,6 +584,13 @@ class FittingLoss(nn.Module):
 
     def init_motion_prior_loss(self, joints, joints_vel, trans_vel, root_orient_vel):
         B = joints.size(0)
+        gmm = self.init_motion_prior['gmm']
+        on_dev = joints.is_cuda or (self._lib is not None and self._lib.emulator)
+        if self.fused and on_dev and gmm.means.shape[0] <= 64 and gmm.means.shape[1] <= 256 and joints.dtype == torch.float32:
+            # value and gradient in two launches (csrc/gmm.hip); frame 0 of the joints is read in place (a strided row per sequence)
+            from . import _lib as _libmod
+            from .fit_kernels import GmmNll
+            return GmmNll.apply(self._lib if self._lib is not None else _libmod.get_lib(), gmm, joints, joints_vel, trans_vel, root_orient_vel)
         state = torch.cat([joints.reshape(B, -1), joints_vel.reshape(B, -1), trans_vel.reshape(B, -1),
                            root_orient_vel.reshape(B, -1)], dim=-1)
         return -torch.sum(self.init_motion_prior['gmm'].log_prob(state))

@@ -343,6 +343,23 @@ int ha_rigid_image_forward(const ha_rigid_image_args* args, void* stream);
 int ha_rigid_image_backward(const ha_rigid_image_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Init-state prior of stage 3 (replaces FittingLoss.init_motion_prior_loss, humor/fitting/fitting_loss.py:416-429: the negative
+ * log-density of frame 0's joints | joint velocities | root velocity | root angular velocity under the Gaussian mixture loaded by
+ * run_fitting.py:248-261), value and gradient in two launches.
+ *   x_b      the nseg (<= 4) segments side by side: seg[s] + b * seg_stride[s], seg_width[s] floats each (D in total, D <= 256)
+ *   means [K,D]; Linv [K,D,D] the inverses of the Cholesky factors of the covariances (row-major) and LinvT their transposes;
+ *   cst [K] = log(weight) - log det(L) - D/2 log(2 pi);  K <= 64
+ *   workspaces lp [B,K], gpart [B,K,D];  outputs nll [B] = -logsumexp_k lp, g_x [B,D] = d nll_b / d x_b
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ha_gmm_args {
+  int B, K, D, nseg;
+  const float* seg[4]; int seg_width[4]; int seg_stride[4];
+  const float* means; const float* Linv; const float* LinvT; const float* cst;
+  float* lp; float* gpart; float* nll; float* g_x;
+} ha_gmm_args;
+int ha_gmm_nll(const ha_gmm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Chamfer distance (replaces humor/utils/chamfer_distance/chamfer_distance.cu: ChamferDistanceKernelLauncher :140-157 and
  * ChamferDistanceGradKernelLauncher :189-208, i.e. chamfer_distance.py's cd.forward_cuda / cd.backward_cuda).
  *   xyz1 [b,n,3], xyz2 [b,m,3];  dist1[b,n] / idx1[b,n]: squared distance to, and index of, the nearest point of xyz2 for every
