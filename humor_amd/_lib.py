@@ -86,6 +86,8 @@ _SIGS = {
     'ha_smpl_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]),
     'ha_smpl_workspace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'ha_smpl_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
+    'ha_smpl_forward_split': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3),
+    'ha_smpl_backward_split': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 6),
     'ha_smpl_backward_dense_workspace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     'ha_smpl_backward_dense': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_void_p]),
     'ha_lbs_skin': (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),

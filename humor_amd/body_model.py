@@ -129,13 +129,12 @@ class _SmplFunction(torch.autograd.Function):
                 joints = torch.cat([joints, verts.index_select(1, cfg['selector_t'])], dim=1)
             v_out = verts
         else:
+            # joints + selector vertices and the remaining subset vertices straight into their own tensors (no cat / slice copies)
             nS = len(cfg['subset_all'])
-            vs = new(N, nS, 3)
-            lib.call('ha_smpl_forward', h.ptr, cfg['slot_all'], N, cfg['n_active'], _lib.ptr(pose), _lib.ptr(betas),
-                     _lib.ptr(transl), _lib.ptr(vs), _lib.ptr(joints), None, None, None, 1, st)
-            if n_sel:
-                joints = torch.cat([joints, vs[:, :n_sel]], dim=1)
-            v_out = vs[:, n_sel:].contiguous()
+            joints = new(N, h.J + n_sel, 3)
+            v_out = new(N, nS - n_sel, 3)
+            lib.call('ha_smpl_forward_split', h.ptr, cfg['slot_all'], N, cfg['n_active'], _lib.ptr(pose), _lib.ptr(betas),
+                     _lib.ptr(transl), n_sel, _lib.ptr(joints), _lib.ptr(v_out) if nS > n_sel else None, st)
         ctx.cfg = cfg
         ctx.dense_ws = None
         if cfg['mode'] == 'dense' and algo == 2 and cfg.get('dense_bwd', True):
@@ -155,33 +154,34 @@ class _SmplFunction(torch.autograd.Function):
             return None, None, None, None
         dev = pose.device
         g_j52 = g_extra = None
+        if cfg['mode'] != 'dense':
+            g_pose = torch.empty_like(pose)
+            g_betas = torch.empty_like(betas)
+            g_transl = torch.empty(N, 3, dtype=torch.float32, device=dev)
+            gj = None if g_joints is None else g_joints.contiguous().float()
+            gv = None if g_v is None else g_v.contiguous().float()
+            lib.call('ha_smpl_backward_split', h.ptr, cfg['slot_all'], N, cfg['n_active'], _lib.ptr(pose), _lib.ptr(betas), n_sel,
+                     _lib.ptr(gj) if gj is not None else None, _lib.ptr(gv) if gv is not None and gv.numel() else None,
+                     _lib.ptr(g_pose), _lib.ptr(g_betas), _lib.ptr(g_transl), _lib.stream_ptr(pose))
+            return g_pose, g_betas, g_transl, None
         if g_joints is not None:
             g_joints = g_joints.contiguous()
             g_j52 = g_joints[:, :h.J].contiguous()
             if n_sel:
                 g_extra = g_joints[:, h.J:]
-        if cfg['mode'] == 'dense':
-            if g_v is not None:
-                slot, g_set = 0, g_v.contiguous()
-                if g_extra is not None:
-                    g_set = g_set.clone()
-                    g_set.index_add_(1, cfg['selector_t'], g_extra)
-            elif g_extra is not None:
-                slot, g_set = cfg['slot_sel'], g_extra.contiguous()
-            else:
-                slot, g_set = 0, None
-        else:
-            slot = cfg['slot_all']
-            nS = len(cfg['subset_all'])
-            g_set = torch.zeros(N, nS, 3, dtype=torch.float32, device=dev)
+        if g_v is not None:
+            slot, g_set = 0, g_v.contiguous()
             if g_extra is not None:
-                g_set[:, :n_sel] = g_extra
-            if g_v is not None:
-                g_set[:, n_sel:] = g_v
+                g_set = g_set.clone()
+                g_set.index_add_(1, cfg['selector_t'], g_extra)
+        elif g_extra is not None:
+            slot, g_set = cfg['slot_sel'], g_extra.contiguous()
+        else:
+            slot, g_set = 0, None
         g_pose = torch.empty_like(pose)
         g_betas = torch.empty_like(betas)
         g_transl = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        if cfg['mode'] == 'dense' and slot == 0 and g_set is not None and ctx.dense_ws is not None:
+        if slot == 0 and g_set is not None and ctx.dense_ws is not None:
             # every vertex carries a gradient: batched streaming / MFMA vertex phase instead of the wave-per-frame adjoint
             nw = C.c_int64()
             lib.call('ha_smpl_backward_dense_workspace', h.ptr, N, cfg['n_active'], C.byref(nw))

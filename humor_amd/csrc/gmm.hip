@@ -28,15 +28,26 @@ __device__ __forceinline__ void gmm_matvec_t(const float* __restrict__ M, const 
   float acc[GMM_NI];
 #pragma unroll
   for (int q = 0; q < GMM_NI; ++q) acc[q] = 0.f;
-#pragma unroll 4
-  for (int j = wave; j < D; j += GMM_WAVES) {
-    const float vj = v[j];
-    const float* row = M + (size_t)j * D;
+  // (latency, not bandwidth, bounds this kernel: eight rows = up to 32 loads in flight per trip; out-of-range lanes / rows read a
+  // valid address and contribute zero)
+  for (int j0 = wave; j0 < D; j0 += 8 * GMM_WAVES) {
+    float m[8][GMM_NI], vj[8];
 #pragma unroll
-    for (int q = 0; q < GMM_NI; ++q) {
-      const int i = lane + 64 * q;
-      if (i < D) acc[q] = fmaf(row[i], vj, acc[q]);
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u * GMM_WAVES;
+      const bool on = j < D;
+      vj[u] = on ? v[j] : 0.f;
+      const float* row = M + (size_t)(on ? j : 0) * D;
+#pragma unroll
+      for (int q = 0; q < GMM_NI; ++q) {
+        const int i = lane + 64 * q;
+        m[u][q] = (64 * q < D) ? row[i < D ? i : 0] : 0.f;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int q = 0; q < GMM_NI; ++q) acc[q] = fmaf(m[u][q], vj[u], acc[q]);
   }
 #pragma unroll
   for (int q = 0; q < GMM_NI; ++q) {
@@ -110,7 +121,14 @@ __global__ __launch_bounds__(256) void gmm_mix_kernel(ha_gmm_args a) {
   __syncthreads();
   for (int i = tid; i < a.D; i += 256) {
     float g = 0.f;
-    for (int k = 0; k < a.K; ++k) g = fmaf(wk[k], a.gpart[((size_t)b * a.K + k) * a.D + i], g);
+    const float* gp = a.gpart + (size_t)b * a.K * a.D + i;
+    for (int k0 = 0; k0 < a.K; k0 += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = gp[(size_t)(k0 + u < a.K ? k0 + u : 0) * a.D];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g = fmaf(k0 + u < a.K ? wk[k0 + u] : 0.f, t[u], g);
+    }
     a.g_x[(size_t)b * a.D + i] = g;
   }
 }

@@ -334,6 +334,9 @@ struct FrameParams {
   const float* pose; const float* betas; const float* transl;
   // forward outputs
   float* verts; float* joints; float* A_out; float* coeffT; int Npad;
+  // "split" form (ha_smpl_forward_split / _backward_split): the first n_head vertices of the set are rows J .. J + n_head - 1 of the
+  // joint tensors (row stride jstride = J + n_head per frame), verts / g_verts hold the remaining nverts - n_head
+  int n_head, jstride;
   // backward io
   const float* g_verts; const float* g_joints;
   float* g_pose; float* g_betas; float* g_transl;
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_fwd_kernel(FrameParams p) 
     if (valid) {
       if (p.joints) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) p.joints[((size_t)f * p.J + lane) * 3 + c] = s.G[9 + c] + tl[c];
+        for (int c = 0; c < 3; ++c) p.joints[((size_t)f * p.jstride + lane) * 3 + c] = s.G[9 + c] + tl[c];
       }
       if (p.A_out) {
 #pragma unroll
@@ -613,7 +616,8 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_fwd_kernel(FrameParams p) 
       if (valid && v < p.nverts) {
         float o[3];
         mat3_vec(T, vp, o);
-        float* dst = p.verts + ((size_t)f * p.nverts + v) * 3;
+        float* dst = v < p.n_head ? p.joints + ((size_t)f * p.jstride + p.J + v) * 3
+                                  : p.verts + ((size_t)f * (p.nverts - p.n_head) + (v - p.n_head)) * 3;
         dst[0] = o[0] + T[9] + tl[0];
         dst[1] = o[1] + T[10] + tl[1];
         dst[2] = o[2] + T[11] + tl[2];
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
   float gAr[12];                    // dL/dA of the lane's joint
 #pragma unroll
   for (int i = 0; i < 12; ++i) gAr[i] = 0.f;
-  if (p.g_verts) {
+  if (p.g_verts || (p.n_head > 0 && p.g_joints)) {
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
       float vp[3], T[12];
       SkinEntries sk;
@@ -693,8 +697,9 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
       const int v = chunk * 64 + lane;
       float g[3] = {0.f, 0.f, 0.f};
       if (v < p.nverts) {
-        const float* src = p.g_verts + ((size_t)f * p.nverts + v) * 3;
-        g[0] = src[0]; g[1] = src[1]; g[2] = src[2];
+        const float* src = v < p.n_head ? (p.g_joints ? p.g_joints + ((size_t)f * p.jstride + J + v) * 3 : nullptr)
+                                        : (p.g_verts ? p.g_verts + ((size_t)f * (p.nverts - p.n_head) + (v - p.n_head)) * 3 : nullptr);
+        if (src) { g[0] = src[0]; g[1] = src[1]; g[2] = src[2]; }
       }
       SPT(1, 2);
       blend_vertex_block(p, chunk, wave, lane, smem, per_wave, smem + FW * per_wave, vp);
@@ -823,7 +828,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
     float gjt[3] = {0.f, 0.f, 0.f};
     if (p.g_joints) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) gjt[c] = p.g_joints[((size_t)f * J + lane) * 3 + c];
+      for (int c = 0; c < 3; ++c) gjt[c] = p.g_joints[((size_t)f * p.jstride + lane) * 3 + c];
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -1380,6 +1385,7 @@ static void fill_model(FrameParams& p, const ha_smpl_model* m, int slot) {
   const VertexSet& s = m->sets[slot];
   p.Pd_v = s.Pd_v; p.Pd_k = s.Pd_k; p.Kp = ceil_div(m->Kfull, 128) * 128; p.w = s.w; p.idx = s.idx; p.Wc = s.Wc;
   p.nverts = s.n; p.nchunks = s.nchunks; p.nnz = m->nnz;
+  p.n_head = 0; p.jstride = m->J;
 }
 
 }  // namespace ha
@@ -1495,6 +1501,47 @@ extern "C" int ha_smpl_backward(const ha_smpl_model* m, int slot, int N, int n_a
   p.pose = pose; p.betas = betas;
   p.g_verts = g_verts; p.g_joints = g_joints;
   p.g_pose = g_pose; p.g_betas = g_betas; p.g_transl = g_transl;
+  const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + FW * 192) * sizeof(float);
+  hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
+  HA_LAUNCH_CHECK();
+  return HA_OK;
+}
+
+extern "C" int ha_smpl_forward_split(const ha_smpl_model* m, int slot, int N, int n_active, const float* pose, const float* betas,
+                                     const float* transl, int n_head, float* joints_ext, float* verts_tail, void* stream) {
+  int rc = check_common("ha_smpl_forward_split", m, slot, N, n_active);
+  if (rc != HA_OK) return rc;
+  HA_REQUIRE(pose && betas && joints_ext, "ha_smpl_forward_split: pose, betas and joints_ext are required");
+  HA_REQUIRE(n_head >= 0 && n_head <= m->sets[slot].n, "ha_smpl_forward_split: n_head=%d out of range 0..%d", n_head, m->sets[slot].n);
+  HA_REQUIRE(verts_tail || n_head == m->sets[slot].n, "ha_smpl_forward_split: verts_tail is required for the vertices behind the head");
+  DeviceGuard guard(m->device);
+  FrameParams p;
+  fill_model(p, m, slot);
+  p.N = N; p.n_active = n_active; p.Kc = m->NB + 1 + (n_active - 1) * 9;
+  p.pose = pose; p.betas = betas; p.transl = transl;
+  p.joints = joints_ext; p.verts = verts_tail ? verts_tail : joints_ext;   // (non-null = "evaluate the vertex set")
+  p.n_head = n_head; p.jstride = m->J + n_head;
+  const size_t lds = ((size_t)FW * (((m->Kfull_pad + 3) & ~3) + m->J * 12) + FW * 192) * sizeof(float);
+  hipLaunchKernelGGL(smpl_frame_fwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
+  HA_LAUNCH_CHECK();
+  return HA_OK;
+}
+
+extern "C" int ha_smpl_backward_split(const ha_smpl_model* m, int slot, int N, int n_active, const float* pose, const float* betas,
+                                      int n_head, const float* g_joints_ext, const float* g_verts_tail, float* g_pose, float* g_betas,
+                                      float* g_transl, void* stream) {
+  int rc = check_common("ha_smpl_backward_split", m, slot, N, n_active);
+  if (rc != HA_OK) return rc;
+  HA_REQUIRE(pose && betas, "ha_smpl_backward_split: pose and betas are required");
+  HA_REQUIRE(n_head >= 0 && n_head <= m->sets[slot].n, "ha_smpl_backward_split: n_head=%d out of range 0..%d", n_head, m->sets[slot].n);
+  DeviceGuard guard(m->device);
+  FrameParams p;
+  fill_model(p, m, slot);
+  p.N = N; p.n_active = n_active; p.Kc = m->NB + 1 + (n_active - 1) * 9;
+  p.pose = pose; p.betas = betas;
+  p.g_verts = g_verts_tail; p.g_joints = g_joints_ext;
+  p.g_pose = g_pose; p.g_betas = g_betas; p.g_transl = g_transl;
+  p.n_head = n_head; p.jstride = m->J + n_head;
   const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + FW * 192) * sizeof(float);
   hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
   HA_LAUNCH_CHECK();

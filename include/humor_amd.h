@@ -91,6 +91,17 @@ int ha_smpl_backward(const ha_smpl_model* m, int slot, int N, int n_active_joint
                      const float* g_verts, const float* g_joints,
                      float* g_pose, float* g_betas, float* g_transl, void* stream);
 
+/* Vertex-subset evaluation whose first n_head vertices are delivered as extra joints (BodyModel(use_vtx_selector=True): the
+ * reference's Jtr = cat(joints, v[:, selector]), humor/body_model/body_model.py:97-99, without the cat / slice copies around the
+ * kernel): joints_ext [N, J + n_head, 3] receives the J joints followed by the first n_head vertices of subset `slot`,
+ * verts_tail [N, n - n_head, 3] the remaining ones (may be NULL when n_head == n).  The backward call reads the gradients in the
+ * same two tensors (either may be NULL = zero). */
+int ha_smpl_forward_split(const ha_smpl_model* m, int slot, int N, int n_active, const float* pose, const float* betas,
+                          const float* transl, int n_head, float* joints_ext, float* verts_tail, void* stream);
+int ha_smpl_backward_split(const ha_smpl_model* m, int slot, int N, int n_active, const float* pose, const float* betas,
+                           int n_head, const float* g_joints_ext, const float* g_verts_tail, float* g_pose, float* g_betas,
+                           float* g_transl, void* stream);
+
 /* Backward of the DENSE forward (slot 0, every vertex carries a gradient: the point-cloud / chamfer term of
  * humor/fitting/fitting_loss.py:378-396 back through BodyModel): g_verts [N, V, 3] is required; v_posed [N, V, 3] and
  * A [N, J, 12] are the forward's `ws_vposed` / `A_out`.  The vertex phase runs as batched kernels over all frames
