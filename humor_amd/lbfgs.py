@@ -126,8 +126,8 @@ class LBFGS:
             max_eval = max_iter * 5 // 4
         if line_search_fn not in (None, 'strong_wolfe'):
             raise RuntimeError("only 'strong_wolfe' is supported")
-        if history_size > 128:
-            raise ValueError('history_size must be <= 128 (ha_lbfgs_coeffs)')
+        if history_size > 127:
+            raise ValueError('history_size must be <= 127 (ha_lbfgs_coeffs holds history_size + 1 slots, at most 128)')
         self.param_groups = [dict(params=self._params, lr=lr, max_iter=max_iter, max_eval=max_eval, tolerance_grad=tolerance_grad,
                                   tolerance_change=tolerance_change, history_size=history_size, line_search_fn=line_search_fn)]
         self.state = {'func_evals': 0, 'n_iter': 0}
@@ -175,25 +175,33 @@ class LBFGS:
 
     # ---- history (device Gram matrix) ------------------------------------------------------------------------------------------
     def _init_history(self, n, device):
-        h = self.param_groups[0]['history_size']
+        # one slot more than the history holds: with a full history the speculative pair goes to the spare slot, and the oldest pair is
+        # retired only by the NEXT allocation -- a failed curvature test restores it (torch.optim.LBFGS keeps it in that case)
+        hmax = self.param_groups[0]['history_size']
+        h = hmax + 1
         lib = self._lib if self._lib is not None else _lib.get_lib()
         npart = C.c_int64()
         lib.call('ha_lbfgs_gram_workspace', n, 2 * h, C.byref(npart))
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
         # M: rows 0..h-1 the s slots, h..2h-1 the y slots, row 2h the current gradient (it doubles as torch's prev_flat_grad)
         self._hist = {'M': z(2 * h + 1, n), 'G': z(2 * h, 2 * h), 'order': [], 'coef': z(2 * h + 1), 'h': h, 'Mg': z(2 * h),
-                      'P': z(2 * h, 3), 'part': z(npart.value), 'scal': z(12)}
+                      'P': z(2 * h, 3), 'part': z(npart.value), 'scal': z(12), 'hmax': hmax, 'evicted': None}
 
     def _pop_pair(self, undo):
-        """Drops the pair stored by the matching _push_pair (its slot's Gram entries become dead: slots outside `order` are ignored).
-        An evicted oldest pair is not restored -- torch would have kept it; this only happens when the curvature test fails with a
-        full history, and only shortens the memory by one pair."""
-        self._hist['order'].remove(undo)
+        """Drops the pair stored by the matching _alloc_slot (its slot's Gram entries become dead: slots outside `order` are ignored) and
+        puts back the oldest pair that allocation had retired from a full history (its slot was not touched), as torch.optim.LBFGS
+        keeps it when the curvature test fails."""
+        H = self._hist
+        H['order'].remove(undo)
+        if H['evicted'] is not None:
+            H['order'].insert(0, H['evicted'])
+            H['evicted'] = None
 
     def _alloc_slot(self):
         H = self._hist
         h, order = H['h'], H['order']
-        slot = order.pop(0) if len(order) == h else next(i for i in range(h) if i not in order)
+        H['evicted'] = order.pop(0) if len(order) == H['hmax'] else None       # (its rows stay intact until the slot is handed out again)
+        slot = next(i for i in range(h) if i not in order and i != H['evicted'])
         order.append(slot)
         return slot
 
@@ -274,6 +282,7 @@ class LBFGS:
             if state['n_iter'] == 1:
                 d = flat_grad.neg()
                 Hh['order'] = []
+                Hh['evicted'] = None
                 H_diag = 1.0
                 g_row.copy_(flat_grad)
             else:

@@ -226,3 +226,25 @@ def test_emu_fused_lbfgs_follows_torch_lbfgs(emu_lib):
     assert c0 == c1, (c0, c1)
     assert max(abs(a - c) / max(1.0, abs(a)) for a, c in zip(t0, t1)) < 1e-5
     assert (x0 - x1).abs().max().item() < 1e-3 and t1[-1] < t1[0] - 1.0
+
+
+def test_lbfgs_failed_curvature_test_keeps_the_oldest_pair(emu_lib):
+    """With a full history the speculative pair goes to the spare slot: dropping it (curvature test failed) puts the retired oldest pair
+    back, untouched, as torch.optim.LBFGS keeps it; its slot is handed out again only after a pair has been accepted."""
+    from humor_amd.lbfgs import LBFGS
+    p = torch.zeros(40, requires_grad=True)
+    opt = LBFGS([p], history_size=3, line_search_fn='strong_wolfe', _lib_override=emu_lib)
+    opt._init_history(40, CPU)
+    H = opt._hist
+    slots = [opt._alloc_slot() for _ in range(3)]
+    assert H['order'] == slots and H['evicted'] is None and len(set(slots)) == 3
+    H['M'][slots[0]].fill_(7.0)                       # the oldest pair's s row
+    s4 = opt._alloc_slot()
+    assert s4 not in slots and H['order'] == slots[1:] + [s4] and H['evicted'] == slots[0]
+    opt._pop_pair(s4)                                 # curvature test failed
+    assert H['order'] == slots and H['evicted'] is None and bool((H['M'][slots[0]] == 7.0).all())
+    s5 = opt._alloc_slot()                            # accepted this time
+    assert s5 == s4 and H['order'] == slots[1:] + [s5]
+    s6 = opt._alloc_slot()
+    assert s6 == slots[0] and H['order'] == [slots[2], s5, s6] and H['evicted'] == slots[1]
+
