@@ -30,9 +30,14 @@ __global__ __launch_bounds__(256) void chamfer_nn_kernel(int n, const float* __r
     const float* q = xyz + ((size_t)i * n + j) * 3;
     x1 = q[0]; y1 = q[1]; z1 = q[2];
   }
-  float best = 0.f;
-  int best_i = 0;
   const float* P = xyz2 + (size_t)i * m * 3;
+  // candidate 0 seeds the search unconditionally, as in the reference's scan (`k == 0 || d < best`): a NaN distance there stays
+  float best;
+  int best_i = 0;
+  {
+    const float x2 = P[0] - x1, y2 = P[1] - y1, z2 = P[2] - z1;
+    best = (x2 * x2 + y2 * y2) + z2 * z2;
+  }
   for (int k2 = 0; k2 < m; k2 += CH_CHUNK) {
     const int cnt = m - k2 < CH_CHUNK ? m - k2 : CH_CHUNK;
     __syncthreads();
@@ -42,22 +47,29 @@ __global__ __launch_bounds__(256) void chamfer_nn_kernel(int n, const float* __r
       (c == 0 ? sx : (c == 1 ? sy : sz))[p] = v;
     }
     __syncthreads();
-    if (live) {
-      const int cnt4 = cnt & ~3;
-      for (int k = 0; k < cnt4; k += 4) {
-        const cvf4 X = *reinterpret_cast<const cvf4*>(sx + k), Y = *reinterpret_cast<const cvf4*>(sy + k), Z = *reinterpret_cast<const cvf4*>(sz + k);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float x2 = X[u] - x1, y2 = Y[u] - y1, z2 = Z[u] - z1;
-          const float d = (x2 * x2 + y2 * y2) + z2 * z2;
-          if ((k2 + k + u == 0) || d < best) { best = d; best_i = k2 + k + u; }
-        }
+    // four candidates per trip: their minimum against the running best; the bookkeeping (which of the four, the index) runs only
+    // when some lane of the wavefront improves -- after the first few hundred candidates almost never (expected improvements per
+    // query ~ ln m), so the steady-state trip is 3 LDS reads + 8 arithmetic instructions per candidate pair of lanes.  Strict `<`
+    // and "first of the four that equals the minimum" keep the reference's tie rule (lowest index); fminf drops NaN distances as
+    // `d < best` does.  (Dead lanes run along: the vote is wave-wide.)
+    const int cnt4 = cnt & ~3;
+    const cvf4 x1v = {-x1, -x1, -x1, -x1}, y1v = {-y1, -y1, -y1, -y1}, z1v = {-z1, -z1, -z1, -z1};
+    for (int k = 0; k < cnt4; k += 4) {
+      const cvf4 X = *reinterpret_cast<const cvf4*>(sx + k), Y = *reinterpret_cast<const cvf4*>(sy + k), Z = *reinterpret_cast<const cvf4*>(sz + k);
+      // (4-vectors: the compiler issues the packed fp32 forms, v_pk_add_f32 / v_pk_mul_f32 -- IEEE results identical to the scalar ones)
+      const cvf4 dx = X + x1v, dy = Y + y1v, dz = Z + z1v;        // x1v = -x1: a - b == a + (-b) exactly
+      const cvf4 d = (dx * dx + dy * dy) + dz * dz;
+      const float mn = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+      const bool better = mn < best;
+      if (__any(better)) {
+        const int uu = d[0] == mn ? 0 : (d[1] == mn ? 1 : (d[2] == mn ? 2 : 3));
+        if (better) { best = mn; best_i = k2 + k + uu; }
       }
-      for (int k = cnt4; k < cnt; ++k) {
-        const float x2 = sx[k] - x1, y2 = sy[k] - y1, z2 = sz[k] - z1;
-        const float d = (x2 * x2 + y2 * y2) + z2 * z2;
-        if ((k2 + k == 0) || d < best) { best = d; best_i = k2 + k; }
-      }
+    }
+    for (int k = cnt4; k < cnt; ++k) {
+      const float x2 = sx[k] - x1, y2 = sy[k] - y1, z2 = sz[k] - z1;
+      const float d = (x2 * x2 + y2 * y2) + z2 * z2;
+      if (d < best) { best = d; best_i = k2 + k; }
     }
   }
   if (live) {

@@ -87,6 +87,12 @@ static inline void __builtin_amdgcn_fence(int, const char*) { std::atomic_thread
 template <typename T> static inline T __shfl(T v, int src) { return simt_emu::shfl_any(v, src); }
 template <typename T> static inline T __shfl_xor(T v, int mask) { return simt_emu::shfl_any(v, simt_emu::lane_id() ^ mask); }
 template <typename T> static inline T __shfl_down(T v, int d) { int s = simt_emu::lane_id() + d; return simt_emu::shfl_any(v, s > 63 ? simt_emu::lane_id() : s); }
+// wave vote (every lane of the wavefront must call it, as with the shuffles)
+static inline int __any(int pred) {
+  int v = pred != 0;
+  for (int off = 32; off >= 1; off >>= 1) v |= simt_emu::shfl_any(v, simt_emu::lane_id() ^ off);
+  return v;
+}
 static inline float atomicAdd(float* p, float v) {
   std::atomic_ref<float> r(*p);
   float old = r.load();
