@@ -18,6 +18,7 @@
 //                           stores of the [N,V,3] arrays through a per-wave LDS transpose, A of the touched frames in LDS.
 #include <stdarg.h>
 #include <string.h>
+#include <algorithm>
 
 #include <vector>
 
@@ -39,6 +40,7 @@ namespace ha {
 // ha_tune_set("skin_variant"): -1 = auto; else bits 0-1: waves per block 4 << b; +4: non-temporal stores;
 // +8 / +16: profiling modes of the streaming kernel (LDS-transposed copy only / every lane gathers bone 0)
 int g_skin_variant = -1;
+int g_dense_gA_sparse = 1;   // ha_tune_set("dense_gA_sparse"): 1 = dL/dA of the dense backward by joint lists (default), 0 = dense MFMA product
 int g_dense_bwd_waves = 0;   // ha_tune_set("dense_bwd_waves"): wave-count target of the dense backward's K split (0 = default)
 extern int g_layer_spb, g_layer_nw, g_layer_finish, g_gemm_rm, g_layer_hsum, g_layer_acc, g_rollout_groups, g_gemm_ks, g_rollout_persist, g_rollout_persist_bwd;   // rollout.hip
 }
@@ -46,6 +48,7 @@ extern "C" int ha_tune_set(const char* key, int value) {
   HA_REQUIRE(key, "ha_tune_set: null key");
   if (strcmp(key, "skin_variant") == 0) { ha::g_skin_variant = value; return HA_OK; }
   if (strcmp(key, "dense_bwd_waves") == 0) { ha::g_dense_bwd_waves = value; return HA_OK; }
+  if (strcmp(key, "dense_gA_sparse") == 0) { ha::g_dense_gA_sparse = value; return HA_OK; }
   if (strcmp(key, "layer_spb") == 0) { ha::g_layer_spb = value; return HA_OK; }
   if (strcmp(key, "layer_nw") == 0) { ha::g_layer_nw = value; return HA_OK; }
   if (strcmp(key, "layer_finish") == 0) { ha::g_layer_finish = value; return HA_OK; }
@@ -262,6 +265,26 @@ extern "C" int ha_smpl_model_create(ha_smpl_model** out, int device, int V, int 
       for (int q = 0; q < nnz; ++q) wd[(size_t)v * 64 + m->h_idx[(size_t)v * nnz + q]] += m->h_w[(size_t)v * nnz + q];
     if ((rc = upload(&m->Wd, wd)) != HA_OK) return fail(rc);
   }
+  {
+    // weights by joint: start offsets, (vertex, weight) entries in vertex order, joints by decreasing list length
+    std::vector<int32_t> start(J + 1, 0), order(J);
+    for (int v = 0; v < V; ++v)
+      for (int q = 0; q < nnz; ++q)
+        if (m->h_w[(size_t)v * nnz + q] != 0.0f) start[m->h_idx[(size_t)v * nnz + q] + 1]++;
+    for (int j = 0; j < J; ++j) start[j + 1] += start[j];
+    std::vector<int32_t> jv(start[J] > 0 ? start[J] : 1, 0), fill(start.begin(), start.end() - 1);
+    std::vector<float> jw(start[J] > 0 ? start[J] : 1, 0.0f);
+    for (int v = 0; v < V; ++v)
+      for (int q = 0; q < nnz; ++q) {
+        const float wv = m->h_w[(size_t)v * nnz + q];
+        if (wv != 0.0f) { const int e = fill[m->h_idx[(size_t)v * nnz + q]]++; jv[e] = v; jw[e] = wv; }
+      }
+    for (int j = 0; j < J; ++j) order[j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return start[a + 1] - start[a] > start[b + 1] - start[b]; });
+    if ((rc = upload(&m->ja_start, start)) != HA_OK || (rc = upload(&m->ja_v, jv)) != HA_OK || (rc = upload(&m->ja_w, jw)) != HA_OK ||
+        (rc = upload(&m->ja_order, order)) != HA_OK)
+      return fail(rc);
+  }
   *out = m;
   return HA_OK;
 }
@@ -270,7 +293,8 @@ extern "C" int ha_smpl_model_destroy(ha_smpl_model* m) {
   if (!m) return HA_OK;
   DeviceGuard guard(m->device);
   for (int s = 0; s < kMaxSubsets; ++s) free_set(m->sets[s]);
-  void* ptrs[] = {m->Jt, m->Js, m->parents, m->jdepth, m->child_start, m->child_idx, m->Pd_m, m->w4, m->idx4, m->Wd};
+  void* ptrs[] = {m->Jt, m->Js, m->parents, m->jdepth, m->child_start, m->child_idx, m->Pd_m, m->w4, m->idx4, m->Wd,
+                  m->ja_start, m->ja_v, m->ja_w, m->ja_order};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete[] m->h_Pd;
@@ -1223,6 +1247,54 @@ __global__ __launch_bounds__(256) void dense_gvp_kernel(const float* __restrict_
 
 // One block per frame; wave w accumulates the 16-vertex groups w, w + 4, ...  Rows of the MFMA tile: (a, b) = (row >> 2, row & 3),
 // a < 3 the gradient component, b < 3 the v_posed component and b = 3 the translation column; columns: joint 4 (l & 15) + tile.
+// dL/dA_j = sum over the joint's vertex list of w [g (x) v_posed | g]: the weights are 4-sparse (27 560 of 6890 x 52 entries for SMPL+H), the
+// dense product above spends 16x the arithmetic and re-reads the 1.7 MB weight operand per frame.  One block per frame; a wave takes
+// the joints order[w], order[w + 4], ... (longest lists first, dealt round-robin); its lanes stride over the joint's entries (sorted
+// by vertex: neighbouring lanes read neighbouring 12-byte records of the frame's g / v_posed, L2-resident after the first touch), then
+// a fixed butterfly over the lanes.
+__global__ __launch_bounds__(256) void sparse_gA_kernel(const float* __restrict__ g_verts, const float* __restrict__ v_posed,
+                                                        const int32_t* __restrict__ jstart, const int32_t* __restrict__ jv,
+                                                        const float* __restrict__ jw, const int32_t* __restrict__ jorder,
+                                                        float* __restrict__ gA_out, int V, int J) {
+  const int f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* gf = g_verts + (size_t)f * V * 3;
+  const float* vf = v_posed + (size_t)f * V * 3;
+  for (int jo = wave; jo < J; jo += 4) {
+    const int j = jorder[jo];
+    const int e0 = jstart[j], e1 = jstart[j + 1];
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+#pragma unroll 4
+    for (int e = e0 + lane; e < e1; e += 64) {
+      const int v = jv[e];
+      const float w = jw[e];
+      const float g0 = gf[(size_t)v * 3], g1 = gf[(size_t)v * 3 + 1], g2 = gf[(size_t)v * 3 + 2];
+      const float p0 = vf[(size_t)v * 3], p1 = vf[(size_t)v * 3 + 1], p2 = vf[(size_t)v * 3 + 2];
+      const float wg[3] = {w * g0, w * g1, w * g2};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        acc[a * 3 + 0] = fmaf(wg[a], p0, acc[a * 3 + 0]);
+        acc[a * 3 + 1] = fmaf(wg[a], p1, acc[a * 3 + 1]);
+        acc[a * 3 + 2] = fmaf(wg[a], p2, acc[a * 3 + 2]);
+        acc[9 + a] += wg[a];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc[i] += __shfl_xor(acc[i], off);
+    }
+    if (lane < 12) {
+      float mine = acc[0];
+#pragma unroll
+      for (int i = 1; i < 12; ++i)
+        if (lane == i) mine = acc[i];
+      gA_out[((size_t)f * J + j) * 12 + lane] = mine;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void dense_gA_kernel(const float* __restrict__ g_verts, const float* __restrict__ v_posed,
                                                        const float* __restrict__ Wd, float* __restrict__ gA_out, int V, int Vpad, int J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];      // [4 waves][64 joints][12]
@@ -1575,8 +1647,12 @@ extern "C" int ha_smpl_backward_dense(const ha_smpl_model* m, int N, int n_activ
   hipLaunchKernelGGL(dense_gvp_kernel, dim3(P.np / 4, N), dim3(256), (size_t)m->J * 12 * sizeof(float), st, g_verts, A, m->w4, m->idx4,
                      ws + P.off_gvp, ws + P.off_gtl, m->V, m->J, P.nchunks, P.np);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dense_gA_kernel, dim3(N), dim3(256), (size_t)4 * 64 * 12 * sizeof(float), st, g_verts, v_posed, m->Wd, ws + P.off_gA, m->V,
-                     m->Vpad, m->J);
+  if (g_dense_gA_sparse)
+    hipLaunchKernelGGL(sparse_gA_kernel, dim3(N), dim3(256), 0, st, g_verts, v_posed, m->ja_start, m->ja_v, m->ja_w, m->ja_order, ws + P.off_gA,
+                       m->V, m->J);
+  else
+    hipLaunchKernelGGL(dense_gA_kernel, dim3(N), dim3(256), (size_t)4 * 64 * 12 * sizeof(float), st, g_verts, v_posed, m->Wd, ws + P.off_gA, m->V,
+                       m->Vpad, m->J);
   HA_LAUNCH_CHECK();
   {
     const int bpk = ceil_div(P.n_rp * P.ngroups, 4);

@@ -50,7 +50,12 @@ struct ha_smpl_model {
   float* Pd_m = nullptr;      // MFMA B-operand layout [Vpad/32][KQ][3][64][4] (KQ = k-pair quads)
   float4* w4 = nullptr;       // [V] (nnz <= 4 fast path)
   uint32_t* idx4 = nullptr;   // [V] 4 x uint8 joint ids
-  float* Wd = nullptr;        // [Vpad][64] dense skinning weights (nnz <= 4 models; dense backward)
+  float* Wd = nullptr;        // [Vpad][64] dense skinning weights (nnz <= 4 models; dense backward, A/B operand of the dense dL/dA product)
+  // the skinning weights by joint (CSR over all V vertices; entries of a joint sorted by vertex): the dense backward's dL/dA sum
+  int32_t* ja_start = nullptr;   // [J+1]
+  int32_t* ja_v = nullptr;       // [E] vertex ids
+  float* ja_w = nullptr;         // [E] weights
+  int32_t* ja_order = nullptr;   // [J] joints by decreasing list length (dealt round-robin to a block's waves)
   ha::VertexSet sets[ha::kMaxSubsets];
   // host copies kept for defining subsets later
   std::string* host_blob = nullptr;  // unused placeholder (keeps struct trivially extendable)

@@ -61,7 +61,11 @@ def main():
           f'({t_frame / t_dense:.1f}x)')
     for name, a, b in zip(('g_pose', 'g_betas', 'g_transl'), out['frame'], out['dense']):
         print(f'  {name}: max |frame - dense| = {(a - b).abs().max().item():.3e}  (scale {a.abs().max().item():.3e})')
-    for waves in [int(w) for w in os.environ.get("WAVES", "800,1600,3200,6400").split(",")]:
+    lib.call('ha_tune_set', b'dense_gA_sparse', 0)
+    t_mfma = timeit(dense, 20)
+    lib.call('ha_tune_set', b'dense_gA_sparse', 1)
+    print(f'  dL/dA as the dense 64-column MFMA product (dense_gA_sparse=0): {t_mfma:.3f} ms; by joint lists (default): {t_dense:.3f} ms')
+    for waves in [int(w) for w in os.environ.get("WAVES", "1600").split(",")]:
         lib.call('ha_tune_set', b'dense_bwd_waves', waves)
         lib.call('ha_smpl_backward_dense_workspace', h.ptr, N, n_active, C.byref(nw))
         ws = new(nw.value)
