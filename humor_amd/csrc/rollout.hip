@@ -54,10 +54,10 @@ int g_layer_hsum = 1;  // summed pre-activation write-back for the adjoint (ha_t
 // next launch: 32x59 fwd+bwd 4.55 -> 4.43 ms only, and the sum order of the partials (hence the last bit) varies run to run.
 int g_layer_acc = 0;
 int g_gemm_rm = 0;    // row tiles per wave of the batched prior GEMM (ha_tune_set "gemm_rm"; 0 = by size)
-// ha_tune_set "gemm_ks" (experiment, default 0 = off): 2 = two waves share a tile pair, each walks half of K, partial tiles summed
-// through LDS before the epilogue.  For small GEMMs (VPoser: 1920 x 512 x 512 is 480 waves on 1024 SIMDs) a launch is exactly one
-// wave's serial MFMA chain (512 MFMAs = 13.7 us of the 16 us); to be measured before it becomes a policy.
-int g_gemm_ks = 0;
+// ha_tune_set "gemm_ks" (default 2): two waves share a tile pair, each walks half of K, partial tiles summed through LDS before the
+// epilogue -- for GEMMs that leave most SIMDs idle (VPoser: 1920 x 512 x 512 is 480 waves on 1024 SIMDs, a frame-0 decode 16 waves:
+// a launch is exactly one wave's serial MFMA chain).  0 = off, 3 = also for large GEMMs (measured slower: tools/gemm_ks_ab.py).
+int g_gemm_ks = 2;
 // ha_tune_set "rollout_groups": 0 = auto, n >= 1 = split the batch into (at most) n row groups that run the chain side by side on
 // their own HIP streams (fork / join on the caller's stream with events; capturable), each with its own stash region and its steps
 // issued round-robin.  Sequences are independent, but side-by-side chains only pay where they change the launch policy: dispatch is
@@ -1722,7 +1722,7 @@ static int launch_prior_gemm(GemmTask& T, hipStream_t st) {
   int ncb = ceil_div(T.ntiles, 8);
   const int rm = g_gemm_rm == 1 || g_gemm_rm == 2 ? g_gemm_rm : ((T.nrt / 2) * ncb >= 2 * 256 ? 2 : 1);
   // K split (experiment knob): only for the one-row-tile-per-wave form and GEMMs that leave most SIMDs idle
-  const int ks = (g_gemm_ks == 2 && rm == 1 && T.nslices >= 4 && ncb * T.nrt * 4 <= 512) ? 2 : 1;
+  const int ks = ((g_gemm_ks == 2 || g_gemm_ks == 3) && rm == 1 && T.nslices >= 4 && (g_gemm_ks == 3 || ncb * T.nrt * 4 <= 512)) ? 2 : 1;
   if (ks == 2) ncb = ceil_div(T.ntiles, 4);
   T.nrg = ceil_div(T.nrt, rm);
   T.nwork = ncb * T.nrg;

@@ -23,6 +23,9 @@
 #include <vector>
 
 #include "smpl_model.h"
+#ifndef HA_SIMT_EMU
+#include "lane_reduce.h"
+#endif
 
 namespace ha {
 
@@ -177,6 +180,16 @@ extern "C" int ha_smpl_model_create(ha_smpl_model** out, int device, int V, int 
     for (int j = 1; j < J; ++j) cidx[fill[par[j]]++] = j;
   }
   if (cidx.empty()) cidx.push_back(0);
+  // ancestors at distance 2^r for the pointer-jumping forward chain
+  m->nrounds = 0;
+  while ((1 << m->nrounds) <= m->depth) ++m->nrounds;
+  std::vector<int32_t> anc((size_t)(m->nrounds > 0 ? m->nrounds : 1) * kMaxJoints, -1);
+  for (int j = 0; j < J; ++j) anc[j] = par[j];
+  for (int r = 1; r < m->nrounds; ++r)
+    for (int j = 0; j < J; ++j) {
+      const int a = anc[(size_t)(r - 1) * kMaxJoints + j];
+      anc[(size_t)r * kMaxJoints + j] = a >= 0 ? anc[(size_t)(r - 1) * kMaxJoints + a] : -1;
+    }
 
   // pre-contracted joint regressor (double accumulation, rounded once)
   std::vector<float> Jt((size_t)J * 3), Js((size_t)(NB > 0 ? NB : 1) * 3 * kMaxJoints, 0.0f);   // Js: [NB][3][64], lane = joint
@@ -229,6 +242,7 @@ extern "C" int ha_smpl_model_create(ha_smpl_model** out, int device, int V, int 
   if ((rc = upload(&m->jdepth, dep)) != HA_OK) return fail(rc);
   if ((rc = upload(&m->child_start, cstart)) != HA_OK) return fail(rc);
   if ((rc = upload(&m->child_idx, cidx)) != HA_OK) return fail(rc);
+  if ((rc = upload(&m->anc, anc)) != HA_OK) return fail(rc);
   if ((rc = build_set(m, 0, nullptr, V)) != HA_OK) return fail(rc);
 
   // MFMA B-operand layout [Vpad/32][KQ][3][64][4]: lane l <-> (vertex = vt*32 + (l&31), k = 2*kp + (l>>5)); the 12 floats a lane
@@ -294,7 +308,7 @@ extern "C" int ha_smpl_model_destroy(ha_smpl_model* m) {
   DeviceGuard guard(m->device);
   for (int s = 0; s < kMaxSubsets; ++s) free_set(m->sets[s]);
   void* ptrs[] = {m->Jt, m->Js, m->parents, m->jdepth, m->child_start, m->child_idx, m->Pd_m, m->w4, m->idx4, m->Wd,
-                  m->ja_start, m->ja_v, m->ja_w, m->ja_order};
+                  m->ja_start, m->ja_v, m->ja_w, m->ja_order, m->anc};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete[] m->h_Pd;
@@ -348,7 +362,7 @@ __device__ unsigned long long g_smpl_pt[2][16];
 struct FrameParams {
   // model
   const float* Jt; const float* Js; const int32_t* parents; const int32_t* jdepth;
-  const int32_t* child_start; const int32_t* child_idx;
+  const int32_t* child_start; const int32_t* child_idx; const int32_t* anc; int nrounds;
   int J, NB, Kfull, Kfull_pad, kf4, depth;   // kf4: Kfull_pad rounded to 4 floats (LDS stride)
   // vertex set
   const float* Pd_v; const float* Pd_k; int Kp; const float* w; const int32_t* idx; const float* Wc;
@@ -370,6 +384,20 @@ struct FrameParams {
 };
 
 constexpr int FW = 4;  // waves (= frames) per block
+
+// 16 values per lane summed over the wavefront, every lane gets the 16 totals: permlane-swap reduce-scatter + DPP adds on the GPU
+// (lane_reduce.h: ~50 instructions against 96 ds_bpermute round trips), a plain butterfly on the host emulator tier
+__device__ __forceinline__ void wave_sum16_all(float (&v)[16]) {
+#ifdef HA_SIMT_EMU
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+  }
+#else
+  lr::wave_sum16(v);
+#endif
+}
 
 // 12 floats at a 16-byte aligned LDS address as three 16-byte accesses
 __device__ __forceinline__ void lds_ld12(const float* src, float o[12]) {
@@ -450,28 +478,37 @@ __device__ __forceinline__ void joint_forward(const FrameParams& p, int f, int l
     const float pj = __shfl(s.Jr[c], psrc);
     s.t[c] = s.parent < 0 ? s.Jr[c] : s.Jr[c] - pj;
   }
-  // chain by level (Gs is the wave's own: ordering inside the wavefront is all that is needed)
-  if (isj && s.parent < 0) {
+  // kinematic chain by pointer jumping: T_j starts as the joint's local transform [R | t] and absorbs, in round r, the accumulated
+  // transform of its 2^r-th ancestor -- ceil(log2(depth + 1)) rounds (4 for SMPL+H) instead of one LDS round trip per tree level (10).
+  // Gs is the wave's own: ordering inside the wavefront is all that is needed.
+  constexpr int kMaxRounds = 6;          // 2^6 > kMaxJoints - 1
+  int ar[kMaxRounds];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) s.G[i] = s.R[i];
+  for (int r = 0; r < kMaxRounds; ++r) ar[r] = (isj && r < p.nrounds) ? p.anc[r * kMaxJoints + j] : -1;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) s.G[9 + c] = s.t[c];
-    lds_st12(Gs + j * 12, s.G);
-  }
-  wave_sync();
-  for (int lvl = 1; lvl <= p.depth; ++lvl) {
-    if (isj && s.depth == lvl) {
-      float Gp[12];
-      lds_ld12(Gs + s.parent * 12, Gp);
-      mat3_mul(Gp, s.R, s.G);
-      float tt[3];
-      mat3_vec(Gp, s.t, tt);
+  for (int i = 0; i < 9; ++i) s.G[i] = s.R[i];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) s.G[9 + c] = tt[c] + Gp[9 + c];
-      lds_st12(Gs + j * 12, s.G);
+  for (int c = 0; c < 3; ++c) s.G[9 + c] = s.t[c];
+#pragma unroll
+  for (int r = 0; r < kMaxRounds; ++r) {
+    if (r < p.nrounds) {
+      if (isj) lds_st12(Gs + j * 12, s.G);
+      wave_sync();
+      if (ar[r] >= 0) {
+        float Ga[12], Rn[9], tt[3];
+        lds_ld12(Gs + ar[r] * 12, Ga);
+        mat3_mul(Ga, s.G, Rn);
+        mat3_vec(Ga, s.G + 9, tt);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s.G[i] = Rn[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s.G[9 + c] = tt[c] + Ga[9 + c];
+      }
+      wave_sync();
     }
-    wave_sync();
   }
+  if (isj) lds_st12(Gs + j * 12, s.G);
+  wave_sync();
 }
 
 // blend-shape accumulation for the lane's vertex of `chunk`: v_posed = sum_k coeff[k] * Pd[k]
@@ -502,9 +539,11 @@ __device__ __forceinline__ void blend_vertex(const FrameParams& p, int chunk, in
 // The same sum for the FW frames of a block at once: every wave streams a quarter of the coefficient range of Pd_v and applies it
 // to all FW coefficient vectors (coeff of frame g at smem + g * per_wave), so the block reads the chunk's slice of Pd once instead
 // of once per frame (the 1920-frame closure call moved 0.7 GB through the L2s per direction for a 170 KB matrix).  The partial
-// sums meet in `vps` [FW][192]: in round r wave w adds its partial of frame (w + r) % FW -- a fixed order per frame.
+// sums meet in the block's exchange area [wave][frame][256] and are added per frame in wave order.
+constexpr int kXchStride = 256;                          // floats per (wave, frame) slot of the block's exchange area
+constexpr int kXchFloats = FW * FW * kXchStride;         // 16 KB behind the per-wave regions
 __device__ __forceinline__ void blend_vertex_block(const FrameParams& p, int chunk, int wave, int lane, const float* smem, int per_wave,
-                                                   float* vps, float vp[3]) {
+                                                   float* xch, float vp[3]) {
   const float* pd = p.Pd_v + (size_t)chunk * p.Kfull * 192 + lane;
   const int kq = (p.Kc + FW - 1) / FW, k0 = wave * kq, k1 = k0 + kq < p.Kc ? k0 + kq : p.Kc;
   float acc[FW][3];
@@ -522,19 +561,20 @@ __device__ __forceinline__ void blend_vertex_block(const FrameParams& p, int chu
       acc[g][2] = fmaf(c, z, acc[g][2]);
     }
   }
+  // every wave posts its partials of all FW frames, one barrier, the frame's wave adds them in wave order (the caller keeps a
+  // barrier between this read and the next call's writes)
 #pragma unroll
-  for (int r = 0; r < FW; ++r) {
-    const int gs = (wave + r) % FW;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-    for (int g = 0; g < FW; ++g)
-      if (g == gs) { a0 = acc[g][0]; a1 = acc[g][1]; a2 = acc[g][2]; }
-    float* dst = vps + gs * 192 + lane;
-    if (r == 0) { dst[0] = a0; dst[64] = a1; dst[128] = a2; }
-    else { dst[0] += a0; dst[64] += a1; dst[128] += a2; }
-    __syncthreads();
+  for (int g = 0; g < FW; ++g) {
+    float* dst = xch + (wave * FW + g) * kXchStride + lane;
+    dst[0] = acc[g][0]; dst[64] = acc[g][1]; dst[128] = acc[g][2];
   }
-  vp[0] = vps[wave * 192 + lane]; vp[1] = vps[wave * 192 + 64 + lane]; vp[2] = vps[wave * 192 + 128 + lane];
+  __syncthreads();
+  vp[0] = vp[1] = vp[2] = 0.f;
+#pragma unroll
+  for (int w = 0; w < FW; ++w) {
+    const float* src = xch + (w * FW + wave) * kXchStride + lane;
+    vp[0] += src[0]; vp[1] += src[64]; vp[2] += src[128];
+  }
 }
 
 // the lane's skinning entries of `chunk` (up to kSkinReg of them in registers, loaded together)
@@ -646,6 +686,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_fwd_kernel(FrameParams p) 
         dst[1] = o[1] + T[10] + tl[1];
         dst[2] = o[2] + T[11] + tl[2];
       }
+      if (chunk + 1 < p.nchunks) __syncthreads();      // the exchange area is rewritten by the next chunk's blend
     }
   }
   SPT(0, 4);
@@ -794,7 +835,22 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
       __syncthreads();
     }
     SPT(1, 5);
-    // per frame: the FW partials in a fixed order (round r: wave w adds its partial of frame (w + r) % FW into that frame's gco)
+    // per frame: the FW partials in wave order -- through the block's exchange area in one step when the coefficient range fits a
+    // slot (Kc <= 256), else in FW rounds (round r: wave w adds its partial of frame (w + r) % FW into that frame's gco)
+    if (p.Kc <= kXchStride) {
+      float* xch = smem + FW * per_wave;
+#pragma unroll
+      for (int g = 0; g < FW; ++g)
+        *reinterpret_cast<float4*>(xch + (wave * FW + g) * kXchStride + 4 * lane) = make_float4(gco_blk[g][0], gco_blk[g][1], gco_blk[g][2], gco_blk[g][3]);
+      __syncthreads();
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < FW; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(xch + (w * FW + wave) * kXchStride + 4 * lane);
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      gco_reg[0] = t.x; gco_reg[1] = t.y; gco_reg[2] = t.z; gco_reg[3] = t.w;
+    } else {
 #pragma unroll
     for (int r = 0; r < FW; ++r) {
       const int gs = (wave + r) % FW;
@@ -814,6 +870,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
     for (int m = 0; m < kMaxKM; ++m) {
       const int k = 256 * (m >> 2) + 4 * lane + (m & 3);
       if (k < p.Kfull_pad) gco_reg[m] = gco[k];
+    }
     }
   }
   if (p.gA_in) {
@@ -866,53 +923,70 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
     mat3_tvec(s.G, gat, tmp);
     gJr[0] = -tmp[0]; gJr[1] = -tmp[1]; gJr[2] = -tmp[2];
   }
+  // With G4 the 4x4 world transform of a joint, the chain G_child = G_parent L_child gives dL/dG_p = sum over the subtree of
+  // own_d (G_p^-1 G_d)^T = [sum_d own_d G4_d^T] G4_p^-T: plain 12-vector subtree sums (one LDS hand-off per tree level, no matrix work
+  // in the dependent chain), then every joint finishes on its own.
   float gR[9], gt[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 9; ++i) gR[i] = 0.f;
-  for (int lvl = p.depth; lvl >= 1; --lvl) {
-    if (isj && s.depth == lvl) {
-      // own gG is final here: emit the message to the parent and the local gradients
-      float Gp[12];
-      lds_ld12(Gs + s.parent * 12, Gp);
-      float m9[9];
-      mat3_mult(gG, s.R, m9);                       // gG.R * R^T
+  {
+    float S[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) S[i] = 0.f;
+    const float own_t[3] = {gG[9], gG[10], gG[11]};
+    if (isj) {
+      mat3_mult(gG, s.G, S);                        // own.R R_w^T
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) S[a * 3 + b] += gG[9 + a] * s.G[9 + b];   // + own.t (x) t_w
+        S[9 + a] = gG[9 + a];
+      }
+    }
+    for (int lvl = p.depth; lvl >= 1; --lvl) {
+      if (isj && s.depth == lvl) lds_st12(msg + lane * 12, S);
+      wave_sync();        // the wave's own sums; a parent's slot is not one its children read, so one ordering point per level
+      if (isj && s.depth == lvl - 1) {
+        auto take = [&](int ch) {
+          float c[12];
+          lds_ld12(msg + ch * 12, c);
+#pragma unroll
+          for (int i = 0; i < 12; ++i) S[i] += c[i];
+        };
+#pragma unroll
+        for (int u = 0; u < kChildReg; ++u)
+          if (ch_reg[u] >= 0) take(ch_reg[u]);
+        for (int ci = ch_c0 + kChildReg; ci < ch_c1; ++ci) take(p.child_idx[ci]);
+      }
+    }
+    if (isj) {
+      // X = S G4^-T: X.R = S.R R_w - S.t (x) (R_w^T t_w), X.t = S.t
+      float w[3], XR[9];
+      mat3_tvec(s.G, s.G + 9, w);
+      mat3_mul(S, s.G, XR);
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) m9[a * 3 + b] += gG[9 + a] * s.t[b];   // + gG.t (x) t
-      mat3_tmul(Gp, gG, gR);                        // gR = Gp.R^T gG.R
-      const float ggt[3] = {gG[9], gG[10], gG[11]};
-      mat3_tvec(Gp, ggt, gt);                       // gt = Gp.R^T gG.t
-      float4* mq = reinterpret_cast<float4*>(msg + lane * 16);
-      mq[0] = make_float4(m9[0], m9[1], m9[2], m9[3]);
-      mq[1] = make_float4(m9[4], m9[5], m9[6], m9[7]);
-      mq[2] = make_float4(m9[8], gG[9], gG[10], gG[11]);
-      mq[3] = make_float4(gt[0], gt[1], gt[2], 0.f);
+        for (int b = 0; b < 3; ++b) XR[a * 3 + b] -= S[9 + a] * w[b];
+      const float Xt[3] = {S[9], S[10], S[11]};
+      if (s.parent >= 0) {
+        float Gp[12];
+        lds_ld12(Gs + s.parent * 12, Gp);
+        mat3_tmul(Gp, XR, gR);                      // gR = Gp.R^T X.R
+        mat3_tvec(Gp, Xt, gt);                      // gt = Gp.R^T X.t
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gR[i] = XR[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gt[c] = Xt[c];
+      }
+      // rest joint: + own translation gradient, - the children's (sum_c gt_c = R_w^T (S.t - own.t))
+      const float dt[3] = {S[9] - own_t[0], S[10] - own_t[1], S[11] - own_t[2]};
+      float q[3];
+      mat3_tvec(s.G, dt, q);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gJr[c] += gt[c] - q[c];
     }
-    wave_sync();        // the wave's own messages; a parent's slot is not one its children read, so one ordering point per level
-    if (isj && s.depth == lvl - 1) {
-      auto take = [&](int ch) {
-        const float4* mq = reinterpret_cast<const float4*>(msg + ch * 16);
-        const float4 a = mq[0], b = mq[1], c = mq[2], d = mq[3];
-        gG[0] += a.x; gG[1] += a.y; gG[2] += a.z; gG[3] += a.w; gG[4] += b.x; gG[5] += b.y; gG[6] += b.z; gG[7] += b.w;
-        gG[8] += c.x; gG[9] += c.y; gG[10] += c.z; gG[11] += c.w;
-        gJr[0] -= d.x; gJr[1] -= d.y; gJr[2] -= d.z;
-      };
-#pragma unroll
-      for (int u = 0; u < kChildReg; ++u)
-        if (ch_reg[u] >= 0) take(ch_reg[u]);
-      for (int ci = ch_c0 + kChildReg; ci < ch_c1; ++ci) take(p.child_idx[ci]);
-    }
-  }
-  if (isj && s.parent < 0) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) gR[i] = gG[i];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) gt[c] = gG[9 + c];
-  }
-  if (isj) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) gJr[c] += gt[c];
   }
 
   SPT(1, 7);
@@ -934,27 +1008,24 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
   SPT(1, 8);
   // ---- betas gradient: coefficient part + rest-joint part ------------------------------------------
   if (p.g_betas) {
-    // rest-joint part: sum over joints (lanes) of gJr . Js[joint][:, l]; 8 shape coefficients per trip, fixed butterfly order
+    // rest-joint part: sum over joints (lanes) of gJr . Js[joint][:, l]; 16 shape coefficients per trip (48 loads in flight, one
+    // 16-value wave sum)
     const float* js = p.Js + (isj ? lane : 0);
-    for (int l0 = 0; l0 < p.NB; l0 += 8) {
-      float part[8];
+    for (int l0 = 0; l0 < p.NB; l0 += 16) {
+      float part[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int l = l0 + u;
         part[u] = 0.f;
         if (isj && l < p.NB)
           part[u] = fmaf(gJr[0], js[(l * 3 + 0) * kMaxJoints], fmaf(gJr[1], js[(l * 3 + 1) * kMaxJoints], gJr[2] * js[(l * 3 + 2) * kMaxJoints]));
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) part[u] += __shfl_xor(part[u], off);
-      }
+      wave_sum16_all(part);
       float mine = part[0];
 #pragma unroll
-      for (int u = 1; u < 8; ++u)
+      for (int u = 1; u < 16; ++u)
         if (lane == u) mine = part[u];
-      if (lane < 8 && l0 + lane < p.NB && valid) p.g_betas[(size_t)f * p.NB + l0 + lane] = gco[l0 + lane] + mine;
+      if (lane < 16 && l0 + lane < p.NB && valid) p.g_betas[(size_t)f * p.NB + l0 + lane] = gco[l0 + lane] + mine;
     }
   }
   SPT(1, 9);
@@ -1452,7 +1523,7 @@ static DenseBwdPlan dense_bwd_plan(const ha_smpl_model* m, int N, int n_active) 
 static void fill_model(FrameParams& p, const ha_smpl_model* m, int slot) {
   memset(&p, 0, sizeof(p));
   p.Jt = m->Jt; p.Js = m->Js; p.parents = m->parents; p.jdepth = m->jdepth;
-  p.child_start = m->child_start; p.child_idx = m->child_idx;
+  p.child_start = m->child_start; p.child_idx = m->child_idx; p.anc = m->anc; p.nrounds = m->nrounds;
   p.J = m->J; p.NB = m->NB; p.Kfull = m->Kfull; p.Kfull_pad = m->Kfull_pad; p.kf4 = (m->Kfull_pad + 3) & ~3; p.depth = m->depth;
   const VertexSet& s = m->sets[slot];
   p.Pd_v = s.Pd_v; p.Pd_k = s.Pd_k; p.Kp = ceil_div(m->Kfull, 128) * 128; p.w = s.w; p.idx = s.idx; p.Wc = s.Wc;
@@ -1532,7 +1603,7 @@ extern "C" int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_ac
   p.N = N; p.n_active = n_active; p.Kc = m->NB + 1 + (n_active - 1) * 9;
   p.pose = pose; p.betas = betas; p.transl = transl;
   p.joints = joints; p.A_out = A_out;
-  const size_t lds = ((size_t)FW * (((m->Kfull_pad + 3) & ~3) + m->J * 12) + FW * 192) * sizeof(float);   // + the block's v_posed exchange
+  const size_t lds = ((size_t)FW * (((m->Kfull_pad + 3) & ~3) + m->J * 12) + kXchFloats) * sizeof(float);   // + the block's exchange area
   const int blocks = ceil_div(N, FW);
   if (algo == 1) {
     p.verts = verts;
@@ -1573,7 +1644,7 @@ extern "C" int ha_smpl_backward(const ha_smpl_model* m, int slot, int N, int n_a
   p.pose = pose; p.betas = betas;
   p.g_verts = g_verts; p.g_joints = g_joints;
   p.g_pose = g_pose; p.g_betas = g_betas; p.g_transl = g_transl;
-  const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + FW * 192) * sizeof(float);
+  const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + kXchFloats) * sizeof(float);
   hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
@@ -1593,7 +1664,7 @@ extern "C" int ha_smpl_forward_split(const ha_smpl_model* m, int slot, int N, in
   p.pose = pose; p.betas = betas; p.transl = transl;
   p.joints = joints_ext; p.verts = verts_tail ? verts_tail : joints_ext;   // (non-null = "evaluate the vertex set")
   p.n_head = n_head; p.jstride = m->J + n_head;
-  const size_t lds = ((size_t)FW * (((m->Kfull_pad + 3) & ~3) + m->J * 12) + FW * 192) * sizeof(float);
+  const size_t lds = ((size_t)FW * (((m->Kfull_pad + 3) & ~3) + m->J * 12) + kXchFloats) * sizeof(float);
   hipLaunchKernelGGL(smpl_frame_fwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
@@ -1614,7 +1685,7 @@ extern "C" int ha_smpl_backward_split(const ha_smpl_model* m, int slot, int N, i
   p.g_verts = g_verts_tail; p.g_joints = g_joints_ext;
   p.g_pose = g_pose; p.g_betas = g_betas; p.g_transl = g_transl;
   p.n_head = n_head; p.jstride = m->J + n_head;
-  const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + FW * 192) * sizeof(float);
+  const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + kXchFloats) * sizeof(float);
   hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
@@ -1669,7 +1740,7 @@ extern "C" int ha_smpl_backward_dense(const ha_smpl_model* m, int N, int n_activ
   p.g_pose = g_pose; p.g_betas = g_betas; p.g_transl = g_transl;
   p.gA_in = ws + P.off_gA; p.gco_part = ws + P.off_gco; p.gco_ks = P.KS; p.gco_rows = N; p.gco_ld = P.ld;
   p.gtl_part = ws + P.off_gtl; p.gtl_np = P.np;
-  const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + FW * 192) * sizeof(float);
+  const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + kXchFloats) * sizeof(float);
   hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, st, p);
   HA_LAUNCH_CHECK();
   return HA_OK;

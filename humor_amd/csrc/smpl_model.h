@@ -46,6 +46,8 @@ struct ha_smpl_model {
   int32_t* jdepth = nullptr;  // [J]
   int32_t* child_start = nullptr;  // [J+1] CSR of children (deterministic parent-side accumulation in backward)
   int32_t* child_idx = nullptr;    // [J]
+  int32_t* anc = nullptr;          // [nrounds][64]: the 2^r-th ancestor of every joint (-1: none) -- pointer-jumping forward chain
+  int nrounds = 0;                 // smallest r with 2^r > depth
   // dense (slot 0) extras
   float* Pd_m = nullptr;      // MFMA B-operand layout [Vpad/32][KQ][3][64][4] (KQ = k-pair quads)
   float4* w4 = nullptr;       // [V] (nnz <= 4 fast path)

@@ -72,14 +72,14 @@ def test_emu_fused_vposer_matches_module(emu_lib):
 
 @pytest.mark.slow
 def test_emu_fused_vposer_k_split(emu_lib):
-    """ha_tune_set("gemm_ks", 2) (experiment knob, off by default): two waves per tile pair, each half of K, partial tiles summed
+    """ha_tune_set("gemm_ks", 2) (the default policy for GEMMs that leave most SIMDs idle): two waves per tile pair, each half of K, partial tiles summed
     through LDS before the epilogue -- same parity bar as the unsplit kernel (forward, LeakyReLU epilogues, 6-D tail, adjoint)."""
     emu_lib.call('ha_tune_set', b'gemm_ks', 2)
     try:
         MC.check_vposer(emu_lib, CPU, N=33, real_shaped=True, seed=5)
         MC.check_posterior(emu_lib, CPU, N=5)          # the GroupNorm (+ReLU) epilogues and their adjoints behind the split
     finally:
-        emu_lib.call('ha_tune_set', b'gemm_ks', 0)
+        emu_lib.call('ha_tune_set', b'gemm_ks', 2)
 
 
 def test_emu_fused_posterior_encoder_matches_module(emu_lib):

@@ -167,14 +167,18 @@ def test_fused_vposer_matches_module(gpu_lib, dev, N):
     MC.check_vposer(gpu_lib, dev, N=N, real_shaped=True, seed=3)
 
 
-def test_fused_vposer_k_split(gpu_lib, dev):
-    """ha_tune_set("gemm_ks", 2) (experiment knob, off by default): K split over two waves per tile pair in the batched GEMM kernel."""
-    gpu_lib.call('ha_tune_set', b'gemm_ks', 2)
+@pytest.mark.parametrize('ks', [0, 2])
+def test_batched_gemm_k_split_policy(gpu_lib, dev, ks):
+    """ha_tune_set("gemm_ks", 2) (default: K split over two waves per tile pair for GEMMs that leave most SIMDs idle) and 0 (off): the
+    LeakyReLU (VPoser) and GroupNorm (posterior encoder, small-batch prior) epilogues behind both."""
+    gpu_lib.call('ha_tune_set', b'gemm_ks', ks)
     try:
         MC.check_vposer(gpu_lib, dev, N=1920, real_shaped=True, seed=5)
         MC.check_vposer(gpu_lib, dev, N=33, real_shaped=True, seed=6)
+        MC.check_posterior(gpu_lib, dev, N=40)
+        RC.check_rollout(gpu_lib, dev, B=4, S=6, seed=11)
     finally:
-        gpu_lib.call('ha_tune_set', b'gemm_ks', 0)
+        gpu_lib.call('ha_tune_set', b'gemm_ks', 2)
 
 
 def test_fused_posterior_encoder_matches_module(gpu_lib, dev):
