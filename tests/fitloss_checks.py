@@ -256,3 +256,32 @@ def check_rigid_image(lib, device, npz, N=5, seed=0, dense=False):
         worst = max(worst, e)
         assert e < 1e-4, (k, e, q.abs().max().item())
     return worst
+
+
+def check_gmm_nll(lib, device, B=5, seed=0):
+    """ha_gmm_nll (init-state mixture, value + gradient) against the op-by-op log-density and its autograd: contiguous segments, frame 0
+    of a [B,T,J,3] tensor read in place (strided rows), a single sequence."""
+    from humor_amd.fit_kernels import GmmNll
+    from humor_amd.fitting_loss import _GMM
+    w, mu, cov = synth.make_gmm(seed=0)
+    gmm = _GMM(w.to(device), mu.to(device), cov.to(device))
+    g = torch.Generator().manual_seed(seed)
+    worst = 0.0
+    for b in (B, 1):
+        jtr = (0.3 * torch.randn(b, 4, 30, 3, generator=g)).to(device).requires_grad_(True)
+        jv = (0.3 * torch.randn(b, 1, 22, 3, generator=g)).to(device).requires_grad_(True)
+        tv = (0.3 * torch.randn(b, 1, 3, generator=g)).to(device).requires_grad_(True)
+        rv = (0.3 * torch.randn(b, 1, 3, generator=g)).to(device).requires_grad_(True)
+        j0 = jtr[:, :, :22][:, 0:1]                                   # a view with contiguous 66-float rows, row stride 4 * 30 * 3
+        nll = GmmNll.apply(lib, gmm, j0, jv, tv, rv)
+        state = torch.cat([j0.reshape(b, -1), jv.reshape(b, -1), tv.reshape(b, -1), rv.reshape(b, -1)], -1)
+        ref = -gmm.log_prob(state).sum()
+        assert abs(nll.item() - ref.item()) <= 1e-6 * abs(ref.item()), (nll.item(), ref.item())
+        g1 = torch.autograd.grad(nll, [jtr, jv, tv, rv])
+        g0 = torch.autograd.grad(ref, [jtr, jv, tv, rv])
+        for a, c in zip(g1, g0):
+            e = (a - c).abs().max().item() / max(1.0, c.abs().max().item())
+            worst = max(worst, e)
+            assert e < 2e-5, e
+    return worst
+

@@ -180,6 +180,12 @@ def test_emu_rigid_image_equals_second_smpl_evaluation(emu_lib, smplh_npz):
     print('rigid image: worst relative gradient difference', FL.check_rigid_image(emu_lib, CPU, smplh_npz, N=3, seed=2))
 
 
+def test_emu_gmm_nll_kernel(emu_lib):
+    """ha_gmm_nll on the SIMT emulator against the op-by-op mixture log-density (strided frame-0 rows, B = 1)."""
+    import fitloss_checks as FL
+    print('gmm nll: worst relative gradient difference', FL.check_gmm_nll(emu_lib, CPU, B=3, seed=1))
+
+
 def test_emu_lbfgs_kernels_long_history(emu_lib):
     """Gram pass, pair installation + coefficient kernel and the scalars kernel on the SIMT emulator with 90 stored pairs in rotated
     slots (lanes own two rows of the recurrences) against the float64 two-loop recursion."""

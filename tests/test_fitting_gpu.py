@@ -239,6 +239,12 @@ def test_rigid_image_equals_second_smpl_evaluation(gpu_lib, dev, smplh_npz):
             assert e < 2e-4, (k, e)
 
 
+def test_gmm_nll_kernel(gpu_lib, dev):
+    """ha_gmm_nll against the op-by-op mixture log-density and its autograd (32 sequences as in the closure, strided frame-0 rows, B = 1)."""
+    import fitloss_checks as FL
+    print('gmm nll: worst relative gradient difference', FL.check_gmm_nll(gpu_lib, dev, B=32, seed=2))
+
+
 def test_fit_pre_kernel_equals_op_chain(gpu_lib, dev, smplh_npz):
     """Fused stage-3 set-up against the op chain it replaces, stand-alone and through the stage-3 objective."""
     import fitloss_checks as FL
