@@ -274,6 +274,23 @@ class HumorModel(nn.Module):
         B = x_past.size(0)
         return self.infer_step(x_past.reshape(B, -1), x_t.reshape(B, -1))
 
+    def single_step(self, past_in, t_in):
+        """One training / evaluation step (humor_model.py:374-404): posterior from (past, next), prior from the past, z sampled from the
+        posterior, decoded; returns the split prediction + 'posterior_distrib' / 'prior_distrib' as (mean, var).  Off the fitting path:
+        the MLPs go through ha_mlp_* when no parameter gradient is needed, the residual composition is plain PyTorch (decode)."""
+        B = past_in.size(0)
+        (pm, pv), (qm, qv) = self.infer_step(past_in, t_in)
+        z = self.rsample(qm, qv)
+        x_pred = self.split_output(self.decode(z, past_in).reshape(B, self.steps_out, -1))
+        x_pred['posterior_distrib'] = (qm, qv)
+        x_pred['prior_distrib'] = (pm, pv)
+        return x_pred
+
+    def forward(self, x_past, x_t):
+        """Single-step full forward pass with the posterior's sample (humor_model.py:352-372).  x_past [B, steps_in, D], x_t [B, steps_out, D]."""
+        B = x_past.size(0)
+        return self.single_step(x_past.reshape(B, -1), x_t.reshape(B, -1))
+
     def _delta_rotmat(self, raw):
         """Residual rotations from the decoder's raw output [N, rot_dim] -> [N,3,3] in plain PyTorch (convert_to_rotmat of the
         out_rot_rep, humor/utils/transforms.py:60-73): Rodrigues, 6-D Gram-Schmidt (:201-220) or the SVD projection (:222-241)."""
@@ -445,13 +462,17 @@ class HumorModel(nn.Module):
         Canonicalises every consecutive frame pair (t, t+1) into frame t's aligned coordinate system and evaluates
         prior and posterior for all pairs at once (humor_model.py:1061-1165 does the same with a Python loop over t).
         '''
-        if full_forward_pass:
-            raise NotImplementedError('full_forward_pass=True is a training/eval option outside the fitting path')
         if self.steps_in != 1 or self.in_rot_rep != 'mat':
             raise NotImplementedError("infer_global_seq implements steps_in=1, in_rot_rep='mat'")
         from .frames import canonicalize_pairs
         x_past, x_t = canonicalize_pairs(global_seq, self.data_names)      # [B*(T-1), D] each
         B, T = global_seq['trans'].shape[0], global_seq['trans'].shape[1]
+        if full_forward_pass:
+            # the full single-step pass for every pair (humor_model.py:1131-1160 stacks its per-step dictionaries along a new time axis);
+            # the posterior's samples are drawn for all pairs at once (one draw per pair, not the reference's per-step stream)
+            pred = self.single_step(x_past, x_t)
+            r4 = lambda a: a.reshape(B, T - 1, *a.shape[1:])
+            return {k: ((r4(v[0]), r4(v[1])) if k in ('posterior_distrib', 'prior_distrib') else r4(v)) for k, v in pred.items()}
         (pm, pv), (qm, qv) = self.infer_step(x_past, x_t)
         r = lambda a: a.reshape(B, T - 1, -1)
         return (r(pm), r(pv)), (r(qm), r(qv))

@@ -375,6 +375,38 @@ def test_infer_global_seq_and_velocities_match_reference_live():
     assert (frames.estimate_angular_velocity(rot, h) - w_ref).abs().max().item() < 1e-6
 
 
+@pytest.mark.skipif(not ref_loader.available(), reason='reference tree only exists in the build container')
+@pytest.mark.parametrize('rep', ['aa', '6d'])
+def test_full_forward_pass_matches_reference_live(rep):
+    """HumorModel.forward / single_step and infer_global_seq(full_forward_pass=True) (humor_model.py:352-404, 1131-1160) against the
+    reference with the posterior's sample replaced by its mean on both sides (the reference draws per step, ours once for all pairs):
+    every prediction key and both distributions.  (Not 3 rows: the reference's dim-less torch.cross in rot6d_to_rotmat)"""
+    from humor_amd.humor_model import HumorModel
+    R = ref_loader.load()
+    sd = synth.humor_state_dict(seed=0) if rep == 'aa' else synth.rotrep_state_dict(rep, seed=0)
+    kw = dict(in_rot_rep='mat', out_rot_rep=rep, latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
+    ours, ref = HumorModel(**kw), R.humor_model.HumorModel(**kw)
+    for m in (ours, ref):
+        m.load_state_dict(sd)
+        m.eval()
+        m.rsample = lambda mu, var: mu
+    B, T = 2, 5
+    g = torch.Generator().manual_seed(8)
+    r = lambda *s, sc=1.0: sc * torch.randn(*s, generator=g)
+    seq = {'trans': r(B, T, 3, sc=0.5), 'trans_vel': r(B, T, 3, sc=0.3),
+           'root_orient': L.batch_rodrigues(r(B * T, 3, sc=0.7)).reshape(B, T, 9), 'root_orient_vel': r(B, T, 3, sc=0.3),
+           'pose_body': L.batch_rodrigues(r(B * T * 21, 3, sc=0.4)).reshape(B, T, 189), 'joints': r(B, T, 66, sc=0.4), 'joints_vel': r(B, T, 66, sc=0.3)}
+    with torch.no_grad():
+        a = ours.infer_global_seq({k: v.clone() for k, v in seq.items()}, full_forward_pass=True)
+        b = ref.infer_global_seq({k: v.clone() for k, v in seq.items()}, full_forward_pass=True)
+    assert set(a.keys()) == set(b.keys()), (sorted(a.keys()), sorted(b.keys()))
+    for k in b:
+        pa, pb = (a[k], b[k]) if isinstance(b[k], tuple) else ((a[k],), (b[k],))
+        for x, y in zip(pa, pb):
+            assert x.shape == y.shape, (k, x.shape, y.shape)
+            assert (x - y).abs().max().item() < 3e-5 * max(1.0, y.abs().max().item()), (k, (x - y).abs().max().item())
+
+
 def test_lbs_restatement_matches_independent_paper_derivation(smplh_npz, smplh_struct):
     """The smplx restatement (written from the smplx op sequence) against oracle/smpl_paper_numpy.py, an fp64 numpy derivation
     written from the SMPL paper's equations with a different structure: breaks common-mode error between the restatement and the
