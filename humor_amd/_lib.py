@@ -184,7 +184,7 @@ def get_lib():
     global _lib
     if _lib is None:
         # HUMOR_AMD_LIB: another gfx950 build of the same sources (A/B measurements of kernel variants); never a fallback
-        _lib = Lib(os.environ.get('HUMOR_AMD_LIB', DEFAULT_LIB))
+        _lib = Lib(os.environ.get('HUMOR_AMD_LIB') or DEFAULT_LIB)      # (an empty value means unset)
         # HUMOR_AMD_ROLLOUT_PERSIST=0: launch-chain roll-out only.  The persistent roll-out kernels need one resident block on every CU;
         # two PROCESSES sharing one GPU (the 2-rank validation runs on a 1-GPU box) can starve each other's launches until their
         # bounded waits run out.  One process per GPU -- the deployment this package is built for -- needs no setting.
