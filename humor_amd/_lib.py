@@ -105,6 +105,7 @@ _SIGS = {
     'ha_humor_rollout_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p]),
     'ha_humor_rollout_sample': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_humor_rollout_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
+    'ha_humor_net_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     'ha_humor_persist_status': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint), C.POINTER(C.c_int64)]),
     'ha_mlp_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(MlpDesc), C.c_int, C.c_float]),
     'ha_mlp_destroy': (C.c_int, [C.c_void_p]),

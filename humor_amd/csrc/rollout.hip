@@ -92,6 +92,7 @@ struct ha_humor_net {
   int device = 0;
   int n_dec = 0, n_pri = 0;
   int rotw = 3;                            // floats per joint of the decoder's output rotation representation (3 aa, 6 6-D, 9 9-D)
+  bool delta = true;                       // the decoder emits residuals (HumorModel(output_delta=True)); ha_humor_net_set_option("output_delta")
   ha::PackedLayer dec[ha::MAXL], pri[ha::MAXL];
   ha::PersistNet* persist = nullptr;      // register-stationary decoder for the persistent forward (null: shape / device not eligible)
 };
@@ -772,45 +773,57 @@ __device__ __forceinline__ void stage_slabs(float* dst, const float* base, int n
   }
 }
 
-template <int ROTW>
+// DELTA: the decoder emits residuals (vectors add to the input state, rotations left-multiply it: output_delta=True, humor_model.py:460-494);
+// !DELTA: it emits the state itself (humor_model.py:331-347 converts only the rotations)
+template <int ROTW, bool DELTA>
 __device__ __forceinline__ void predict_joints(const float* sX, const float* sRAW, int j, PredState& s) {
   using RL = RawLayout<ROTW>;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    s.pj[c] = sRAW[RL::JNT + 3 * j + c] + sX[207 + 3 * j + c];
-    s.jv[c] = sRAW[RL::JVEL + 3 * j + c] + sX[273 + 3 * j + c];
+    s.pj[c] = sRAW[RL::JNT + 3 * j + c] + (DELTA ? sX[207 + 3 * j + c] : 0.f);
+    s.jv[c] = sRAW[RL::JVEL + 3 * j + c] + (DELTA ? sX[273 + 3 * j + c] : 0.f);
   }
 }
-template <int ROTW>
+template <int ROTW, bool DELTA>
 __device__ __forceinline__ void predict_body(const float* sX, const float* sRAW, int bidx, PredState& s) {
   using RL = RawLayout<ROTW>;
 #pragma unroll
   for (int c = 0; c < ROTW; ++c) s.raw_aa_b[c] = sRAW[RL::BODY + ROTW * bidx + c];
   delta_rot<ROTW>(s.raw_aa_b, s.dB);
+  if constexpr (DELTA) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) s.Bin[i] = sX[18 + 9 * bidx + i];
-  mat3_mul(s.dB, s.Bin, s.pB);
+    for (int i = 0; i < 9; ++i) s.Bin[i] = sX[18 + 9 * bidx + i];
+    mat3_mul(s.dB, s.Bin, s.pB);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { s.Bin[i] = 0.f; s.pB[i] = s.dB[i]; }
+  }
 }
-template <int ROTW>
+template <int ROTW, bool DELTA>
 __device__ __forceinline__ void predict_root(const float* sX, const float* sRAW, PredState& s) {
   using RL = RawLayout<ROTW>;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    s.ptrans[c] = sRAW[c] + sX[c];
-    s.ptvel[c] = sRAW[3 + c] + sX[3 + c];
-    s.prvel[c] = sRAW[RL::RVEL + c] + sX[15 + c];
+    s.ptrans[c] = sRAW[c] + (DELTA ? sX[c] : 0.f);
+    s.ptvel[c] = sRAW[3 + c] + (DELTA ? sX[3 + c] : 0.f);
+    s.prvel[c] = sRAW[RL::RVEL + c] + (DELTA ? sX[15 + c] : 0.f);
   }
 #pragma unroll
   for (int c = 0; c < ROTW; ++c) s.raw_aa_r[c] = sRAW[RL::ROOT + c];
   delta_rot<ROTW>(s.raw_aa_r, s.dR);
+  if constexpr (DELTA) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) s.Rin[i] = sX[6 + i];
-  mat3_mul(s.dR, s.Rin, s.pR);
+    for (int i = 0; i < 9; ++i) s.Rin[i] = sX[6 + i];
+    mat3_mul(s.dR, s.Rin, s.pR);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { s.Rin[i] = 0.f; s.pR[i] = s.dR[i]; }
+  }
 }
 
 // Forward glue of step t.  Three waves per sequence (the same split as glue_bwd_kernel): wave 0 the root (lane 0), wave 1
 // the joints, wave 2 the body rotations, contact logits and the prior outputs.
-template <int ROTW>
+template <int ROTW, bool DELTA>
 __global__ __launch_bounds__(192) void glue_fwd_kernel(GlueParams p) {
   using RL = RawLayout<ROTW>;
   const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -845,7 +858,7 @@ __global__ __launch_bounds__(192) void glue_fwd_kernel(GlueParams p) {
   if (wave == 0) {
     // heading alignment from the predicted root orientation
     if (lane == 0) {
-      predict_root<ROTW>(sX, sRAW, s);
+      predict_root<ROTW, DELTA>(sX, sRAW, s);
       W2A wa;
       w2a_fwd(s.pR, wa);
 #pragma unroll
@@ -854,10 +867,10 @@ __global__ __launch_bounds__(192) void glue_fwd_kernel(GlueParams p) {
       for (int c = 0; c < 3; ++c) sSH[9 + c] = s.ptrans[c];
     }
   } else if (wave == 1) {
-    if (lane < NJT) predict_joints<ROTW>(sX, sRAW, lane, s);
+    if (lane < NJT) predict_joints<ROTW, DELTA>(sX, sRAW, lane, s);
   } else {
     if (lane >= 1 && lane < NJT) {
-      predict_body<ROTW>(sX, sRAW, lane - 1, s);
+      predict_body<ROTW, DELTA>(sX, sRAW, lane - 1, s);
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         XN[qoff(18 + 9 * (lane - 1) + i)] = s.pB[i];
@@ -966,7 +979,7 @@ __device__ __forceinline__ void outer_acc(float M[9], const float a[3], const fl
 // body rotations, wave 3 the latent / prior / contact adjoints -- and meet at two barriers (W from the root's forward
 // recomputation; the joint wave's reduced shared adjoints back to the root).
 
-template <int ROTW>
+template <int ROTW, bool DELTA>
 __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
   using RL = RawLayout<ROTW>;
   const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1047,7 +1060,7 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
   // ---- phase 1 (before W is known) ---------------------------------------------------------------------
   if (wave == 0) {
     if (lane == 0) {
-      predict_root<ROTW>(sX, sRAW, s);
+      predict_root<ROTW, DELTA>(sX, sRAW, s);
       w2a_fwd(s.pR, wa);
 #pragma unroll
       for (int i = 0; i < 9; ++i) sSH[i] = wa.W[i];
@@ -1055,17 +1068,22 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
       for (int c = 0; c < 3; ++c) sSH[9 + c] = s.ptrans[c];
     }
   } else if (wave == 1) {
-    if (lane < NJT) predict_joints<ROTW>(sX, sRAW, lane, s);
+    if (lane < NJT) predict_joints<ROTW, DELTA>(sX, sRAW, lane, s);
   } else if (wave == 2) {
     // body rotation: pB = dB * Bin goes unchanged to both outputs (no dependence on W or G)
     if (lane >= 1 && lane < NJT) {
       const int bidx = lane - 1;
-      predict_body<ROTW>(sX, sRAW, bidx, s);
+      predict_body<ROTW, DELTA>(sX, sRAW, bidx, s);
       float gpB[9], gdB[9], gBin[9], gaa[ROTW];
 #pragma unroll
       for (int i = 0; i < 9; ++i) gpB[i] = gw(18 + 9 * bidx + i) + GXN(18 + 9 * bidx + i);
-      mat3_mult(gpB, s.Bin, gdB);      // gdB = gpB * Bin^T
-      mat3_tmul(s.dB, gpB, gBin);      // gBin = dB^T * gpB
+      if constexpr (DELTA) {
+        mat3_mult(gpB, s.Bin, gdB);      // gdB = gpB * Bin^T
+        mat3_tmul(s.dB, gpB, gBin);      // gBin = dB^T * gpB
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { gdB[i] = gpB[i]; gBin[i] = 0.f; }
+      }
       delta_rot_bwd<ROTW>(s.raw_aa_b, gdB, gaa);
 #pragma unroll
       for (int c = 0; c < ROTW; ++c) GD[qoff(RL::BODY + ROTW * bidx + c)] = gaa[c];
@@ -1141,9 +1159,9 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       GD[qoff(RL::JNT + 3 * j + c)] = gpj[c];
-      GX[qoff(207 + 3 * j + c)] = gpj[c];
+      GX[qoff(207 + 3 * j + c)] = DELTA ? gpj[c] : 0.f;
       GD[qoff(RL::JVEL + 3 * j + c)] = gjv[c];
-      GX[qoff(273 + 3 * j + c)] = gjv[c];
+      GX[qoff(273 + 3 * j + c)] = DELTA ? gjv[c] : 0.f;
     }
     }
     // reduce the joint lanes' partial sums and hand them to the root
@@ -1247,14 +1265,19 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
     gpR[3] += g3;
     // pR = dR * Rin
     float gdR[9], gRin[9], gaa[ROTW];
-    mat3_mult(gpR, s.Rin, gdR);
-    mat3_tmul(s.dR, gpR, gRin);
+    if constexpr (DELTA) {
+      mat3_mult(gpR, s.Rin, gdR);
+      mat3_tmul(s.dR, gpR, gRin);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { gdR[i] = gpR[i]; gRin[i] = 0.f; }
+    }
     delta_rot_bwd<ROTW>(s.raw_aa_r, gdR, gaa);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      GD[qoff(c)] = gptrans[c];        GX[qoff(c)] = gptrans[c];
-      GD[qoff(3 + c)] = gptvel[c];   GX[qoff(3 + c)] = gptvel[c];
-      GD[qoff(RL::RVEL + c)] = gprvel[c];   GX[qoff(15 + c)] = gprvel[c];
+      GD[qoff(c)] = gptrans[c];        GX[qoff(c)] = DELTA ? gptrans[c] : 0.f;
+      GD[qoff(3 + c)] = gptvel[c];   GX[qoff(3 + c)] = DELTA ? gptvel[c] : 0.f;
+      GD[qoff(RL::RVEL + c)] = gprvel[c];   GX[qoff(15 + c)] = DELTA ? gprvel[c] : 0.f;
     }
 #pragma unroll
     for (int c = 0; c < ROTW; ++c) GD[qoff(RL::ROOT + c)] = gaa[c];
@@ -1268,17 +1291,19 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
   }
 }
 
-static inline void launch_glue_fwd(int rotw, int rows, hipStream_t st, const GlueParams& g) {
+static inline void launch_glue_fwd(int rotw, bool delta, int rows, hipStream_t st, const GlueParams& g) {
   const size_t lds = S_TOTAL_BWD * sizeof(float);
-  if (rotw == 3) hipLaunchKernelGGL(glue_fwd_kernel<3>, dim3(rows), dim3(192), lds, st, g);
-  else if (rotw == 6) hipLaunchKernelGGL(glue_fwd_kernel<6>, dim3(rows), dim3(192), lds, st, g);
-  else hipLaunchKernelGGL(glue_fwd_kernel<9>, dim3(rows), dim3(192), lds, st, g);
+#define HA_GLUE_FWD(R, D) hipLaunchKernelGGL((glue_fwd_kernel<R, D>), dim3(rows), dim3(192), lds, st, g)
+  if (delta) { if (rotw == 3) HA_GLUE_FWD(3, true); else if (rotw == 6) HA_GLUE_FWD(6, true); else HA_GLUE_FWD(9, true); }
+  else { if (rotw == 3) HA_GLUE_FWD(3, false); else if (rotw == 6) HA_GLUE_FWD(6, false); else HA_GLUE_FWD(9, false); }
+#undef HA_GLUE_FWD
 }
-static inline void launch_glue_bwd(int rotw, int rows, hipStream_t st, const GlueParams& g) {
+static inline void launch_glue_bwd(int rotw, bool delta, int rows, hipStream_t st, const GlueParams& g) {
   const size_t lds = S_TOTAL_BWD * sizeof(float);
-  if (rotw == 3) hipLaunchKernelGGL(glue_bwd_kernel<3>, dim3(rows), dim3(256), lds, st, g);
-  else if (rotw == 6) hipLaunchKernelGGL(glue_bwd_kernel<6>, dim3(rows), dim3(256), lds, st, g);
-  else hipLaunchKernelGGL(glue_bwd_kernel<9>, dim3(rows), dim3(256), lds, st, g);
+#define HA_GLUE_BWD(R, D) hipLaunchKernelGGL((glue_bwd_kernel<R, D>), dim3(rows), dim3(256), lds, st, g)
+  if (delta) { if (rotw == 3) HA_GLUE_BWD(3, true); else if (rotw == 6) HA_GLUE_BWD(6, true); else HA_GLUE_BWD(9, true); }
+  else { if (rotw == 3) HA_GLUE_BWD(3, false); else if (rotw == 6) HA_GLUE_BWD(6, false); else HA_GLUE_BWD(9, false); }
+#undef HA_GLUE_BWD
 }
 
 // z_t = mu + eps * sqrt(var) (or mu when eps is null) from the prior output slabs of step t; writes the transposed
@@ -1859,6 +1884,21 @@ extern "C" int ha_humor_persist_status(const ha_humor_net* net, int* available, 
   return HA_OK;
 }
 
+extern "C" int ha_humor_net_set_option(ha_humor_net* net, const char* key, int value) {
+  HA_REQUIRE(net && key, "ha_humor_net_set_option: null argument");
+  if (strcmp(key, "output_delta") == 0) {
+    net->delta = value != 0;
+    if (!net->delta && net->persist) {       // the persistent kernels compose residuals: absolute-output networks take the launch chain
+      DeviceGuard guard(net->device);
+      persist_destroy(net->persist);
+      net->persist = nullptr;
+    }
+    return HA_OK;
+  }
+  set_error("ha_humor_net_set_option: unknown option '%s'", key);
+  return HA_ERR_INVALID_ARG;
+}
+
 #ifdef HA_PERSIST_DEBUG
 // debugging build only (tools/build_variant.sh pdebug -DHA_PERSIST_DEBUG): stash offsets (floats) of the regions the persistent
 // kernels exchange, so that a script can read them back: [xT, steps, per_step, off_G, off_dec0..3, off_gn0..2, off_gl, dz_part, single]
@@ -1965,7 +2005,7 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
     g.Gs_next = step_ptr(t + 1) + L.off_G;
     g.t2j = stash + L.t2j;
     g.world = world;
-    launch_glue_fwd(net->rotw, rows, st, g);
+    launch_glue_fwd(net->rotw, net->delta, rows, st, g);
     HA_LAUNCH_CHECK();
     return HA_OK;
   }
@@ -2043,7 +2083,7 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
     g.t2j = stash + L.t2j;
     g.world = world;
     g.prior_mu = prior_mu; g.prior_var = prior_var;
-    launch_glue_fwd(net->rotw, rows, st, g);
+    launch_glue_fwd(net->rotw, net->delta, rows, st, g);
     HA_LAUNCH_CHECK();
   }
   return HA_OK;
@@ -2133,7 +2173,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
   if (phase == PH_STEP) {
     GlueParams g;
     fill_glue(g, t);
-    launch_glue_bwd(net->rotw, rows, st, g);
+    launch_glue_bwd(net->rotw, net->delta, rows, st, g);
     HA_LAUNCH_CHECK();
     float* sp = step_ptr(t);
     for (int l = nd - 1; l >= 0; --l) {
@@ -2157,7 +2197,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
   }
   GlueParams g;
   fill_glue(g, -1);
-  launch_glue_bwd(net->rotw, rows, st, g);
+  launch_glue_bwd(net->rotw, net->delta, rows, st, g);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

@@ -7,8 +7,9 @@ reference checkpoint loads with ``load_state_dict``), the attributes the optimis
 ``infer_global_seq`` / ``prior`` / ``posterior`` / ``decode`` / ``sample_step`` / ``split_output`` / ``prepare_input``.
 
 The roll-out kernels implement the configuration the fitting pipeline uses (in_rot_rep='mat', out_rot_rep='aa',
-steps_in=1, 'smpl+joints(+contacts)', output_delta=True) and its output-rotation variants out_rot_rep='6d' / '9d'
-(humor_model.py:476-484; these take the launch-chain kernels, the persistent roll-out is built for the 216-wide decoder).
+steps_in=1, 'smpl+joints(+contacts)', output_delta=True) and its output variants: out_rot_rep='6d' / '9d' (humor_model.py:476-484) and
+output_delta=False (the decoder emits the state itself, :331-347); these take the launch-chain kernels, the persistent roll-out is
+built for the residual 216-wide decoder.
 Other configurations raise NotImplementedError instead of silently running somewhere else.
 """
 import ctypes as C
@@ -88,7 +89,7 @@ class MLP(nn.Module):
 
 
 class _NetHandle:
-    def __init__(self, lib, device_index, decoder, prior):
+    def __init__(self, lib, device_index, decoder, prior, output_delta=True):
         self.lib = lib
         self.ptr = C.c_void_p()
         keep = []
@@ -113,6 +114,8 @@ class _NetHandle:
             return d
         dd, dp = desc(decoder), desc(prior)
         lib.call('ha_humor_net_create', C.byref(self.ptr), device_index, C.byref(dd), C.byref(dp))
+        if not output_delta:
+            lib.call('ha_humor_net_set_option', self.ptr, b'output_delta', 0)
 
     def __del__(self):
         try:
@@ -315,8 +318,10 @@ class HumorModel(nn.Module):
         B = z.size(0)
         past_in = past_in.reshape(B, -1)
         raw = self.decoder(torch.cat([past_in, z], dim=1))
-        if not (self.output_delta and self.in_rot_rep == 'mat'):
-            raise NotImplementedError("decode implements output_delta=True, in_rot_rep='mat'")
+        if not self.output_delta:
+            return raw                       # the network's output is the state itself; split_output converts its rotations
+        if self.in_rot_rep != 'mat':
+            raise NotImplementedError("decode implements in_rot_rep='mat'")
         w = self.output_rot_dim
         o_root, o_rvel, o_body, o_j = 6, 6 + w, 9 + w, 9 + 22 * w
         dR = self._delta_rotmat(raw[:, o_root:o_root + w])
@@ -354,8 +359,11 @@ class HumorModel(nn.Module):
         for n, d in zip(names, dims):
             out[n] = decoder_out[:, :, s:s + d]
             s += d
-        if convert_rots and not self.output_delta:
-            raise NotImplementedError('output_delta=False models are outside the fitting path')
+        if convert_rots and not self.output_delta:     # residual outputs already are rotation matrices (humor_model.py:341-346)
+            for n in ('root_orient', 'pose_body'):
+                if n in out:
+                    v = out[n]
+                    out[n] = self._delta_rotmat(v.reshape(-1, self.output_rot_dim)).reshape(B, self.steps_out, -1)
         return out
 
     def prepare_input(self, data_in, device, data_out=None, return_input_dict=False, return_global_dict=False):
@@ -375,10 +383,10 @@ class HumorModel(nn.Module):
     # roll-out (hot path)
     # ------------------------------------------------------------------------------------------------
     def _check_rollout_config(self):
-        if not (self.in_rot_rep == 'mat' and self.steps_in == 1 and self.output_delta and self.input_data_dim == 339):
+        if not (self.in_rot_rep == 'mat' and self.steps_in == 1 and self.input_data_dim == 339):
             raise NotImplementedError("humor_amd roll-out kernels implement in_rot_rep='mat', out_rot_rep 'aa' / '6d' / '9d', steps_in=1, "
-                                      "output_delta=True, 'smpl+joints(+contacts)' (the fitting configuration and its output "
-                                      "rotation variants)")
+                                      "output_delta True / False, 'smpl+joints(+contacts)' (the fitting configuration and its output "
+                                      "variants)")
         if not self.use_conditional_prior:
             raise NotImplementedError('roll-out kernels expect the conditional prior network')
         if not self.pred_contacts:
@@ -396,7 +404,7 @@ class HumorModel(nn.Module):
         key = (device.type, index)
         cached = self._net_handles.get(key)
         if cached is None or cached[0] != ver:
-            self._net_handles[key] = (ver, _NetHandle(lib, index, self.decoder, self.prior_net))
+            self._net_handles[key] = (ver, _NetHandle(lib, index, self.decoder, self.prior_net, output_delta=self.output_delta))
         return self._net_handles[key][1]
 
     def roll_out(self, x_past, init_input_dict, num_steps, use_mean=False, z_seq=None, return_prior=False, gender=None,

@@ -221,6 +221,13 @@ def rotrep_state_dict(out_rot_rep, seed=0, yaw_rate=0.1):
     return sd
 
 
+def nodelta_state_dict(seed=0):
+    """Well-conditioned synthetic weights for a model with output_delta=False (the decoder emits the next state itself): scaled-down
+    weights as in contractive_state_dict, a moderate output layer and a 0.3 rad heading so that the predicted root orientation stays
+    away from the singularity of the heading alignment (see contractive_state_dict)."""
+    return humor_state_dict(seed=seed, weight_scale=CONTRACTIVE['weight_scale'], out_scale=0.3, yaw_rate=0.3)
+
+
 # --------------------------------------------------------------------------------------------------
 # VPoser stand-in and init-state GMM
 # --------------------------------------------------------------------------------------------------

@@ -191,6 +191,11 @@ int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float
                               const float* g_world, const float* g_prior_mu, const float* g_prior_var,
                               float* stash, float* g_past_in0, float* g_z_seq, void* stream);
 
+/* Per-network options.  "output_delta" (default 1): the decoder emits residuals that are composed with the input state
+ * (HumorModel(output_delta=True), humor/models/humor_model.py:460-494); 0: it emits the next state itself and only its rotations are
+ * converted (humor_model.py:331-347).  Networks with output_delta = 0 run the launch chain. */
+int ha_humor_net_set_option(ha_humor_net* net, const char* key, int value);
+
 /* Persistent forward (ha_tune_set "rollout_persist" != 0, B <= 32): state of the weight-stationary one-launch forward of this
  * network.  *available = 1 when the network / device qualify and no launch has reported a failure; *error_word = the kernel's
  * host-mapped error word (0 = none; 0x1xx an XCD received more than its 32 blocks, 0x2xx a team member's bounded wait ran out),

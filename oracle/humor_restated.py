@@ -136,10 +136,17 @@ def rot9d_to_rotmat(x):
 RAW_WIDTH = {216: 3, 282: 6, 348: 9}     # decoder output width -> floats per joint of out_rot_rep ('aa', '6d', '9d')
 
 
-def decode_compose(past_in, raw):
+def decode_compose(past_in, raw, output_delta=True):
     """decoder residual composition (humor_model.py:460-494): vectors add, rotations left-multiply.  The output rotation
-    representation follows from the raw width: 216 'aa' (Rodrigues), 282 '6d', 348 '9d' (convert_to_rotmat, transforms.py:60-73)."""
+    representation follows from the raw width: 216 'aa' (Rodrigues), 282 '6d', 348 '9d' (convert_to_rotmat, transforms.py:60-73).
+    output_delta=False: the raw output is the state itself, only its rotations are converted (split_output, humor_model.py:331-347)."""
     B = past_in.shape[0]
+    if not output_delta:
+        w = RAW_WIDTH[raw.shape[1]]
+        conv = {3: batch_rodrigues, 6: rot6d_to_rotmat, 9: rot9d_to_rotmat}[w]
+        o_rvel, o_body, o_j = 6 + w, 9 + w, 9 + 22 * w
+        return torch.cat([raw[:, 0:6], conv(raw[:, 6:6 + w]).reshape(B, 9), raw[:, o_rvel:o_rvel + 3],
+                          conv(raw[:, o_body:o_body + NBODY * w].reshape(-1, w)).reshape(B, NBODY * 9), raw[:, o_j:o_j + 141]], dim=1)
     w = RAW_WIDTH[raw.shape[1]]
     conv = {3: batch_rodrigues, 6: rot6d_to_rotmat, 9: rot9d_to_rotmat}[w]
     o_rvel, o_body, o_j = 6 + w, 9 + w, 9 + 22 * w
@@ -183,7 +190,7 @@ def to_world(state, G, gt, t2j):
     return torch.cat([trans, tvel, R_root, rvel, state[:, 18:207], joints, jvel, state[:, 339:348]], dim=1)
 
 
-def roll_out(sd, past_in0, z_seq, return_prior=True, eps_seq=None, G0=None, gt0=None, t2j=None):
+def roll_out(sd, past_in0, z_seq, return_prior=True, eps_seq=None, G0=None, gt0=None, t2j=None, output_delta=True):
     """past_in0 [B,339] (already canonical), z_seq [B,S,48] -> world states [B,S,348], (pm, pv) [B,S,48] each.
     With z_seq=None the latent is sampled per step: z_t = pm_t + eps_seq[:, t] * sqrt(pv_t) (sample_step,
     humor_model.py:1029-1047; eps_seq=0 reproduces use_mean=True).  (G0, gt0, t2j) seed the accumulated world transform
@@ -208,7 +215,7 @@ def roll_out(sd, past_in0, z_seq, return_prior=True, eps_seq=None, G0=None, gt0=
             pvs.append(torch.exp(po[:, LATENT:]))
         z = pms[-1] + eps_seq[:, t] * torch.sqrt(pvs[-1]) if sampling else z_seq[:, t]
         raw = mlp_forward(torch.cat([past_in, z], dim=1), dec_lin, dec_gn, skip=z)
-        pred = decode_compose(past_in, raw)
+        pred = decode_compose(past_in, raw, output_delta)
         W = world2aligned(pred[:, 6:15].reshape(B, 3, 3))
         wt = torch.cat([-pred[:, 0:2], zero], dim=1)
         past_in = to_local(pred, W, wt, t2j)

@@ -228,14 +228,22 @@ def check_rollout_golden(lib, device):
     assert np.abs(aa_root.detach().cpu().numpy().reshape(gd['aa_root'].shape) - gd['aa_root']).max() < FWD_TOL
 
 
+def rotrep_model(lib, rep, seed):
+    """The fixture's model for `rep`: out_rot_rep '6d' / '9d', or 'nd' = axis-angle outputs with output_delta=False."""
+    delta = rep != 'nd'
+    sd = synth.rotrep_state_dict(rep, seed=seed) if delta else synth.nodelta_state_dict(seed=seed)
+    hm = HumorModel(in_rot_rep='mat', out_rot_rep=rep if delta else 'aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1,
+                    output_delta=delta, _lib_override=lib)
+    hm.load_state_dict(sd)
+    return hm, sd, delta
+
+
 def check_rollout_rotrep_short(lib, device, rep, B=2, S=2):
     """The first S steps of B sequences of the rotation-representation fixture (emulator-sized): forward against the reference's
     outputs, gradients against the restated oracle's autograd on the same inputs."""
     gd = golden('rollout_rotrep.npz')
     p = 'r' + rep + '_'
-    sd = synth.rotrep_state_dict(rep, seed=int(gd['weight_seed']))
-    hm = HumorModel(in_rot_rep='mat', out_rot_rep=rep, latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1, _lib_override=lib)
-    hm.load_state_dict(sd)
+    hm, sd, delta = rotrep_model(lib, rep, int(gd['weight_seed']))
     hm = hm.to(device).eval()
     pc = torch.tensor(gd[p + 'past0'][:B]).requires_grad_(True)
     zc = torch.tensor(gd[p + 'z'][:B, :S]).requires_grad_(True)
@@ -246,7 +254,7 @@ def check_rollout_rotrep_short(lib, device, rep, B=2, S=2):
     assert np.abs(pm.detach().cpu().numpy() - gd[p + 'prior_mu'][:B, :S]).max() < FWD_TOL
     t = lambda k: torch.tensor(gd[p + k][:B, :S])
     g0, gz = torch.autograd.grad((world * t('gw').to(device)).sum() + (pm * t('gm').to(device)).sum() + (pv * t('gv').to(device)).sum(), [past, z])
-    wo, (pmo, pvo) = H.roll_out(sd, pc, zc)
+    wo, (pmo, pvo) = H.roll_out(sd, pc, zc, output_delta=delta)
     r0, rz = torch.autograd.grad((wo * t('gw')).sum() + (pmo * t('gm')).sum() + (pvo * t('gv')).sum(), [pc, zc])
     e0 = (g0.cpu() - r0).abs().max().item() / max(1.0, r0.abs().max().item())
     ez = (gz.cpu() - rz).abs().max().item() / max(1.0, rz.abs().max().item())
@@ -260,9 +268,7 @@ def check_rollout_rotrep_golden(lib, device, rep):
     oracle's on the first step."""
     gd = golden('rollout_rotrep.npz')
     p = 'r' + rep + '_'
-    sd = synth.rotrep_state_dict(rep, seed=int(gd['weight_seed']))
-    hm = HumorModel(in_rot_rep='mat', out_rot_rep=rep, latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1, _lib_override=lib)
-    hm.load_state_dict(sd)
+    hm, sd, delta = rotrep_model(lib, rep, int(gd['weight_seed']))
     hm = hm.to(device).eval()
     past = torch.tensor(gd[p + 'past0']).to(device).requires_grad_(True)
     z = torch.tensor(gd[p + 'z']).to(device).requires_grad_(True)
@@ -281,12 +287,12 @@ def check_rollout_rotrep_golden(lib, device, rep):
     # single step in plain PyTorch (HumorModel.decode) against the oracle's residual composition
     with torch.no_grad():
         pc, zc = torch.tensor(gd[p + 'past0']), torch.tensor(gd[p + 'z'])[:, 0]
-        hc = HumorModel(in_rot_rep='mat', out_rot_rep=rep, latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1, _lib_override=lib)
-        hc.load_state_dict(sd)
-        hc.eval()
+        hc = rotrep_model(lib, rep, int(gd['weight_seed']))[0].eval()
         dec_lin, dec_gn = H.mlp_params(sd, 'decoder')
         raw = H.mlp_forward(torch.cat([pc, zc], 1), dec_lin, dec_gn, skip=zc)
-        assert (hc.decode(zc, pc) - H.decode_compose(pc, raw)).abs().max().item() < 1e-5
+        got = hc.split_output(hc.decode(zc, pc).reshape(pc.shape[0], 1, -1))
+        got = torch.cat([got[k] for k in KEYS], 2).reshape(pc.shape[0], -1)
+        assert (got - H.decode_compose(pc, raw, output_delta=delta)).abs().max().item() < 1e-5
     return ew, e0, ez
 
 

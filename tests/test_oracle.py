@@ -306,7 +306,7 @@ def test_rot6d_formula_matches_reference_live():
     assert torch.equal(ours, R.transforms.rot6d_to_rotmat(x))
 
 
-@pytest.mark.parametrize('rep', ['6d', '9d'])
+@pytest.mark.parametrize('rep', ['6d', '9d', 'nd'])
 def test_oracle_rollout_rotation_representations_match_the_golden_fixture(rep):
     """The restated roll-out with the 6-D / 9-D residual rotations against the reference-generated rollout_rotrep.npz."""
     from conftest import golden
@@ -314,10 +314,11 @@ def test_oracle_rollout_rotation_representations_match_the_golden_fixture(rep):
     from oracle import humor_restated as H
     gd = golden('rollout_rotrep.npz')
     p = 'r' + rep + '_'
-    sd = synth.rotrep_state_dict(rep, seed=int(gd['weight_seed']))
+    delta = rep != 'nd'          # 'nd': axis-angle outputs, output_delta=False
+    sd = synth.rotrep_state_dict(rep, seed=int(gd['weight_seed'])) if delta else synth.nodelta_state_dict(seed=int(gd['weight_seed']))
     past = torch.tensor(gd[p + 'past0']).requires_grad_(True)
     z = torch.tensor(gd[p + 'z']).requires_grad_(True)
-    world, (pm, pv) = H.roll_out(sd, past, z)
+    world, (pm, pv) = H.roll_out(sd, past, z, output_delta=delta)
     assert np.abs(world.detach().numpy() - gd[p + 'world']).max() < 2e-5
     assert np.abs(pm.detach().numpy() - gd[p + 'prior_mu']).max() < 2e-5
     t = lambda k: torch.tensor(gd[p + k])

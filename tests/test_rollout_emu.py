@@ -43,34 +43,37 @@ def test_emu_prior_gemm_two_row_tiles_per_wave(emu_lib):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize('rep', ['6d', '9d'])
+@pytest.mark.parametrize('rep', ['6d', '9d', 'nd'])
 def test_emu_rollout_output_rotation_representations(emu_lib, rep):
     # glue_fwd / glue_bwd instantiated for 6 / 9 floats per rotation (Gram-Schmidt / Jacobi-SVD residual rotations and their adjoints)
     # (two sequences x two steps of the reference-generated fixture; the full 4 x 12 fixture is the GPU tier's, 24 min per case here)
     print(rep, RC.check_rollout_rotrep_short(emu_lib, CPU, rep))
 
 
-@pytest.mark.parametrize('rep', ['aa', '6d', '9d'])
+@pytest.mark.parametrize('rep', ['aa', '6d', '9d', 'nd'])
 def test_decode_follows_the_output_rotation_representation(rep):
-    """HumorModel.decode (one step in plain PyTorch, humor_model.py:445-498) against the oracle's residual composition for every
-    out_rot_rep, on the first step of the reference-generated fixtures' inputs."""
+    """HumorModel.decode + split_output (one step in plain PyTorch, humor_model.py:331-347, 445-498) against the oracle's composition for every
+    out_rot_rep and for output_delta=False ('nd'), on the first step of the reference-generated fixtures' inputs."""
     from conftest import golden
     from humor_amd import synth
     from humor_amd.humor_model import HumorModel
     from oracle import humor_restated as H
     if rep == 'aa':
-        gd, p, sd = golden('rollout.npz'), '', synth.humor_state_dict(seed=0)
+        gd, p, sd, delta = golden('rollout.npz'), '', synth.humor_state_dict(seed=0), True
+        hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
+        hm.load_state_dict(sd)
     else:
-        gd, p, sd = golden('rollout_rotrep.npz'), 'r' + rep + '_', synth.rotrep_state_dict(rep, seed=0)
+        gd, p = golden('rollout_rotrep.npz'), 'r' + rep + '_'
+        hm, sd, delta = RC.rotrep_model(None, rep, 0)
     pc, zc = torch.tensor(gd[p + 'past0']), torch.tensor(gd[p + 'z'])[:, 0]
-    hm = HumorModel(in_rot_rep='mat', out_rot_rep=rep, latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
-    hm.load_state_dict(sd)
     hm.eval()
     with torch.no_grad():
         dec_lin, dec_gn = H.mlp_params(sd, 'decoder')
         raw = H.mlp_forward(torch.cat([pc, zc], 1), dec_lin, dec_gn, skip=zc)
-        assert raw.shape[1] == {'aa': 216, '6d': 282, '9d': 348}[rep]
-        assert (hm.decode(zc, pc) - H.decode_compose(pc, raw)).abs().max().item() < 1e-5
+        assert raw.shape[1] == {'aa': 216, '6d': 282, '9d': 348, 'nd': 216}[rep]
+        got = hm.split_output(hm.decode(zc, pc).reshape(pc.shape[0], 1, -1))
+        got = torch.cat([got[k] for k in RC.KEYS], 2).reshape(pc.shape[0], -1)
+        assert (got - H.decode_compose(pc, raw, output_delta=delta)).abs().max().item() < 1e-5
 
 
 def test_rollout_refuses_cpu():

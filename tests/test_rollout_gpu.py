@@ -44,9 +44,10 @@ def test_rollout_golden(gpu_lib, dev, fwd_path):
     RC.check_rollout_golden(gpu_lib, dev)
 
 
-@pytest.mark.parametrize('rep', ['6d', '9d'])
+@pytest.mark.parametrize('rep', ['6d', '9d', 'nd'])
 def test_rollout_output_rotation_representations(gpu_lib, dev, rep):
-    """HumorModel(out_rot_rep='6d' / '9d') (humor_model.py:476-484) against the reference-generated fixture: flat 1e-4 / 1e-3 bars."""
+    """HumorModel(out_rot_rep='6d' / '9d') (humor_model.py:476-484) and HumorModel(output_delta=False) ('nd', :331-347) against the
+    reference-generated fixture: flat 1e-4 / 1e-3 bars."""
     print(rep, RC.check_rollout_rotrep_golden(gpu_lib, dev, rep))
 
 
