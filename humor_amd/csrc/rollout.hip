@@ -31,8 +31,7 @@ template <int ROTW>
 struct RawLayout {
   static constexpr int ROOT = 6, RVEL = 6 + ROTW, BODY = 9 + ROTW, JNT = 9 + 22 * ROTW, JVEL = JNT + 66, CONT = JVEL + 66, D = CONT + 9;
 };
-constexpr int D_RAW = RawLayout<3>::D;       // 216: the fitting configuration
-constexpr int D_RAW_MAX = RawLayout<9>::D;   // 348
+static_assert(RawLayout<3>::D == 216 && RawLayout<6>::D == 282 && RawLayout<9>::D == 348, "decoder output widths of the three representations");
 constexpr int D_INP = 340;       // D_IN rounded up to a channel quad (the pad channel of a state slab is kept at zero)
 constexpr int SLICE = 64;        // channels per wave K-slice
 constexpr int MAXL = 8;
@@ -734,7 +733,7 @@ __device__ __forceinline__ void delta_rot_bwd(const float* raw, const float gR[9
 // LDS staging of one row's vectors: every lane issues its (independent) loads back-to-back, one barrier, then the
 // per-joint math reads LDS.  (The kernels are pure latency: a runtime slab loop per element would serialise ~100 L2/HBM
 // round trips per lane.)
-constexpr int S_X = 0, S_RAW = 352, S_GXN = 704, S_GW = 1056, S_TOTAL = 1408;      // (the raw area holds up to D_RAW_MAX channels)
+constexpr int S_X = 0, S_RAW = 352, S_GXN = 704, S_GW = 1056, S_TOTAL = 1408;      // (the raw area holds up to RawLayout<9>::D = 348 channels)
 constexpr int S_SH = 1408, S_RED = 1424, S_TOTAL_BWD = 1456;   // + W(9) ptr(3) of the root | the joint wave's sums (27)
 
 template <int NQ, int NT = 64>   // NQ = ceil(channel quads / NT): thread l stages quads l, l + NT, ... (16-byte loads)

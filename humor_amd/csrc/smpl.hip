@@ -511,32 +511,8 @@ __device__ __forceinline__ void joint_forward(const FrameParams& p, int f, int l
   wave_sync();
 }
 
-// blend-shape accumulation for the lane's vertex of `chunk`: v_posed = sum_k coeff[k] * Pd[k]
-__device__ __forceinline__ void blend_vertex(const FrameParams& p, int chunk, int lane, const float* coeff, float vp[3]) {
-  const float* pd = p.Pd_v + (size_t)chunk * p.Kfull * 192 + lane;
-  float ax = 0.f, ay = 0.f, az = 0.f;
-  int k = 0;
-  for (; k + 4 <= p.Kc; k += 4) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float c = coeff[k + u];
-      const float* q = pd + (size_t)(k + u) * 192;
-      ax = fmaf(c, q[0], ax);
-      ay = fmaf(c, q[64], ay);
-      az = fmaf(c, q[128], az);
-    }
-  }
-  for (; k < p.Kc; ++k) {
-    const float c = coeff[k];
-    const float* q = pd + (size_t)k * 192;
-    ax = fmaf(c, q[0], ax);
-    ay = fmaf(c, q[64], ay);
-    az = fmaf(c, q[128], az);
-  }
-  vp[0] = ax; vp[1] = ay; vp[2] = az;
-}
-
-// The same sum for the FW frames of a block at once: every wave streams a quarter of the coefficient range of Pd_v and applies it
+// blend-shape accumulation for the vertices of `chunk`: v_posed = sum_k coeff[k] * Pd[k], for the FW frames of a block at once:
+// every wave streams a quarter of the coefficient range of Pd_v and applies it
 // to all FW coefficient vectors (coeff of frame g at smem + g * per_wave), so the block reads the chunk's slice of Pd once instead
 // of once per frame (the 1920-frame closure call moved 0.7 GB through the L2s per direction for a 170 KB matrix).  The partial
 // sums meet in the block's exchange area [wave][frame][256] and are added per frame in wave order.
