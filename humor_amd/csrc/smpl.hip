@@ -43,7 +43,8 @@ namespace ha {
 // ha_tune_set("skin_variant"): -1 = auto; else bits 0-1: waves per block 4 << b; +4: non-temporal stores;
 // +8 / +16: profiling modes of the streaming kernel (LDS-transposed copy only / every lane gathers bone 0)
 int g_skin_variant = -1;
-int g_dense_gA_sparse = 1;   // ha_tune_set("dense_gA_sparse"): 1 = dL/dA of the dense backward by joint lists (default), 0 = dense MFMA product
+int g_dense_gA_sparse = 1;   // ha_tune_set("dense_gA_sparse"): 1 = dL/dA of the dense backward by joint lists (default), 0 = dense MFMA product,
+                             // 2 = MFMA product over the joints each 64-vertex chunk touches (experiment, unmeasured)
 int g_dense_bwd_waves = 0;   // ha_tune_set("dense_bwd_waves"): wave-count target of the dense backward's K split (0 = default)
 extern int g_layer_spb, g_layer_nw, g_layer_finish, g_gemm_rm, g_layer_hsum, g_layer_acc, g_rollout_groups, g_gemm_ks, g_rollout_persist, g_rollout_persist_bwd;   // rollout.hip
 }
@@ -298,6 +299,35 @@ extern "C" int ha_smpl_model_create(ha_smpl_model** out, int device, int V, int 
     if ((rc = upload(&m->ja_start, start)) != HA_OK || (rc = upload(&m->ja_v, jv)) != HA_OK || (rc = upload(&m->ja_w, jw)) != HA_OK ||
         (rc = upload(&m->ja_order, order)) != HA_OK)
       return fail(rc);
+    // chunk-local compressed joint dimension (experiment): the joints touched by each 64-vertex chunk, in slots
+    const int nch = m->Vpad / 64;
+    std::vector<int32_t> gcj((size_t)nch * 32, -1), gng(nch, 1);
+    std::vector<float> gcw((size_t)nch * 64 * 32, 0.0f);
+    bool fits = true;
+    for (int c = 0; c < nch && fits; ++c) {
+      int used = 0;
+      for (int vl = 0; vl < 64 && fits; ++vl) {
+        const int v = c * 64 + vl;
+        if (v >= V) break;
+        for (int q = 0; q < nnz; ++q) {
+          const float wv = m->h_w[(size_t)v * nnz + q];
+          if (wv == 0.0f) continue;
+          const int j = m->h_idx[(size_t)v * nnz + q];
+          int slot = -1;
+          for (int u = 0; u < used; ++u)
+            if (gcj[(size_t)c * 32 + u] == j) slot = u;
+          if (slot < 0) {
+            if (used == 32) { fits = false; break; }
+            slot = used++;
+            gcj[(size_t)c * 32 + slot] = j;
+          }
+          gcw[((size_t)c * 64 + vl) * 32 + slot] += wv;
+        }
+      }
+      gng[c] = used > 16 ? 2 : 1;
+    }
+    if (fits && ((rc = upload(&m->gc_joint, gcj)) != HA_OK || (rc = upload(&m->gc_w, gcw)) != HA_OK || (rc = upload(&m->gc_ng, gng)) != HA_OK))
+      return fail(rc);
   }
   *out = m;
   return HA_OK;
@@ -308,7 +338,7 @@ extern "C" int ha_smpl_model_destroy(ha_smpl_model* m) {
   DeviceGuard guard(m->device);
   for (int s = 0; s < kMaxSubsets; ++s) free_set(m->sets[s]);
   void* ptrs[] = {m->Jt, m->Js, m->parents, m->jdepth, m->child_start, m->child_idx, m->Pd_m, m->w4, m->idx4, m->Wd,
-                  m->ja_start, m->ja_v, m->ja_w, m->ja_order, m->anc};
+                  m->ja_start, m->ja_v, m->ja_w, m->ja_order, m->anc, m->gc_joint, m->gc_w, m->gc_ng};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete[] m->h_Pd;
@@ -1342,6 +1372,56 @@ __global__ __launch_bounds__(256) void sparse_gA_kernel(const float* __restrict_
   }
 }
 
+// Experiment (ha_tune_set("dense_gA_sparse", 2); correct on the emulator tier, not measured on the GPU yet): the dense product below
+// restricted, per 64-vertex chunk, to the joints the chunk touches, 16 slots per MFMA tile (one tile for 105 of the 108 chunks of the
+// synthetic model, two for the rest) instead of four tiles over all 64 joint columns, an 8 KB weight operand per chunk instead of 16 KB,
+// every vertex record read once.  A wave takes the chunks w, w + 4, ...; after a tile's 16 MFMAs lane (a = l >> 4, slot = l & 15) adds
+// its four values into the wave's own [joint][12] table in LDS (two slots of a chunk never share a joint: no conflicts, fixed order).
+__global__ __launch_bounds__(256) void compressed_gA_kernel(const float* __restrict__ g_verts, const float* __restrict__ v_posed,
+                                                            const int32_t* __restrict__ gcj, const float* __restrict__ gcw,
+                                                            const int32_t* __restrict__ gng, float* __restrict__ gA_out, int V, int Vpad, int J) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [4 waves][64 joints][12]
+  const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int row = lane & 15, kq = lane >> 4, a = row >> 2, b = row & 3, col = lane & 15;
+  const float* gf = g_verts + (size_t)f * V * 3;
+  const float* vf = v_posed + (size_t)f * V * 3;
+  float* tab = smem + wave * 768;
+  for (int i = lane; i < 768; i += 64) tab[i] = 0.f;
+  wave_sync();
+  for (int c = wave; c < Vpad / 64; c += 4) {
+    float av[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int v = c * 64 + 4 * e + kq;
+      const bool live = v < V && a < 3;
+      const float gval = live ? gf[(size_t)v * 3 + a] : 0.f;
+      const float pval = (live && b < 3) ? vf[(size_t)v * 3 + b] : 1.f;
+      av[e] = gval * pval;
+    }
+    const int ng = gng[c];
+    for (int grp = 0; grp < ng; ++grp) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      float bw[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bw[e] = gcw[((size_t)c * 64 + 4 * e + kq) * 32 + 16 * grp + col];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e], acc, 0, 0, 0);
+      // accumulator register r of lane l: row 4 (l >> 4) + r = (a = l >> 4, b = r), slot l & 15
+      const int joint = gcj[(size_t)c * 32 + 16 * grp + col];
+      if (joint >= 0 && kq < 3) {
+        float* d = tab + joint * 12;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) d[kq * 3 + r] += acc[r];
+        d[9 + kq] += acc[3];
+      }
+      wave_sync();
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < J * 12; i += 256)
+    gA_out[(size_t)f * J * 12 + i] = (smem[i] + smem[768 + i]) + (smem[1536 + i] + smem[2304 + i]);
+}
+
 __global__ __launch_bounds__(256) void dense_gA_kernel(const float* __restrict__ g_verts, const float* __restrict__ v_posed,
                                                        const float* __restrict__ Wd, float* __restrict__ gA_out, int V, int Vpad, int J) {
   extern __shared__ __attribute__((aligned(16))) float smem[];      // [4 waves][64 joints][12]
@@ -1694,7 +1774,10 @@ extern "C" int ha_smpl_backward_dense(const ha_smpl_model* m, int N, int n_activ
   hipLaunchKernelGGL(dense_gvp_kernel, dim3(P.np / 4, N), dim3(256), (size_t)m->J * 12 * sizeof(float), st, g_verts, A, m->w4, m->idx4,
                      ws + P.off_gvp, ws + P.off_gtl, m->V, m->J, P.nchunks, P.np);
   HA_LAUNCH_CHECK();
-  if (g_dense_gA_sparse)
+  if (g_dense_gA_sparse == 2 && m->gc_joint)
+    hipLaunchKernelGGL(compressed_gA_kernel, dim3(N), dim3(256), (size_t)4 * 64 * 12 * sizeof(float), st, g_verts, v_posed, m->gc_joint, m->gc_w,
+                       m->gc_ng, ws + P.off_gA, m->V, m->Vpad, m->J);
+  else if (g_dense_gA_sparse)
     hipLaunchKernelGGL(sparse_gA_kernel, dim3(N), dim3(256), 0, st, g_verts, v_posed, m->ja_start, m->ja_v, m->ja_w, m->ja_order, ws + P.off_gA,
                        m->V, m->J);
   else

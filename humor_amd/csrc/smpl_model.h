@@ -58,6 +58,11 @@ struct ha_smpl_model {
   int32_t* ja_v = nullptr;       // [E] vertex ids
   float* ja_w = nullptr;         // [E] weights
   int32_t* ja_order = nullptr;   // [J] joints by decreasing list length (dealt round-robin to a block's waves)
+  // experiment (ha_tune_set("dense_gA_sparse", 2)): per 64-vertex chunk the joints it touches, in groups of 16 slots, and its weights
+  // against those slots (SMPL's vertex order is coherent: 8 joints per chunk on average, 17-18 at most -> one or two groups)
+  int32_t* gc_joint = nullptr;   // [Vpad/64][32], -1 = unused slot; null when some chunk touches more than 32 joints
+  float* gc_w = nullptr;         // [Vpad/64][64][32]
+  int32_t* gc_ng = nullptr;      // [Vpad/64] slot groups in use (1 or 2)
   ha::VertexSet sets[ha::kMaxSubsets];
   // host copies kept for defining subsets later
   std::string* host_blob = nullptr;  // unused placeholder (keeps struct trivially extendable)

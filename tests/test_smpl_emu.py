@@ -75,6 +75,13 @@ def test_emu_dense_backward_kernels(emu_lib, tmp_path):
         SC.check_forward_backward(emu_lib, npz, ds, N=2, device=CPU, hands=False, selector=False, algo=2, dense_grad=True, seed=3)
     finally:
         emu_lib.call('ha_tune_set', b'dense_bwd_waves', 0)
+    # dL/dA variants: the dense 64-column MFMA product (0) and the chunk-local compressed product (2, experiment) behind the default (1)
+    for variant in (0, 2):
+        emu_lib.call('ha_tune_set', b'dense_gA_sparse', variant)
+        try:
+            SC.check_forward_backward(emu_lib, npz, ds, N=2, device=CPU, hands=True, selector=False, algo=2, dense_grad=True, seed=4 + variant)
+        finally:
+            emu_lib.call('ha_tune_set', b'dense_gA_sparse', 1)
 
 
 @pytest.mark.slow
