@@ -16,6 +16,14 @@ def test_emu_subset_fwd_bwd(emu_lib, smplh_npz, smplh_struct):
     SC.check_forward_backward(emu_lib, smplh_npz, smplh_struct, N=6, device=CPU, subset=SC.KEYPT_VERTS)
 
 
+def test_emu_subset_two_chunks_split_outputs(emu_lib, smplh_npz, smplh_struct):
+    """A subset of 21 selector + 100 requested vertices = two 64-vertex chunks: the selector vertices leave with the joints, the rest as `v`
+    (ha_smpl_forward_split / _backward_split), the block-wide blend exchange is reused between the chunks; and no selector at all (n_head = 0)."""
+    sub = list(range(5, 6805, 68))          # 100 vertices spread over the mesh
+    SC.check_forward_backward(emu_lib, smplh_npz, smplh_struct, N=3, device=CPU, subset=sub, seed=7)
+    SC.check_forward_backward(emu_lib, smplh_npz, smplh_struct, N=2, device=CPU, subset=sub[:30], selector=False, seed=8)
+
+
 def test_emu_hands_dense_grad(emu_lib, smplh_npz, smplh_struct):
     SC.check_forward_backward(emu_lib, smplh_npz, smplh_struct, N=3, device=CPU, hands=True, selector=False, algo=1, dense_grad=True)
 
