@@ -195,7 +195,7 @@ class GmmNll(torch.autograd.Function):
         for s in segs:
             s = s.detach()
             w = s[0].numel()
-            if s.dtype == torch.float32 and s[0].is_contiguous():
+            if s.dtype == torch.float32 and s[0].is_contiguous() and (B == 1 or s.stride(0) >= w):
                 rows.append((s, w, s.stride(0) if B > 1 else w))         # row b starts at data_ptr + b * stride(0)
             else:
                 s = s.reshape(B, -1).contiguous().float()
