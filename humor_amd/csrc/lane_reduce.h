@@ -42,15 +42,51 @@ HA_LR_DPP_ADD(add_ror1, 1)
 
 // every lane of a 16-lane row gets the row's sum, N (>= 4) values side by side
 template <int N>
+__device__ __forceinline__ void row_sum(float (&t)[N]);
+
+// Four (eight) independent values, each summed over its 16-lane row, every lane of the row ending up with the (bitwise identical)
+// total: ONE asm block, the adds of the values interleaved so that a result is read by DPP only four (eight) instructions after it
+// was written -- one `s_nop 1` for the whole block instead of one per add.  This is the GroupNorm reduction of the persistent
+// kernels (rollout_persist.hip: a 16-lane row holds exactly one normalisation group).
+__device__ __forceinline__ void row_sum4(float (&t)[4]) {
+#define HA_LR_STAGE4(ROR)                                                             \
+  "v_add_f32_dpp %0, %0, %0 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %1, %1, %1 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %2, %2, %2 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %3, %3, %3 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" HA_LR_STAGE4(8) HA_LR_STAGE4(4) HA_LR_STAGE4(2) HA_LR_STAGE4(1)
+               : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+#undef HA_LR_STAGE4
+}
+__device__ __forceinline__ void row_sum8(float (&t)[8]) {
+#define HA_LR_STAGE8(ROR)                                                             \
+  "v_add_f32_dpp %0, %0, %0 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %1, %1, %1 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %2, %2, %2 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %3, %3, %3 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %4, %4, %4 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %5, %5, %5 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %6, %6, %6 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %7, %7, %7 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" HA_LR_STAGE8(8) HA_LR_STAGE8(4) HA_LR_STAGE8(2) HA_LR_STAGE8(1)
+               : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#undef HA_LR_STAGE8
+}
+
+template <int N>
 __device__ __forceinline__ void row_sum(float (&t)[N]) {
+  if constexpr (N == 4) row_sum4(t);
+  else if constexpr (N == 8) row_sum8(t);
+  else {
 #pragma unroll
-  for (int n = 0; n < N; ++n) t[n] = add_ror8(t[n]);
+    for (int n = 0; n < N; ++n) t[n] = add_ror8(t[n]);
 #pragma unroll
-  for (int n = 0; n < N; ++n) t[n] = add_ror4(t[n]);
+    for (int n = 0; n < N; ++n) t[n] = add_ror4(t[n]);
 #pragma unroll
-  for (int n = 0; n < N; ++n) t[n] = add_ror2(t[n]);
+    for (int n = 0; n < N; ++n) t[n] = add_ror2(t[n]);
 #pragma unroll
-  for (int n = 0; n < N; ++n) t[n] = add_ror1(t[n]);
+    for (int n = 0; n < N; ++n) t[n] = add_ror1(t[n]);
+  }
 }
 
 // 16 values, each summed over all 64 lanes; every lane ends up with all 16 sums (in place)

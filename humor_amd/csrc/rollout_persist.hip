@@ -188,52 +188,63 @@ __device__ __forceinline__ bool sweep(__amdgpu_buffer_rsrc_t rs, unsigned off, u
   }
 }
 
-// consumer side of a hidden activation: sweep, GroupNorm (two-pass statistics per row and group of GROUP channels) + ReLU, the
+// Exchange slots of a GroupNorm'ed activation.  The consumer sweeps slot tid + 256 q (coalesced: one wave = 2 KB per load) and wants
+// its NQ = GW / 16 values of a row to belong to ONE normalisation group, the group spread over exactly one 16-lane DPP row:
+//     slot (tid, q)  <->  channel GW (tid / 16) + 16 q + (tid % 16)
+// so a group's statistics are NQ - 1 lane-local adds + one 4-stage DPP row reduction (lr::row_sum4: every lane of the row gets the
+// bitwise identical total) -- no v_permlane swaps, no operand copies (round 3: channel = tid + 256 q, a group = a whole wave,
+// 2 x wave_sum16 per layer = the issue-bound 2.1 k cycles of the phase tables).  GW = 0: identity (no GroupNorm on the consumer side).
+template <int GW>
+__device__ __forceinline__ int xslot(int col) {
+  if constexpr (GW == 0) return col;
+  else return 16 * (col / GW) + (col & 15) + 256 * ((col >> 4) & (GW / 16 - 1));
+}
+template <int GW>
+__device__ __forceinline__ int xchan(int tid, int q) { return GW * (tid >> 4) + 16 * q + (tid & 15); }
+
+// consumer side of a hidden activation: sweep, GroupNorm (two-pass statistics per row and group of GROUP = 16 NQ channels) + ReLU, the
 // finished A operand to LDS as [channel][4 rows]
 // stats (or null): the (mean, rstd) of every (group, row) go to stats[group][32 rows][2] for the adjoint (one CU of the team writes)
 template <int NQ, int GROUP, int PTI = 0>
 __device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float (&gam)[NQ], const float (&bet)[NQ],
                                             float* xs, int tid, float* stats, int row0 PT_ARGS) {
+  static_assert(GROUP == 16 * NQ, "a 16-lane row holds one group");
   float x[NQ][4];
   if (!sweep<NQ>(rs, off, tag, NQ * 256, tid, x)) return false;
   PT(PTI);
-  // two-pass statistics of the lane's NQ x 4 (channel quarter, row) values over their groups: all sums of a pass in one
-  // reduce-scatter / all-gather (lane_reduce.h)
   const float inv_n = 1.0f / (float)GROUP;
-  float mu[NQ * 4], var[NQ * 4];
+  float mu[4], var[4];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (NQ == 4) mu[i] = (x[0][i] + x[1][i]) + (x[2][i] + x[3][i]);
+    else mu[i] = x[0][i] + x[1][i];
+  }
+  lr::row_sum4(mu);
+  float d[NQ][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) mu[4 * q + i] = x[q][i];
-  if constexpr (GROUP == 64) lr::wave_sum16(mu);
-  else lr::half_sum8(mu);
+  for (int i = 0; i < 4; ++i) {
+    mu[i] *= inv_n;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
+    for (int q = 0; q < NQ; ++q) d[q][i] = x[q][i] - mu[i];
+    if constexpr (NQ == 4) var[i] = (d[0][i] * d[0][i] + d[1][i] * d[1][i]) + (d[2][i] * d[2][i] + d[3][i] * d[3][i]);
+    else var[i] = d[0][i] * d[0][i] + d[1][i] * d[1][i];
+  }
+  lr::row_sum4(var);
+  float rs4[4];
+  // (v_rsq_f32 itself: the argument is >= 1e-5, so rsqrtf's denormal pre-scaling never applies and the result is the same)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      mu[4 * q + i] *= inv_n;
-      const float d = x[q][i] - mu[4 * q + i];
-      var[4 * q + i] = d * d;
-    }
-  if constexpr (GROUP == 64) lr::wave_sum16(var);
-  else lr::half_sum8(var);
+  for (int i = 0; i < 4; ++i) rs4[i] = __builtin_amdgcn_rsqf(var[i] * inv_n + 1e-5f);
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     pvf4 o;
-    float rs4[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // (v_rsq_f32 itself: the argument is >= 1e-5, so rsqrtf's denormal pre-scaling never applies and the result is the same)
-      rs4[i] = __builtin_amdgcn_rsqf(var[4 * q + i] * inv_n + 1e-5f);
-      o[i] = fmaxf((x[q][i] - mu[4 * q + i]) * rs4[i] * gam[q] + bet[q], 0.f);
-    }
-    *reinterpret_cast<pvf4*>(xs + (size_t)(tid + 256 * q) * 4) = o;
-    if (stats && (tid & (GROUP - 1)) == 0) {        // one lane per group: its channel tid + 256 q lies in group (tid + 256 q) / GROUP
-      const int grp = (tid + 256 * q) / GROUP;
-      pvf4* sp = reinterpret_cast<pvf4*>(stats + ((size_t)grp * 32 + row0) * 2);
-      sp[0] = pvf4{mu[4 * q], rs4[0], mu[4 * q + 1], rs4[1]};
-      sp[1] = pvf4{mu[4 * q + 2], rs4[2], mu[4 * q + 3], rs4[3]};
-    }
+    for (int i = 0; i < 4; ++i) o[i] = fmaxf(d[q][i] * rs4[i] * gam[q] + bet[q], 0.f);
+    *reinterpret_cast<pvf4*>(xs + (size_t)xchan<GROUP>(tid, q) * 4) = o;
+  }
+  if (stats && (tid & 15) == 0) {        // one lane per group (= 16-lane row)
+    pvf4* sp = reinterpret_cast<pvf4*>(stats + ((size_t)(tid >> 4) * 32 + row0) * 2);
+    sp[0] = pvf4{mu[0], rs4[0], mu[1], rs4[1]};
+    sp[1] = pvf4{mu[2], rs4[2], mu[3], rs4[3]};
   }
   return true;
 }
@@ -341,7 +352,8 @@ __device__ __forceinline__ void mma_layer(const float* xs, const float* zs, cons
 // the same lanes write the plain pre-activation slab [channel quads][32 rows][4] for the adjoint / prior.
 // ht (or null): a second copy of the pre-activations in the team's own layout [channel][4 rows] (16 contiguous bytes per channel: the
 // persistent adjoint reads its h with one coalesced 16-byte load per channel instead of four scattered 4-byte loads from the slab)
-template <int NCG, bool SC1>
+// GW: the consumer's slot mapping (xslot)
+template <int NCG, bool SC1, int GW>
 __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias_lane, int col0, unsigned char* team_xch, __amdgpu_buffer_rsrc_t rs,
                                         unsigned off, unsigned tag, float* slab, int row0, int lane, float* ht = nullptr) {
   const int h = lane >> 5, p = (lane >> 4) & 1, j = lane & 3;
@@ -353,7 +365,7 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
       const int col = col0 + 4 * h + j;
       const float v0 = o[0] + bias_lane, v1 = o[1] + bias_lane;
       const puv4 gr = {as_u(v0), tag, as_u(v1), tag};
-      const unsigned goff = off + (unsigned)col * 32u + (unsigned)p * 16u;
+      const unsigned goff = off + (unsigned)xslot<GW>(col) * 32u + (unsigned)p * 16u;
       if (SC1) __builtin_amdgcn_raw_buffer_store_b128(gr, rs, goff, 0, 16);
       else *reinterpret_cast<puv4*>(team_xch + goff) = gr;
       if (slab) {
@@ -373,7 +385,7 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
       const float v0 = t + bias_lane;
       typedef unsigned puv2 __attribute__((ext_vector_type(2)));
       const puv2 gr = {as_u(v0), tag};
-      const unsigned goff = off + (unsigned)col * 32u + (unsigned)row * 8u;
+      const unsigned goff = off + (unsigned)xslot<GW>(col) * 32u + (unsigned)row * 8u;
       if (SC1) __builtin_amdgcn_raw_buffer_store_b64(gr, rs, goff, 0, 16);
       else *reinterpret_cast<puv2*>(team_xch + goff) = gr;
       if (slab) slab[pq(col) + (size_t)(row0 + row) * 4] = v0;
@@ -468,11 +480,11 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   float gam1[4], bet1[4], gam2[4], bet2[4], gam3[2], bet3[2];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    gam1[q] = a.gamma[0][tid + 256 * q]; bet1[q] = a.beta[0][tid + 256 * q];
-    gam2[q] = a.gamma[1][tid + 256 * q]; bet2[q] = a.beta[1][tid + 256 * q];
+    gam1[q] = a.gamma[0][xchan<64>(tid, q)]; bet1[q] = a.beta[0][xchan<64>(tid, q)];
+    gam2[q] = a.gamma[1][xchan<64>(tid, q)]; bet2[q] = a.beta[1][xchan<64>(tid, q)];
   }
 #pragma unroll
-  for (int q = 0; q < 2; ++q) { gam3[q] = a.gamma[2][tid + 256 * q]; bet3[q] = a.beta[2][tid + 256 * q]; }
+  for (int q = 0; q < 2; ++q) { gam3[q] = a.gamma[2][xchan<32>(tid, q)]; bet3[q] = a.beta[2][xchan<32>(tid, q)]; }
 
   // ---- initial state: x_0 (row-major copy for the glue, [channel][row] copy as the A operand), z_0, world transform ---------
   for (int e = tid; e < ROWS * P_XPAD; e += 256) {
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float acc[8];
       mma_layer<NC0, NCZ, 2, R0>(xs0, zs, wa, wv, lane, acc);
       PT(1);
-      publish<2, SC1>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, sp + a.off_dec[0], row0, lane, sp + a.off_ht[0] + (size_t)team * P_H0 * 4);
+      publish<2, SC1, 64>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, sp + a.off_dec[0], row0, lane, sp + a.off_ht[0] + (size_t)team * P_H0 * 4);
       PT(2);
     }
     // ---- layer 1 ----------------------------------------------------------------------------------------------------------
@@ -555,7 +567,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float acc[8];
       mma_layer<NC1, NCZ, 2, R1>(xs1, zs, wa, wv, lane, acc);
       PT(6);
-      publish<2, SC1>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, sp + a.off_dec[1], row0, lane, sp + a.off_ht[1] + (size_t)team * P_H1 * 4);
+      publish<2, SC1, 64>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, sp + a.off_dec[1], row0, lane, sp + a.off_ht[1] + (size_t)team * P_H1 * 4);
       PT(7);
     }
     // ---- layer 2 ----------------------------------------------------------------------------------------------------------
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float acc[4];
       mma_layer<NC2, NCZ, 1, R2>(xs2, zs, wa, wv, lane, acc);
       PT(11);
-      publish<1, SC1>(acc, b2, 4 * g, team_xch, rs, ACT_OFF2, tag + 3, sp + a.off_dec[2], row0, lane, sp + a.off_ht[2] + (size_t)team * P_H2 * 4);
+      publish<1, SC1, 32>(acc, b2, 4 * g, team_xch, rs, ACT_OFF2, tag + 3, sp + a.off_dec[2], row0, lane, sp + a.off_ht[2] + (size_t)team * P_H2 * 4);
       PT(12);
     }
     // ---- layer 3 (GroupNorm groups of 32) -------------------------------------------------------------------------------
@@ -583,7 +595,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float acc[4];
       mma_layer<NC3, NCZ, 1, R3>(xs3, zs, wa, wv, lane, acc);
       PT(16);
-      publish<1, SC1>(acc, b3, 4 * g, team_xch, rs, ACT_OFF3, tag + 4, sp + a.off_dec[3], row0, lane);
+      publish<1, SC1, 0>(acc, b3, 4 * g, team_xch, rs, ACT_OFF3, tag + 4, sp + a.off_dec[3], row0, lane);
       PT(17);
     }
     // ---- glue: decoder output of the 4 rows -> every CU --------------------------------------------------------------------
@@ -862,56 +874,58 @@ __device__ __forceinline__ void w2a_bwd_sc(const W2A& o, const float gW[9], floa
 template <int NQ>
 struct GnbRegs {
   pvf4 h[NQ];                 // the channel's four rows
-  pvf4 s0[NQ], s1[NQ];        // (mean, rstd) of rows 0-1 and 2-3 of the channel's group
+  pvf4 s0, s1;                // (mean, rstd) of rows 0-1 and 2-3 of the thread's group (one group per 16-lane row: xchan)
 };
 // ht: the team's copy of the pre-activations, [channel][4 rows]
 template <int NQ, int GROUP>
 __device__ __forceinline__ void gnb_issue(const float* ht, const float* stats, int row0, int tid, GnbRegs<NQ>& r) {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int c = tid + 256 * q;
-    r.h[q] = *reinterpret_cast<const pvf4*>(ht + (size_t)c * 4);
-    const pvf4* sp = reinterpret_cast<const pvf4*>(stats + ((size_t)(c / GROUP) * 32 + row0) * 2);
-    r.s0[q] = sp[0];
-    r.s1[q] = sp[1];
-  }
+  for (int q = 0; q < NQ; ++q) r.h[q] = *reinterpret_cast<const pvf4*>(ht + (size_t)xchan<GROUP>(tid, q) * 4);
+  const pvf4* sp = reinterpret_cast<const pvf4*>(stats + ((size_t)(tid >> 4) * 32 + row0) * 2);
+  r.s0 = sp[0];
+  r.s1 = sp[1];
 }
 template <int NQ, int GROUP, int PTI = 0>
 __device__ __forceinline__ bool gather_norm_bwd(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float* gam_lds, const float* bet_lds,
                                                 const GnbRegs<NQ>& r, float* ds, int tid PTB_ARGS) {
-  float xh[NQ][4], rstd[NQ][4];
+  static_assert(GROUP == 16 * NQ, "a 16-lane row holds one group");
+  const float mean[4] = {r.s0.x, r.s0.z, r.s1.x, r.s1.z}, rstd[4] = {r.s0.y, r.s0.w, r.s1.y, r.s1.w};
+  float xh[NQ][4];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    rstd[q][0] = r.s0[q].y; rstd[q][1] = r.s0[q].w; rstd[q][2] = r.s1[q].y; rstd[q][3] = r.s1[q].w;
-    xh[q][0] = (r.h[q][0] - r.s0[q].x) * r.s0[q].y; xh[q][1] = (r.h[q][1] - r.s0[q].z) * r.s0[q].w;
-    xh[q][2] = (r.h[q][2] - r.s1[q].x) * r.s1[q].y; xh[q][3] = (r.h[q][3] - r.s1[q].z) * r.s1[q].w;
-  }
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xh[q][i] = (r.h[q][i] - mean[i]) * rstd[i];
   float ga[NQ][4];
   if (!sweep<NQ>(rs, off, tag, NQ * 256, tid, ga)) return false;
   PTB(PTI);
   const float inv_n = 1.0f / (float)GROUP;
-  float dxh[NQ * 4], m2[NQ * 4];
+  float dxh[NQ][4], m[8];           // m[0..3] = sum of dxh, m[4..7] = sum of dxh xh over the group, per row
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const float gam = gam_lds[tid + 256 * q], bet = bet_lds[tid + 256 * q];
+    const float gam = gam_lds[xchan<GROUP>(tid, q)], bet = bet_lds[xchan<GROUP>(tid, q)];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float y = xh[q][i] * gam + bet;
-      dxh[4 * q + i] = (y > 0.f ? ga[q][i] : 0.f) * gam;
-      m2[4 * q + i] = dxh[4 * q + i] * xh[q][i];
+      dxh[q][i] = (y > 0.f ? ga[q][i] : 0.f) * gam;
     }
   }
-  float m1[NQ * 4];
 #pragma unroll
-  for (int k = 0; k < NQ * 4; ++k) m1[k] = dxh[k];
-  if constexpr (GROUP == 64) { lr::wave_sum16(m1); lr::wave_sum16(m2); }
-  else { lr::half_sum8(m1); lr::half_sum8(m2); }
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (NQ == 4) {
+      m[i] = (dxh[0][i] + dxh[1][i]) + (dxh[2][i] + dxh[3][i]);
+      m[4 + i] = (dxh[0][i] * xh[0][i] + dxh[1][i] * xh[1][i]) + (dxh[2][i] * xh[2][i] + dxh[3][i] * xh[3][i]);
+    } else {
+      m[i] = dxh[0][i] + dxh[1][i];
+      m[4 + i] = dxh[0][i] * xh[0][i] + dxh[1][i] * xh[1][i];
+    }
+  }
+  lr::row_sum8(m);
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     pvf4 o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = rstd[q][i] * (dxh[4 * q + i] - m1[4 * q + i] * inv_n - xh[q][i] * (m2[4 * q + i] * inv_n));
-    *reinterpret_cast<pvf4*>(ds + (size_t)(tid + 256 * q) * 4) = o;
+    for (int i = 0; i < 4; ++i) o[i] = rstd[i] * (dxh[q][i] - m[i] * inv_n - xh[q][i] * (m[4 + i] * inv_n));
+    *reinterpret_cast<pvf4*>(ds + (size_t)xchan<GROUP>(tid, q) * 4) = o;
   }
   return true;
 }
@@ -1259,7 +1273,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       float acc[4];
       mma_layer<BC3, 0, 1, BR3>(sD3, sD3, wa, wv, lane, acc);
       PTB(5);
-      publish<1, SC1>(acc, 0.f, 4 * g, team_xch, rs, GA_OFF3, tag + 1, nullptr, row0, lane);
+      publish<1, SC1, 32>(acc, 0.f, 4 * g, team_xch, rs, GA_OFF3, tag + 1, nullptr, row0, lane);
       if (g < DZ3_WAVES) {
         float accz[4];
         dz_mma<DZ3_CH>(sD3 + 64 * DZ3_CH * (g % (BC3 / DZ3_CH)), sWz + (BRZ3 - BRZ0) * 64, lane, accz);
@@ -1282,7 +1296,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       float acc[8];
       mma_layer<BC2, 0, 2, BR2>(sD2, sD2, wa, wv, lane, acc);
       PTB(10);
-      publish<2, SC1>(acc, 0.f, 8 * g, team_xch, rs, GA_OFF2, tag + 2, nullptr, row0, lane);
+      publish<2, SC1, 64>(acc, 0.f, 8 * g, team_xch, rs, GA_OFF2, tag + 2, nullptr, row0, lane);
       if (g < DZ2_WAVES) {
         float accz[4];
         dz_mma<DZ2_CH>(sD2 + 64 * DZ2_CH * (g % (BC2 / DZ2_CH)), sWz + (BRZ2 - BRZ0) * 64, lane, accz);
@@ -1303,7 +1317,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       float acc[8];
       mma_layer<BC1, 0, 2, BR1>(sD1, sD1, wa, wv, lane, acc);
       PTB(15);
-      publish<2, SC1>(acc, 0.f, 8 * g, team_xch, rs, GA_OFF1, tag + 3, nullptr, row0, lane);
+      publish<2, SC1, 64>(acc, 0.f, 8 * g, team_xch, rs, GA_OFF1, tag + 3, nullptr, row0, lane);
       if (g < DZ1_WAVES) {
         float accz[4];
         dz_mma<DZ1_CH>(sD1 + 64 * DZ1_CH * (g % (BC1 / DZ1_CH)), sWz + (BRZ1 - BRZ0) * 64, lane, accz);
@@ -1328,7 +1342,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
         for (int i = 0; i < 4; ++i) acc[i] += tail[i];
       } else { acc[0] = acc[1] = acc[2] = acc[3] = 0.f; }
       PTB(20);
-      if (g < P_XPAD / 4) publish<1, SC1>(acc, 0.f, 4 * g, team_xch, rs, GX_OFF0, tag + 4, nullptr, row0, lane);     // (waves 85..87: the zero padding)
+      if (g < P_XPAD / 4) publish<1, SC1, 0>(acc, 0.f, 4 * g, team_xch, rs, GX_OFF0, tag + 4, nullptr, row0, lane);     // (waves 85..87: the zero padding)
       if (g < DZ0_WAVES) {
         float accz[4];
         dz_mma<DZ0_CH>(sD0 + 64 * DZ0_CH * (g % (BC0 / DZ0_CH)), sWz, lane, accz);
