@@ -44,7 +44,24 @@ constexpr int TEAM_CUS = 32, NTEAMS = 8, ROWS = 4, NWAVES_TEAM = TEAM_CUS * 4;
 constexpr int NC0 = P_XPAD / 16, NC1 = P_H0 / 16, NC2 = P_H1 / 16, NC3 = P_H2 / 16, NCZ = P_ZD / 16;
 // weight registers of a wave: [chunk][column group] per layer
 constexpr int R0 = 0, R1 = R0 + (NC0 + NCZ) * 2, R2 = R1 + (NC1 + NCZ) * 2, R3 = R2 + (NC2 + NCZ), NREG = R3 + (NC3 + NCZ);
-constexpr int NWA = 200;                // weight registers kept in AGPRs (the MFMAs' B operand reads them there); the rest in VGPRs
+// Register plan of a wave (512 registers: 256 AGPRs + 256 VGPRs).  The MFMAs' B operand is read where the weight lives; everything the
+// VALU touches must be a VGPR.  Round 4: the ACCUMULATORS are VGPR quads (the results are summed and published by VALU code: no
+// v_accvgpr_read per value) and the AGPR half holds weights only -- all 256 of it in the forward (the remaining 30 weights are VGPRs),
+// 224 of the adjoint's 246 (its prefetch registers keep the VGPR half full; beyond 224 the allocator starts copying weights INTO AGPRs in front of the asm MFMAs -- an unguarded hazard, wrong gradients measured: tools/isa_census.py reports such copies and tests/test_build.py refuses them).  Round 3 had 200 weights + the 32
+// accumulator registers in AGPRs and 86 / 46 VGPR-class weights that the allocator parked in AGPRs and copied back (v_accvgpr_read +
+// s_nop) in front of every use: L2 / L3 products at 17 cycles per MFMA instead of 8 (profiles/r04_persist).
+#ifndef HA_NWA
+#define HA_NWA 256
+#endif
+#ifndef HA_NWA_B
+#define HA_NWA_B 224
+#endif
+#ifdef HA_ACC_A
+#define HA_ACC "a"
+#else
+#define HA_ACC "v"
+#endif
+constexpr int NWA = HA_NWA;                // weight registers kept in AGPRs (the MFMAs' B operand reads them there); the rest in VGPRs
 constexpr int L3_WAVES = P_RAW / 4;      // 54 waves own the 216 output columns of the last layer
 // exchange space (bytes): 64-byte header, then per team the four activations as granules [channel][4 rows] x 8 B
 constexpr unsigned XCH_HDR = 256;
@@ -71,7 +88,7 @@ constexpr int DZ0_WAVES = 12 * (BC0 / DZ0_CH), DZ1_WAVES = 12 * (BC1 / DZ1_CH), 
 constexpr int BRZ0 = BR0 + BC0_REG, BRZ1 = BRZ0 + DZ0_CH, BRZ2 = BRZ1 + DZ1_CH, BRZ3 = BRZ2 + DZ2_CH, NREG_B_ALL = BRZ3 + DZ3_CH;
 constexpr int NREG_B = BRZ0, NDZ = NREG_B_ALL - NREG_B;       // registers: the main products; LDS: the wave's dL/dz weights [NDZ][64 lanes]
 constexpr int NLW = NDZ + BC0_LDS;                            // LDS-resident weight vectors per wave: dL/dz tasks, then layer 0's tail
-constexpr int NWA_B = 200;
+constexpr int NWA_B = HA_NWA_B;
 constexpr int L0T_WAVES = P_XPAD / 4 - 3;      // 85 waves own the 340 columns of dL/dx through layer 0
 // partial dL/dz slots per (step, sequence): K splits of the four layers, summed in this order by dz_reduce_kernel
 constexpr int DZ_S0 = 0, DZ_S1 = DZ_S0 + BC0 / DZ0_CH, DZ_S2 = DZ_S1 + BC1 / DZ1_CH, DZ_S3 = DZ_S2 + BC2 / DZ2_CH, DZ_SLOTS = DZ_S3 + BC3 / DZ3_CH;
@@ -275,13 +292,13 @@ template <int R, bool FIRST, int NWAS, int NWVS>
 __device__ __forceinline__ void mfma_w(pvf4& acc, float av, const float (&wa)[NWAS], const float (&wv)[NWVS]) {
   constexpr int NWA = NWAS;
   if constexpr (R < NWA) {
-    if constexpr (FIRST) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(av), "a"(wa[R]));
-    else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "a"(wa[R]));
+    if constexpr (FIRST) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&" HA_ACC(acc) : "v"(av), "a"(wa[R]));
+    else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+" HA_ACC(acc) : "v"(av), "a"(wa[R]));
   } else {
     // (a VGPR-class weight may be parked in an AGPR by the register allocator and copied back right in front of the asm: that copy
     // is a VALU write the MFMA must not read within two wait states, and the hazard recogniser does not look inside the asm)
-    if constexpr (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(av), "v"(wv[R - NWA]));
-    else asm volatile("s_nop 1\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(wv[R - NWA]));
+    if constexpr (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&" HA_ACC(acc) : "v"(av), "v"(wv[R - NWA]));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+" HA_ACC(acc) : "v"(av), "v"(wv[R - NWA]));
   }
 }
 template <int NC_MAIN, int NZ, int NCG, int ROFF, int FIRST, int NWAS, int NWVS>
@@ -331,9 +348,9 @@ __device__ __forceinline__ void mma_layer(const float* xs, const float* zs, cons
   // MFMA results -> VALU reads: a hazard the compiler cannot see (the MFMAs are opaque asm to it).  The wait is tied to every
   // accumulator ("+a"), otherwise the scheduler may place an accumulator read between the last MFMA and a free-standing s_nop.
   if constexpr (NCG == 2)
-    asm volatile("s_nop 7" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]));
+    asm volatile("s_nop 7" : "+" HA_ACC(acc[0][0]), "+" HA_ACC(acc[0][1]), "+" HA_ACC(acc[0][2]), "+" HA_ACC(acc[0][3]), "+" HA_ACC(acc[1][0]), "+" HA_ACC(acc[1][1]), "+" HA_ACC(acc[1][2]), "+" HA_ACC(acc[1][3]));
   else if constexpr (NACC == 8)
-    asm volatile("s_nop 7" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[0][4]), "+a"(acc[0][5]), "+a"(acc[0][6]), "+a"(acc[0][7]));
+    asm volatile("s_nop 7" : "+" HA_ACC(acc[0][0]), "+" HA_ACC(acc[0][1]), "+" HA_ACC(acc[0][2]), "+" HA_ACC(acc[0][3]), "+" HA_ACC(acc[0][4]), "+" HA_ACC(acc[0][5]), "+" HA_ACC(acc[0][6]), "+" HA_ACC(acc[0][7]));
   else
     static_assert(NCG == 2 || NACC == 8, "accumulator fence");
 #pragma unroll
@@ -465,7 +482,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   const bool writer = m == 0;                 // member 0 writes the per-sequence results (world states, state slabs)
 
   // ---- resident weights -------------------------------------------------------------------------------------------------
-  float wa[NWA], wv[NREG - NWA];
+  float wa[NWA], wv[NREG - NWA > 0 ? NREG - NWA : 1];
   {
     const float* wp = a.Wreg + (size_t)g * NREG * 64 + lane;
 #pragma unroll
@@ -962,12 +979,12 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(team_xch, 0, TEAM_BYTES, 0x00020000);
 
   // ---- resident transposed weights ------------------------------------------------------------------------------------------
-  float wa[NWA_B], wv[NREG_B - NWA_B];
+  float wa[NWA_B < NREG_B ? NWA_B : NREG_B], wv[NREG_B - NWA_B > 0 ? NREG_B - NWA_B : 1];
   float* sWz = smem + LB_WZ + wave * NLW * 64;
   {
     const float* wp = a.Wreg + (size_t)g * (NREG_B_ALL + BC0_LDS) * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < NWA_B; ++r) wa[r] = wp[(size_t)r * 64];
+    for (int r = 0; r < NWA_B && r < NREG_B; ++r) wa[r] = wp[(size_t)r * 64];
 #pragma unroll
     for (int r = NWA_B; r < NREG_B; ++r) wv[r - NWA_B] = wp[(size_t)r * 64];
 #pragma unroll

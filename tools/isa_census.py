@@ -57,7 +57,8 @@ def main():
         nop_cycles = sum(int(t.split()[1]) + 1 for t in loop if t.startswith('s_nop'))
         print(f'   s_nop wait states {nop_cycles}, v_mfma {sum(v for k, v in mix.items() if k.startswith("v_mfma"))}, '
               f'permlane swaps {sum(v for k, v in mix.items() if "permlane" in k)}, dpp adds {mix.get("v_add_f32_dpp", 0)}, '
-              f'ds ops {sum(v for k, v in mix.items() if k.startswith("ds_"))}, global/buffer {sum(v for k, v in mix.items() if k.startswith(("global_", "buffer_")))}')
+              f'v_accvgpr_write IN THE LOOP {mix.get("v_accvgpr_write_b32", 0)} (must be 0: a copy into an AGPR in front of an inline-asm MFMA is an unguarded hazard), v_accvgpr_read {mix.get("v_accvgpr_read_b32", 0)}, '
+              f'scratch ops {sum(v for k, v in mix.items() if k.startswith("scratch_"))}, ds ops {sum(v for k, v in mix.items() if k.startswith("ds_"))}, global/buffer {sum(v for k, v in mix.items() if k.startswith(("global_", "buffer_")))}')
 
 
 if __name__ == '__main__':
