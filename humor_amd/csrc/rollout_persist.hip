@@ -26,6 +26,7 @@
 
 #include <string.h>
 
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -70,8 +71,11 @@ constexpr unsigned TEAM_BYTES = ACT_OFF3 + P_XPAD * 32;       // (the adjoint's 
 constexpr unsigned XCH_BYTES = XCH_HDR + NTEAMS * TEAM_BYTES;
 // LDS (floats)
 constexpr int L_XS0 = 0, L_XS1 = L_XS0 + P_XPAD * 4, L_XS2 = L_XS1 + P_H0 * 4, L_XS3 = L_XS2 + P_H1 * 4, L_ZS = L_XS3 + P_H2 * 4;
-constexpr int L_SX = L_ZS + P_ZD * 4, L_SRAW = L_SX + ROWS * P_XPAD, L_SW = L_SRAW + ROWS * P_RAWPAD, L_SG = L_SW + ROWS * P_XPAD;
-constexpr int L_SGL = L_SG + ROWS * 12 + 16, L_DUMMY = L_SGL + ROWS * 32, L_MISC = L_DUMMY + P_XPAD * 4, L_TOTAL = L_MISC + 64;      // (L_DUMMY: sink of group 1's second store)
+// (the state rows and the accumulated transforms are double-buffered: step t reads buffer t & 1 and writes the other one, so the
+// waves of a CU can work on the same sequence side by side -- see the glue)
+constexpr int L_SX = L_ZS + P_ZD * 4, L_SRAW = L_SX + 2 * ROWS * P_XPAD, L_SW = L_SRAW + ROWS * P_RAWPAD, L_SG = L_SW + ROWS * P_XPAD;
+constexpr int L_GSZ = ROWS * 12 + 16;
+constexpr int L_SGL = L_SG + 2 * L_GSZ, L_T2J = L_SGL + ROWS * 32, L_ZERO = L_T2J + 16, L_MISC = L_ZERO + 16, L_TOTAL = L_MISC + 64;
 // per-step results of a team (world states, next state slab, accumulated transforms) leave through all 32 CUs, COPY_PER_CU floats each
 constexpr int COPY_WORLD = ROWS * P_STATE, COPY_XT = ROWS * P_DINP, COPY_G = ROWS * 12, COPY_GL = ROWS * 32;
 constexpr int COPY_TOTAL = COPY_WORLD + COPY_XT + COPY_G + COPY_GL;
@@ -158,6 +162,12 @@ __device__ unsigned long long g_pts[2][8][PT_N];      // [0]: team 0 member 5 (a
 #define PT_ARGS , bool pt_on, int pt_slot, int t
 #define PT_PASS , pt_on, pt_slot, t
 __device__ unsigned long long g_ptb[8][PT_N];         // adjoint: team 0 member 5, steps S-1-PT_T0 downwards
+__device__ unsigned g_spin_hist[1024][8];             // per wave: sweeps (all steps) that needed 0, 1, .. 6, >= 7 extra polls
+#ifdef HA_PERSIST_SPINS
+#define PT_SPINS(n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_spin_hist[blockIdx.x * 4 + (threadIdx.x >> 6)][(n) < 7 ? (n) : 7], 1u); } while (0)
+#else
+#define PT_SPINS(n)
+#endif
 #define PTB(i)                                                                                       \
   do {                                                                                               \
     if (ptb_on && (a.S - 1 - t) >= PT_T0 && (a.S - 1 - t) < PT_T0 + 8) g_ptb[a.S - 1 - t - PT_T0][i] = clock64(); \
@@ -165,6 +175,7 @@ __device__ unsigned long long g_ptb[8][PT_N];         // adjoint: team 0 member 
 #define PTB_ARGS , bool ptb_on, int t, const PersistBwdArgs& a
 #define PTB_PASS , ptb_on, t, a
 #else
+#define PT_SPINS(n)
 #define PT(i)
 #define PT_ARGS
 #define PT_PASS
@@ -199,7 +210,7 @@ __device__ __forceinline__ bool sweep(__amdgpu_buffer_rsrc_t rs, unsigned off, u
       diff |= (lo[q].y ^ tag) | (lo[q].w ^ tag) | (hi[q].y ^ tag) | (hi[q].w ^ tag);
       x[q][0] = as_f(lo[q].x); x[q][1] = as_f(lo[q].z); x[q][2] = as_f(hi[q].x); x[q][3] = as_f(hi[q].z);
     }
-    if (__all(diff == 0)) return true;
+    if (__all(diff == 0)) { PT_SPINS(spins); return true; }
     if (spins > SPIN_LIMIT) return false;
     __builtin_amdgcn_s_sleep(1);
   }
@@ -411,11 +422,13 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
   }
 }
 
-// rodrigues() of common.h with ONE argument reduction for sine and cosine (the glue is a dependent chain: every instruction counts)
+// rodrigues() of common.h with ONE argument reduction for sine and cosine and one reciprocal of the norm (the glue is a dependent
+// chain: every instruction counts; r * (1 / t) differs from r / t by at most one ulp of the unit axis)
 __device__ __forceinline__ void rodrigues_sc(const float r[3], float R[9]) {
   const float ux = r[0] + 1e-8f, uy = r[1] + 1e-8f, uz = r[2] + 1e-8f;
   const float t = sqrtf(ux * ux + uy * uy + uz * uz);
-  const float nx = r[0] / t, ny = r[1] / t, nz = r[2] / t;
+  const float it = 1.0f / t;
+  const float nx = r[0] * it, ny = r[1] * it, nz = r[2] * it;
   float s, c;
   sincosf(t, &s, &c);
   const float c1 = 1.0f - c;
@@ -430,15 +443,32 @@ __device__ __forceinline__ void rodrigues_sc(const float r[3], float R[9]) {
   R[7] = s * nx + c1 * (ny * nz);
   R[8] = 1.0f + c1 * (nz * nz - nn);
 }
-// w2a_fwd() of rot_math.h (heading alignment, transforms.py:17-42) through rodrigues_sc; returns the heading angle
+// w2a_fwd() of rot_math.h (heading alignment, transforms.py:17-42); returns the heading angle.  The rotation is rodrigues() of the
+// axis-angle (0, 0, az) written out: nx = ny = 0 exactly, so only the z-rotation block is computed (same operations on the entries
+// that are not identically 0 / 1).
 __device__ __forceinline__ float w2a_sc(const float pR[9], float W[9]) {
   const float rx = -pR[0], ry = -pR[3];
   const float nrm = sqrtf(rx * rx + ry * ry);
   const float u = rx / (nrm + 1e-6f);
   const float angle = acosf(fminf(fmaxf(u, -1.0f), 1.0f));
   const float sg = -ry / (fabsf(ry) + 1e-6f);
-  const float aa[3] = {0.f, 0.f, sg * angle};
-  rodrigues_sc(aa, W);
+  const float az = sg * angle;
+  const float e = 1e-8f, uz = az + 1e-8f;
+  const float t = sqrtf(e * e + e * e + uz * uz);
+  const float nz = az * (1.0f / t);
+  float s, c;
+  sincosf(t, &s, &c);
+  const float c1 = 1.0f - c;
+  const float nn = nz * nz;
+  W[0] = 1.0f + c1 * (0.f - nn);
+  W[1] = -s * nz;
+  W[2] = 0.f;
+  W[3] = s * nz;
+  W[4] = W[0];
+  W[5] = 0.f;
+  W[6] = 0.f;
+  W[7] = 0.f;
+  W[8] = 1.0f;
   return angle;
 }
 
@@ -455,7 +485,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   float* sW = smem + L_SW;
   float* sG = smem + L_SG;
   float* sGL = smem + L_SGL;
-  float* sDummy = smem + L_DUMMY;
+  float* sT2J = smem + L_T2J;
   volatile int* misc = reinterpret_cast<volatile int*>(smem + L_MISC);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
@@ -514,26 +544,32 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   const int zi = tid / P_ZD, zc = tid - zi * P_ZD;          // thread <-> (row, latent channel) for tid < 192
   const bool zlive = tid < ROWS * P_ZD && row0 + zi < a.B;
   if (tid < ROWS * P_ZD) zs[zc * 4 + zi] = zlive ? a.z_seq[((size_t)(row0 + zi) * a.S) * P_ZD + zc] : 0.f;
-  // per-sequence state of wave `wave`'s row (identical in every lane)
-  const int myrow = row0 + wave;
-  float G[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, gt[3] = {0.f, 0.f, 0.f}, t2j[3] = {0.f, 0.f, 0.f};
-  if (myrow < a.B) {
-    t2j[0] = -a.past_in0[(size_t)myrow * P_DIN + 207];
-    t2j[1] = -a.past_in0[(size_t)myrow * P_DIN + 208];
-  }
-  if (writer && lane == 0) {
-    float* Gs = a.steps + a.off_G + (size_t)myrow * 12;
+  // per-sequence constants / accumulated world transform of the team's rows in LDS: t2j = -(x0[207], x0[208], 0); G = I, gt = 0
+  if (tid < ROWS) {
+    const int r = row0 + tid;
+    const bool live = r < a.B;
+    float* Gs0 = sG + tid * 12;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) Gs[i] = G[i];
-    Gs[9] = Gs[10] = Gs[11] = 0.f;
+    for (int i = 0; i < 12; ++i) Gs0[i] = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+    sT2J[tid * 4 + 0] = live ? -a.past_in0[(size_t)r * P_DIN + 207] : 0.f;
+    sT2J[tid * 4 + 1] = live ? -a.past_in0[(size_t)r * P_DIN + 208] : 0.f;
+    sT2J[tid * 4 + 2] = 0.f;
+    sT2J[tid * 4 + 3] = 0.f;
+    if (writer) {
+      float* Gs = a.steps + a.off_G + (size_t)r * 12;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) a.t2j[(size_t)myrow * 3 + c] = t2j[c];
+      for (int i = 0; i < 12; ++i) Gs[i] = Gs0[i];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.t2j[(size_t)r * 3 + c] = sT2J[tid * 4 + c];
+    }
   }
 
   // The results of step t (world states of the team's sequences, the next state slab, the accumulated transforms) sit in every CU's
   // LDS after the glue (every CU computes them): CU m writes elements [m, m + 1) x COPY_PER_CU of the team's record, one coalesced
   // store per thread.  Element order: world [row][348] | state slab quads [quad][row][4] | transforms [row][12] | glue record [row][32].
   auto copy_out = [&](int t) {
+    const float* sXn = sX + ((t + 1) & 1) * ROWS * P_XPAD;        // written by the glue of step t
+    const float* sGn = sG + ((t + 1) & 1) * L_GSZ;
     if (tid < COPY_PER_CU) {
       const int e = m * COPY_PER_CU + tid;
       if (e < COPY_WORLD) {
@@ -541,13 +577,70 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
         if (row0 + i < a.B) a.world[((size_t)(row0 + i) * a.S + t) * P_STATE + c] = sW[i * P_XPAD + c];
       } else if (e < COPY_WORLD + COPY_XT) {
         const int e2 = e - COPY_WORLD, q = e2 >> 4, i = (e2 >> 2) & 3, k = e2 & 3;
-        a.xT[(size_t)(t + 1) * P_DINP * 32 + (size_t)q * 128 + (size_t)(row0 + i) * 4 + k] = sX[i * P_XPAD + 4 * q + k];
+        a.xT[(size_t)(t + 1) * P_DINP * 32 + (size_t)q * 128 + (size_t)(row0 + i) * 4 + k] = sXn[i * P_XPAD + 4 * q + k];
       } else if (e < COPY_WORLD + COPY_XT + COPY_G) {
         const int e3 = e - COPY_WORLD - COPY_XT;
-        a.steps[(size_t)(t + 1) * a.per_step + a.off_G + (size_t)row0 * 12 + e3] = sG[e3];
+        a.steps[(size_t)(t + 1) * a.per_step + a.off_G + (size_t)row0 * 12 + e3] = sGn[e3];
       } else if (e < COPY_TOTAL) {
         const int e4 = e - COPY_WORLD - COPY_XT - COPY_G;
         a.steps[(size_t)t * a.per_step + a.off_gl + (size_t)row0 * 32 + e4] = sGL[e4];
+      }
+    }
+  };
+  // phase-2 task of this lane (wave = sequence): lanes 0..21 joint positions, 22 root translation, 23..44 joint velocities, 45 / 46 root
+  // linear / angular velocity, 47..49 the columns of the predicted root rotation (source: the glue record; stride 3)
+  int p2_a, p2_b, p2_dst;
+  float p2_fA, p2_fT;
+  bool p2_col;
+  {
+    int ra, xa;
+    if (lane < 22) { ra = 75 + 3 * lane; xa = 207 + 3 * lane; }
+    else if (lane == 22) { ra = 0; xa = 0; }
+    else if (lane < 45) { ra = 141 + 3 * (lane - 23); xa = 273 + 3 * (lane - 23); }
+    else if (lane == 45) { ra = 3; xa = 3; }
+    else { ra = 9; xa = 15; }
+    p2_col = lane >= 47;
+    p2_fA = lane <= 22 ? 1.f : 0.f;
+    p2_fT = lane < 22 ? 1.f : 0.f;
+    p2_a = p2_col ? L_ZERO : L_SRAW + wave * P_RAWPAD + ra;
+    p2_b = p2_col ? L_SGL + wave * 32 + 9 + (lane - 47) : L_SX + wave * P_XPAD + xa;
+    p2_dst = p2_col ? 6 + (lane - 47) : xa;
+  }
+  if (tid < 16) smem[L_ZERO + tid] = 0.f;
+  // What step t leaves for later (nothing of the next step's input depends on it): the world-frame columns of the root rotation
+  // G^T R_root (lanes 50..52 of the sequence's wave) and the transform update G' = G W, gt' (lane 53).  They run in the shadow of the
+  // NEXT step's layer-1 sweep (after its layer-0 publish); copy_out follows one barrier later.
+  auto deferred = [&](int tp) {
+    if (lane >= 50 && lane < 54) {
+      const int i = wave;
+      const float* X = sX + (tp & 1) * ROWS * P_XPAD + i * P_XPAD;
+      const float* RW = sRAW + i * P_RAWPAD;
+      const float* GL = sGL + i * 32;
+      const float* Gp = sG + (tp & 1) * L_GSZ + i * 12;
+      float G[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) G[e] = Gp[e];
+      if (lane < 53) {
+        const int kk = lane - 50;
+        float v[3], o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = GL[9 + 3 * c + kk];
+        mat3_tvec(G, v, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sW[i * P_XPAD + 6 + 3 * c + kk] = o[c];
+      } else {
+        // wtrans = G^T ptrans - gt ; G' = G W ; gt' = (-wtrans.x, -wtrans.y, 0)
+        float W[9], GW[9], ptr[3], wtr[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) W[e] = GL[e];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ptr[c] = RW[c] + X[c];
+        mat3_tvec(G, ptr, wtr);
+        mat3_mul(G, W, GW);
+        pvf4* gs = reinterpret_cast<pvf4*>(sG + ((tp + 1) & 1) * L_GSZ + i * 12);
+        gs[0] = pvf4{GW[0], GW[1], GW[2], GW[3]};
+        gs[1] = pvf4{GW[4], GW[5], GW[6], GW[7]};
+        gs[2] = pvf4{GW[8], -(wtr[0] - Gp[9]), -(wtr[1] - Gp[10]), 0.f};
       }
     }
   };
@@ -563,7 +656,6 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     float z_next = 0.f;
     if (zlive && t + 1 < a.S) z_next = a.z_seq[((size_t)(row0 + zi) * a.S + (t + 1)) * P_ZD + zc];
     __syncthreads();                                   // xs0 / zs of this step are complete
-    if (t > 0) copy_out(t - 1);                        // (stores only: nothing waits for them)
     PT(0);
     // ---- layer 0: [x_t | z_t] (raw) -> 1024 ---------------------------------------------------------------------------
     {
@@ -573,6 +665,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       publish<2, SC1, 64>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, sp + a.off_dec[0], row0, lane, sp + a.off_ht[0] + (size_t)team * P_H0 * 4);
       PT(2);
     }
+    if (t > 0) deferred(t - 1);       // (in the shadow of the layer-1 sweep)
     // ---- layer 1 ----------------------------------------------------------------------------------------------------------
     if (!gather_norm<4, 64, 3>(rs, ACT_OFF0, tag + 1, gam1, bet1, xs1, tid, m == 1 ? sp + a.off_gn[0] : nullptr, row0 PT_PASS)) fail = true;
     PT(4);
@@ -587,6 +680,8 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       publish<2, SC1, 64>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, sp + a.off_dec[1], row0, lane, sp + a.off_ht[1] + (size_t)team * P_H1 * 4);
       PT(7);
     }
+    if (t > 0) copy_out(t - 1);       // the previous step's results leave in the shadow of the layer-2 sweep (stores only; the deferred
+                                      // tasks' LDS writes are one barrier back)
     // ---- layer 2 ----------------------------------------------------------------------------------------------------------
     if (!gather_norm<4, 64, 8>(rs, ACT_OFF1, tag + 2, gam2, bet2, xs2, tid, m == 2 ? sp + a.off_gn[1] : nullptr, row0 PT_PASS)) fail = true;
     PT(9);
@@ -630,132 +725,125 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     if (misc[2]) break;
     PT(19);
     if (tid < ROWS * P_ZD) zs[zc * 4 + zi] = z_next;
+    // ---- glue (humor_model.py:870-1001 after the decoder): the CU's four waves work on the team's four sequences side by side ----
+    // Round 3 ran one wave per sequence through the whole chain (rotations -> heading alignment -> both frame changes -> ~90 LDS
+    // stores per lane): ~1 100 instructions per wave and step, 5.5-6 k cycles.  Now the chain is cut where its dependences are:
+    //   phase 1, waves 0-1: the rotations -- lane (row, joint): R = rodrigues(delta) R_in for the 21 body joints and the root; the
+    //            root lane goes on to the heading alignment W = world2aligned(R_root) and writes the glue record;
+    //            waves 2-3: everything that needs only the OLD accumulated transform -- the world-frame positions / velocities
+    //            G^T (p + t2j) - t2j - gt, G^T v and the contact logits;
+    //   phase 2, wave = sequence: the frame change by W, one 3-vector task per lane (22 joint positions, root translation, 22 joint
+    //            velocities, root velocities, the three columns of R_root -> W R_root), three lanes for the world-frame columns
+    //            G^T R_root and one for the transform update G' = G W.
+    // States and transforms are double-buffered in LDS (read t & 1, write the other), so no wave overwrites what another still reads.
     {
-      // One wave per sequence, two lane groups running the same instruction stream: group 0 (lanes 0..31) produces the next input
-      // state (frame change by the heading alignment W), group 1 (lanes 32..63) the world-frame output (frame change by the
-      // accumulated G^T).  In a group: lanes 0..21 = joints, lanes 0..20 also body rotation b, lane 21 the root.  Results go to LDS
-      // (next state: row-major for the next glue + [channel][row] as the next A operand; world state: staging); the global copies
-      // are written afterwards by all CUs of the team, one coalesced slice each (copy_out).
-      const int jj = lane & 31, grp = lane >> 5;
-      const float* X = sX + wave * P_XPAD;
-      const float* RW = sRAW + wave * P_RAWPAD;
-      const bool jl = jj < 22, root = jj == 21;
-      const int aoff = jj < 21 ? 12 + 3 * jj : 6, roff = jj < 21 ? 18 + 9 * jj : 6;
-      float pj[3] = {0.f, 0.f, 0.f}, jv[3] = {0.f, 0.f, 0.f}, pR[9], ptrans[3] = {0.f, 0.f, 0.f}, ptvel[3] = {0.f, 0.f, 0.f}, prvel[3] = {0.f, 0.f, 0.f};
-      float Wm[9];
+      const float* Xc = sX + (t & 1) * ROWS * P_XPAD;
+      float* Xn = sX + ((t + 1) & 1) * ROWS * P_XPAD;
+      const float* Gc = sG + (t & 1) * L_GSZ;
+      float* Gn = sG + ((t + 1) & 1) * L_GSZ;
+      if (wave < 2) {
+        const int i = 2 * wave + (lane >> 5), jj = lane & 31;            // sequence of the team, joint (21 = root)
+        if (jj < 22) {
+          const float* X = Xc + i * P_XPAD;
+          const float* RW = sRAW + i * P_RAWPAD;
+          const bool root = jj == 21;
+          const int aoff = root ? 6 : 12 + 3 * jj, roff = root ? 6 : 18 + 9 * jj;
+          float aa[3], Rin[9], dR[9], pR[9];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) { pR[i] = 0.f; Wm[i] = 0.f; }
-      float dR[9];
+          for (int c = 0; c < 3; ++c) aa[c] = RW[aoff + c];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) dR[i] = 0.f;
-      if (jl) {
-        float aa[3], Rin[9];
+          for (int k = 0; k < 9; ++k) Rin[k] = X[roff + k];
+          rodrigues_sc(aa, dR);
+          mat3_mul(dR, Rin, pR);
+          if (!root) {
+            float* d1 = Xn + i * P_XPAD + roff;
+            float* d2 = xs0 + roff * 4 + i;
+            float* d3 = sW + i * P_XPAD + roff;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          pj[c] = RW[75 + 3 * jj + c] + X[207 + 3 * jj + c];
-          jv[c] = RW[141 + 3 * jj + c] + X[273 + 3 * jj + c];
-          aa[c] = RW[aoff + c];
+            for (int k = 0; k < 9; ++k) { d1[k] = pR[k]; d2[4 * k] = pR[k]; d3[k] = pR[k]; }
+          } else {
+            // record for phase 2 and for the adjoint of this step: heading alignment W, predicted root rotation pR = dR Rin, dR, heading angle
+            float Wm[9];
+            const float angle = w2a_sc(pR, Wm);
+            float* gl = sGL + i * 32;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { gl[k] = Wm[k]; gl[9 + k] = pR[k]; gl[18 + k] = dR[k]; }
+            gl[27] = angle;
+          }
         }
+      } else {
+        const int i = 2 * (wave - 2) + (lane >> 5), k = lane & 31;
+        const float* X = Xc + i * P_XPAD;
+        const float* RW = sRAW + i * P_RAWPAD;
+        float* Wn = sW + i * P_XPAD;
+        float G[9], gt[3], t2[3];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Rin[i] = X[roff + i];
-        rodrigues_sc(aa, dR);
-        mat3_mul(dR, Rin, pR);
-      }
-      if (root) {
+        for (int e = 0; e < 9; ++e) G[e] = Gc[i * 12 + e];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          ptrans[c] = RW[c] + X[c];
-          ptvel[c] = RW[3 + c] + X[3 + c];
-          prvel[c] = RW[9 + c] + X[15 + c];
-        }
-      }
-      if (lane == 21) {
-        const float angle = w2a_sc(pR, Wm);
-        // record for the adjoint of this step: heading alignment W, predicted root rotation pR = dR Rin, dR, heading angle
-        float* gl = sGL + wave * 32;
+        for (int c = 0; c < 3; ++c) { gt[c] = Gc[i * 12 + 9 + c]; t2[c] = sT2J[i * 4 + c]; }
+        // position-like: joints (k < 22): G^T (p + t2j) - t2j - gt ; root translation (k = 22): G^T p - gt ; lanes 23..31: contact logits
+        if (k <= 22) {
+          const int ra = k < 22 ? 75 + 3 * k : 0, xa = k < 22 ? 207 + 3 * k : 0;
+          const float fT = k < 22 ? 1.f : 0.f;
+          float q[3], o[3];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { gl[i] = Wm[i]; gl[9 + i] = pR[i]; gl[18 + i] = dR[i]; }
-        gl[27] = angle;
-      }
-      const float craw = (lane >= 32 && lane < 41) ? RW[207 + lane - 32] : 0.f;      // contact logits
-      // the root's heading alignment and translation to every lane
-      float W[9], ptr[3];
+          for (int c = 0; c < 3; ++c) q[c] = (RW[ra + c] + X[xa + c]) + fT * t2[c];
+          mat3_tvec(G, q, o);
 #pragma unroll
-      for (int i = 0; i < 9; ++i) W[i] = as_f(__builtin_amdgcn_readlane(as_u(Wm[i]), 21));
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ptr[c] = as_f(__builtin_amdgcn_readlane(as_u(ptrans[c]), 21));
-      // group 0: y = W (p + wt + t2j) - t2j ; W v        group 1: y = G^T (p + t2j) - t2j - gt ; G^T v
-      float M[9], add[3], sub[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) M[3 * i + k] = grp ? G[3 * k + i] : W[3 * i + k];
-      add[0] = grp ? 0.f : -ptr[0];
-      add[1] = grp ? 0.f : -ptr[1];
-      add[2] = 0.f;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) sub[c] = grp ? gt[c] : 0.f;
-      float* Wn = sW + wave * P_XPAD;
-      // group 0 -> next state (row-major + [channel][row]), group 1 -> world staging (+ a sink): two unconditional stores per value
-      float* dst1 = grp ? Wn : sX + wave * P_XPAD;
-      float* dst2 = (grp ? sDummy : xs0) + wave;
-      auto put = [&](int c, float v) {
-        dst1[c] = v;
-        dst2[c * 4] = v;
-      };
-      if (jl) {
-        float q[3], o[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) q[c] = pj[c] + add[c] + t2j[c];
-        mat3_vec(M, q, o);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) put(207 + 3 * jj + c, o[c] - t2j[c] - sub[c]);
-        mat3_vec(M, jv, o);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) put(273 + 3 * jj + c, o[c]);
-        if (!root) {
-#pragma unroll
-          for (int i = 0; i < 9; ++i) put(18 + 9 * jj + i, pR[i]);
+          for (int c = 0; c < 3; ++c) Wn[xa + c] = (o[c] - fT * t2[c]) - gt[c];
         } else {
-          // root: trans' = M (ptrans + add) - sub ; tvel' = M ptvel ; R' = M pR ; rvel' = M prvel
-          float Rm[9];
+          Wn[339 + k - 23] = RW[207 + k - 23];
+        }
+        // velocity-like: joint velocities (k < 22), root linear (22) and angular (23) velocity: G^T v
+        if (k <= 23) {
+          const int ra = k < 22 ? 141 + 3 * k : (k == 22 ? 3 : 9), xa = k < 22 ? 273 + 3 * k : (k == 22 ? 3 : 15);
+          float q[3], o[3];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) q[c] = ptrans[c] + add[c];
-          mat3_vec(M, q, o);
+          for (int c = 0; c < 3; ++c) q[c] = RW[ra + c] + X[xa + c];
+          mat3_tvec(G, q, o);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) put(c, o[c] - sub[c]);
-          mat3_vec(M, ptvel, o);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) put(3 + c, o[c]);
-          mat3_mul(M, pR, Rm);
-#pragma unroll
-          for (int i = 0; i < 9; ++i) put(6 + i, Rm[i]);
-          mat3_vec(M, prvel, o);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) put(15 + c, o[c]);
+          for (int c = 0; c < 3; ++c) Wn[xa + c] = o[c];
         }
       }
-      if (lane >= 32 && lane < 41) Wn[339 + lane - 32] = craw;
-      // accumulate the world transform (every lane, identical): wtrans = G^T ptrans - gt ; G' = G W ; gt' = (-wtrans.x, -wtrans.y, 0)
-      float wtr[3], GW[9];
-      mat3_tvec(G, ptr, wtr);
-      mat3_mul(G, W, GW);
+      PT(20);
+      __syncthreads();
+      PT(21);
+      if (lane < 50) {
+        // phase 2, wave = sequence: q = (source) + fA (-ptrans.xy) + fT t2j ; o = W q - fT t2j, one 3-vector task per lane (the lane's
+        // constants -- LDS offsets, strides, flags -- are set up once before the step loop: p2_*)
+        const int i = wave;
+        const float* X = Xc + i * P_XPAD;
+        const float* RW = sRAW + i * P_RAWPAD;
+        const float* GL = sGL + i * 32;
+        const float* A = smem + p2_a;
+        const float* Bq = smem + p2_b + (p2_col ? 0 : (t & 1) * ROWS * P_XPAD);
+        const int sb = p2_col ? 3 : 1, sa = p2_col ? 0 : 1;
+        float M[9], q[3], o[3];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) G[i] = GW[i];
-      gt[0] = -(wtr[0] - gt[0]);
-      gt[1] = -(wtr[1] - gt[1]);
-      gt[2] = 0.f;
-      if (lane == 0) {
-        pvf4* gs = reinterpret_cast<pvf4*>(sG + wave * 12);
-        gs[0] = pvf4{GW[0], GW[1], GW[2], GW[3]};
-        gs[1] = pvf4{GW[4], GW[5], GW[6], GW[7]};
-        gs[2] = pvf4{GW[8], gt[0], gt[1], gt[2]};
+        for (int e = 0; e < 9; ++e) M[e] = GL[e];
+        const float ad0 = -(RW[0] + X[0]), ad1 = -(RW[1] + X[1]);          // - predicted root translation (x, y)
+        const float t20 = sT2J[i * 4], t21 = sT2J[i * 4 + 1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[c] = A[c * sa] + Bq[c * sb];
+        q[0] = (q[0] + p2_fA * ad0) + p2_fT * t20;
+        q[1] = (q[1] + p2_fA * ad1) + p2_fT * t21;
+        mat3_vec(M, q, o);
+        o[0] -= p2_fT * t20;
+        o[1] -= p2_fT * t21;
+        float* d1 = Xn + i * P_XPAD + p2_dst;
+        float* d2 = xs0 + p2_dst * 4 + i;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { d1[c * sb] = o[c]; d2[4 * c * sb] = o[c]; }
       }
     }
-    PT(20);
+    PT(22);
   }
   __syncthreads();
-  if (!misc[2]) copy_out(a.S - 1);
+  if (!misc[2]) {
+    deferred(a.S - 1);
+    __syncthreads();
+    copy_out(a.S - 1);
+  }
   if (misc[2] && tid == 0) __hip_atomic_store(a.err, 0x200u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -1411,6 +1499,19 @@ __global__ void dz_reduce_kernel(const float* __restrict__ part, float* __restri
 extern "C" int ha_debug_persist_timing(unsigned long long* out /* [2][8][24] */) {
   HA_CHECK_HIP(hipDeviceSynchronize());
   HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_pts), sizeof(unsigned long long) * 2 * 8 * 24));
+  return HA_OK;
+}
+extern "C" int ha_debug_persist_spins(unsigned* out /* [8] */, int reset) {
+  HA_CHECK_HIP(hipDeviceSynchronize());
+  std::vector<unsigned> h(1024 * 8);
+  HA_CHECK_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(ha::g_spin_hist), sizeof(unsigned) * 8 * 1024));
+  for (int b = 0; b < 8; ++b) out[b] = 0;
+  for (int w = 0; w < 1024; ++w)
+    for (int b = 0; b < 8; ++b) out[b] += h[w * 8 + b];
+  if (reset) {
+    std::fill(h.begin(), h.end(), 0u);
+    HA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ha::g_spin_hist), h.data(), sizeof(unsigned) * 8 * 1024));
+  }
   return HA_OK;
 }
 extern "C" int ha_debug_persist_timing_bwd(unsigned long long* out /* [8][24] */) {

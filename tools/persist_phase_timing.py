@@ -20,15 +20,26 @@ with torch.no_grad():
     for _ in range(3):
         hm.roll_out(past, None, S, z_seq=z)
 torch.cuda.synchronize()
+def spins(label):
+    h = (C.c_uint * 8)()
+    f = lib._dll.ha_debug_persist_spins
+    f.restype = C.c_int
+    assert f(h, 1) == 0
+    h = list(h)
+    n = max(1, sum(h))
+    print(label, 'sweeps by number of extra polls (0, 1, .. 6, >= 7):', h, ' mean extra polls %.2f' % (sum(i * v for i, v in enumerate(h)) / n))
+
+
+spins('forward:')
 buf = (C.c_ulonglong * (2 * 8 * 24))()
 fn = lib._dll.ha_debug_persist_timing
 fn.restype = C.c_int
 assert fn(buf) == 0
 both = np.array(list(buf), dtype=np.int64).reshape(2, 8, 24)
 names = ['top', 'L0 mma', 'L0 publish', 'L1 sweep', 'L1 GN', 'L1 barrier', 'L1 mma', 'L1 publish', 'L2 sweep', 'L2 GN', 'L2 barrier', 'L2 mma',
-         'L2 publish', 'L3 sweep', 'L3 GN', 'L3 barrier', 'L3 mma', 'L3 publish', 'raw sweep', 'raw barrier', 'glue']
+         'L2 publish', 'L3 sweep', 'L3 GN', 'L3 barrier', 'L3 mma', 'L3 publish', 'raw sweep', 'raw barrier', 'glue ph1', 'glue barrier', 'glue ph2']
 for who, ts in (('member 5 (ordinary CU, layer-3 producer)', both[0]), ('member 0 (writer of the per-sequence results)', both[1])):
-    d = np.diff(ts[:, :21], axis=1)
+    d = np.diff(ts[:, :23], axis=1)
     step = ts[1:, 0] - ts[:-1, 0]
     print(who, '-- cycles per step (s_memtime = shader clock):', step.tolist())
     print('%-12s %s' % ('phase', 'cycles to reach it from the previous phase, steps 8..15 | median'))
@@ -44,6 +55,7 @@ for _ in range(3):
     out, (pm, pv) = hm.roll_out(pz, None, S, z_seq=zz, return_prior=True)
     (out['trans'].sum() + out['joints'].sum() + out['root_orient'].sum() + pm.sum()).backward()
 torch.cuda.synchronize()
+spins('forward + adjoint:')
 bufb = (C.c_ulonglong * (8 * 24))()
 fb = lib._dll.ha_debug_persist_timing_bwd
 fb.restype = C.c_int
