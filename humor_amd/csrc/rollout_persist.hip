@@ -422,12 +422,15 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
   }
 }
 
-// rodrigues() of common.h with ONE argument reduction for sine and cosine and one reciprocal of the norm (the glue is a dependent
-// chain: every instruction counts; r * (1 / t) differs from r / t by at most one ulp of the unit axis)
+// rodrigues() of common.h with ONE argument reduction for sine and cosine and the norm / its reciprocal from v_sqrt_f32 / v_rcp_f32
+// (1 ulp each, arguments >= 1e-8: no denormals).  The glue is a dependent chain on one lane per sequence: the IEEE sqrtf and division
+// are ~10 dependent instructions each, and the unit axis they produce differs from the correctly rounded one by an ulp or two.
+__device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ void rodrigues_sc(const float r[3], float R[9]) {
   const float ux = r[0] + 1e-8f, uy = r[1] + 1e-8f, uz = r[2] + 1e-8f;
-  const float t = sqrtf(ux * ux + uy * uy + uz * uz);
-  const float it = 1.0f / t;
+  const float t = hw_sqrt(ux * ux + uy * uy + uz * uz);
+  const float it = hw_rcp(t);
   const float nx = r[0] * it, ny = r[1] * it, nz = r[2] * it;
   float s, c;
   sincosf(t, &s, &c);
@@ -448,14 +451,14 @@ __device__ __forceinline__ void rodrigues_sc(const float r[3], float R[9]) {
 // that are not identically 0 / 1).
 __device__ __forceinline__ float w2a_sc(const float pR[9], float W[9]) {
   const float rx = -pR[0], ry = -pR[3];
-  const float nrm = sqrtf(rx * rx + ry * ry);
-  const float u = rx / (nrm + 1e-6f);
+  const float nrm = hw_sqrt(rx * rx + ry * ry);
+  const float u = rx * hw_rcp(nrm + 1e-6f);
   const float angle = acosf(fminf(fmaxf(u, -1.0f), 1.0f));
-  const float sg = -ry / (fabsf(ry) + 1e-6f);
+  const float sg = -ry * hw_rcp(fabsf(ry) + 1e-6f);
   const float az = sg * angle;
   const float e = 1e-8f, uz = az + 1e-8f;
-  const float t = sqrtf(e * e + e * e + uz * uz);
-  const float nz = az * (1.0f / t);
+  const float t = hw_sqrt(e * e + e * e + uz * uz);
+  const float nz = az * hw_rcp(t);
   float s, c;
   sincosf(t, &s, &c);
   const float c1 = 1.0f - c;
@@ -728,9 +731,9 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     // ---- glue (humor_model.py:870-1001 after the decoder): the CU's four waves work on the team's four sequences side by side ----
     // Round 3 ran one wave per sequence through the whole chain (rotations -> heading alignment -> both frame changes -> ~90 LDS
     // stores per lane): ~1 100 instructions per wave and step, 5.5-6 k cycles.  Now the chain is cut where its dependences are:
-    //   phase 1, waves 0-1: the rotations -- lane (row, joint): R = rodrigues(delta) R_in for the 21 body joints and the root; the
-    //            root lane goes on to the heading alignment W = world2aligned(R_root) and writes the glue record;
-    //            waves 2-3: everything that needs only the OLD accumulated transform -- the world-frame positions / velocities
+    //   phase 1, waves 0-1: the body rotations -- lane (sequence, joint): R = rodrigues(delta) R_in for the 21 body joints;
+    //            wave 2: the four root rotations, the heading alignment W = world2aligned(R_root) and the glue record (the long chain);
+    //            wave 3: everything that needs only the OLD accumulated transform -- the world-frame positions / velocities
     //            G^T (p + t2j) - t2j - gt, G^T v and the contact logits;
     //   phase 2, wave = sequence: the frame change by W, one 3-vector task per lane (22 joint positions, root translation, 22 joint
     //            velocities, root velocities, the three columns of R_root -> W R_root), three lanes for the world-frame columns
@@ -741,12 +744,14 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float* Xn = sX + ((t + 1) & 1) * ROWS * P_XPAD;
       const float* Gc = sG + (t & 1) * L_GSZ;
       float* Gn = sG + ((t + 1) & 1) * L_GSZ;
-      if (wave < 2) {
-        const int i = 2 * wave + (lane >> 5), jj = lane & 31;            // sequence of the team, joint (21 = root)
-        if (jj < 22) {
+      if (wave < 3) {
+        // waves 0, 1: the 21 body rotations of sequences (0, 1) / (2, 3), lane = (sequence, joint); wave 2: the four roots (lanes 0..3),
+        // the one long dependent chain of the step, on a wave of its own
+        const int i = wave < 2 ? 2 * wave + (lane >> 5) : (lane & 3), jj = wave < 2 ? (lane & 31) : 21;
+        const bool root = wave == 2;
+        if (root ? lane < ROWS : jj < 21) {
           const float* X = Xc + i * P_XPAD;
           const float* RW = sRAW + i * P_RAWPAD;
-          const bool root = jj == 21;
           const int aoff = root ? 6 : 12 + 3 * jj, roff = root ? 6 : 18 + 9 * jj;
           float aa[3], Rin[9], dR[9], pR[9];
 #pragma unroll
@@ -755,7 +760,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
           for (int k = 0; k < 9; ++k) Rin[k] = X[roff + k];
           rodrigues_sc(aa, dR);
           mat3_mul(dR, Rin, pR);
-          if (!root) {
+          if (!root) {         // (wave-uniform)
             float* d1 = Xn + i * P_XPAD + roff;
             float* d2 = xs0 + roff * 4 + i;
             float* d3 = sW + i * P_XPAD + roff;
@@ -772,37 +777,41 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
           }
         }
       } else {
-        const int i = 2 * (wave - 2) + (lane >> 5), k = lane & 31;
-        const float* X = Xc + i * P_XPAD;
-        const float* RW = sRAW + i * P_RAWPAD;
-        float* Wn = sW + i * P_XPAD;
-        float G[9], gt[3], t2[3];
+        // wave 3: everything that needs only the OLD accumulated transform, two sequences per pass
 #pragma unroll
-        for (int e = 0; e < 9; ++e) G[e] = Gc[i * 12 + e];
+        for (int pass = 0; pass < 2; ++pass) {
+          const int i = 2 * pass + (lane >> 5), k = lane & 31;
+          const float* X = Xc + i * P_XPAD;
+          const float* RW = sRAW + i * P_RAWPAD;
+          float* Wn = sW + i * P_XPAD;
+          float G[9], gt[3], t2[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { gt[c] = Gc[i * 12 + 9 + c]; t2[c] = sT2J[i * 4 + c]; }
-        // position-like: joints (k < 22): G^T (p + t2j) - t2j - gt ; root translation (k = 22): G^T p - gt ; lanes 23..31: contact logits
-        if (k <= 22) {
-          const int ra = k < 22 ? 75 + 3 * k : 0, xa = k < 22 ? 207 + 3 * k : 0;
-          const float fT = k < 22 ? 1.f : 0.f;
-          float q[3], o[3];
+          for (int e = 0; e < 9; ++e) G[e] = Gc[i * 12 + e];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) q[c] = (RW[ra + c] + X[xa + c]) + fT * t2[c];
-          mat3_tvec(G, q, o);
+          for (int c = 0; c < 3; ++c) { gt[c] = Gc[i * 12 + 9 + c]; t2[c] = sT2J[i * 4 + c]; }
+          // position-like: joints (k < 22): G^T (p + t2j) - t2j - gt ; root translation (k = 22): G^T p - gt ; lanes 23..31: contact logits
+          if (k <= 22) {
+            const int ra = k < 22 ? 75 + 3 * k : 0, xa = k < 22 ? 207 + 3 * k : 0;
+            const float fT = k < 22 ? 1.f : 0.f;
+            float q[3], o[3];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) Wn[xa + c] = (o[c] - fT * t2[c]) - gt[c];
-        } else {
-          Wn[339 + k - 23] = RW[207 + k - 23];
-        }
-        // velocity-like: joint velocities (k < 22), root linear (22) and angular (23) velocity: G^T v
-        if (k <= 23) {
-          const int ra = k < 22 ? 141 + 3 * k : (k == 22 ? 3 : 9), xa = k < 22 ? 273 + 3 * k : (k == 22 ? 3 : 15);
-          float q[3], o[3];
+            for (int c = 0; c < 3; ++c) q[c] = (RW[ra + c] + X[xa + c]) + fT * t2[c];
+            mat3_tvec(G, q, o);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) q[c] = RW[ra + c] + X[xa + c];
-          mat3_tvec(G, q, o);
+            for (int c = 0; c < 3; ++c) Wn[xa + c] = (o[c] - fT * t2[c]) - gt[c];
+          } else {
+            Wn[339 + k - 23] = RW[207 + k - 23];
+          }
+          // velocity-like: joint velocities (k < 22), root linear (22) and angular (23) velocity: G^T v
+          if (k <= 23) {
+            const int ra = k < 22 ? 141 + 3 * k : (k == 22 ? 3 : 9), xa = k < 22 ? 273 + 3 * k : (k == 22 ? 3 : 15);
+            float q[3], o[3];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) Wn[xa + c] = o[c];
+            for (int c = 0; c < 3; ++c) q[c] = RW[ra + c] + X[xa + c];
+            mat3_tvec(G, q, o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Wn[xa + c] = o[c];
+          }
         }
       }
       PT(20);
