@@ -106,7 +106,10 @@ constexpr int LB_PF = 0, LB_D3 = LB_PF + 2 * PF_SIZE, LB_D1 = LB_D3 + P_RAWPAD *
 constexpr int LB_D2 = LB_D0;       // (dh2 and dh0 live two phases apart: same space)
 constexpr int LB_GXN = LB_D0 + P_H0 * 4, LB_GXD = LB_GXN + ROWS * P_XPAD, LB_CARRY = LB_GXD + ROWS * P_XPAD, LB_MISC = LB_CARRY + 80;
 constexpr int LB_GB = LB_MISC + 64, LB_WZ = LB_GB + 2 * (P_H0 + P_H1 + P_H2);      // GroupNorm affine: gamma | beta of the three activations
-constexpr int LB_TOTAL = LB_WZ + 4 * NLW * 64;                                      // LDS-resident weights of the CU's four waves
+constexpr int LB_EXTRA = LB_WZ + 4 * NLW * 64;                                     // (LDS-resident weights of the CU's four waves end here)
+// glue adjoint hand-offs: rotation set-ups [row][root | heading][8], dL/dpR columns [row][12], t2j [row][4]
+constexpr int LB_PREP = LB_EXTRA, LB_COL = LB_PREP + ROWS * 16, LB_T2J = LB_COL + ROWS * 12, LB_TOTAL = LB_T2J + ROWS * 4;
+static_assert(LB_TOTAL * 4 <= 160 * 1024, "the adjoint's LDS fits one CU");
 }  // namespace
 
 size_t persist_ws_floats() { return (XCH_BYTES + 3) / 4; }
@@ -425,8 +428,13 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
 // rodrigues() of common.h with ONE argument reduction for sine and cosine and the norm / its reciprocal from v_sqrt_f32 / v_rcp_f32
 // (1 ulp each, arguments >= 1e-8: no denormals).  The glue is a dependent chain on one lane per sequence: the IEEE sqrtf and division
 // are ~10 dependent instructions each, and the unit axis they produce differs from the correctly rounded one by an ulp or two.
+#ifdef HA_GLUE_IEEE      // (A/B builds only: correctly rounded division / square root in the glue chains)
+__device__ __forceinline__ float hw_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float hw_sqrt(float x) { return sqrtf(x); }
+#else
 __device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#endif
 __device__ __forceinline__ void rodrigues_sc(const float r[3], float R[9]) {
   const float ux = r[0] + 1e-8f, uy = r[1] + 1e-8f, uz = r[2] + 1e-8f;
   const float t = hw_sqrt(ux * ux + uy * uy + uz * uz);
@@ -915,16 +923,21 @@ struct PersistBwdArgs {
   unsigned* err;
 };
 
-// R = rodrigues(r) and gr = dL/dr for gR = dL/dR, sharing the norm, the direction and ONE sine/cosine evaluation
-// (rodrigues() / rodrigues_bwd() of common.h fused)
-__device__ __forceinline__ void rod_fwd_bwd(const float r[3], const float gR[9], float R[9], float gr[3]) {
+// rodrigues() / rodrigues_bwd() of common.h in two parts, so that the part that does not depend on the incoming gradient (norm, reciprocal, sine / cosine: the long
+// dependent chain) can run early and on another wave: rod_prep() -> {n, s, c, 1/t}; rod_adj() = dL/dr from dL/dR.  Norm and
+// reciprocal from v_sqrt_f32 / v_rcp_f32 as in the forward's rodrigues_sc.
+struct RodPrep {
+  float n[3], s, c, it;
+};
+__device__ __forceinline__ void rod_prep(const float r[3], RodPrep& p) {
   const float ux = r[0] + 1e-8f, uy = r[1] + 1e-8f, uz = r[2] + 1e-8f;
-  const float t = sqrtf(ux * ux + uy * uy + uz * uz);
-  const float it = 1.0f / t;
-  const float nx = r[0] * it, ny = r[1] * it, nz = r[2] * it;      // (one reciprocal: the adjoint is a dependent chain)
-  float s, c;
-  sincosf(t, &s, &c);
-  const float c1 = 1.0f - c;
+  const float t = hw_sqrt(ux * ux + uy * uy + uz * uz);
+  p.it = hw_rcp(t);
+  p.n[0] = r[0] * p.it; p.n[1] = r[1] * p.it; p.n[2] = r[2] * p.it;
+  sincosf(t, &p.s, &p.c);
+}
+__device__ __forceinline__ void rod_R(const RodPrep& p, float R[9]) {
+  const float nx = p.n[0], ny = p.n[1], nz = p.n[2], s = p.s, c1 = 1.0f - p.c;
   const float nn = nx * nx + ny * ny + nz * nz;
   R[0] = 1.0f + c1 * (nx * nx - nn);
   R[1] = -s * nz + c1 * (nx * ny);
@@ -935,6 +948,10 @@ __device__ __forceinline__ void rod_fwd_bwd(const float r[3], const float gR[9],
   R[6] = -s * ny + c1 * (nx * nz);
   R[7] = s * nx + c1 * (ny * nz);
   R[8] = 1.0f + c1 * (nz * nz - nn);
+}
+__device__ __forceinline__ void rod_adj(const RodPrep& p, const float r[3], const float gR[9], float gr[3]) {
+  const float nx = p.n[0], ny = p.n[1], nz = p.n[2], s = p.s, c = p.c, it = p.it, c1 = 1.0f - p.c;
+  const float nn = nx * nx + ny * ny + nz * nz;
   const float gK_dot = -nz * gR[1] + ny * gR[2] + nz * gR[3] - nx * gR[5] - ny * gR[6] + nx * gR[7];
   const float tr = gR[0] + gR[4] + gR[8];
   const float nGn = nx * (gR[0] * nx + gR[1] * ny + gR[2] * nz) + ny * (gR[3] * nx + gR[4] * ny + gR[5] * nz) +
@@ -949,31 +966,44 @@ __device__ __forceinline__ void rod_fwd_bwd(const float r[3], const float gR[9],
   const float gnz = s * (gR[3] - gR[1]) + c1 * (sz - 2.0f * tr * nz);
   const float gn_r = gnx * r[0] + gny * r[1] + gnz * r[2];
   const float k = (gt - gn_r * it * it) * it;
-  gr[0] = gnx * it + k * ux;
-  gr[1] = gny * it + k * uy;
-  gr[2] = gnz * it + k * uz;
+  gr[0] = gnx * it + k * (r[0] + 1e-8f);
+  gr[1] = gny * it + k * (r[1] + 1e-8f);
+  gr[2] = gnz * it + k * (r[2] + 1e-8f);
 }
-
-// w2a_bwd() of rot_math.h with the rotation adjoint through rod_fwd_bwd (one sine/cosine evaluation)
-__device__ __forceinline__ void w2a_bwd_sc(const W2A& o, const float gW[9], float& g_p0, float& g_p3) {
+// the heading alignment's scalars from the glue record (pR[0], pR[3], angle): everything w2a_bwd needs besides dL/dW
+struct HeadPrep {
+  float rx, ry, nrm, u, xp, angle, s, az;
+};
+__device__ __forceinline__ void head_prep(float pR0, float pR3, float angle, HeadPrep& o) {
+  o.rx = -pR0;
+  o.ry = -pR3;
+  o.nrm = hw_sqrt(o.rx * o.rx + o.ry * o.ry);
+  o.u = o.rx * hw_rcp(o.nrm + 1e-6f);
+  o.xp = fminf(fmaxf(o.u, -1.0f), 1.0f);
+  o.angle = angle;
+  o.s = -o.ry * hw_rcp(fabsf(o.ry) + 1e-6f);
+  o.az = o.s * o.angle;
+}
+// w2a_bwd() of rot_math.h given the rotation set-up of (0, 0, az): dL/dpR[0], dL/dpR[3] from dL/dW
+__device__ __forceinline__ void head_adj(const HeadPrep& o, const RodPrep& p, const float gW[9], float& g_p0, float& g_p3) {
   const float aa[3] = {0.f, 0.f, o.az};
-  float gaa[3], Runused[9];
-  rod_fwd_bwd(aa, gW, Runused, gaa);
+  float gaa[3];
+  rod_adj(p, aa, gW, gaa);
   const float g_az = gaa[2];
   const float g_s = o.angle * g_az;
   const float g_angle = o.s * g_az;
   const float g_xp = -g_angle * __builtin_amdgcn_rsqf(1.0f - o.xp * o.xp);
   const float g_u = (o.u >= -1.0f && o.u <= 1.0f) ? g_xp : 0.f;
-  const float id = 1.0f / (o.nrm + 1e-6f);
+  const float id = hw_rcp(o.nrm + 1e-6f);
   float g_rx = g_u * id;
   float g_ry = 0.f;
   const float g_nrm = -g_u * o.rx * (id * id);
   if (o.nrm > 0.f) {
-    const float inr = 1.0f / o.nrm;
+    const float inr = hw_rcp(o.nrm);
     g_rx += g_nrm * o.rx * inr;
     g_ry += g_nrm * o.ry * inr;
   }
-  const float ar = fabsf(o.ry), da = ar + 1e-6f, ida = 1.0f / da;
+  const float ar = fabsf(o.ry), da = ar + 1e-6f, ida = hw_rcp(da);
   const float sgn = o.ry > 0.f ? 1.f : (o.ry < 0.f ? -1.f : 0.f);
   const float ds = -(da - o.ry * sgn) * (ida * ida);
   g_ry += g_s * ds;
@@ -1151,8 +1181,8 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
 
   // per-sequence carried adjoints of wave `wave`'s row (identical in every lane): dL/dG', dL/dgt', dL/dt2j so far
   // (kept in LDS between the steps, sCarry[row][16]: dL/dG' 9 | dL/dgt' 3 | dL/dt2j 3 -- and the row's t2j at [row][64 + ..])
-  const int myrow = row0 + wave;
   if (lane < 16) sCarry[wave * 16 + lane] = 0.f;
+  if (tid < ROWS * 4) smem[LB_T2J + tid] = (tid & 3) < 3 ? a.t2j[(size_t)(row0 + (tid >> 2)) * 3 + (tid & 3)] : 0.f;
   for (int e = tid; e < ROWS * P_XPAD; e += 256) { sGXD[e] = 0.f; sGXN[e] = 0.f; }
 
   prefetch_a_issue(a.S - 1);
@@ -1194,137 +1224,193 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     __syncthreads();
     if (misc[2]) break;
     PTB(2);
-    // ---- glue adjoint: one wave per sequence ------------------------------------------------------------------------------
+    // ---- glue adjoint: the CU's four waves side by side (round 3: one wave per sequence, 9.2 k cycles) --------------------------
+    //   waves 0-1, lane = (sequence, rotation): the 21 body-rotation adjoints of sequences (0, 1) / (2, 3), p = dR R_in, complete; and
+    //              in the same instruction stream the rotation SET-UPS (norm, reciprocal, sine / cosine) of the root rotation (lane 21)
+    //              and of the heading rotation (lane 22), handed to the other waves through LDS;
+    //   waves 2-3, lane = (sequence, vector task): the 27 vector tasks (22 joints, root translation / velocities, the three columns of
+    //              the predicted root rotation), their 27 sums over the half-wave, the carried transform adjoint; then, behind one
+    //              barrier, the heading-alignment adjoint and the root-rotation adjoint from the prepared set-ups.
+    float gpos[3] = {0.f, 0.f, 0.f}, gvel[3] = {0.f, 0.f, 0.f};            // (waves 2-3: results of the lane's vector task)
+    float gW[9], gG[9], ggt[3] = {0.f, 0.f, 0.f}, gwt[3] = {0.f, 0.f, 0.f}, gt2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { gW[i] = 0.f; gG[i] = 0.f; }
+    const int gi = 2 * (wave & 1) + (lane >> 5), gv = lane & 31;          // sequence of the team, rotation / vector task of this lane
     {
-      const float* X = cur + PF_X + wave * P_XPAD;
-      const float* RW = cur + PF_RAW + wave * P_RAWPAD;
-      const float* GWp = cur + PF_GW + wave * P_XPAD;
-      const float* GL = cur + PF_GL + wave * 32;
-      const float* Gp = cur + PF_G + wave * 12;
-      const float* GXN = sGXN + wave * P_XPAD;
-      float* GXD = sGXD + wave * P_XPAD;
-      // (per-sequence values are wave-uniform: readfirstlane moves them to scalar registers -- the vector file holds the weights)
-      auto uni = [](float v) { return as_f(__builtin_amdgcn_readfirstlane(as_u(v))); };
-      float W[9], G[9], gt[3], gGn[9], ggtn[3], t2j[3];
-      float* carry = sCarry + wave * 16;
+      const float* X = cur + PF_X + gi * P_XPAD;
+      const float* RW = cur + PF_RAW + gi * P_RAWPAD;
+      const float* GWp = cur + PF_GW + gi * P_XPAD;
+      const float* GL = cur + PF_GL + gi * 32;
+      const float* Gp = cur + PF_G + gi * 12;
+      const float* GXN = sGXN + gi * P_XPAD;
+      float* GXD = sGXD + gi * P_XPAD;
+      if (wave < 2) {
+        if (gv < 23) {
+          const bool body = gv < 21;
+          float aa[3];
+          if (gv < 22) {
+            const int ao = body ? 12 + 3 * gv : 6;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) { W[i] = uni(GL[i]); G[i] = uni(Gp[i]); gGn[i] = uni(carry[i]); }
+            for (int c = 0; c < 3; ++c) aa[c] = RW[ao + c];
+          } else {
+            HeadPrep hp;
+            head_prep(GL[9], GL[12], GL[27], hp);
+            aa[0] = 0.f; aa[1] = 0.f; aa[2] = hp.az;
+          }
+          RodPrep rp;
+          rod_prep(aa, rp);
+          if (body) {
+            const int ao = 12 + 3 * gv, ro = 18 + 9 * gv;
+            float gp[9], Rin[9], gd[9], dRm[9], gRin[9], gaa[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { gt[c] = uni(Gp[9 + c]); ggtn[c] = uni(carry[9 + c]); t2j[c] = uni(a.t2j[(size_t)myrow * 3 + c]); }
-      // vector tasks, lanes 0..26: joints (position + velocity), root translation / velocity, root angular velocity, the three
-      // columns of the predicted root rotation (velocity-type: frame change only)
-      const int v = lane;
-      const bool has_pos = v <= 22, has_t2j = v < 22, active = v <= 26;
-      // channel offsets: position (raw, x), velocity (raw, x), adjoints (world / next) use the x offsets
-      int rp = 0, xp = 0, rv = 0, xv = 0;
-      if (v < 22) { rp = 75 + 3 * v; xp = 207 + 3 * v; rv = 141 + 3 * v; xv = 273 + 3 * v; }
-      else if (v == 22) { rp = 0; xp = 0; rv = 3; xv = 3; }
-      else if (v == 23) { rv = 9; xv = 15; }
-      float pos[3] = {0.f, 0.f, 0.f}, vel[3] = {0.f, 0.f, 0.f}, gwp[3] = {0.f, 0.f, 0.f}, gwv[3] = {0.f, 0.f, 0.f}, gxp[3] = {0.f, 0.f, 0.f}, gxv[3] = {0.f, 0.f, 0.f};
-      if (active) {
-        if (v <= 23) {
+            for (int i = 0; i < 9; ++i) { Rin[i] = X[ro + i]; gp[i] = GWp[ro + i] + GXN[ro + i]; }
+            mat3_mult(gp, Rin, gd);            // dL/ddR = dL/dp Rin^T
+            rod_adj(rp, aa, gd, gaa);
+            rod_R(rp, dRm);
+            mat3_tmul(dRm, gp, gRin);          // dL/dRin = dR^T dL/dp
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            vel[c] = RW[rv + c] + X[xv + c];
-            gwv[c] = GWp[xv + c];
-            gxv[c] = GXN[xv + c];
-            if (has_pos) {
-              pos[c] = RW[rp + c] + X[xp + c];
-              gwp[c] = GWp[xp + c];
-              gxp[c] = GXN[xp + c];
+            for (int c = 0; c < 3; ++c) sD3[(ao + c) * 4 + gi] = gaa[c];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) GXD[ro + i] = gRin[i];
+          } else {
+            float* pp = smem + LB_PREP + gi * 16 + (gv - 21) * 8;
+            pp[0] = rp.n[0]; pp[1] = rp.n[1]; pp[2] = rp.n[2]; pp[3] = rp.s; pp[4] = rp.c; pp[5] = rp.it;
+          }
+        } else {
+          // lanes 23..31: the contact logits pass straight through; the padding channels of the operand stay zero
+          const int k = gv - 23;
+          sD3[(207 + k) * 4 + gi] = GWp[339 + k];
+          if (k < P_RAWPAD - P_RAW) sD3[(P_RAW + k) * 4 + gi] = 0.f;
+        }
+      } else {
+        // vector tasks, gv = 0..26: joints (position + velocity), root translation / velocity (22), root angular velocity (23), the three
+        // columns of the predicted root rotation (24..26; velocity-type: frame change only)
+        float W[9], G[9], ggtn[2], t2j[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { W[i] = GL[i]; G[i] = Gp[i]; }
+        ggtn[0] = sCarry[gi * 16 + 9];
+        ggtn[1] = sCarry[gi * 16 + 10];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t2j[c] = smem[LB_T2J + gi * 4 + c];
+        const int v = gv;
+        const bool has_pos = v <= 22, has_t2j = v < 22, active = v <= 26;
+        int rp = 0, xp = 0, rv = 0, xv = 0;
+        if (v < 22) { rp = 75 + 3 * v; xp = 207 + 3 * v; rv = 141 + 3 * v; xv = 273 + 3 * v; }
+        else if (v == 22) { rp = 0; xp = 0; rv = 3; xv = 3; }
+        else if (v == 23) { rv = 9; xv = 15; }
+        float pos[3] = {0.f, 0.f, 0.f}, vel[3] = {0.f, 0.f, 0.f}, gwp[3] = {0.f, 0.f, 0.f}, gwv[3] = {0.f, 0.f, 0.f}, gxp[3] = {0.f, 0.f, 0.f}, gxv[3] = {0.f, 0.f, 0.f};
+        if (active) {
+          if (v <= 23) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              vel[c] = RW[rv + c] + X[xv + c];
+              gwv[c] = GWp[xv + c];
+              gxv[c] = GXN[xv + c];
+              if (has_pos) {
+                pos[c] = RW[rp + c] + X[xp + c];
+                gwp[c] = GWp[xp + c];
+                gxp[c] = GXN[xp + c];
+              }
+            }
+            if (v == 22) { gwp[0] -= ggtn[0]; gwp[1] -= ggtn[1]; }          // carried gt' = (-wtrans.x, -wtrans.y, 0)
+          } else {
+            const int k = v - 24;                                             // column k of pR (rows at stride 3)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              vel[c] = GL[9 + 3 * c + k];
+              gwv[c] = GWp[6 + 3 * c + k];
+              gxv[c] = GXN[6 + 3 * c + k];
             }
           }
-          if (v == 22) { gwp[0] -= ggtn[0]; gwp[1] -= ggtn[1]; }          // carried gt' = (-wtrans.x, -wtrans.y, 0)
-        } else {
-          const int k = v - 24;                                             // column k of pR (rows at stride 3)
+        }
+        const float wt[3] = {-(RW[0] + X[0]), -(RW[1] + X[1]), 0.f};           // - predicted root translation (x, y)
+        const float tj[3] = {has_t2j ? t2j[0] : 0.f, has_t2j ? t2j[1] : 0.f, has_t2j ? t2j[2] : 0.f};
+        if (active) {
+          float o[3], q[3];
+          if (has_pos) {
+            // world: G^T (p + tj) - tj - gt
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            vel[c] = GL[9 + 3 * c + k];
-            gwv[c] = GWp[6 + 3 * c + k];
-            gxv[c] = GXN[6 + 3 * c + k];
+            for (int c = 0; c < 3; ++c) q[c] = pos[c] + tj[c];
+            mat3_vec(G, gwp, o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { gpos[c] += o[c]; if (has_t2j) gt2[c] += o[c] - gwp[c]; ggt[c] -= gwp[c]; }
+            outer_acc3(gG, q, gwp);
+            // next input: W (p + wt + tj) - tj
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[c] = pos[c] + wt[c] + tj[c];
+            mat3_tvec(W, gxp, o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { gpos[c] += o[c]; gwt[c] += o[c]; if (has_t2j) gt2[c] += o[c] - gxp[c]; }
+            outer_acc3(gW, gxp, q);
           }
+          // velocity-type: world G^T v, next input W v
+          mat3_vec(G, gwv, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gvel[c] += o[c];
+          outer_acc3(gG, vel, gwv);
+          mat3_tvec(W, gxv, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gvel[c] += o[c];
+          outer_acc3(gW, gxv, vel);
+        }
+        if (v >= 24 && v <= 26) {        // dL/dpR columns -> the root-rotation lane (same wave, LDS is in order)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) smem[LB_COL + gi * 12 + 3 * (v - 24) + c] = gvel[c];
+        }
+        // sums over the half-wave's lanes: dL/dW (9), dL/dG (9), dL/dgt (3), dL/dwt (3), dL/dt2j (3)
+        float r1[8], r2[8], r3[8], r4[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { r1[i] = gW[i]; r2[i] = gG[i]; }
+        r3[0] = gW[8]; r3[1] = gG[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { r3[2 + c] = ggt[c]; r3[5 + c] = gwt[c]; r4[c] = gt2[c]; }
+#pragma unroll
+        for (int k = 3; k < 8; ++k) r4[k] = 0.f;
+        lr::half_sum8(r1);
+        lr::half_sum8(r2);
+        lr::half_sum8(r3);
+        lr::half_sum8(r4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gW[i] = r1[i]; gG[i] = r2[i]; }
+        gW[8] = r3[0]; gG[8] = r3[1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { ggt[c] = r3[2 + c]; gwt[c] = r3[5 + c]; gt2[c] = r4[c]; }
+        // carried: G' = G W : dL/dG += dL/dG' W^T ; dL/dW += G^T dL/dG'
+        {
+          float gGn[9], M[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) gGn[i] = sCarry[gi * 16 + i];
+          mat3_mult(gGn, W, M);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) gG[i] += M[i];
+          mat3_tmul(G, gGn, M);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) gW[i] += M[i];
         }
       }
-      const float ptx = as_f(__builtin_amdgcn_readlane(as_u(pos[0]), 22)), pty = as_f(__builtin_amdgcn_readlane(as_u(pos[1]), 22));
-      const float wt[3] = {-ptx, -pty, 0.f};
-      const float tj[3] = {has_t2j ? t2j[0] : 0.f, has_t2j ? t2j[1] : 0.f, has_t2j ? t2j[2] : 0.f};
-      float gW[9], gG[9], ggt[3] = {0.f, 0.f, 0.f}, gwt[3] = {0.f, 0.f, 0.f}, gt2[3] = {0.f, 0.f, 0.f};
-      float gpos[3] = {0.f, 0.f, 0.f}, gvel[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { gW[i] = 0.f; gG[i] = 0.f; }
-      if (active) {
-        float o[3], q[3];
-        if (has_pos) {
-          // world: G^T (p + tj) - tj - gt
-#pragma unroll
-          for (int c = 0; c < 3; ++c) q[c] = pos[c] + tj[c];
-          mat3_vec(G, gwp, o);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) { gpos[c] += o[c]; if (has_t2j) gt2[c] += o[c] - gwp[c]; ggt[c] -= gwp[c]; }
-          outer_acc3(gG, q, gwp);
-          // next input: W (p + wt + tj) - tj
-#pragma unroll
-          for (int c = 0; c < 3; ++c) q[c] = pos[c] + wt[c] + tj[c];
-          mat3_tvec(W, gxp, o);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) { gpos[c] += o[c]; gwt[c] += o[c]; if (has_t2j) gt2[c] += o[c] - gxp[c]; }
-          outer_acc3(gW, gxp, q);
-        }
-        // velocity-type: world G^T v, next input W v
-        mat3_vec(G, gwv, o);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gvel[c] += o[c];
-        outer_acc3(gG, vel, gwv);
-        mat3_tvec(W, gxv, o);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gvel[c] += o[c];
-        outer_acc3(gW, gxv, vel);
-      }
-      // sums over the lanes: dL/dW (9), dL/dG (9), dL/dgt (3), dL/dwt (3), dL/dt2j (3)
-      float r1[16], r2[16];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { r1[i] = gW[i]; r2[i] = gG[i]; }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { r1[9 + c] = ggt[c]; r1[12 + c] = gwt[c]; r2[9 + c] = gt2[c]; }
-      r1[15] = 0.f;
-#pragma unroll
-      for (int k = 12; k < 16; ++k) r2[k] = 0.f;
-      lr::wave_sum16(r1);
-      lr::wave_sum16(r2);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { gW[i] = r1[i]; gG[i] = r2[i]; }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { ggt[c] = r1[9 + c]; gwt[c] = r1[12 + c]; gt2[c] = r2[9 + c]; }
-      // carried: G' = G W : dL/dG += dL/dG' W^T ; dL/dW += G^T dL/dG'
-      {
-        float M[9];
-        mat3_mult(gGn, W, M);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) gG[i] += M[i];
-        mat3_tmul(G, gGn, M);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) gW[i] += M[i];
-      }
+    }
+    __syncthreads();                     // the rotation set-ups of waves 0-1 are in LDS
+    if (wave >= 2) {
+      const float* X = cur + PF_X + gi * P_XPAD;
+      const float* RW = cur + PF_RAW + gi * P_RAWPAD;
+      const float* GL = cur + PF_GL + gi * 32;
+      float* GXD = sGXD + gi * P_XPAD;
+      const int v = gv;
       // heading alignment W = world2aligned(pR): dL/dpR[0], dL/dpR[3]
       float g0, g3;
       {
-        W2A wa2;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) wa2.W[i] = W[i];
-        wa2.rx = -GL[9];
-        wa2.ry = -GL[12];
-        wa2.nrm = sqrtf(wa2.rx * wa2.rx + wa2.ry * wa2.ry);
-        wa2.u = wa2.rx / (wa2.nrm + 1e-6f);
-        wa2.xp = fminf(fmaxf(wa2.u, -1.0f), 1.0f);
-        wa2.angle = GL[27];
-        wa2.s = -wa2.ry / (fabsf(wa2.ry) + 1e-6f);
-        wa2.az = wa2.s * wa2.angle;
-        w2a_bwd_sc(wa2, gW, g0, g3);
+        const float* pw = smem + LB_PREP + gi * 16 + 8;
+        RodPrep rp;
+        rp.n[0] = pw[0]; rp.n[1] = pw[1]; rp.n[2] = pw[2]; rp.s = pw[3]; rp.c = pw[4]; rp.it = pw[5];
+        HeadPrep hp;
+        head_prep(GL[9], GL[12], GL[27], hp);
+        head_adj(hp, rp, gW, g0, g3);
       }
       // root translation: wt = (-ptrans.x, -ptrans.y, 0)
       if (v == 22) { gpos[0] -= gwt[0]; gpos[1] -= gwt[1]; }
       // carry to step t-1
-      if (lane == 0) {
+      if (v == 0) {
+        float* carry = sCarry + gi * 16;
 #pragma unroll
         for (int i = 0; i < 9; ++i) carry[i] = gG[i];
 #pragma unroll
@@ -1333,48 +1419,42 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       // outputs of the vector tasks: dL/d(decoder output) (A operand of the transposed last layer, [channel][row]) and the direct
       // part of dL/dx_t
       if (v <= 23) {
+        int rp = 0, xp = 0, rv = 0, xv = 0;
+        if (v < 22) { rp = 75 + 3 * v; xp = 207 + 3 * v; rv = 141 + 3 * v; xv = 273 + 3 * v; }
+        else if (v == 22) { rp = 0; xp = 0; rv = 3; xv = 3; }
+        else { rv = 9; xv = 15; }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          sD3[(rv + c) * 4 + wave] = gvel[c];
+          sD3[(rv + c) * 4 + gi] = gvel[c];
           GXD[xv + c] = gvel[c];
-          if (has_pos) {
-            sD3[(rp + c) * 4 + wave] = gpos[c];
+          if (v <= 22) {
+            sD3[(rp + c) * 4 + gi] = gpos[c];
             GXD[xp + c] = gpos[c];
           }
         }
-      }
-      // rotation adjoints, lanes 32..52 = body rotations, lane 53 = the root: p = dR Rin
-      float gcol[3][3];                                // dL/dpR columns from lanes 24..26
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gcol[k][c] = as_f(__builtin_amdgcn_readlane(as_u(gvel[c]), 24 + k));
-      if (lane >= 32 && lane <= 53) {
-        const bool rt = lane == 53;
-        const int b = lane - 32;
-        const int ao = rt ? 6 : 12 + 3 * b, ro = rt ? 6 : 18 + 9 * b;
-        float gp[9], Rin[9], aa[3], gd[9], dRm[9], gRin[9], gaa[3];
+      } else if (v == 27) {
+        // root rotation p = dR Rin: dL/dp = the three column adjoints (+ the heading alignment's part)
+        float gp[9], Rin[9], aa[3], gd[9], gRin[9], gaa[3];
+        const float* col = smem + LB_COL + gi * 12;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-          Rin[i] = X[ro + i];
-          gp[i] = rt ? gcol[i % 3][i / 3] : GWp[ro + i] + GXN[ro + i];
+          Rin[i] = X[6 + i];
+          gp[i] = col[3 * (i % 3) + i / 3];
         }
-        if (rt) { gp[0] += g0; gp[3] += g3; }
+        gp[0] += g0;
+        gp[3] += g3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) aa[c] = RW[ao + c];
+        for (int c = 0; c < 3; ++c) aa[c] = RW[6 + c];
+        const float* pr = smem + LB_PREP + gi * 16;
+        RodPrep rp;
+        rp.n[0] = pr[0]; rp.n[1] = pr[1]; rp.n[2] = pr[2]; rp.s = pr[3]; rp.c = pr[4]; rp.it = pr[5];
         mat3_mult(gp, Rin, gd);            // dL/ddR = dL/dp Rin^T
-        rod_fwd_bwd(aa, gd, dRm, gaa);
-        mat3_tmul(dRm, gp, gRin);          // dL/dRin = dR^T dL/dp
+        rod_adj(rp, aa, gd, gaa);
+        mat3_tmul(GL + 18, gp, gRin);      // dL/dRin = dR^T dL/dp (dR from the forward's glue record)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) sD3[(ao + c) * 4 + wave] = gaa[c];
+        for (int c = 0; c < 3; ++c) sD3[(6 + c) * 4 + gi] = gaa[c];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) GXD[ro + i] = gRin[i];
-      }
-      // contact logits pass straight through; padding channels of the operand stay zero
-      if (lane >= 54 && lane < 63) sD3[(207 + lane - 54) * 4 + wave] = GWp[339 + lane - 54];
-      if (lane == 63) {
-#pragma unroll
-        for (int c = P_RAW; c < P_RAWPAD; ++c) sD3[c * 4 + wave] = 0.f;
+        for (int i = 0; i < 9; ++i) GXD[6 + i] = gRin[i];
       }
     }
     PTB(3);

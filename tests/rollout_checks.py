@@ -544,15 +544,34 @@ def check_persistent_vs_chain(lib, device, B, S, seed=0, variant=1, contractive=
     gm, gv = torch.randn(B, S, 48, generator=g).to(device), torch.randn(B, S, 48, generator=g).to(device)
     res = []
     n0 = persist_status(lib, hm, device)[2]
+
+    def run(pz, zz):
+        p, zq = pz.clone().requires_grad_(True), zz.clone().requires_grad_(True)
+        out, (pm, pv) = hm.roll_out(p, None, S, z_seq=zq, return_prior=True)
+        w = world_of(out)
+        ((w * gw).sum() + (pm * gm).sum() + (pv * gv).sum()).backward()
+        return w.detach(), pm.detach(), pv.detach(), p.grad.clone(), zq.grad.clone()
     try:
         for knob, bwd in ((0, 0), (variant, 0), (variant, 1)):
             lib.call('ha_tune_set', b'rollout_persist', knob)
             lib.call('ha_tune_set', b'rollout_persist_bwd', bwd)
-            p, zz = past.clone().requires_grad_(True), z.clone().requires_grad_(True)
-            out, (pm, pv) = hm.roll_out(p, None, S, z_seq=zz, return_prior=True)
-            w = world_of(out)
-            ((w * gw).sum() + (pm * gm).sum() + (pv * gv).sum()).backward()
-            res.append((w.detach(), pm.detach(), pv.detach(), p.grad.clone(), zz.grad.clone()))
+            res.append(run(past, z))
+        # (gradient bar 3e-4: typical sequences agree to 1e-6; the worst-conditioned unflagged one -- heading within 1e-2 rad of the acos
+        # singularity -- is 0.8e-4 .. 1.4e-4 from the float64 gradient on EVERY path, tools/persist_grad_accuracy.py, profiles/r04_persist)
+        # Kink flags from the REFERENCE side of this comparison (the launch chain): a sequence whose launch-chain gradient itself moves
+        # under 1-ulp changes of the latents has a ReLU unit within rounding of its kink; any other correct fp32 evaluation may land on
+        # the other side.  Only those sequences get the kink bar, every other one the flat tolerance (no count allowance).
+        lib.call('ha_tune_set', b'rollout_persist', 0)
+        lib.call('ha_tune_set', b'rollout_persist_bwd', 0)
+        flagged = torch.zeros(B, dtype=torch.bool)
+        gp = torch.Generator().manual_seed(5)
+        for _ in range(32):          # (the set found grows with the number of perturbations tried: DESIGN section 6)
+            sign = (torch.rand(z.shape, generator=gp) > 0.5).float().to(device) * 2 - 1
+            sgp = (torch.rand(past.shape, generator=gp) > 0.5).float().to(device) * 2 - 1
+            r = run(past * (1.0 + sgp * 2.0 ** -23), z * (1.0 + sign * 2.0 ** -23))
+            for a, b in zip(res[0][3:], r[3:]):
+                mv = (a - b).abs().reshape(B, -1).amax(dim=1) / max(1.0, a.abs().max().item())
+                flagged |= (mv > 1e-4).cpu()
     finally:
         lib.call('ha_tune_set', b'rollout_persist', 1)
         lib.call('ha_tune_set', b'rollout_persist_bwd', 1)
@@ -562,14 +581,16 @@ def check_persistent_vs_chain(lib, device, B, S, seed=0, variant=1, contractive=
     assert av == 1 and (n1 & 0xffffffff) == (n0 & 0xffffffff) + 2 and (n1 >> 32) == (n0 >> 32) + 1, (av, n0, n1)
     errs = []
     for k in (1, 2):
-        for name, a, b, tol in zip(('world', 'prior_mu', 'prior_var', 'g_past', 'g_z'), res[0], res[k], (2e-5, 2e-5, 2e-5, 2e-4, 2e-4)):
+        for name, a, b, tol in zip(('world', 'prior_mu', 'prior_var', 'g_past', 'g_z'), res[0], res[k], (2e-5, 2e-5, 2e-5, 3e-4, 3e-4)):
             assert torch.isfinite(b).all(), (name, k)
             e = (a - b).abs().reshape(B, -1).amax(dim=1) / max(1.0, a.abs().max().item())       # per sequence
             errs.append(e.max().item())
             if name.startswith('g_'):
-                # two fp32 evaluations with different summation orders: a sequence with a ReLU unit within rounding of its kink moves
-                # by ~1e-3 (see check_rollout_full_tiles); at most one sequence in ten may, and never beyond the kink bar
-                assert int((e > tol).sum()) <= max(1, B // 10) and e.max().item() <= KINK_RTOL, (name, k, e.tolist(), B, S)
+                e = e.cpu()
+                over = [(i, float(f'{x:.2g}'), bool(flagged[i])) for i, x in enumerate(e.tolist()) if x > tol]
+                print(f'persistent (path {k}) vs launch chain, {name}: sequences over {tol:g} (index, error, kink-flagged):', over, '| flagged:', int(flagged.sum()))
+                assert e[~flagged].numel() == 0 or e[~flagged].max().item() <= tol, (name, k, over, B, S)
+                assert e.max().item() <= KINK_RTOL, (name, k, over, B, S)
             else:
                 assert e.max().item() <= tol, (name, k, e.max().item(), B, S)
     return errs
