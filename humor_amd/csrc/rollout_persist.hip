@@ -107,8 +107,12 @@ constexpr int LB_D2 = LB_D0;       // (dh2 and dh0 live two phases apart: same s
 constexpr int LB_GXN = LB_D0 + P_H0 * 4, LB_GXD = LB_GXN + ROWS * P_XPAD, LB_CARRY = LB_GXD + ROWS * P_XPAD, LB_MISC = LB_CARRY + 80;
 constexpr int LB_GB = LB_MISC + 64, LB_WZ = LB_GB + 2 * (P_H0 + P_H1 + P_H2);      // GroupNorm affine: gamma | beta of the three activations
 constexpr int LB_EXTRA = LB_WZ + 4 * NLW * 64;                                     // (LDS-resident weights of the CU's four waves end here)
-// glue adjoint hand-offs: rotation set-ups [row][root | heading][8], dL/dpR columns [row][12], t2j [row][4]
-constexpr int LB_PREP = LB_EXTRA, LB_COL = LB_PREP + ROWS * 16, LB_T2J = LB_COL + ROWS * 12, LB_TOTAL = LB_T2J + ROWS * 4;
+// glue adjoint hand-offs: heading | root rotation set-ups [row][16 | 8], dL/dpR columns | dL/dW [row][12 | 12], t2j [row][4]
+constexpr int LB_PREP = LB_EXTRA, LB_COL = LB_PREP + ROWS * 24, LB_T2J = LB_COL + ROWS * 24, LB_TOTAL = LB_T2J + ROWS * 4;
+// the 27 sums of the glue adjoint go through LDS (transposed partials, stride RED_LD: conflict-free 16-byte row reads), in the space of
+// the dh1 operand, which is dead between the end of one step and the layer-1 phase of the next
+constexpr int RED_LD = 36, RED_BLOCK = 27 * RED_LD + 36;
+static_assert(4 * RED_BLOCK <= P_H1 * 4, "reduction scratch fits the dh1 operand");
 static_assert(LB_TOTAL * 4 <= 160 * 1024, "the adjoint's LDS fits one CU");
 }  // namespace
 
@@ -177,6 +181,11 @@ __device__ unsigned g_spin_hist[1024][8];             // per wave: sweeps (all s
   } while (0)
 #define PTB_ARGS , bool ptb_on, int t, const PersistBwdArgs& a
 #define PTB_PASS , ptb_on, t, a
+__device__ unsigned long long g_ptc[2][8][8];         // adjoint glue, finer: [0] = wave 0 (rotations), [1] = wave 2 (vector tasks) of team 0 member 5
+#define PTC(w, i)                                                                                                   \
+  do {                                                                                                              \
+    if (team == 0 && m == 5 && tid == 128 * (w) && (a.S - 1 - t) >= PT_T0 && (a.S - 1 - t) < PT_T0 + 8) g_ptc[w][a.S - 1 - t - PT_T0][i] = clock64(); \
+  } while (0)
 #else
 #define PT_SPINS(n)
 #define PT(i)
@@ -185,6 +194,7 @@ __device__ unsigned g_spin_hist[1024][8];             // per wave: sweeps (all s
 #define PTB(i)
 #define PTB_ARGS
 #define PTB_PASS
+#define PTC(w, i)
 #endif
 
 __device__ __forceinline__ size_t pq(int c) { return (size_t)(c >> 2) * 128 + (c & 3); }
@@ -425,6 +435,43 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
   }
 }
 
+// The 3x3 helpers of common.h with contraction allowed (the library is built -ffp-contract=off; the glue chains of this file are
+// instruction-issue bound on one or two waves per CU, and a*b + c*d + e*f as mul + 2 fma is 3 instructions instead of 5 -- and rounds
+// once less).  Only the persistent kernels' glue uses them.
+namespace pg {
+__device__ __forceinline__ void mat3_mul(const float A[9], const float B[9], float C[9]) {
+#pragma clang fp contract(fast)
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+__device__ __forceinline__ void mat3_tmul(const float A[9], const float B[9], float C[9]) {
+#pragma clang fp contract(fast)
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+__device__ __forceinline__ void mat3_mult(const float A[9], const float B[9], float C[9]) {
+#pragma clang fp contract(fast)
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
+}
+__device__ __forceinline__ void mat3_vec(const float A[9], const float v[3], float o[3]) {
+#pragma clang fp contract(fast)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = A[i * 3] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2];
+}
+__device__ __forceinline__ void mat3_tvec(const float A[9], const float v[3], float o[3]) {
+#pragma clang fp contract(fast)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = A[i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2];
+}
+}  // namespace pg
+
 // rodrigues() of common.h with ONE argument reduction for sine and cosine and the norm / its reciprocal from v_sqrt_f32 / v_rcp_f32
 // (1 ulp each, arguments >= 1e-8: no denormals).  The glue is a dependent chain on one lane per sequence: the IEEE sqrtf and division
 // are ~10 dependent instructions each, and the unit axis they produce differs from the correctly rounded one by an ulp or two.
@@ -436,6 +483,7 @@ __device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(
 __device__ __forceinline__ float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 #endif
 __device__ __forceinline__ void rodrigues_sc(const float r[3], float R[9]) {
+#pragma clang fp contract(fast)
   const float ux = r[0] + 1e-8f, uy = r[1] + 1e-8f, uz = r[2] + 1e-8f;
   const float t = hw_sqrt(ux * ux + uy * uy + uz * uz);
   const float it = hw_rcp(t);
@@ -458,6 +506,7 @@ __device__ __forceinline__ void rodrigues_sc(const float r[3], float R[9]) {
 // axis-angle (0, 0, az) written out: nx = ny = 0 exactly, so only the z-rotation block is computed (same operations on the entries
 // that are not identically 0 / 1).
 __device__ __forceinline__ float w2a_sc(const float pR[9], float W[9]) {
+#pragma clang fp contract(fast)
   const float rx = -pR[0], ry = -pR[3];
   const float nrm = hw_sqrt(rx * rx + ry * ry);
   const float u = rx * hw_rcp(nrm + 1e-6f);
@@ -636,7 +685,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
         float v[3], o[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = GL[9 + 3 * c + kk];
-        mat3_tvec(G, v, o);
+        pg::mat3_tvec(G, v, o);
 #pragma unroll
         for (int c = 0; c < 3; ++c) sW[i * P_XPAD + 6 + 3 * c + kk] = o[c];
       } else {
@@ -646,8 +695,8 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
         for (int e = 0; e < 9; ++e) W[e] = GL[e];
 #pragma unroll
         for (int c = 0; c < 3; ++c) ptr[c] = RW[c] + X[c];
-        mat3_tvec(G, ptr, wtr);
-        mat3_mul(G, W, GW);
+        pg::mat3_tvec(G, ptr, wtr);
+        pg::mat3_mul(G, W, GW);
         pvf4* gs = reinterpret_cast<pvf4*>(sG + ((tp + 1) & 1) * L_GSZ + i * 12);
         gs[0] = pvf4{GW[0], GW[1], GW[2], GW[3]};
         gs[1] = pvf4{GW[4], GW[5], GW[6], GW[7]};
@@ -767,7 +816,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
 #pragma unroll
           for (int k = 0; k < 9; ++k) Rin[k] = X[roff + k];
           rodrigues_sc(aa, dR);
-          mat3_mul(dR, Rin, pR);
+          pg::mat3_mul(dR, Rin, pR);
           if (!root) {         // (wave-uniform)
             float* d1 = Xn + i * P_XPAD + roff;
             float* d2 = xs0 + roff * 4 + i;
@@ -785,6 +834,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
           }
         }
       } else {
+#pragma clang fp contract(fast)
         // wave 3: everything that needs only the OLD accumulated transform, two sequences per pass
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -804,7 +854,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
             float q[3], o[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) q[c] = (RW[ra + c] + X[xa + c]) + fT * t2[c];
-            mat3_tvec(G, q, o);
+            pg::mat3_tvec(G, q, o);
 #pragma unroll
             for (int c = 0; c < 3; ++c) Wn[xa + c] = (o[c] - fT * t2[c]) - gt[c];
           } else {
@@ -816,7 +866,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
             float q[3], o[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) q[c] = RW[ra + c] + X[xa + c];
-            mat3_tvec(G, q, o);
+            pg::mat3_tvec(G, q, o);
 #pragma unroll
             for (int c = 0; c < 3; ++c) Wn[xa + c] = o[c];
           }
@@ -826,6 +876,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       __syncthreads();
       PT(21);
       if (lane < 50) {
+#pragma clang fp contract(fast)
         // phase 2, wave = sequence: q = (source) + fA (-ptrans.xy) + fT t2j ; o = W q - fT t2j, one 3-vector task per lane (the lane's
         // constants -- LDS offsets, strides, flags -- are set up once before the step loop: p2_*)
         const int i = wave;
@@ -844,7 +895,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
         for (int c = 0; c < 3; ++c) q[c] = A[c * sa] + Bq[c * sb];
         q[0] = (q[0] + p2_fA * ad0) + p2_fT * t20;
         q[1] = (q[1] + p2_fA * ad1) + p2_fT * t21;
-        mat3_vec(M, q, o);
+        pg::mat3_vec(M, q, o);
         o[0] -= p2_fT * t20;
         o[1] -= p2_fT * t21;
         float* d1 = Xn + i * P_XPAD + p2_dst;
@@ -923,6 +974,16 @@ struct PersistBwdArgs {
   unsigned* err;
 };
 
+// Lanes of ONE wave handing data to each other through LDS.  The hardware executes a wave's LDS instructions in program order, but to the
+// compiler two divergent regions (`if (lane == a) store` ... `if (lane == b) load`) are independent and it may emit them in either
+// order (seen: the consumer region ahead of the producer region, NaNs).  wave_barrier is a convergent no-op the optimiser cannot move
+// code across; the empty asm keeps memory accesses on their side of it.
+__device__ __forceinline__ void wave_lds_order() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // rodrigues() / rodrigues_bwd() of common.h in two parts, so that the part that does not depend on the incoming gradient (norm, reciprocal, sine / cosine: the long
 // dependent chain) can run early and on another wave: rod_prep() -> {n, s, c, 1/t}; rod_adj() = dL/dr from dL/dR.  Norm and
 // reciprocal from v_sqrt_f32 / v_rcp_f32 as in the forward's rodrigues_sc.
@@ -930,6 +991,7 @@ struct RodPrep {
   float n[3], s, c, it;
 };
 __device__ __forceinline__ void rod_prep(const float r[3], RodPrep& p) {
+#pragma clang fp contract(fast)
   const float ux = r[0] + 1e-8f, uy = r[1] + 1e-8f, uz = r[2] + 1e-8f;
   const float t = hw_sqrt(ux * ux + uy * uy + uz * uz);
   p.it = hw_rcp(t);
@@ -937,6 +999,7 @@ __device__ __forceinline__ void rod_prep(const float r[3], RodPrep& p) {
   sincosf(t, &p.s, &p.c);
 }
 __device__ __forceinline__ void rod_R(const RodPrep& p, float R[9]) {
+#pragma clang fp contract(fast)
   const float nx = p.n[0], ny = p.n[1], nz = p.n[2], s = p.s, c1 = 1.0f - p.c;
   const float nn = nx * nx + ny * ny + nz * nz;
   R[0] = 1.0f + c1 * (nx * nx - nn);
@@ -950,6 +1013,7 @@ __device__ __forceinline__ void rod_R(const RodPrep& p, float R[9]) {
   R[8] = 1.0f + c1 * (nz * nz - nn);
 }
 __device__ __forceinline__ void rod_adj(const RodPrep& p, const float r[3], const float gR[9], float gr[3]) {
+#pragma clang fp contract(fast)
   const float nx = p.n[0], ny = p.n[1], nz = p.n[2], s = p.s, c = p.c, it = p.it, c1 = 1.0f - p.c;
   const float nn = nx * nx + ny * ny + nz * nz;
   const float gK_dot = -nz * gR[1] + ny * gR[2] + nz * gR[3] - nx * gR[5] - ny * gR[6] + nx * gR[7];
@@ -986,6 +1050,7 @@ __device__ __forceinline__ void head_prep(float pR0, float pR3, float angle, Hea
 }
 // w2a_bwd() of rot_math.h given the rotation set-up of (0, 0, az): dL/dpR[0], dL/dpR[3] from dL/dW
 __device__ __forceinline__ void head_adj(const HeadPrep& o, const RodPrep& p, const float gW[9], float& g_p0, float& g_p3) {
+#pragma clang fp contract(fast)
   const float aa[3] = {0.f, 0.f, o.az};
   float gaa[3];
   rod_adj(p, aa, gW, gaa);
@@ -1183,6 +1248,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
   // (kept in LDS between the steps, sCarry[row][16]: dL/dG' 9 | dL/dgt' 3 | dL/dt2j 3 -- and the row's t2j at [row][64 + ..])
   if (lane < 16) sCarry[wave * 16 + lane] = 0.f;
   if (tid < ROWS * 4) smem[LB_T2J + tid] = (tid & 3) < 3 ? a.t2j[(size_t)(row0 + (tid >> 2)) * 3 + (tid & 3)] : 0.f;
+  if (tid < ROWS) smem[LB_PREP + tid * 24 + 22] = 0.f;          // the glue adjoint's hand-off flags (a step publishes t + 1 >= 1)
   for (int e = tid; e < ROWS * P_XPAD; e += 256) { sGXD[e] = 0.f; sGXN[e] = 0.f; }
 
   prefetch_a_issue(a.S - 1);
@@ -1225,17 +1291,23 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     if (misc[2]) break;
     PTB(2);
     // ---- glue adjoint: the CU's four waves side by side (round 3: one wave per sequence, 9.2 k cycles) --------------------------
-    //   waves 0-1, lane = (sequence, rotation): the 21 body-rotation adjoints of sequences (0, 1) / (2, 3), p = dR R_in, complete; and
-    //              in the same instruction stream the rotation SET-UPS (norm, reciprocal, sine / cosine) of the root rotation (lane 21)
-    //              and of the heading rotation (lane 22), handed to the other waves through LDS;
+    //   waves 0-1, lane = (sequence, rotation): the 21 body-rotation adjoints of sequences (0, 1) / (2, 3), p = dR R_in, complete; in the
+    //              same instruction stream the rotation SET-UPS (norm, reciprocal, sine / cosine) of the root rotation (lane 21) and of
+    //              the heading rotation (lane 22); lanes 23..31 pass the contact logits on.  Lane 21 then waits (LDS flag, no barrier)
+    //              for dL/dW and the dL/dpR columns and runs the one dependent chain of the step: heading-alignment adjoint ->
+    //              root-rotation adjoint;
     //   waves 2-3, lane = (sequence, vector task): the 27 vector tasks (22 joints, root translation / velocities, the three columns of
-    //              the predicted root rotation), their 27 sums over the half-wave, the carried transform adjoint; then, behind one
-    //              barrier, the heading-alignment adjoint and the root-rotation adjoint from the prepared set-ups.
-    float gpos[3] = {0.f, 0.f, 0.f}, gvel[3] = {0.f, 0.f, 0.f};            // (waves 2-3: results of the lane's vector task)
-    float gW[9], gG[9], ggt[3] = {0.f, 0.f, 0.f}, gwt[3] = {0.f, 0.f, 0.f}, gt2[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { gW[i] = 0.f; gG[i] = 0.f; }
-    const int gi = 2 * (wave & 1) + (lane >> 5), gv = lane & 31;          // sequence of the team, rotation / vector task of this lane
+    //              the predicted root rotation), branch-free (per-lane offsets, strides and 0 / 1 factors), in two halves: FIRST what the
+    //              chain above needs -- the next-input frame change (dL/dW: 9 sums + the carried part) and the dL/dpR columns, published
+    //              with a flag -- then the world-frame half (dL/dG, dL/dgt, dL/dwt, dL/dt2j: 18 sums), the carries and the outputs.
+    //   Sums over the half-wave go through LDS: partials transposed [quantity][lane], lane q sums row q (fixed order) and OWNS total q
+    //   (adds its element of the carried product, writes it where it is needed): a third of the instructions of the cross-lane form.
+    PTC(0, 0);
+    PTC(1, 0);
+    int gi = 2 * (wave & 1) + (lane >> 5), gv = lane & 31;                // sequence of the team, rotation / vector task of this lane
+    // (opaque to the optimiser: otherwise every lane-dependent LDS offset below is hoisted out of the step loop and lives in a VGPR for
+    // the whole launch -- the register file holds the weights, and the allocator then starts copying weights around, tests/test_build.py)
+    asm volatile("" : "+v"(gi), "+v"(gv));
     {
       const float* X = cur + PF_X + gi * P_XPAD;
       const float* RW = cur + PF_RAW + gi * P_RAWPAD;
@@ -1244,38 +1316,48 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       const float* Gp = cur + PF_G + gi * 12;
       const float* GXN = sGXN + gi * P_XPAD;
       float* GXD = sGXD + gi * P_XPAD;
+      // hand-off flag of this sequence: plain LDS accesses (ds_read / ds_write) fenced by compiler barriers -- a `volatile int*` made from
+      // the LDS array turns into FLAT accesses, which are not ordered with the wave's ds_write stream (measured: stale dL/dW on the consumer)
+      float* flag = smem + LB_PREP + gi * 24 + 22;
+      RodPrep rp_root;
+      float aa_root[3] = {0.f, 0.f, 0.f};
+      rp_root.n[0] = rp_root.n[1] = rp_root.n[2] = rp_root.s = rp_root.c = rp_root.it = 0.f;
       if (wave < 2) {
         if (gv < 23) {
           const bool body = gv < 21;
           float aa[3];
+          HeadPrep hp;
           if (gv < 22) {
             const int ao = body ? 12 + 3 * gv : 6;
 #pragma unroll
             for (int c = 0; c < 3; ++c) aa[c] = RW[ao + c];
           } else {
-            HeadPrep hp;
             head_prep(GL[9], GL[12], GL[27], hp);
             aa[0] = 0.f; aa[1] = 0.f; aa[2] = hp.az;
           }
           RodPrep rp;
           rod_prep(aa, rp);
+          PTC(0, 1);
           if (body) {
             const int ao = 12 + 3 * gv, ro = 18 + 9 * gv;
             float gp[9], Rin[9], gd[9], dRm[9], gRin[9], gaa[3];
 #pragma unroll
             for (int i = 0; i < 9; ++i) { Rin[i] = X[ro + i]; gp[i] = GWp[ro + i] + GXN[ro + i]; }
-            mat3_mult(gp, Rin, gd);            // dL/ddR = dL/dp Rin^T
+            pg::mat3_mult(gp, Rin, gd);            // dL/ddR = dL/dp Rin^T
             rod_adj(rp, aa, gd, gaa);
             rod_R(rp, dRm);
-            mat3_tmul(dRm, gp, gRin);          // dL/dRin = dR^T dL/dp
+            pg::mat3_tmul(dRm, gp, gRin);          // dL/dRin = dR^T dL/dp
 #pragma unroll
             for (int c = 0; c < 3; ++c) sD3[(ao + c) * 4 + gi] = gaa[c];
 #pragma unroll
             for (int i = 0; i < 9; ++i) GXD[ro + i] = gRin[i];
-          } else {
-            float* pp = smem + LB_PREP + gi * 16 + (gv - 21) * 8;
-            pp[0] = rp.n[0]; pp[1] = rp.n[1]; pp[2] = rp.n[2]; pp[3] = rp.s; pp[4] = rp.c; pp[5] = rp.it;
+          } else if (gv == 22) {
+            float* pp = smem + LB_PREP + gi * 24;        // heading set-up -> lane 21 (same wave: LDS is in order)
+            pp[0] = hp.rx; pp[1] = hp.ry; pp[2] = hp.nrm; pp[3] = hp.u; pp[4] = hp.xp; pp[5] = hp.angle; pp[6] = hp.s; pp[7] = hp.az;
+            pp[8] = rp.n[0]; pp[9] = rp.n[1]; pp[10] = rp.n[2]; pp[11] = rp.s; pp[12] = rp.c; pp[13] = rp.it;
           }
+          PTC(0, 2);
+          if (gv == 21) { rp_root = rp; aa_root[0] = aa[0]; aa_root[1] = aa[1]; aa_root[2] = aa[2]; }
         } else {
           // lanes 23..31: the contact logits pass straight through; the padding channels of the operand stay zero
           const int k = gv - 23;
@@ -1283,159 +1365,168 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
           if (k < P_RAWPAD - P_RAW) sD3[(P_RAW + k) * 4 + gi] = 0.f;
         }
       } else {
-        // vector tasks, gv = 0..26: joints (position + velocity), root translation / velocity (22), root angular velocity (23), the three
-        // columns of the predicted root rotation (24..26; velocity-type: frame change only)
-        float W[9], G[9], ggtn[2], t2j[3];
+#pragma clang fp contract(fast)
+        // ---- vector tasks, v = 0..26 (27..31 idle: all their factors are 0) ----------------------------------------------------
+        const int v = gv;
+        const bool isj = v < 22, isroot = v == 22, iscol = v >= 24 && v < 27;
+        const int kc = v - 24;
+        const int rp = isj ? 75 + 3 * v : 0, xp = isj ? 207 + 3 * v : 0;                      // position sources (raw, x)
+        const int rv = isj ? 141 + 3 * v : (isroot ? 3 : 9);                                  // velocity source (raw)
+        const int xv = isj ? 273 + 3 * v : (isroot ? 3 : (v == 23 ? 15 : 6 + kc));            // velocity channels (x; columns: stride 3)
+        const int sv = iscol ? 3 : 1;
+        const float fpos = v <= 22 ? 1.f : 0.f, ft2 = isj ? 1.f : 0.f, fact = v < 27 ? 1.f : 0.f, f22 = isroot ? 1.f : 0.f, fraw = iscol ? 0.f : 1.f;
+        float W[9], G[9], t2j[3];
 #pragma unroll
         for (int i = 0; i < 9; ++i) { W[i] = GL[i]; G[i] = Gp[i]; }
-        ggtn[0] = sCarry[gi * 16 + 9];
-        ggtn[1] = sCarry[gi * 16 + 10];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) t2j[c] = smem[LB_T2J + gi * 4 + c];
-        const int v = gv;
-        const bool has_pos = v <= 22, has_t2j = v < 22, active = v <= 26;
-        int rp = 0, xp = 0, rv = 0, xv = 0;
-        if (v < 22) { rp = 75 + 3 * v; xp = 207 + 3 * v; rv = 141 + 3 * v; xv = 273 + 3 * v; }
-        else if (v == 22) { rp = 0; xp = 0; rv = 3; xv = 3; }
-        else if (v == 23) { rv = 9; xv = 15; }
-        float pos[3] = {0.f, 0.f, 0.f}, vel[3] = {0.f, 0.f, 0.f}, gwp[3] = {0.f, 0.f, 0.f}, gwv[3] = {0.f, 0.f, 0.f}, gxp[3] = {0.f, 0.f, 0.f}, gxv[3] = {0.f, 0.f, 0.f};
-        if (active) {
+        for (int c = 0; c < 3; ++c) t2j[c] = ft2 * smem[LB_T2J + gi * 4 + c];
+        const float* velB = iscol ? GL + 9 + kc : X + xv;
+        float pos[3], vel[3], gwp[3], gwv[3], gxp[3], gxv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          pos[c] = RW[rp + c] + X[xp + c];
+          vel[c] = fraw * RW[rv + c] + velB[c * sv];
+          gwp[c] = fpos * GWp[xp + c];
+          gxp[c] = fpos * GXN[xp + c];
+          gwv[c] = fact * GWp[xv + c * sv];
+          gxv[c] = fact * GXN[xv + c * sv];
+        }
+        gwp[0] -= f22 * sCarry[gi * 16 + 9];          // carried gt' = (-wtrans.x, -wtrans.y, 0)
+        gwp[1] -= f22 * sCarry[gi * 16 + 10];
+        const float wt0 = -(RW[0] + X[0]), wt1 = -(RW[1] + X[1]);           // - predicted root translation (x, y)
+        float* red = smem + LB_D1 + ((wave - 2) * 2 + (lane >> 5)) * RED_BLOCK;
+        float* mine = red + v;
+        float* carry = sCarry + gi * 16;
+        // ---- first half: next input  y = W (p + wt + tj) - tj ,  W v  ->  dL/dW, the W^T parts of dL/dp, dL/dv, dL/dwt, dL/dt2j ----
+        float gpos[3], gvel[3], gwt[3], gt2[3];
+        {
+          float q[3], gW[9];
+          q[0] = pos[0] + wt0 + t2j[0];
+          q[1] = pos[1] + wt1 + t2j[1];
+          q[2] = pos[2] + t2j[2];
+          pg::mat3_tvec(W, gxp, gpos);
+          pg::mat3_tvec(W, gxv, gvel);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { gwt[c] = gpos[c]; gt2[c] = ft2 * (gpos[c] - gxp[c]); }
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gW[3 * i + k] = fmaf(gxp[i], q[k], gxv[i] * vel[k]);
+          // the world-frame part of the velocity-type adjoint already here: lanes 24..26 hold dL/dpR columns the chain waits for
+          float o[3];
+          pg::mat3_vec(G, gwv, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gvel[c] += o[c];
+          PTC(1, 1);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) mine[i * RED_LD] = gW[i];
+          wave_lds_order();
+          if (v < 9) {
+            const pvf4* row = reinterpret_cast<const pvf4*>(red + v * RED_LD);
+            pvf4 acc = row[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) acc += row[k];
+            // carried: G' = G W : dL/dW += G^T dL/dG' -- element 3 i + j = sum_k G[3 k + i] dG'[3 k + j]
+            const int i = v / 3, j = v - 3 * i;
+            const float cr = (Gp[i] * carry[j] + Gp[3 + i] * carry[3 + j]) + Gp[6 + i] * carry[6 + j];
+            smem[LB_COL + gi * 24 + 12 + v] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + cr;
+          }
+          if (iscol) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) smem[LB_COL + gi * 24 + 3 * kc + c] = gvel[c];
+          }
+          wave_lds_order();          // dL/dW (lanes 0..8) and the columns (lanes 24..26) are stored before the flag (lane 0)
+          if (v == 0) *flag = as_f((unsigned)(t + 1));          // (after the stores above in program order: LDS executes a wave's operations in order)
+          PTC(1, 2);
+        }
+        // ---- second half: world  y = G^T (p + tj) - tj - gt ,  G^T v  ->  dL/dG, dL/dgt, the G parts of dL/dp, dL/dt2j -------------
+        {
+          float q[3], o[3], gG[9];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) q[c] = pos[c] + t2j[c];
+          pg::mat3_vec(G, gwp, o);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { gpos[c] += o[c]; gt2[c] += ft2 * (o[c] - gwp[c]); }
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gG[3 * i + k] = fmaf(q[i], gwp[k], vel[i] * gwv[k]);
+          wave_lds_order();        // (the first half's rows have been read)
+#pragma unroll
+          for (int i = 0; i < 9; ++i) mine[i * RED_LD] = gG[i];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { mine[(9 + c) * RED_LD] = -gwp[c]; mine[(12 + c) * RED_LD] = gwt[c]; mine[(15 + c) * RED_LD] = gt2[c]; }
+          wave_lds_order();
+          PTC(1, 3);
+          float tot = 0.f;
+          if (v < 18) {
+            const pvf4* row = reinterpret_cast<const pvf4*>(red + v * RED_LD);
+            pvf4 acc = row[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) acc += row[k];
+            tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            red[27 * RED_LD + v] = tot;
+          }
+          // owner lanes: 0..8 dL/dG (+ dL/dG' W^T, element 3 i + j = sum_k dG'[3 i + k] W[3 j + k]) -> carry; 9..11 dL/dgt -> carry;
+          // 12..14 dL/dwt (lane 22 reads it back); 15..17 dL/dt2j, accumulated over the steps
+          float r = tot;
+          if (v < 9) {
+            const int i = v / 3, j = v - 3 * i;
+            r = tot + ((carry[3 * i] * GL[3 * j] + carry[3 * i + 1] * GL[3 * j + 1]) + carry[3 * i + 2] * GL[3 * j + 2]);
+          }
+          wave_lds_order();          // every lane has read the old carry and the totals are stored
+          if (v < 12) carry[v] = r;
+          else if (v >= 15 && v < 18) carry[12 + v - 15] += r;
+          // root translation: wt = (-ptrans.x, -ptrans.y, 0)
+          wave_lds_order();
+          gpos[0] -= f22 * red[27 * RED_LD + 12];
+          gpos[1] -= f22 * red[27 * RED_LD + 13];
+          PTC(1, 4);
+          // outputs of the vector tasks: dL/d(decoder output) (A operand of the transposed last layer, [channel][row]) and the direct
+          // part of dL/dx_t
           if (v <= 23) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              vel[c] = RW[rv + c] + X[xv + c];
-              gwv[c] = GWp[xv + c];
-              gxv[c] = GXN[xv + c];
-              if (has_pos) {
-                pos[c] = RW[rp + c] + X[xp + c];
-                gwp[c] = GWp[xp + c];
-                gxp[c] = GXN[xp + c];
+              sD3[(rv + c) * 4 + gi] = gvel[c];
+              GXD[xv + c] = gvel[c];
+            }
+            if (v <= 22) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                sD3[(rp + c) * 4 + gi] = gpos[c];
+                GXD[xp + c] = gpos[c];
               }
             }
-            if (v == 22) { gwp[0] -= ggtn[0]; gwp[1] -= ggtn[1]; }          // carried gt' = (-wtrans.x, -wtrans.y, 0)
-          } else {
-            const int k = v - 24;                                             // column k of pR (rows at stride 3)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              vel[c] = GL[9 + 3 * c + k];
-              gwv[c] = GWp[6 + 3 * c + k];
-              gxv[c] = GXN[6 + 3 * c + k];
-            }
           }
+          PTC(1, 5);
         }
-        const float wt[3] = {-(RW[0] + X[0]), -(RW[1] + X[1]), 0.f};           // - predicted root translation (x, y)
-        const float tj[3] = {has_t2j ? t2j[0] : 0.f, has_t2j ? t2j[1] : 0.f, has_t2j ? t2j[2] : 0.f};
-        if (active) {
-          float o[3], q[3];
-          if (has_pos) {
-            // world: G^T (p + tj) - tj - gt
-#pragma unroll
-            for (int c = 0; c < 3; ++c) q[c] = pos[c] + tj[c];
-            mat3_vec(G, gwp, o);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { gpos[c] += o[c]; if (has_t2j) gt2[c] += o[c] - gwp[c]; ggt[c] -= gwp[c]; }
-            outer_acc3(gG, q, gwp);
-            // next input: W (p + wt + tj) - tj
-#pragma unroll
-            for (int c = 0; c < 3; ++c) q[c] = pos[c] + wt[c] + tj[c];
-            mat3_tvec(W, gxp, o);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { gpos[c] += o[c]; gwt[c] += o[c]; if (has_t2j) gt2[c] += o[c] - gxp[c]; }
-            outer_acc3(gW, gxp, q);
-          }
-          // velocity-type: world G^T v, next input W v
-          mat3_vec(G, gwv, o);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) gvel[c] += o[c];
-          outer_acc3(gG, vel, gwv);
-          mat3_tvec(W, gxv, o);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) gvel[c] += o[c];
-          outer_acc3(gW, gxv, vel);
+      }
+      wave_lds_order();          // lane 22's heading set-up is in LDS before lane 21 reads it
+      if (wave < 2 && gv == 21) {
+#pragma clang fp contract(fast)
+        // ---- the chain: wait for dL/dW and the dL/dpR columns of this sequence (waves 2-3, first half) ----
+        for (int spins = 0; spins < SPIN_LIMIT; ++spins) {
+          asm volatile("" ::: "memory");
+          if (as_u(*flag) == (unsigned)(t + 1)) break;
+          __builtin_amdgcn_s_sleep(1);
         }
-        if (v >= 24 && v <= 26) {        // dL/dpR columns -> the root-rotation lane (same wave, LDS is in order)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) smem[LB_COL + gi * 12 + 3 * (v - 24) + c] = gvel[c];
-        }
-        // sums over the half-wave's lanes: dL/dW (9), dL/dG (9), dL/dgt (3), dL/dwt (3), dL/dt2j (3)
-        float r1[8], r2[8], r3[8], r4[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { r1[i] = gW[i]; r2[i] = gG[i]; }
-        r3[0] = gW[8]; r3[1] = gG[8];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { r3[2 + c] = ggt[c]; r3[5 + c] = gwt[c]; r4[c] = gt2[c]; }
-#pragma unroll
-        for (int k = 3; k < 8; ++k) r4[k] = 0.f;
-        lr::half_sum8(r1);
-        lr::half_sum8(r2);
-        lr::half_sum8(r3);
-        lr::half_sum8(r4);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { gW[i] = r1[i]; gG[i] = r2[i]; }
-        gW[8] = r3[0]; gG[8] = r3[1];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { ggt[c] = r3[2 + c]; gwt[c] = r3[5 + c]; gt2[c] = r4[c]; }
-        // carried: G' = G W : dL/dG += dL/dG' W^T ; dL/dW += G^T dL/dG'
+        asm volatile("" ::: "memory");
+        // heading alignment W = world2aligned(pR): dL/dpR[0], dL/dpR[3]
+        float g0, g3;
         {
-          float gGn[9], M[9];
+          const float* pp = smem + LB_PREP + gi * 24;
+          HeadPrep h2;
+          h2.rx = pp[0]; h2.ry = pp[1]; h2.nrm = pp[2]; h2.u = pp[3]; h2.xp = pp[4]; h2.angle = pp[5]; h2.s = pp[6]; h2.az = pp[7];
+          RodPrep rw;
+          rw.n[0] = pp[8]; rw.n[1] = pp[9]; rw.n[2] = pp[10]; rw.s = pp[11]; rw.c = pp[12]; rw.it = pp[13];
+          float gW[9];
 #pragma unroll
-          for (int i = 0; i < 9; ++i) gGn[i] = sCarry[gi * 16 + i];
-          mat3_mult(gGn, W, M);
-#pragma unroll
-          for (int i = 0; i < 9; ++i) gG[i] += M[i];
-          mat3_tmul(G, gGn, M);
-#pragma unroll
-          for (int i = 0; i < 9; ++i) gW[i] += M[i];
+          for (int i = 0; i < 9; ++i) gW[i] = smem[LB_COL + gi * 24 + 12 + i];
+          head_adj(h2, rw, gW, g0, g3);
         }
-      }
-    }
-    __syncthreads();                     // the rotation set-ups of waves 0-1 are in LDS
-    if (wave >= 2) {
-      const float* X = cur + PF_X + gi * P_XPAD;
-      const float* RW = cur + PF_RAW + gi * P_RAWPAD;
-      const float* GL = cur + PF_GL + gi * 32;
-      float* GXD = sGXD + gi * P_XPAD;
-      const int v = gv;
-      // heading alignment W = world2aligned(pR): dL/dpR[0], dL/dpR[3]
-      float g0, g3;
-      {
-        const float* pw = smem + LB_PREP + gi * 16 + 8;
-        RodPrep rp;
-        rp.n[0] = pw[0]; rp.n[1] = pw[1]; rp.n[2] = pw[2]; rp.s = pw[3]; rp.c = pw[4]; rp.it = pw[5];
-        HeadPrep hp;
-        head_prep(GL[9], GL[12], GL[27], hp);
-        head_adj(hp, rp, gW, g0, g3);
-      }
-      // root translation: wt = (-ptrans.x, -ptrans.y, 0)
-      if (v == 22) { gpos[0] -= gwt[0]; gpos[1] -= gwt[1]; }
-      // carry to step t-1
-      if (v == 0) {
-        float* carry = sCarry + gi * 16;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) carry[i] = gG[i];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { carry[9 + c] = ggt[c]; carry[12 + c] += gt2[c]; }
-      }
-      // outputs of the vector tasks: dL/d(decoder output) (A operand of the transposed last layer, [channel][row]) and the direct
-      // part of dL/dx_t
-      if (v <= 23) {
-        int rp = 0, xp = 0, rv = 0, xv = 0;
-        if (v < 22) { rp = 75 + 3 * v; xp = 207 + 3 * v; rv = 141 + 3 * v; xv = 273 + 3 * v; }
-        else if (v == 22) { rp = 0; xp = 0; rv = 3; xv = 3; }
-        else { rv = 9; xv = 15; }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          sD3[(rv + c) * 4 + gi] = gvel[c];
-          GXD[xv + c] = gvel[c];
-          if (v <= 22) {
-            sD3[(rp + c) * 4 + gi] = gpos[c];
-            GXD[xp + c] = gpos[c];
-          }
-        }
-      } else if (v == 27) {
         // root rotation p = dR Rin: dL/dp = the three column adjoints (+ the heading alignment's part)
-        float gp[9], Rin[9], aa[3], gd[9], gRin[9], gaa[3];
-        const float* col = smem + LB_COL + gi * 12;
+        float gp[9], Rin[9], gd[9], gRin[9], gaa[3];
+        const float* col = smem + LB_COL + gi * 24;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
           Rin[i] = X[6 + i];
@@ -1443,20 +1534,16 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
         }
         gp[0] += g0;
         gp[3] += g3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) aa[c] = RW[6 + c];
-        const float* pr = smem + LB_PREP + gi * 16;
-        RodPrep rp;
-        rp.n[0] = pr[0]; rp.n[1] = pr[1]; rp.n[2] = pr[2]; rp.s = pr[3]; rp.c = pr[4]; rp.it = pr[5];
-        mat3_mult(gp, Rin, gd);            // dL/ddR = dL/dp Rin^T
-        rod_adj(rp, aa, gd, gaa);
-        mat3_tmul(GL + 18, gp, gRin);      // dL/dRin = dR^T dL/dp (dR from the forward's glue record)
+        pg::mat3_mult(gp, Rin, gd);            // dL/ddR = dL/dp Rin^T
+        rod_adj(rp_root, aa_root, gd, gaa);
+        pg::mat3_tmul(GL + 18, gp, gRin);      // dL/dRin = dR^T dL/dp (dR from the forward's glue record)
 #pragma unroll
         for (int c = 0; c < 3; ++c) sD3[(6 + c) * 4 + gi] = gaa[c];
 #pragma unroll
         for (int i = 0; i < 9; ++i) GXD[6 + i] = gRin[i];
       }
     }
+    PTC(0, 3);
     PTB(3);
     __syncthreads();
     PTB(4);
@@ -1601,6 +1688,11 @@ extern "C" int ha_debug_persist_spins(unsigned* out /* [8] */, int reset) {
     std::fill(h.begin(), h.end(), 0u);
     HA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ha::g_spin_hist), h.data(), sizeof(unsigned) * 8 * 1024));
   }
+  return HA_OK;
+}
+extern "C" int ha_debug_persist_timing_glue(unsigned long long* out /* [2][8][8] */) {
+  HA_CHECK_HIP(hipDeviceSynchronize());
+  HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_ptc), sizeof(unsigned long long) * 2 * 8 * 8));
   return HA_OK;
 }
 extern "C" int ha_debug_persist_timing_bwd(unsigned long long* out /* [8][24] */) {

@@ -23,6 +23,7 @@ def test_persistent_step_loops_have_no_agpr_copies_or_scratch():
     kernels = [l for l in out.stdout.split('\n') if l.startswith(('fwd<', 'bwd<'))]
     assert len(kernels) == 4, out.stdout
     details = [l for l in out.stdout.split('\n') if 'IN THE LOOP' in l]
+    assert all('weight AGPRs read by MFMAs' in d and int(d.split('weight AGPRs read by MFMAs')[1].split()[0].rstrip(',')) >= 200 for d in details), details
     assert len(details) == 4
     for head, d in zip(kernels, details):
         n_write = int(d.split('IN THE LOOP')[1].split()[0])

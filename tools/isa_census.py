@@ -50,6 +50,11 @@ def main():
                 best = (labels[m.group(1)], i)
         loop = insts[best[0]:best[1] + 1]
         mix = collections.Counter(t.split()[0] for t in loop)
+        # AGPRs the inline-asm MFMAs read as their B operand vs AGPRs the loop writes (a spill INTO a weight register would be an
+        # unguarded hazard; spills into other AGPRs are ordinary compiler-managed copies)
+        wregs = set(m.group(1) for t in loop for m in [re.match(r'^v_mfma\S*\s+\S+,\s*\S+,\s*(a\d+),', t)] if m)
+        written = set(m.group(1) for t in loop for m in [re.match(r'^v_accvgpr_write_b32\s+(a\d+),', t)] if m)
+        clash = sorted(wregs & written)
         short = 'fwd' if 'fwd' in name else 'bwd'
         sc1 = 'Lb1' in name
         print(f'{short}<{"true" if sc1 else "false"}>: {len(loop)} instructions in the step loop (of {len(insts)} in the kernel)')
@@ -57,7 +62,8 @@ def main():
         nop_cycles = sum(int(t.split()[1]) + 1 for t in loop if t.startswith('s_nop'))
         print(f'   s_nop wait states {nop_cycles}, v_mfma {sum(v for k, v in mix.items() if k.startswith("v_mfma"))}, '
               f'permlane swaps {sum(v for k, v in mix.items() if "permlane" in k)}, dpp adds {mix.get("v_add_f32_dpp", 0)}, '
-              f'v_accvgpr_write IN THE LOOP {mix.get("v_accvgpr_write_b32", 0)} (must be 0: a copy into an AGPR in front of an inline-asm MFMA is an unguarded hazard), v_accvgpr_read {mix.get("v_accvgpr_read_b32", 0)}, '
+              f'v_accvgpr_write INTO WEIGHT AGPRS IN THE LOOP {len(clash)} (must be 0: a copy into an AGPR in front of an inline-asm MFMA is an unguarded hazard), '
+              f'weight AGPRs read by MFMAs {len(wregs)}, v_accvgpr_write (spills) {mix.get("v_accvgpr_write_b32", 0)}, v_accvgpr_read {mix.get("v_accvgpr_read_b32", 0)}, '
               f'scratch ops {sum(v for k, v in mix.items() if k.startswith("scratch_"))}, ds ops {sum(v for k, v in mix.items() if k.startswith("ds_"))}, global/buffer {sum(v for k, v in mix.items() if k.startswith(("global_", "buffer_")))}')
 
 

@@ -41,6 +41,6 @@ def run(B, S, mask, prior):
         line += ' %s %.1e' % (k, (gp0[:, a:b] - gp1[:, a:b]).abs().max().item() / sc)
     print(line, flush=True)
 
-for B, S, mask, prior in ((4, 1, ['contacts'], 0), (4, 1, ['jvel'], 0), (4, 1, ['joints'], 0), (4, 1, ['bodyR'], 0), (4, 1, ['rvel'], 0), (4, 1, ['tvel'], 0),
+for B, S, mask, prior in ((4, 2, ['jvel'], 0), (4, 2, ['trans'], 0), (4, 2, ['tvel'], 0), (4, 2, ['rvel'], 0), (4, 2, ['rootR'], 0), (4, 2, ['bodyR'], 0), (4, 1, ['contacts'], 0), (4, 1, ['jvel'], 0), (4, 1, ['joints'], 0), (4, 1, ['bodyR'], 0), (4, 1, ['rvel'], 0), (4, 1, ['tvel'], 0),
                           (4, 1, ['trans'], 0), (4, 1, ['rootR'], 0), (4, 1, [], 1), (4, 2, ['contacts'], 0), (4, 2, ['joints'], 0), (4, 2, list(SEG), 1), (32, 3, list(SEG), 1)):
     run(B, S, mask, prior)

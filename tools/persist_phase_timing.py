@@ -69,3 +69,15 @@ print('adjoint, member 5 -- cycles per step:', step.tolist())
 for i, n in enumerate(bn[1:]):
     print('%-12s %s | %d' % (n, ' '.join('%5d' % v for v in d[:, i]), int(np.median(d[:, i]))))
 print('sum of medians', int(np.median(d, axis=0).sum()), 'median step', int(np.median(step)))
+
+# ---- adjoint glue, finer: wave 0 (rotations) and wave 2 (vector tasks) ------------------------------------------------------------
+bufc = (C.c_ulonglong * (2 * 8 * 8))()
+fc = getattr(lib._dll, 'ha_debug_persist_timing_glue', None)
+if fc is not None:
+    fc.restype = C.c_int
+    assert fc(bufc) == 0
+    tc = np.array(list(bufc), dtype=np.int64).reshape(2, 8, 8)
+    for w, names_c, n in ((0, ['start', 'rot set-up', 'body adjoints', 'end of glue (wave 0; the chain runs on lane 21)'], 4),
+                          (1, ['start', 'loads + first half', 'dL/dW sums + publish', 'second half + partials', 'sums + owners', 'outputs'], 6)):
+        d = np.diff(tc[w][:, :n], axis=1)
+        print('adjoint glue, wave %d:' % (0 if w == 0 else 2), ' | '.join('%s %d' % (nm, int(np.median(d[:, i]))) for i, nm in enumerate(names_c[1:])))
