@@ -129,3 +129,42 @@ def check_posterior_param_grads(lib, device, N=5, seed=0):
     (_, _), (qm2, _) = hm.infer_step(past, nxt)          # frozen: the fused path
     assert len(hm._net_handles) > 0, 'frozen networks are expected to run through ha_mlp_*'
     _cmp(qm2, ref_q.cpu(), 1e-4, 'fused posterior vs module')
+
+
+def check_infer_global_seq_golden(lib, device, tol=2e-5):
+    """HumorModel.infer_global_seq (humor_model.py:1061-1165) and the stage-3 velocity estimators
+    (motion_optimizer.py:744-800) on `device` tensors against the reference-generated fixture tests/golden/infer_global_seq.npz
+    (oracle/make_golden_infer.py).  On a HIP device (and the emulator tier) the prior / posterior run through ha_mlp_*: the check
+    asserts that the fused handles were built, i.e. that this is not the PyTorch-module branch."""
+    import numpy as np
+    from conftest import golden
+    from humor_amd import frames, synth
+    from humor_amd.humor_model import HumorModel
+    gd = golden('infer_global_seq.npz')
+    worst = 0.0
+    for name in ('a', 'b'):
+        hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1,
+                        _lib_override=lib)
+        hm.load_state_dict(synth.humor_state_dict(seed=int(gd[f'{name}_weight_seed'])))
+        hm = hm.to(device).eval()
+        for p in hm.parameters():
+            p.requires_grad_(False)
+        seq = {k: torch.from_numpy(gd[f'{name}_{k}']).to(device) for k in
+               ('trans', 'trans_vel', 'root_orient', 'root_orient_vel', 'pose_body', 'joints', 'joints_vel')}
+        with torch.no_grad():
+            (pm, pv), (qm, qv) = hm.infer_global_seq(seq)
+        fused = device.type == 'cuda' or (lib is not None and lib.emulator)
+        if fused:
+            assert {k[0] for k in hm._net_handles} >= {'encoder', 'prior_net'}, 'the fused MLP path did not run'
+        for got, key in ((pm, 'prior_mu'), (pv, 'prior_var'), (qm, 'post_mu'), (qv, 'post_var')):
+            ref = gd[f'{name}_{key}']
+            assert tuple(got.shape) == ref.shape, (name, key, got.shape, ref.shape)
+            e = np.abs(got.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+            assert e < tol, (name, key, e)
+            worst = max(worst, e)
+        h = float(gd[f'{name}_vel_h'])
+        x, rot = torch.from_numpy(gd[f'{name}_vel_x']).to(device), torch.from_numpy(gd[f'{name}_vel_rot']).to(device)
+        lv, av = frames.estimate_linear_velocity(x, h).cpu().numpy(), frames.estimate_angular_velocity(rot, h).cpu().numpy()
+        assert np.abs(lv - gd[f'{name}_lin_vel']).max() <= 1e-6 * max(1.0, np.abs(gd[f'{name}_lin_vel']).max()), name
+        assert np.abs(av - gd[f'{name}_ang_vel']).max() <= 1e-5 * max(1.0, np.abs(gd[f'{name}_ang_vel']).max()), name
+    return worst

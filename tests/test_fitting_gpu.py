@@ -34,9 +34,17 @@ def test_stage_objectives_at_baseline_sizes(gpu_lib, dev, smplh_npz, name):
     print(name, FC.check_objectives_long(gpu_lib, dev, smplh_npz, name))
 
 
-@pytest.mark.parametrize('name,kind', [('c2', 'amass'), ('c4', 'rgb')])
+@pytest.mark.parametrize('name,kind', [('c2', 'amass'), ('c3', 'rgb'), ('c4', 'rgb')])
 def test_short_run_at_baseline_sizes(gpu_lib, dev, smplh_npz, name, kind):
+    """C2 (2 x 60, joints3d), C3 (1 x 90, joints2d + floor: fit_rgb_demo_no_split) and the C4 slice (8 x 60, overlap 10)."""
     FC.check_short_run(gpu_lib, dev, smplh_npz, kind, long_name=name)
+
+
+@pytest.mark.parametrize('name,kind', [('c2', 'amass'), ('c3', 'rgb'), ('c4', 'rgb')])
+def test_lbfgs_trajectory_equals_torch_lbfgs_on_the_same_closure(gpu_lib, dev, smplh_npz, name, kind):
+    """humor_amd.lbfgs.LBFGS against torch.optim.LBFGS, both driving THIS implementation's closures on the fixture problems: the identical
+    evaluation sequence, stage by stage (the optimiser's deterministic pin; the closures are pinned by the objective tests)."""
+    FC.check_lbfgs_trajectory(gpu_lib, dev, smplh_npz, kind, long_name=name)
 
 
 @pytest.mark.parametrize('n,h,k', [(94752, 100, 100), (73472, 100, 71), (301, 128, 128), (1000, 100, 3)])

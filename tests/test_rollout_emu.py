@@ -113,6 +113,11 @@ def test_emu_fused_posterior_encoder_matches_module(emu_lib):
     MC.check_posterior(emu_lib, CPU, N=7)
 
 
+def test_infer_global_seq_fixture_module_path():
+    """The reference-generated infer_global_seq fixture against the PyTorch-module branch (host tensors)."""
+    print('infer_global_seq (module path) vs fixture', MC.check_infer_global_seq_golden(None, CPU))
+
+
 def test_emu_posterior_gives_parameter_gradients(emu_lib):
     """a training-mode infer_step must leave gradients on the encoder / prior weights (module forward), frozen nets run fused."""
     MC.check_posterior_param_grads(emu_lib, CPU, N=3)

@@ -187,6 +187,12 @@ def test_fused_posterior_encoder_matches_module(gpu_lib, dev):
     MC.check_posterior(gpu_lib, dev, N=5)
 
 
+def test_infer_global_seq_on_device_matches_reference_fixture(gpu_lib, dev):
+    """SURVEY 8(a) a15 on the GPU: infer_global_seq (+ the stage-3 velocity estimators) on device tensors -- the fused prior / posterior
+    MLPs (ha_mlp_*), not the module branch -- against the reference-generated tests/golden/infer_global_seq.npz (2 x 9 and 4 x 60)."""
+    print('infer_global_seq vs reference fixture: worst relative deviation', MC.check_infer_global_seq_golden(gpu_lib, dev))
+
+
 def test_posterior_gives_parameter_gradients(gpu_lib, dev):
     """a training-mode infer_step must leave gradients on the encoder / prior weights (module forward), frozen nets run fused."""
     MC.check_posterior_param_grads(gpu_lib, dev, N=9)
