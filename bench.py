@@ -444,8 +444,9 @@ def cpu_baseline(npz, gpu_eval=None):
             for n in og:
                 flagged |= per_seq(pg2[n], og[n]) >= 2e-4
         by_oracle = int(flagged.sum())
-        if gpu_eval.get('gpu_unstable') is not None:
-            flagged |= gpu_eval['gpu_unstable']
+        # (the bar applies to every sub-sequence the ORACLE's perturbations do not flag; sub-sequences whose own GPU gradient is unstable
+        # are reported, not excused: a GPU-side bug that made gradients noisy must not clear itself)
+        gpu_unstable = gpu_eval.get('gpu_unstable')
         worst_all, worst_stable, per = 0.0, 0.0, {}
         over = torch.zeros(B_SEQ, dtype=torch.bool)
         for n in og:
@@ -458,14 +459,15 @@ def cpu_baseline(npz, gpu_eval=None):
         parity = {'loss_rel': float('%.3g' % (abs(gpu_eval['loss'] - oloss) / abs(oloss))),
                   'grad_rel_max': float('%.3g' % worst_stable), 'grad_rel_max_incl_kink_sequences': float('%.3g' % worst_all),
                   'kink_flagged_sequences': int(flagged.sum()), 'kink_flagged_by_oracle_perturbations': by_oracle,
-                  'kink_flagged_by_gpu_perturbations': int(gpu_eval['gpu_unstable'].sum()) if gpu_eval.get('gpu_unstable') is not None else None,
+                  'gpu_unstable_sequences_informational': int(gpu_unstable.sum()) if gpu_unstable is not None else None,
+                  'gpu_unstable_not_oracle_flagged': int((gpu_unstable & ~flagged).sum()) if gpu_unstable is not None else None,
                   'unflagged_sequences_over_1e-3': int((over & ~flagged).sum()),
                   'sequences_within_1e-3': int((~over).sum()), 'sequences': B_SEQ,
                   'grad_rel_by_tensor_incl_kink_sequences': per, 'oracle_loss': oloss, 'gpu_loss': gpu_eval['loss'],
                   'what': 'GPU stage-3 closure of the timed workload (32x60) vs oracle/closure_restated.py at the same variables; gradient error per '
-                          'sub-sequence relative to max(1, max|oracle gradient|) of the tensor; kink-flagged = sub-sequences whose gradient moves >= 2e-4 '
-                          'under 1-ulp perturbations of the variables, either the ORACLE gradient (six perturbations, 4.8 s each) or the GPU closure\'s own '
-                          'gradient (48 perturbations): a ReLU(GroupNorm) unit within fp32 rounding of its kink, where no two fp32 evaluations agree to 1e-3 '
+                          'sub-sequence relative to max(1, max|oracle gradient|) of the tensor; kink-flagged = sub-sequences whose ORACLE gradient moves >= 2e-4 '
+                          'under 1-ulp perturbations of the variables (six perturbations, 4.8 s each; the GPU closure\'s own sensitivity under 48 perturbations is '
+                          'reported as gpu_unstable_*, it excuses nothing): a ReLU(GroupNorm) unit within fp32 rounding of its kink, where no two fp32 evaluations agree to 1e-3 '
                           '(the set grows with the number of perturbations tried, tests/rollout_checks.py); bars: loss 1e-4, gradients 1e-3 on the unflagged '
                           'sub-sequences'}
     g = torch.Generator().manual_seed(3)

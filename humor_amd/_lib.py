@@ -189,8 +189,9 @@ def get_lib():
         # HUMOR_AMD_ROLLOUT_PERSIST=0: launch-chain roll-out only.  The persistent roll-out kernels need one resident block on every CU;
         # two PROCESSES sharing one GPU (the 2-rank validation runs on a 1-GPU box) can starve each other's launches until their
         # bounded waits run out.  One process per GPU -- the deployment this package is built for -- needs no setting.
-        if os.environ.get('HUMOR_AMD_ROLLOUT_PERSIST') is not None:
-            _lib.call('ha_tune_set', b'rollout_persist', int(os.environ['HUMOR_AMD_ROLLOUT_PERSIST']))
+        v = os.environ.get('HUMOR_AMD_ROLLOUT_PERSIST')
+        if v:                                                            # (an empty value means unset, as for HUMOR_AMD_LIB)
+            _lib.call('ha_tune_set', b'rollout_persist', int(v))
     return _lib
 
 

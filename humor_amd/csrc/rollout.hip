@@ -16,6 +16,8 @@
 // layer's prologue sums those partial slabs (the launch-boundary reduce).
 #include <string.h>
 
+#include <algorithm>
+#include <unordered_map>
 #include <vector>
 
 #include "rollout_persist.h"
@@ -72,6 +74,9 @@ int g_rollout_persist = 1;
 // ha_tune_set "rollout_persist_bwd": 1 (default) = behind a persistent forward the adjoint is ONE persistent launch too (reverse scan,
 // transposed weights resident, rollout_persist.hip); 0 = the launch-chain adjoint reads the persistent forward's stash.
 int g_rollout_persist_bwd = 1;
+// ha_tune_set "rollout_persist_inject": test hook -- 1 = the persistent forward drops one CU of team 0, so that the team's bounded waits run
+// out and the failure path (NaN results, host-mapped error word, fall-back to the launch chain) can be exercised on a healthy GPU
+int g_rollout_persist_inject = 0;
 
 struct PackedLayer {
   int Cin = 0, skip = 0, Nout = 0;
@@ -94,6 +99,10 @@ struct ha_humor_net {
   bool delta = true;                       // the decoder emits residuals (HumorModel(output_delta=True)); ha_humor_net_set_option("output_delta")
   ha::PackedLayer dec[ha::MAXL], pri[ha::MAXL];
   ha::PersistNet* persist = nullptr;      // register-stationary decoder for the persistent forward (null: shape / device not eligible)
+  // The stash layout of a call depends on whether the persistent kernels serve it, which in turn depends on mutable state (the tune
+  // knob, the asynchronous error word).  A forward call decides ONCE and records the decision for the stash it fills; every later
+  // phase of that call and the backward over the same stash use the recorded mode (one host thread per device: no lock).
+  mutable std::unordered_map<const void*, int> stash_mode;
 };
 
 namespace ha {
@@ -1600,6 +1609,8 @@ struct StashLayout {
 // row groups of the call being served on this host thread (for_each_group): side-by-side groups run on their own streams, and two
 // persistent launches cannot share the chip (each needs one block on every CU), so the one-launch path serves single-group calls only
 static thread_local int tl_groups = 1;
+// -1: make_layout decides from the live state (workspace queries); 0 / 1: the mode decided at the entry point of the call being served
+static thread_local int tl_single_mode = -1;
 
 static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, bool allow_acc = true) {
   L.RT = ceil_div(B, 32);
@@ -1615,7 +1626,8 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, b
   for (int i = 0; i < net->n_dec; ++i) { L.nsf_dec[i] = ceil_div(net->dec[i].nslices_f, L.spb); L.nsb_dec[i] = ceil_div(net->dec[i].nslices_b, L.spb); }
   // GroupNorm prologues once per activation in gn_finish_kernel (see there and the policy note above)
   L.finish = (L.RT >= 2 && g_layer_finish != 0) || g_layer_finish == 2;     // 0: never, 2: always (A/B runs)
-  L.single = allow_acc && !L.finish && B <= 32 && tl_groups == 1 && g_rollout_persist != 0 && persist_usable(net->persist);
+  const bool may_single = allow_acc && !L.finish && B <= 32 && tl_groups == 1;
+  L.single = may_single && (tl_single_mode >= 0 ? tl_single_mode == 1 : (g_rollout_persist != 0 && persist_usable(net->persist)));
   L.acc = allow_acc && !L.finish && !L.single && g_layer_acc != 0;
   L.hsum = !L.finish && !L.acc && !L.single && g_layer_hsum != 0;
   size_t o = 0;
@@ -1823,10 +1835,18 @@ static void group_plan(int B, int& ngroups, int& rows_per_group) {
 }
 
 static size_t group_stash_floats(const ha_humor_net* net, int rows, int S) {
-  StashLayout L, Ls;
-  make_layout(net, rows, S, L);
-  make_layout(net, rows, S, Ls, false);
-  return L.total > Ls.total ? L.total : Ls.total;
+  // the largest of: persistent mode, launch-chain mode, sampling roll-out (the mode may change between the query and the call)
+  const int saved = tl_single_mode;
+  size_t best = 0;
+  for (int mode = 0; mode < 2; ++mode) {
+    tl_single_mode = mode;
+    StashLayout L, Ls;
+    make_layout(net, rows, S, L);
+    make_layout(net, rows, S, Ls, false);
+    best = std::max(best, std::max(L.total, Ls.total));
+  }
+  tl_single_mode = saved;
+  return best;
 }
 
 }  // namespace ha
@@ -1960,7 +1980,7 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
       f.off_gl = L.off_gl;
       f.t2j = stash + L.t2j;
       f.ws = stash + L.persist_ws;
-      return persist_forward(net->persist, f, g_rollout_persist >> 1, st);
+      return persist_forward(net->persist, f, (g_rollout_persist >> 1) | (g_rollout_persist_inject ? 2 : 0), st);
     }
     if (phase == PH_STEP) return HA_OK;
   }
@@ -2281,12 +2301,19 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
   tl_groups = ng;
   const size_t gs = ng > 1 ? group_stash_floats(net, rpg, S) : 0;
   tl_groups = 1;
-  return for_each_group(net->device, B, S, false, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
+  // the roll-out mode of this call, decided once (see ha_humor_net::stash_mode)
+  const int mode = (g_rollout_persist != 0 && persist_usable(net->persist)) ? 1 : 0;
+  if (net->stash_mode.size() > 256) net->stash_mode.clear();
+  net->stash_mode[stash] = mode;
+  tl_single_mode = mode;
+  const int rc = for_each_group(net->device, B, S, false, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
     const size_t r = (size_t)r0;
     return rollout_forward_impl(net, rows, S, past_in0 + r * D_IN, z_seq + r * S * ZD, world + r * S * D_STATE,
                                 prior_mu ? prior_mu + r * S * ZD : nullptr, prior_var ? prior_var + r * S * ZD : nullptr,
                                 stash + (size_t)g * gs, st, phase, t);
   });
+  tl_single_mode = -1;
+  return rc;
 }
 
 extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float* z_seq, const float* g_world,
@@ -2306,12 +2333,17 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
   tl_groups = ng;
   const size_t gs = ng > 1 ? group_stash_floats(net, rpg, S) : 0;
   tl_groups = 1;
-  return for_each_group(net->device, B, S, true, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
+  // the mode the forward over this stash recorded (a stash this library has not seen: decided from the live state, as before)
+  const auto it = net->stash_mode.find(stash);
+  tl_single_mode = it != net->stash_mode.end() ? it->second : -1;
+  const int rc = for_each_group(net->device, B, S, true, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
     const size_t r = (size_t)r0;
     return rollout_backward_impl(net, rows, S, g_world ? g_world + r * S * D_STATE : nullptr,
                                  g_prior_mu ? g_prior_mu + r * S * ZD : nullptr, g_prior_var ? g_prior_var + r * S * ZD : nullptr,
                                  stash + (size_t)g * gs, g_past_in0 + r * D_IN, g_z_seq + r * S * ZD, st, phase, t);
   });
+  tl_single_mode = -1;
+  return rc;
 }
 
 // ---- rotation conversions -------------------------------------------------------------------------

@@ -136,6 +136,7 @@ struct PersistArgs {
   float* t2j;
   unsigned char* xch;
   unsigned* err;            // host-mapped error word
+  int inject;               // test hook (ha_tune_set "rollout_persist_inject"): member 3 of team 0 leaves at once -> the team's bounded waits run out
 };
 
 struct PersistNet {
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     return;
   }
   if (a.S == 0) return;       // residency / placement probe
+  if (a.inject && team == 0 && m == 3) return;
   const int g = m * 4 + wave;                 // wave of the team
   const int row0 = team * ROWS;               // the team's sequences
   unsigned char* team_xch = a.xch + XCH_HDR + (size_t)team * TEAM_BYTES;
@@ -912,7 +914,18 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     __syncthreads();
     copy_out(a.S - 1);
   }
-  if (misc[2] && tid == 0) __hip_atomic_store(a.err, 0x200u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (misc[2]) {
+    // A team that did not complete (a bounded wait ran out): the launch is asynchronous -- inside a captured hipGraph no entry point sees
+    // the error word before the results are consumed -- so the results themselves say so: every output row of this team becomes NaN
+    // (every CU that noticed fills all of it: the failure may BE a missing member), and the loss and gradients computed from them with
+    // it.  The host-mapped word tells the optimiser why.
+    const float nanv = as_f(0x7fc00000u);
+    for (size_t e = tid; e < (size_t)ROWS * a.S * P_STATE; e += 256) {
+      const int i = (int)(e / ((size_t)a.S * P_STATE));
+      if (row0 + i < a.B) a.world[(size_t)row0 * a.S * P_STATE + e] = nanv;
+    }
+    if (tid == 0) __hip_atomic_store(a.err, 0x200u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 
@@ -1655,7 +1668,19 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       }
     }
   }
-  if (misc[2] && tid == 0) __hip_atomic_store(a.err, 0x400u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (misc[2]) {
+    // (as in the forward: the failed team's gradients become NaN -- dL/dpast_in0 directly, dL/dz through its partial products)
+    const float nanv = as_f(0x7fc00000u);
+    for (int e = tid; e < ROWS * P_DIN; e += 256) {
+      const int i = e / P_DIN;
+      if (row0 + i < a.B) a.g_past0[(size_t)row0 * P_DIN + e] = nanv;
+    }
+    for (size_t e = tid; e < (size_t)a.S * ROWS * P_ZD; e += 256) {
+      const int tt = (int)(e / (ROWS * P_ZD)), r = (int)(e % (ROWS * P_ZD));
+      a.dz_part[(((size_t)tt * DZ_SLOTS) * 32 + row0) * P_ZD + r] = nanv;          // slot 0 of every step
+    }
+    if (tid == 0) __hip_atomic_store(a.err, 0x400u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // g_z[b][t][c] = sum of the DZ_SLOTS partial products, fixed order
@@ -1886,6 +1911,7 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
   a.t2j = f.t2j;
   a.xch = reinterpret_cast<unsigned char*>(f.ws);
   a.err = p->err_dev;
+  a.inject = (variant >> 1) & 1;
   if (variant & 1) hipLaunchKernelGGL(rollout_persist_fwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
   else hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
   HA_LAUNCH_CHECK();

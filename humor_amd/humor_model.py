@@ -407,6 +407,16 @@ class HumorModel(nn.Module):
             self._net_handles[key] = (ver, _NetHandle(lib, index, self.decoder, self.prior_net, output_delta=self.output_delta))
         return self._net_handles[key][1]
 
+    def persistent_rollout_status(self, device):
+        """(available, error word, launches) of the one-launch persistent roll-out kernels on `device`.  A persistent launch is asynchronous:
+        a team that did not complete fills its results with NaN and sets the host-mapped error word (rollout_persist.hip); read this
+        after the stream has been synchronised (e.g. after L-BFGS's host read) -- captured hipGraphs never pass an entry point that
+        would report it.  `error word != 0` means: results since then are invalid, the launch chain serves this network from now on."""
+        h = self._net_handle(device)
+        av, err, n = C.c_int(), C.c_uint(), C.c_int64()
+        h.lib.call('ha_humor_persist_status', h.ptr, C.byref(av), C.byref(err), C.byref(n))
+        return av.value, err.value, n.value
+
     def roll_out(self, x_past, init_input_dict, num_steps, use_mean=False, z_seq=None, return_prior=False, gender=None,
                  betas=None, return_z=False, canonicalize_input=False, uncanonicalize_output=False, eps_seq=None, return_world=False):
         '''

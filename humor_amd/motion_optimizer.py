@@ -76,6 +76,7 @@ class MotionOptimizer():
         self.fused_vposer = bool(fused_vposer)
         self._vposer_handle = None
         self.closure_evals = 0
+        self._graph_states = []     # capture states of the closures made so far (invalidated when the persistent roll-out reports a failure)
         self.stage_profile = None   # set to {} before run(): wall time / closure evaluations / outer iterations per stage (3 syncs per phase)
         self.loss_trace = None      # set to a list to record (stage, loss) of every closure evaluation (host sync per eval)
         if motion_prior is None:
@@ -212,6 +213,7 @@ class MotionOptimizer():
             closure.discard_last = self._discard_last_eval
             return closure
         state = {'graph': None, 'loss': None, 'grads': None, 'failed': False}
+        self._graph_states.append(state)
 
         def eager():
             for p in params:
@@ -260,6 +262,24 @@ class MotionOptimizer():
             return state['loss']
         closure.discard_last = self._discard_last_eval
         return closure
+
+    def _check_rollout_health(self):
+        """Called after every stage-3 outer iteration (L-BFGS has just read its scalars: the stream is drained).  The persistent roll-out
+        kernels report a team that did not complete -- another process's kernel held part of the chip, say -- only through NaN results
+        and a host-mapped error word; closures replayed from a hipGraph never pass an entry point that returns it.  On a reported
+        failure: the captured graphs (they contain the persistent launches) are dropped, the network serves later calls through the
+        launch chain, and this fit is aborted with an error (run_fitting.py:437-439 skips the batch)."""
+        if self.motion_prior is None or self.device is None or torch.device(self.device).type != 'cuda':
+            return
+        status = getattr(self.motion_prior, 'persistent_rollout_status', None)
+        if status is None:
+            return
+        _, err, _ = status(torch.device(self.device))
+        if err != 0:
+            for st in self._graph_states:
+                st['graph'], st['failed'] = None, True
+            raise RuntimeError('humor_amd: the persistent roll-out reported an incomplete launch (error word 0x%x): the objective values of '
+                               'this fit are invalid; later evaluations use the launch-chain roll-out' % err)
 
     def _discard_last_eval(self):
         """humor_amd.lbfgs.LBFGS issues the first trial evaluation of an iteration before it has read the direction's scalars; in the
@@ -446,6 +466,7 @@ class MotionOptimizer():
                         obs_local, obs_init, prior_opt_params, tp, n_init, ims, og_overlap_w, has_overlap, fit_gender),
                     motion_params, None, short=tune_phase)
             motion_optim.step(closures3[phase])
+            self._check_rollout_health()
         if last_phase_name is not None:
             self._mark(last_phase_name, phase_iters)
 

@@ -219,3 +219,32 @@ def test_persistent_forward_determinism_and_reuse(gpu_lib, dev):
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
     assert RC.persist_status(gpu_lib, hm, dev)[1] == 0
+
+
+def test_persistent_failure_poisons_results_and_is_reported(gpu_lib, dev):
+    """a persistent launch whose team does not complete must not hand garbage to a caller that never passes an entry
+    point (a captured hipGraph).  Test hook ha_tune_set("rollout_persist_inject"): one CU of team 0 leaves at once, the team's bounded
+    waits run out.  Then: the team's output rows are NaN (the loss computed from them is NaN), the host-mapped error word is set, the next
+    entry point returns the error once, and from then on the launch chain serves the network with correct results."""
+    from humor_amd import _lib
+    hm, _ = RC.make_model(gpu_lib, dev, seed=3, contractive=True)          # its own network handle (the failure is sticky per handle)
+    g = torch.Generator().manual_seed(11)
+    B, S = 12, 4
+    past, z = RC.canonical_state(B, g).to(dev), torch.randn(B, S, 48, generator=g).to(dev)
+    with torch.no_grad():
+        ref = RC.world_of(hm.roll_out(past, None, S, z_seq=z))                # healthy persistent launch
+        assert hm.persistent_rollout_status(dev)[:2] == (1, 0)
+        gpu_lib.call('ha_tune_set', b'rollout_persist_inject', 1)
+        try:
+            bad = RC.world_of(hm.roll_out(past, None, S, z_seq=z))
+            torch.cuda.synchronize()
+        finally:
+            gpu_lib.call('ha_tune_set', b'rollout_persist_inject', 0)
+        assert torch.isnan(bad[:4]).all(), 'the incomplete team\'s rows must be NaN'
+        assert torch.equal(bad[4:], ref[4:]), 'the other teams are unaffected'
+        av, err, _ = hm.persistent_rollout_status(dev)
+        assert av == 0 and (err & 0xf00) == 0x200, (av, hex(err))
+        with pytest.raises(_lib.HumorAmdError):
+            hm.roll_out(past, None, S, z_seq=z)                               # reported once
+        again = RC.world_of(hm.roll_out(past, None, S, z_seq=z))             # the launch chain from now on
+        assert torch.isfinite(again).all() and (again - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
