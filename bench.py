@@ -39,15 +39,41 @@ HBM_PEAK_GBS = 8000.0                   # /opt/skills/guides/MI355X_MICROARCH.md
 V, J = 6890, 52
 # algorithmic HBM bytes per frame of the LBS skinning kernel = read v_posed (V*12) + A (J*48), write verts (V*12)
 SKIN_BYTES_PER_FRAME = V * 12 * 2 + J * 48
-# HBM traffic of one ha_lbs_skin launch at N=1920 from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
-# tools/skin_once.py via tools/pmc_lbs.sh, launches cycling over 4 operand sets like the timed launches here; FETCH_SIZE doubled
-# per MI355X_MICROARCH.md 'HBM', WRITE_SIZE as reported, KiB; both calibrated in the same passes on a device copy of exactly
-# 155,025 KiB, which reads back as 2 x 77,524 and 155,025).  Offline measurement (counters cannot be read inside bench.py).
-PMC_TRAFFIC_BYTES = int((2 * 88692.2 + 155025.2) * 1024)
-# the same passes at the C5 size (N = 30720 frames, operands >> the 256 MiB Infinity Cache): profiles/r02_pmc_lbs/SUMMARY.txt
-PMC_TRAFFIC_BYTES_C5 = int((2 * 1345686.9 + 2480400.8) * 1024)
-PMC_TRAFFIC_SOURCE = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over 4 rotating operand sets, profiles/r03_pmc_lbs (FETCH x2 gfx950 correction; '
-                      'LDS bank-conflict cycles are 1.4 % of the LDS-active cycles in the same passes)')
+# HBM traffic of one ha_lbs_skin launch comes from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/skin_once.py
+# via tools/pmc_lbs.sh, launches cycling over 4 operand sets like the timed launches here; FETCH_SIZE doubled per MI355X_MICROARCH.md
+# 'HBM', WRITE_SIZE as reported; calibrated in the same passes on a device copy).  Counters cannot be read inside bench.py, so the
+# summary tool leaves a machine-readable record next to its SUMMARY.txt -- profiles/<run>/traffic.json, with a fingerprint of the
+# kernel's source -- and bench.py reads the newest record at run time: a record whose fingerprint no longer matches the kernel is
+# reported as stale (traffic = null), never silently reused.
+
+
+def lbs_kernel_fingerprint():
+    """sha1 of the source text of lbs_skin_wave_kernel (humor_amd/csrc/smpl.hip): what a PMC record is valid for."""
+    import hashlib
+    lines = open(os.path.join(ROOT, 'humor_amd', 'csrc', 'smpl.hip')).read().split('\n')
+    start = next(i for i, l in enumerate(lines) if 'void lbs_skin_wave_kernel(' in l)
+    while start > 0 and not lines[start - 1].startswith('}') and lines[start - 1].strip():
+        start -= 1
+    end = next(i for i in range(start + 1, len(lines)) if lines[i] == '}')
+    return hashlib.sha1('\n'.join(lines[start:end + 1]).encode()).hexdigest()[:16]
+
+
+def pmc_traffic(frames):
+    """(HBM bytes per launch at `frames` frames, source note) from the newest profiles/*/traffic.json that has this size."""
+    import glob
+    fp = lbs_kernel_fingerprint()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic.json')), reverse=True):
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            continue
+        for e in rec.get('launches', []):
+            if int(e.get('frames', -1)) == frames:
+                rel = os.path.relpath(f, ROOT)
+                if rec.get('kernel_fingerprint') != fp:
+                    return None, f'STALE: {rel} was measured on another version of lbs_skin_wave_kernel (re-run tools/pmc_lbs.sh)'
+                return int(e['hbm_bytes']), f'{rel}: {rec.get("how", "")}'
+    return None, 'no PMC record for this size under profiles/*/traffic.json'
 
 
 def parse():
@@ -61,6 +87,7 @@ def parse():
     ap.add_argument('--graph', dest='auto', action='store_false', help='always replay the captured hipGraph (default at N=1: time graph replay against eager launches once and keep the faster)')
     ap.add_argument('--scaling', choices=['weak', 'strong', 'both'], default='both',
                     help='N>1: weak = 32 sub-sequences per GPU (the headline value), strong = 32 in total; both = time both')
+    ap.add_argument('--no-c5-weak', action='store_true', help='skip the 32 x 120 per-GPU closure line (BASELINE config 5 shape, weak)')
     ap.add_argument('--no-lbfgs', action='store_true', help='skip the staged L-BFGS outer-iteration measurement (N=1)')
     ap.add_argument('--no-rccl-check', action='store_true', help='skip the world-size-1 RCCL self-check (N=1)')
     return ap.parse_args()
@@ -112,19 +139,20 @@ def humor_weights():
     return synth.contractive_state_dict(0)
 
 
-def build_optimizer(dev, npz, B, shard=None, use_graphs=False):
+def build_optimizer(dev, npz, B, shard=None, use_graphs=False, T=None):
+    T = T_SEQ if T is None else T
     from humor_amd import synth
     from humor_amd.body_model import BodyModel
     from humor_amd.humor_model import HumorModel
     from humor_amd.motion_optimizer import MotionOptimizer
-    bm = BodyModel(npz, num_betas=16, batch_size=B * T_SEQ, use_vtx_selector=True)
+    bm = BodyModel(npz, num_betas=16, batch_size=B * T, use_vtx_selector=True)
     hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1)
     hm.load_state_dict(humor_weights())
     hm = hm.to(dev).eval()
     for p in hm.parameters():
         p.requires_grad_(False)
     w, mu, cov = synth.make_gmm(seed=0)
-    return MotionOptimizer(dev, bm, 16, B, T_SEQ, ['joints2d'], loss_weights(), synth.SynthVPoser(seed=0).to(dev).eval(), hm,
+    return MotionOptimizer(dev, bm, 16, B, T, ['joints2d'], loss_weights(), synth.SynthVPoser(seed=0).to(dev).eval(), hm,
                            {'gmm': (w.to(dev), mu.to(dev), cov.to(dev))}, optim_floor=True, camera_matrix=camera_matrix(B, dev),
                            robust_loss_type='bisquare', joint2d_sigma=100, shard=shard, use_graphs=use_graphs)
 
@@ -132,14 +160,15 @@ def build_optimizer(dev, npz, B, shard=None, use_graphs=False):
 class FitClosure:
     """Stage-3 closure of humor_amd.MotionOptimizer on this rank's share of the problem."""
 
-    def __init__(self, dev, npz, world, rank, group, use_graphs=True, B_total=None):
+    def __init__(self, dev, npz, world, rank, group, use_graphs=True, B_total=None, T=None):
         B = B_SEQ * world if B_total is None else B_total
+        T = T_SEQ if T is None else T
         shard = None
         if group is not None or world > 1:
             from humor_amd.distributed import Shard
             shard = Shard(B, group)
-        obs, init = make_problem(B, T_SEQ, seed=100, device=dev)      # same problem on every rank (replicated variables)
-        self.opt = build_optimizer(dev, npz, B, shard=shard, use_graphs=use_graphs)
+        obs, init = make_problem(B, T, seed=100, device=dev)      # same problem on every rank (replicated variables)
+        self.opt = build_optimizer(dev, npz, B, shard=shard, use_graphs=use_graphs, T=T)
         o = self.opt
         o.trans, o.root_orient, o.latent_pose, o.betas = init['trans'], init['root_orient'], init['latent_pose'], init['betas']
         o.fitting_loss.set_stage(2)
@@ -216,7 +245,7 @@ def time_events(fn, iters, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
-def skin_roofline(dev, npz, N=B_SEQ * T_SEQ, traffic=PMC_TRAFFIC_BYTES, rotate=1):
+def skin_roofline(dev, npz, N=B_SEQ * T_SEQ, rotate=1):
     """The streaming LBS kernel alone (ha_lbs_skin) at N frames: algorithmic bytes / event-timed launch duration.
     Launched on torch's current stream, so the HIP events bracket exactly these launches.
     rotate = number of operand sets the launches cycle through.  At the metric's batch (N = 1920) one set is 159 MB read + 159 MB
@@ -242,8 +271,9 @@ def skin_roofline(dev, npz, N=B_SEQ * T_SEQ, traffic=PMC_TRAFFIC_BYTES, rotate=1
     ms = time_events(launch, iters=(48 if rotate > 1 else 50) if small else 30, warm=(6 if rotate > 1 else 5) if small else 30)
     nbytes = SKIN_BYTES_PER_FRAME * N
     gbs = nbytes / (ms * 1e-3) / 1e9
+    traffic, traffic_source = pmc_traffic(N)
     return {'kernel': 'lbs_skin (ha_lbs_skin)', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': PMC_TRAFFIC_SOURCE,
+            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
             'avg_launch_us': round(ms * 1e3, 2), 'operand_sets': rotate,
             'bytes_per_launch': nbytes, 'frames_per_launch': N}
 
@@ -628,9 +658,12 @@ def run(args):
             d = t.item()
         return d
     dt = timed(fc)
+    # Two more jobs beside the headline (SCALE runs: make the curves unambiguous).
+    #   strong  -- the ONE 32-sequence job BASELINE.json / north_star name ("batch=32 sub-seqs of 60 frames sharded over 8 MI355X": 4 per GPU
+    #              at N = 8).  Chain-bound: a rank's closure is a 59-step dependent chain whatever its share is.
+    #   c5_weak -- BASELINE config 5's shape per GPU: 32 sub-sequences x 120 frames on every rank (256 x 120 at N = 8).
     strong = None
     if world > 1 and args.scaling in ('strong', 'both') and B_SEQ >= world:
-        # strong scaling: the SAME 32-sequence job (north_star: "batch=32 sub-seqs sharded over 8 GPUs" = 4 per GPU at N=8)
         del fc
         torch.cuda.empty_cache()
         fc = FitClosure(dev, npz, world, rank, None, use_graphs=False, B_total=B_SEQ)
@@ -638,6 +671,20 @@ def run(args):
         dts = timed(fc)
         strong = {'scaling': 'strong', 'global_batch': B_SEQ, 'sequences_per_gpu': [B_SEQ // world + (1 if r < B_SEQ % world else 0) for r in range(world)],
                   'value': round(args.steps / dts, 3), 'unit': 'closure-evals/s of the one 32x60 job', 'ms_per_step': round(dts / args.steps * 1e3, 4)}
+    elif world == 1:
+        strong = {'scaling': 'strong', 'global_batch': B_SEQ, 'sequences_per_gpu': [B_SEQ], 'value': round(args.steps / dt, 3),
+                  'unit': 'closure-evals/s of the one 32x60 job', 'ms_per_step': round(dt / args.steps * 1e3, 4), 'note': 'N = 1: the same run as `value`'}
+    c5_weak = None
+    if not args.no_c5_weak:
+        keep = fc
+        f5 = FitClosure(dev, npz, world, rank, None, use_graphs=False, T=120)
+        f5.mode_note = None
+        dt5 = timed(f5)
+        del f5
+        torch.cuda.empty_cache()
+        fc = keep
+        c5_weak = {'scaling': 'weak', 'workload': f'32 sub-sequences x 120 frames per GPU ({B_SEQ * world} x 120 in all; BASELINE config 5 is 256 x 120 = N 8)',
+                   'value': round(args.steps * world / dt5, 3), 'unit': 'closure-evals/s (32x120-batch equivalents)', 'ms_per_step': round(dt5 / args.steps * 1e3, 4)}
     coll = None
     if dist is not None:
         n = sum(p.numel() for p in fc.params) + 1
@@ -664,11 +711,16 @@ def run(args):
             'value': round(args.steps * world / dt, 3), 'unit': 'closure-evals/s (32x60-batch equivalents)',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'strong_value': strong['value'] if strong is not None else None,
+            'strong_ms_per_step': strong['ms_per_step'] if strong is not None else None,
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'C4 fit_rgb_demo_use_split shape: 32 overlapping sub-sequences x 60 frames per GPU (one coupled job of '
-                                   f'{B_SEQ * world} sub-sequences), joints2d + floor + overlap-consistency, SMPL+H 6890 verts / 52 joints / '
-                                   '16 betas, HuMoR 48-d latent, 59-step roll-out; step = one stage-3 closure (fwd+bwd)',
-                       'global_batch': B_SEQ * world, 'seq_len': T_SEQ, 'parallelism': f'dp{world} (sub-sequence sharding, replicated L-BFGS)'},
+            'config': {'workload': 'value (WEAK): C4 fit_rgb_demo_use_split shape with 32 overlapping sub-sequences x 60 frames PER GPU (one coupled job '
+                                   f'of {B_SEQ * world} sub-sequences); strong_value (STRONG): the ONE 32 x 60 job of BASELINE.json, {B_SEQ} sub-sequences '
+                                   f'sharded {B_SEQ // world if world <= B_SEQ else 0} per GPU -- at N = 1 the two are the same run.  Both: joints2d + floor + '
+                                   'overlap-consistency, SMPL+H 6890 verts / 52 joints / 16 betas, HuMoR 48-d latent, 59-step roll-out; step = one stage-3 '
+                                   'closure (fwd+bwd).  c5_weak: 32 x 120 per GPU (BASELINE config 5 shape)',
+                       'global_batch': B_SEQ * world, 'strong_global_batch': B_SEQ, 'seq_len': T_SEQ,
+                       'parallelism': f'dp{world} (sub-sequence sharding, replicated L-BFGS)'},
             'closure_mode': closure_mode(args, fc),
             'smpl_verts_per_sec': round(B_SEQ * T_SEQ * V / (ms_dense * 1e-3), 1),
             'smpl_dense_fwd_ms': round(ms_dense, 4),
@@ -679,6 +731,8 @@ def run(args):
         }
         if strong is not None:
             res['strong'] = strong
+        if c5_weak is not None:
+            res['c5_weak'] = c5_weak
         if coll is not None:
             res['rccl'] = coll
         if world == 1 and not args.no_lbfgs:
@@ -694,7 +748,7 @@ def run(args):
             # the roofline kernel again at the C5 size: operands far beyond the Infinity Cache, i.e. the cache-free figure
             fc = None
             torch.cuda.empty_cache()
-            res['roofline_c5'] = skin_roofline(dev, npz, N=256 * 120, traffic=PMC_TRAFFIC_BYTES_C5)
+            res['roofline_c5'] = skin_roofline(dev, npz, N=256 * 120)
             res['roofline_c5']['note'] = ('cache-free size (5.2 GB per launch); at this size the kernel\'s own copy-only mode reaches 5.77 TB/s '
                                           'and a torch device copy 4.94 TB/s (profiles/r02_pmc_lbs/SUMMARY.txt)')
             res['roofline']['note'] = ('the metric\'s batch (32 x 60) on 4 rotating operand sets = streamed from / to HBM; cache_warm_single_set = the '
@@ -710,8 +764,9 @@ def run(args):
             res['cpu_baseline'] = cpu_baseline(npz, gpu_eval)
             res['parity'] = res['cpu_baseline'].pop('parity')
         # the contract's keys first (a reader that truncates the line keeps them), the detailed side measurements after
-        head = ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
-                'data', 'config', 'roofline', 'cpu_baseline', 'parity', 'outer_iters_per_sec', 'smpl_verts_per_sec', 'closure_mode', 'strong', 'rccl']
+        head = ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'strong_value', 'strong_ms_per_step',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'parity', 'outer_iters_per_sec', 'smpl_verts_per_sec', 'closure_mode',
+                'strong', 'c5_weak', 'rccl']
         res = {**{k: res[k] for k in head if k in res}, **{k: v for k, v in res.items() if k not in head}}
         line = json.dumps(res)
     else:

@@ -8,7 +8,7 @@ import os
 import sys
 
 out = sys.argv[1]
-V, N = 6890, 1920
+V, N = 6890, int(sys.argv[2]) if len(sys.argv) > 2 else 1920
 ALG = N * (V * 12 * 2 + 52 * 48 + 12)        # v_posed in + verts out + A + transl, bytes per launch
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
@@ -29,6 +29,20 @@ r = rows.get('lbs_skin', {})
 if 'FETCH_SIZE' in r and 'WRITE_SIZE' in r:
     fe, wr = sum(r['FETCH_SIZE']) / len(r['FETCH_SIZE']), sum(r['WRITE_SIZE']) / len(r['WRITE_SIZE'])
     cal = rows.get('copy', {})
+    # machine-readable record for bench.py (roofline.traffic): bytes per launch + the fingerprint of the kernel source it was measured on
+    try:
+        import json
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        recf = os.path.join(out, 'traffic.json')
+        rec = json.load(open(recf)) if os.path.exists(recf) else {'launches': []}
+        rec['kernel_fingerprint'] = bench.lbs_kernel_fingerprint()
+        rec['how'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over rotating operand sets; FETCH x 2 (gfx950 wide-read correction) + WRITE, KiB'
+        rec['launches'] = [e for e in rec['launches'] if e.get('frames') != N] + [
+            {'frames': N, 'fetch_kib': round(fe, 1), 'write_kib': round(wr, 1), 'hbm_bytes': int((2 * fe + wr) * 1024), 'algorithmic_bytes': ALG}]
+        json.dump(rec, open(recf, 'w'), indent=1)
+    except Exception as e:          # the summary itself must not fail on this
+        print('traffic.json not written:', e)
     print(f'lbs_skin HBM traffic per launch: FETCH_SIZE {fe:.1f} KiB x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE {wr:.1f} KiB'
           f' = {(2 * fe + wr) * 1024 / 1e6:.1f} MB; algorithmic {ALG / 1e6:.1f} MB -> ratio {(2 * fe + wr) * 1024 / ALG:.3f}')
     if 'FETCH_SIZE' in cal and 'WRITE_SIZE' in cal:
