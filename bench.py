@@ -278,6 +278,35 @@ def skin_roofline(dev, npz, N=B_SEQ * T_SEQ, rotate=1):
             'bytes_per_launch': nbytes, 'frames_per_launch': N}
 
 
+def skin_ceilings(dev, npz, roof):
+    """What the same bytes cost WITHOUT the skinning arithmetic, measured in the same run on the same rotating operand sets:
+    (i) the kernel's own copy-only mode (ha_tune_set skin_variant 13: identical access geometry, weights still loaded, the LDS
+    transposition kept, the bone gather and the blend dropped) and (ii) a plain device copy of the v_posed array (torch).  The 8 TB/s
+    in `peak` is the HBM3E spec; these are what a read + write stream reaches on this box."""
+    from humor_amd import _lib
+    lib = _lib.get_lib()
+    lib.call('ha_tune_set', b'skin_variant', 13)
+    try:
+        co = skin_roofline(dev, npz, rotate=roof['operand_sets'])
+    finally:
+        lib.call('ha_tune_set', b'skin_variant', -1)
+    N = roof['frames_per_launch']
+    srcs = [torch.randn(N * V * 3, device=dev) for _ in range(roof['operand_sets'])]
+    dsts = [torch.empty(N * V * 3, device=dev) for _ in range(roof['operand_sets'])]
+    st = {'i': 0}
+
+    def cp():
+        k = st['i'] % len(srcs)
+        st['i'] += 1
+        dsts[k].copy_(srcs[k])
+    ms = time_events(cp, iters=48, warm=6)
+    cp_gbs = 2 * N * V * 12 / (ms * 1e-3) / 1e9
+    return {'kernel_copy_only_mode_gbs': co['achieved'], 'frac_of_kernel_copy_only_mode': round(roof['achieved'] / co['achieved'], 4),
+            'device_copy_gbs': round(cp_gbs, 1), 'frac_of_device_copy': round(roof['achieved'] / cp_gbs, 4),
+            'note': 'profiles/r04_lbs/README.txt: why the gap to the copy-only mode is the LDS return path (192 B of bone matrices per vertex), and the '
+                    'weight-stationary / software-pipelined form that was tried and lost'}
+
+
 def dense_smpl_ms(dev, npz):
     from humor_amd import synth
     from humor_amd.body_model import BodyModel
@@ -705,6 +734,7 @@ def run(args):
         # lines between two uses of any line); the single-set (Infinity-Cache-assisted) figure of rounds 1-2 is kept beside it
         roof = skin_roofline(dev, npz, rotate=4)
         roof['cache_warm_single_set'] = {k: v for k, v in skin_roofline(dev, npz, rotate=1).items() if k in ('achieved', 'frac', 'avg_launch_us')}
+        roof['ceilings'] = skin_ceilings(dev, npz, roof)
         ms_dense, ms_dense_fb = dense_smpl_ms(dev, npz)
         res = {
             'metric': 'fitting closure evaluations/s (stage-3 objective fwd+bwd), batch=32 seq=60 per GPU',

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """LBS skinning kernel at the metric's batch (N = 1920) on rotating operand sets (HBM figure), launch variants side by side:
 ha_tune_set("skin_variant", v): bits 0-1 waves per block 4 << b, +4 non-temporal stores, 13 = the kernel's copy-only mode.
-usage: skin_rotating_ab.py [N] [sets]"""
++32 = the weight-stationary form (bit 0: 8 waves per block, upper bits (>> 6): pairs per block).
+usage: skin_rotating_ab.py [N] [sets] [variants, comma separated]"""
 import os
 import sys
 
@@ -19,7 +20,7 @@ def main():
     npz = synth.write_smplh_npz('/tmp/model_sra.npz', seed=0)
     lib = _lib.get_lib()
     for rnd in range(2):
-        for v in (-1, 4, 5, 6, 1, 13):
+        for v in ([int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else (-1, 4, 5, 6, 1, 13)):
             lib.call('ha_tune_set', b'skin_variant', v)
             r = bench.skin_roofline(dev, npz, N=N, rotate=sets)
             print(f'round {rnd} variant {v:3d}: {r["avg_launch_us"]:7.2f} us  {r["achieved"]:7.1f} GB/s  {r["frac"]:.3f}')
