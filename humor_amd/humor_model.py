@@ -231,6 +231,23 @@ class HumorModel(nn.Module):
         self.smpl_batch_size = model_smpl_batch_size
         self._lib = _lib_override
         self._net_handles = {}
+        self._plists = {}           # parameter lists by sub-network name (None = all): walking the module tree costs ~0.15 ms per roll_out
+
+    def _params_of(self, name=None):
+        """The parameters of sub-network `name` (all when None) as a cached list.  Module._apply (.to / .cuda / .float) and
+        load_state_dict may replace parameter objects: both reset the cache."""
+        lst = self._plists.get(name)
+        if lst is None:
+            lst = self._plists[name] = list((self if name is None else getattr(self, name)).parameters())
+        return lst
+
+    def _apply(self, fn, *args, **kwargs):
+        self._plists = {}
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._plists = {}
+        return super().load_state_dict(*args, **kwargs)
 
     # ------------------------------------------------------------------------------------------------
     # single-step API (off the hot path; the prior / posterior MLPs run through ha_mlp_* on a HIP device)
@@ -242,12 +259,13 @@ class HumorModel(nn.Module):
         on_dev = x.is_cuda or (self._lib is not None and self._lib.emulator)
         # the fused path snapshots the weights and returns only dL/dx: it serves the frozen-network uses (fitting, inference).
         # A caller that needs weight gradients (a training step whose KL term comes from infer()) gets the module's own forward.
-        needs_param_grad = torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())
+        plist = self._params_of(name)
+        needs_param_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
         if not on_dev or net.skip_input_idx is not None or needs_param_grad:
             return net(x)
         from .mlp import humor_mlp
         lib = self._lib if self._lib is not None else _lib.get_lib()
-        ver = tuple(p._version for p in net.parameters())
+        ver = tuple(p._version for p in plist)
         key = (name, x.device.type, x.device.index or 0)
         cached = self._net_handles.get(key)
         if cached is None or cached[0] != ver:
@@ -400,7 +418,7 @@ class HumorModel(nn.Module):
             index = 0
         else:
             raise _lib.HumorAmdError('HumorModel.roll_out runs on the GPU only (no CPU fallback): move the model inputs to a HIP device')
-        ver = tuple(p._version for p in self.parameters())
+        ver = tuple(p._version for p in self._params_of())
         key = (device.type, index)
         cached = self._net_handles.get(key)
         if cached is None or cached[0] != ver:
