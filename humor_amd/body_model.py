@@ -123,8 +123,12 @@ class _SmplFunction(torch.autograd.Function):
             # algo 0 (auto) resolved here as ha_smpl_forward does (MFMA blend + streaming skinning when the model allows it), so that
             # the backward knows whether v_posed / A were materialised
             algo = cfg['algo'] if cfg['algo'] != 0 else (2 if (h.info(3) <= 4 and h.V >= 1024) else 1)
+            if algo == 2 and cfg['algo'] == 0 and not any(ctx.needs_input_grad[:3]) and h.J <= 53 and N >= cfg.get('fused_min_frames', 4096):
+                # forward-only call (no input requires a gradient): the blend GEMM skins in its epilogue, v_posed -- the dense adjoint's
+                # input -- is never written (ha_smpl_forward algo 3).  A draw with blend + lbs_skin at N = 1920, +6 % at N = 30720 (smpl.hip).
+                algo = 3
             lib.call('ha_smpl_forward', h.ptr, 0, N, cfg['n_active'], _lib.ptr(pose), _lib.ptr(betas), _lib.ptr(transl),
-                     _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(A), _lib.ptr(ws_v), _lib.ptr(ws_c), algo, st)
+                     _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(A), _lib.ptr(ws_v) if algo != 3 else None, _lib.ptr(ws_c), algo, st)
             if n_sel:
                 joints = torch.cat([joints, verts.index_select(1, cfg['selector_t'])], dim=1)
             v_out = verts
@@ -227,6 +231,8 @@ class BodyModel(nn.Module):
         self.bm_path = bm_path
         self._lib = _lib_override
         self._algo = algo
+        # forward-only dense calls of at least this many frames take the fused blend + skin kernel (ha_smpl_forward algo 3)
+        self.fused_min_frames = 4096
         self._handles = {}
         self._sel_cache = {}
         self._zero_cache = {}
@@ -305,7 +311,7 @@ class BodyModel(nn.Module):
         else:
             subset_all = self._selector + self._subset
             cfg = dict(mode='subset', subset_all=subset_all, slot_all=h.subset_slot(subset_all))
-        cfg.update(handle=h, n_active=n_active, selector=self._selector, algo=self._algo)
+        cfg.update(handle=h, n_active=n_active, selector=self._selector, algo=self._algo, fused_min_frames=self.fused_min_frames)
         if self._selector:
             key = str(ref.device)
             if key not in self._sel_cache:

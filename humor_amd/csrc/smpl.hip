@@ -1264,6 +1264,124 @@ __global__ __launch_bounds__(64 * NW) void lbs_skin_wave_kernel(const float* __r
 }
 
 // ===================================================================================================
+// dense path, forward-only callers: pose-blend GEMM with the skinning in its epilogue (ha_smpl_forward algo 3; round 4).
+// v_posed is never materialised: 2 x 159 MB of HBM traffic less per 1920-frame call, and the skinning's LDS gather (192 B of bone
+// matrices per vertex) runs under another wave's MFMA chain instead of under an HBM stream.
+//   * round 3's attempt staged A for 64 frames x 128 vertices per block (160 KB of A for 98 KB of output) and lost.  Here a block owns
+//     ONE tile of 32 frames -- their A matrices (78 KB) are loaded once and stay in LDS -- and walks over 27 vertex tiles (864 vertices
+//     per block, 6912 per frame tile and XCD): A traffic is 3 % of the output;
+//   * block b runs on XCD b % 8 and owns vertex-tile group b % 8: an XCD's share of the blend matrix (2.1 MB) stays in its 4 MB L2;
+//   * two blocks per CU (2 x 80 384 B of LDS): one wave's epilogue (16 skin_one per lane: LDS + VALU) overlaps the other's MFMAs;
+//   * accumulator register i of lane l is vertex l & 31, frame slot (i & 3) + 8 (i >> 2) + 4 (l >> 5); x / y / z are the three column
+//     tiles, so the epilogue is skin_one on registers (bit-identical to blend + lbs_skin) and lanes 0..31 store 384 contiguous bytes.
+// Measured (round 4, tools/dense_fwd_timing.py + rocprofv3): N = 1920: 240 us against 184 (blend) + 54 (lbs_skin) -- a draw, the epilogues of two
+// waves per SIMD do not hide completely; N = 30720: 3.32 ms against 3.52 (+6 %).  An 8-waves-per-block form (one tile per wave, 128
+// registers) spills.  BodyModel therefore takes this path for forward-only calls of >= 4096 frames.
+// ===================================================================================================
+constexpr int kFusedTilesPerBlock = 27;      // vertex tiles of 32 per block (8 groups cover Vpad = 6912)
+
+template <int NWB, bool PAIR>
+__global__ __launch_bounds__(64 * NWB) HA_WAVES_PER_EU(NWB / 2, NWB / 2) void pose_blend_skin_kernel(
+    const float* __restrict__ coeffQ, int Npad, int KQ, int KQfull, const float* __restrict__ Pd_m, int N, int V, int n_vt, int n_groups,
+    const float* __restrict__ A, const float* __restrict__ transl, const float4* __restrict__ w4, const uint32_t* __restrict__ idx4,
+    float* __restrict__ verts, int J) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // A of the tile's 32 frames [32][J * 12] | transl [32][4]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = blockIdx.x % n_groups, ft = blockIdx.x / n_groups;
+  const int f0 = ft * 32;
+  const int fstride = J * 12, q_per = J * 3;                       // floats / 16-byte quads per frame
+  float* s_T = smem + 32 * fstride;
+  // ---- the frame tile's A matrices and translations -> LDS (frames beyond N: the last frame's, never stored) ----
+  for (int e = threadIdx.x; e < 32 * q_per; e += 64 * NWB) {
+    const int slot = e / q_per, q = e - slot * q_per;
+    const int f = f0 + slot < N ? f0 + slot : N - 1;
+    reinterpret_cast<vf4*>(smem + slot * fstride)[q] = reinterpret_cast<const vf4*>(A + (size_t)f * fstride)[q];
+  }
+  if (threadIdx.x < 96) {
+    const int slot = threadIdx.x / 3, c = threadIdx.x - 3 * slot;
+    const int f = f0 + slot < N ? f0 + slot : N - 1;
+    s_T[slot * 4 + c] = transl ? transl[(size_t)f * 3 + c] : 0.f;
+  }
+  __syncthreads();
+  const bool hi = lane >= 32;
+  const int hl = lane >> 5;
+  const float4* a_ptr = reinterpret_cast<const float4*>(coeffQ) + f0 + (lane & 31);
+  // A wave works on TWO vertex tiles at a time (tiles vt and vt + 4: 96 accumulators): per four k-pairs 2 coefficient loads and 6
+  // blend-matrix loads feed 24 MFMAs -- the operand-to-MFMA ratio of the unfused kernel (one tile: 5 loads per 12 MFMAs, measured
+  // at 45 % of the fp32 MFMA rate).  kFusedTilesPerBlock = 27 = 3 x 8 + 3: three pairs per wave, the last three tiles single.
+  const int vt_end = (grp + 1) * kFusedTilesPerBlock < n_vt ? (grp + 1) * kFusedTilesPerBlock : n_vt;
+  auto epilogue = [&](int vt, const f32x16 (&acc)[3]) {
+    const int v = vt * 32 + (lane & 31);
+    const bool vok = v < V;
+    const float4 wv = vok ? w4[v] : float4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t id = vok ? idx4[v] : 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int slot = (i & 3) + 8 * (i >> 2) + 4 * hl;
+      float ox, oy, oz;
+      skin_one(smem, J, slot, wv, id, acc[0][i], acc[1][i], acc[2][i], s_T[slot * 4], s_T[slot * 4 + 1], s_T[slot * 4 + 2], ox, oy, oz);
+      if (vok && f0 + slot < N) {
+        float* dst = verts + ((size_t)(f0 + slot) * V + v) * 3;
+        dst[0] = ox; dst[1] = oy; dst[2] = oz;
+      }
+      if ((i & 1) == 1) HA_SCHED_FENCE();          // (two frames' gathers in flight, not sixteen: the accumulators hold the registers)
+    }
+  };
+  for (int vt = grp * kFusedTilesPerBlock + wave; vt < vt_end; vt += (PAIR ? 2 : 1) * NWB) {
+    const bool pair = PAIR && vt + NWB < vt_end;                     // (wave-uniform)
+    const float4* b_ptr = reinterpret_cast<const float4*>(Pd_m) + (size_t)vt * KQfull * 192 + lane;
+    const size_t b_next = (size_t)NWB * KQfull * 192;                // float4 offset of tile vt + NWB
+    f32x16 acc[PAIR ? 2 : 1][3];
+#pragma unroll
+    for (int t2 = 0; t2 < (PAIR ? 2 : 1); ++t2)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t2][c][i] = 0.f;
+    if constexpr (PAIR) if (pair) {
+#pragma unroll 2
+      for (int kq = 0; kq < KQ; ++kq) {
+        // coefficient quads 2 kq and 2 kq + 1 = k-pairs 4 kq .. 4 kq + 3
+        const float4 aq0 = a_ptr[(size_t)(2 * kq) * Npad], aq1 = a_ptr[(size_t)(2 * kq + 1) * Npad];
+        const float4 b0 = b_ptr[(size_t)kq * 192], b1 = b_ptr[(size_t)kq * 192 + 64], b2 = b_ptr[(size_t)kq * 192 + 128];
+        const float4 c0 = b_ptr[b_next + (size_t)kq * 192], c1 = b_ptr[b_next + (size_t)kq * 192 + 64], c2 = b_ptr[b_next + (size_t)kq * 192 + 128];
+        const float a0[4] = {hi ? aq0.y : aq0.x, hi ? aq0.w : aq0.z, hi ? aq1.y : aq1.x, hi ? aq1.w : aq1.z};
+        const float bb[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+        const float cc[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[3 * j], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[3 * j + 1], acc[0][1], 0, 0, 0);
+          acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[3 * j + 2], acc[0][2], 0, 0, 0);
+          acc[PAIR ? 1 : 0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], cc[3 * j], acc[PAIR ? 1 : 0][0], 0, 0, 0);
+          acc[PAIR ? 1 : 0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], cc[3 * j + 1], acc[PAIR ? 1 : 0][1], 0, 0, 0);
+          acc[PAIR ? 1 : 0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], cc[3 * j + 2], acc[PAIR ? 1 : 0][2], 0, 0, 0);
+        }
+      }
+      epilogue(vt, acc[0]);
+      epilogue(vt + NWB, acc[PAIR ? 1 : 0]);
+      continue;
+    }
+    {
+#pragma unroll 2
+      for (int kq = 0; kq < KQ; ++kq) {
+        const float4 aq0 = a_ptr[(size_t)(2 * kq) * Npad], aq1 = a_ptr[(size_t)(2 * kq + 1) * Npad];
+        const float4 b0 = b_ptr[(size_t)kq * 192], b1 = b_ptr[(size_t)kq * 192 + 64], b2 = b_ptr[(size_t)kq * 192 + 128];
+        const float a0[4] = {hi ? aq0.y : aq0.x, hi ? aq0.w : aq0.z, hi ? aq1.y : aq1.x, hi ? aq1.w : aq1.z};
+        const float bb[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[3 * j], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[3 * j + 1], acc[0][1], 0, 0, 0);
+          acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[3 * j + 2], acc[0][2], 0, 0, 0);
+        }
+      }
+      epilogue(vt, acc[0]);
+    }
+  }
+}
+
+// ===================================================================================================
 // dense backward (all V vertices carry a gradient: point-cloud / chamfer terms).  The wave-per-frame adjoint re-blends every
 // vertex and walks the blend matrix twice per frame (2 x 18 MB of L2 traffic per frame at V = 6890); here the vertex phase
 // is three batched kernels over all frames, and smpl_frame_bwd_kernel only finishes the kinematic chain:
@@ -1645,10 +1763,15 @@ extern "C" int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_ac
   int rc = check_common("ha_smpl_forward", m, slot, N, n_active);
   if (rc != HA_OK) return rc;
   HA_REQUIRE(pose && betas, "ha_smpl_forward: pose and betas are required");
-  HA_REQUIRE(algo >= 0 && algo <= 2, "ha_smpl_forward: unknown algo %d", algo);
-  const bool dense_ok = slot == 0 && m->nnz <= 4 && m->V >= kSkinMinVerts && ws_vposed && ws_coeff && A_out;
+  HA_REQUIRE(algo >= 0 && algo <= 3, "ha_smpl_forward: unknown algo %d", algo);
+  const bool fused_ok = slot == 0 && m->nnz <= 4 && m->V >= kSkinMinVerts && ws_coeff && A_out;
+  const bool dense_ok = fused_ok && ws_vposed;
   if (algo == 2 && !dense_ok) {
     set_error("ha_smpl_forward: algo 2 needs slot 0, <=4 skinning influences, V>=%d and the A/vposed/coeff workspaces", kSkinMinVerts);
+    return HA_ERR_INVALID_ARG;
+  }
+  if (algo == 3 && !(fused_ok && verts)) {
+    set_error("ha_smpl_forward: algo 3 needs slot 0, <=4 skinning influences, V>=%d, verts and the A/coeff workspaces", kSkinMinVerts);
     return HA_ERR_INVALID_ARG;
   }
   if (algo == 0) algo = (dense_ok && verts) ? 2 : 1;
@@ -1668,7 +1791,7 @@ extern "C" int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_ac
     HA_LAUNCH_CHECK();
     return HA_OK;
   }
-  // algo 2: joints/A/coefficients by the frame kernel, then MFMA blend, then streaming skinning
+  // algo 2 / 3: joints / A / coefficients by the frame kernel, then MFMA blend, then streaming skinning (2) or the skinning in the blend's epilogue (3)
   p.verts = nullptr;
   p.nchunks = 0;
   p.coeffT = ws_coeff;
@@ -1681,6 +1804,23 @@ extern "C" int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_ac
     const int n_vtg = ceil_div(n_vt, 4);
     const int n_vtg8 = ceil_div(n_vtg, 8) * 8;
     const int KQ = (p.Kc + 7) / 8;      // quads of k-pairs
+    if (algo == 3) {
+      // blend + skin in one kernel (forward-only callers: v_posed, the adjoint's input, is never written)
+      const int n_groups = ceil_div(n_vt, kFusedTilesPerBlock);
+      const size_t lds_f = (size_t)(32 * m->J * 12 + 128) * sizeof(float);
+#ifndef HA_SIMT_EMU
+      static bool attr_set = false;          // (more than the default 64 KB of dynamic LDS)
+      if (!attr_set) {
+        HA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pose_blend_skin_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_set = true;
+      }
+#endif
+      HA_REQUIRE(lds_f <= 80 * 1024, "ha_smpl_forward: algo 3 keeps the A matrices of 32 frames in LDS (J <= 53)");
+      hipLaunchKernelGGL((pose_blend_skin_kernel<4, true>), dim3(n_groups * (p.Npad / 32)), dim3(256), lds_f, st, ws_coeff, p.Npad, KQ,
+                           ceil_div(m->Kfull_pad / 2, 4), m->Pd_m, N, m->V, n_vt, n_groups, A_out, transl, m->w4, m->idx4, verts, m->J);
+      HA_LAUNCH_CHECK();
+      return HA_OK;
+    }
     hipLaunchKernelGGL(pose_blend_mfma_kernel, dim3(n_vtg8 * n_ft), dim3(256), 0, st, ws_coeff, p.Npad, KQ, ceil_div(m->Kfull_pad / 2, 4),
                        m->Pd_m, ws_vposed, N, m->V, n_vt, n_ft);
     HA_LAUNCH_CHECK();

@@ -116,3 +116,21 @@ def check_skin_variants(lib, npz, ds, device, N=3, variants=(5, 4, 6, 0, 1, 2), 
     assert (first.double() - ref).abs().max().item() < 2e-6 * scale
     for var, o in outs.items():
         assert torch.equal(o, first), f'skin variant {var} differs from variant {variants[0]}'
+
+
+def check_fused_forward(lib, npz, ds, N, device, seed=0, hands=False):
+    """Forward-only dense call (no input requires a gradient): BodyModel takes ha_smpl_forward algo 3 -- the pose-blend GEMM with the
+    skinning in its epilogue, v_posed never materialised.  Same arithmetic as blend + lbs_skin (algo 2): the vertices must be
+    bit-identical to the two-kernel path, and both within the forward tolerance of the oracle."""
+    inputs = {k: v.detach() for k, v in make_inputs(N, seed, device, hands).items()}
+    ref, _ = oracle_forward(ds, inputs, True)
+    bm = BodyModel(npz, num_betas=16, batch_size=N, use_vtx_selector=True, _lib_override=lib)
+    bm.fused_min_frames = 0                                               # (the default policy takes this path from 4096 frames on)
+    with torch.no_grad():
+        fused = bm(**inputs)                                              # algo 0 (auto) + nothing requires grad -> algo 3
+    two = BodyModel(npz, num_betas=16, batch_size=N, use_vtx_selector=True, algo=2, _lib_override=lib)(**inputs)
+    assert torch.equal(fused.v, two.v), (fused.v - two.v).abs().max().item()
+    assert torch.equal(fused.Jtr, two.Jtr)
+    dv = (fused.v.cpu() - ref.vertices.detach()).abs().max().item()
+    assert dv < FWD_TOL, dv
+    return dv

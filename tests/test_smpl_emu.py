@@ -47,6 +47,12 @@ def test_no_cpu_fallback(smplh_npz):
         bm(root_orient=torch.zeros(1, 3), pose_body=torch.zeros(1, 63), betas=torch.zeros(1, 16), trans=torch.zeros(1, 3))
 
 
+def test_emu_fused_blend_skin_forward(emu_lib, smplh_npz, smplh_struct):
+    """ha_smpl_forward algo 3 (forward-only dense calls) on the emulator: bit-identical to blend + lbs_skin; a frame count that is not a
+    multiple of the 32-frame tile."""
+    print('fused dense forward vs oracle', SC.check_fused_forward(emu_lib, smplh_npz, smplh_struct, N=3, device=CPU))
+
+
 def test_emu_skin_kernel_variants(emu_lib, smplh_npz, smplh_struct):
     SC.check_skin_variants(emu_lib, smplh_npz, smplh_struct, torch.device('cpu'), N=2, variants=(5, 4, 2))
 

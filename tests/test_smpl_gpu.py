@@ -13,6 +13,12 @@ def dev():
     return torch.device('cuda:0')
 
 
+@pytest.mark.parametrize('N,hands', [(1, False), (33, False), (64, True), (130, False), (1920, False)])
+def test_fused_blend_skin_forward(gpu_lib, smplh_npz, smplh_struct, dev, N, hands):
+    """Forward-only dense calls take the fused blend + skin kernel (ha_smpl_forward algo 3): bit-identical to the two-kernel path."""
+    print('fused dense forward vs oracle', SC.check_fused_forward(gpu_lib, smplh_npz, smplh_struct, N=N, device=dev, seed=N, hands=hands))
+
+
 @pytest.mark.parametrize('N', [1, 2, 7, 64, 130])
 @pytest.mark.parametrize('algo', [1, 2])
 def test_dense_forward_backward(gpu_lib, smplh_npz, smplh_struct, dev, N, algo):

@@ -21,10 +21,12 @@ def main():
         root, body, trans = synth.smooth_pose_sequence(B, 60, seed=1)
         args = dict(root_orient=root.reshape(N, 3).to(dev), pose_body=body.reshape(N, 63).to(dev), trans=trans.reshape(N, 3).to(dev),
                     betas=torch.randn(N, 16, device=dev))
-        bm = BodyModel(npz, num_betas=16, use_vtx_selector=True)
-        with torch.no_grad():
-            ms = bench.time_events(lambda: bm(**args), iters=20, warm=10)
-        print(f'N={N}: dense SMPL forward {ms:.4f} ms = {N * 6890 / ms / 1e6:.1f} G verts/s', flush=True)
+        for name, algo in (('auto: fused blend + skin (algo 3)', 0), ('blend, then lbs_skin (algo 2)', 2)):
+            bm = BodyModel(npz, num_betas=16, use_vtx_selector=True, algo=algo)
+            bm.fused_min_frames = 0
+            with torch.no_grad():
+                ms = bench.time_events(lambda: bm(**args), iters=20, warm=10)
+            print(f'N={N}: dense SMPL forward, {name}: {ms:.4f} ms = {N * 6890 / ms / 1e6:.1f} G verts/s', flush=True)
 
 
 if __name__ == '__main__':
