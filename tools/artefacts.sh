@@ -1,7 +1,7 @@
 # Artefact session of a round: GPU tests, smoke, bench (+CPU baseline, parity), rocprofv3 --kernel-trace --stats of the same bench command.
 # usage (on the GPU box, via gpurun):  bash tools/artefacts.sh r03_final [skip-tests]
 R=$GRAFT_REPO_ROOT
-RUN=${1:-r03_final}
+RUN=${1:-r04_mid}
 OUT=$R/gpurun_out/$RUN
 rm -rf $OUT && mkdir -p $OUT
 cd $R

@@ -59,13 +59,18 @@ def measure(B=256, T=120, dev=None):
     def chain_only():
         lib.call('ha_smpl_forward', h.ptr, 0, N, 22, p(pose), p(betas), p(tr), None, p(joints), p(A), p(ws_v), p(ws_c), 2, st)
     # sustained figures: the first ~20 launches at this size ride a power-management transient (tools/skin_jitter.py)
+    def fused():          # forward-only callers: blend + skin in one kernel, v_posed never written (ha_smpl_forward algo 3)
+        lib.call('ha_smpl_forward', h.ptr, 0, N, 22, p(pose), p(betas), p(tr), p(verts), p(joints), p(A), None, p(ws_c), 3, st)
     ms_dense, ms_skin, ms_chain = ev(dense, 10, 10), ev(skin, 20, 20), ev(chain_only, 10, 3)
+    ms_fused = ev(fused, 10, 10)
     ms_blend = ms_dense - ms_skin - ms_chain
     Kc = NB + 1 + 21 * 9
     blend_flops = 2.0 * N * Kc * V * 3
     skin_bytes = N * (V * 24 + J * 48)
     res = {'config': f'C5 B={B} T={T} N={N}', 'smpl_dense_fwd_ms': round(ms_dense, 3),
            'smpl_verts_per_sec': round(N * V / (ms_dense * 1e-3), 1),
+           'smpl_dense_fwd_fused_ms': round(ms_fused, 3), 'smpl_verts_per_sec_fused_forward_only': round(N * V / (ms_fused * 1e-3), 1),
+           'fused_blend_skin_TFLOPs': round(2.0 * N * (NB + 1 + 21 * 9) * V * 3 / (ms_fused - ms_chain) / 1e9, 1),
            'lbs_skin': {'ms': round(ms_skin, 3), 'GBps': round(skin_bytes / ms_skin / 1e6, 1), 'frac_hbm': round(skin_bytes / ms_skin / 1e6 / HBM_PEAK, 4)},
            'pose_blend_mfma': {'ms_est': round(ms_blend, 3), 'TFLOPs': round(blend_flops / ms_blend / 1e9, 1),
                                'frac_fp32_mfma': round(blend_flops / ms_blend / 1e9 / MFMA_F32_PEAK, 4)},
