@@ -34,7 +34,7 @@ const char* ha_last_error(void);
 int ha_abi_version(void);
 /* Writes the device's gcnArchName (e.g. "gfx950:sramecc+:xnack-") into buf. */
 int ha_device_arch(int device, char* buf, int buflen);
-/* Development knobs for kernel launch variants (A/B measurements), process-wide: "skin_variant" (-1 = auto), "layer_spb" (K-slices per block of the roll-out layer kernel, 0 = default), "layer_finish" (0 never / 1 auto / 2 always use the GroupNorm finishing pass), "gemm_rm" (row tiles per wave of the batched prior GEMM: 0 by size / 1 / 2). */
+/* Development knobs for kernel launch variants (A/B measurements), process-wide: "skin_variant" (-1 = auto), "layer_spb" (K-slices per block of the roll-out layer kernel, 0 = default), "layer_finish" (0 never / 1 auto / 2 always use the GroupNorm finishing pass), "gemm_rm" (row tiles per wave of the batched prior GEMM: 0 by size / 1 / 2), "rollout_persist" / "rollout_persist_bwd" (0 = launch chain; 1 = persistent kernels, 3 = with write-through publishes), "rollout_persist_inject" (test hook: 1 = the next persistent forwards drop one CU of team 0, so that the failure path -- NaN results, error word -- can be exercised). */
 int ha_tune_set(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------
@@ -72,7 +72,9 @@ int ha_smpl_model_define_subset(ha_smpl_model* m, int slot, const int32_t* ids, 
  * optional workspace outputs (NULL to skip), needed by the tiled dense path and for debugging:
  *   A_out  [N, J, 12]  relative joint transforms (3x4 row-major)
  * `algo`: 0 = auto, 1 = wave-per-frame VALU kernel, 2 = tiled MFMA pose-blend + streaming skinning
- *         (slot 0 only; needs A_out, ws_vposed [N,V,3](+4) and ws_coeff [Kc, Npad] sized by ha_smpl_workspace). */
+ *         (slot 0 only; needs A_out, ws_vposed [N,V,3](+4) and ws_coeff [Kc, Npad] sized by ha_smpl_workspace),
+ *         3 = the pose-blend GEMM with the skinning in its epilogue (forward-only callers: v_posed -- the dense adjoint's input --
+ *         is never written; slot 0, needs verts, A_out and ws_coeff, ws_vposed may be NULL; J <= 53; same bits as algo 2). */
 int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_active_joints,
                     const float* pose, const float* betas, const float* transl,
                     float* verts, float* joints, float* A_out,
@@ -198,7 +200,8 @@ int ha_humor_net_set_option(ha_humor_net* net, const char* key, int value);
 
 /* Persistent forward (ha_tune_set "rollout_persist" != 0, B <= 32): state of the weight-stationary one-launch forward of this
  * network.  *available = 1 when the network / device qualify and no launch has reported a failure; *error_word = the kernel's
- * host-mapped error word (0 = none; 0x1xx an XCD received more than its 32 blocks, 0x2xx a team member's bounded wait ran out),
+ * host-mapped error word (0 = none; 0x1xx / 0x3xx an XCD received more than its 32 blocks (forward / adjoint), 0x2xx / 0x4xx a team's
+ * bounded wait ran out (forward / adjoint): that team's output rows -- world states; dL/dpast_in0 and dL/dz -- are filled with NaN),
  * meaningful once the stream of the last roll-out has been synchronised; *launches = persistent forwards issued so far for this
  * network in the low 32 bits, persistent adjoints in the high 32 bits.  After a failure the library uses the launch chain. */
 int ha_humor_persist_status(const ha_humor_net* net, int* available, unsigned int* error_word, int64_t* launches);
