@@ -47,6 +47,7 @@ def test_no_cpu_fallback(smplh_npz):
         bm(root_orient=torch.zeros(1, 3), pose_body=torch.zeros(1, 63), betas=torch.zeros(1, 16), trans=torch.zeros(1, 3))
 
 
+@pytest.mark.slow          # (two minutes on the emulator: 216 vertex tiles of MFMAs; the GPU tier checks the same bit-equality at five sizes)
 def test_emu_fused_blend_skin_forward(emu_lib, smplh_npz, smplh_struct):
     """ha_smpl_forward algo 3 (forward-only dense calls) on the emulator: bit-identical to blend + lbs_skin; a frame count that is not a
     multiple of the 32-frame tile."""
