@@ -75,6 +75,7 @@ class FusedFit(torch.autograd.Function):
         a.terms, a.loss, a.partial = base + ng * esz, base + (ng + NT) * esz, base + (ng + NT + 1) * esz
         lib.call('ha_fit_loss', C.byref(a), _lib.stream_ptr(ref))
         ctx.flat, ctx.views, ctx.ng = flat, views, ng
+        ctx.prior_grad_hook = spec.get('prior_grad_hook')
         ctx.set_materialize_grads(False)
         loss, terms = flat[ng + NT], flat[ng:ng + NT]
         ctx.mark_non_differentiable(terms)
@@ -86,6 +87,10 @@ class FusedFit(torch.autograd.Function):
             return (None, None) + (None,) * len(DIFF_INPUTS)
         scaled = ctx.flat[:ctx.ng] * g_loss           # one launch for all inputs
         out = [None if v is None else scaled[v[0]:v[0] + v[1]].view(v[2]) for v in ctx.views]
+        if ctx.prior_grad_hook is not None:
+            # dL/d(prior_mu, prior_var) are complete here: the prior network's adjoint may start (HumorModel.mark_prior_grad)
+            names = [n for n, _ in DIFF_INPUTS]
+            ctx.prior_grad_hook(out[names.index('prior_mu')], out[names.index('prior_var')])
         return (None, None) + tuple(out)
 
 

@@ -109,6 +109,7 @@ class FittingLoss(nn.Module):
         # (humor_amd/csrc/fitloss.hip, fit_kernels.FusedFit) whenever the predictions live on the GPU; the term-by-term
         # PyTorch evaluation below remains for the cases the kernel does not cover (cross-batch `prev_batch_overlap_res`).
         self.fused = fused
+        self.prior_grad_hook = None        # callable(g_prior_mu, g_prior_var) run when the fused loss has produced them (MotionOptimizer)
         self._lib = _lib_override
         self.all_stage_loss_weights = loss_weights
         self.cur_stage_idx = 0
@@ -300,6 +301,8 @@ class FittingLoss(nn.Module):
                 if use_f:
                     t['floor'] = c(cam['floor_plane'])
         spec['w'] = w
+        if cond_prior is not None and self.prior_grad_hook is not None:
+            spec['prior_grad_hook'] = self.prior_grad_hook
         loss, terms = FK.FusedFit.apply(lib, spec, *[t[n] for n, _ in FK.DIFF_INPUTS])
         stats = {FK.TERM_NAMES[k]: terms[k] for k in range(FK.NT) if w[k] != 0.0}
         stats.update(stats_extra)

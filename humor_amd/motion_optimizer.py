@@ -36,7 +36,7 @@ class MotionOptimizer():
                  robust_tuning_const=4.6851, joint2d_sigma=100, stage3_tune_init_state=True, stage3_tune_init_num_frames=15,
                  stage3_tune_init_freeze_start=30, stage3_tune_init_freeze_end=50, stage3_contact_refine_only=False,
                  use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs='auto', fused_loss=True, lbfgs='fused', fused_post=True, fused_pre=True, fused_vposer=True,
-                 rigid_cam_body=True):
+                 rigid_cam_body=True, defer_prior=False):
         B, T = batch_size, seq_len
         self.device = device
         self.batch_size, self.seq_len = B, T
@@ -72,6 +72,13 @@ class MotionOptimizer():
         # stage 3 evaluates the body model on the same pose and shape under two root trajectories (prior frame, camera frame):
         # the second evaluation as the rigid image of the first (ha_rigid_image_*) instead of a second SMPL forward + backward
         self.rigid_cam_body = bool(rigid_cam_body)
+        # stage 3, opt-in: the conditional prior's batched GEMMs (forward and adjoint, ~0.27 ms of a 1.8 ms evaluation at 32 x 60) on the
+        # library's side stream beside the SMPL evaluations and their adjoints (HumorModel.roll_out(defer_prior=True) / join_prior /
+        # mark_prior_grad) instead of in line between the decoder chain and them.  Bit-identical results, but MEASURED SLOWER on one
+        # MI355X (tools/defer_prior_ab.py: 1.823 ms in stream order, 1.908 forward on the side stream, 1.863 adjoint, 1.877 both): the
+        # GEMMs fill every CU, so the small kernels beside them wait for wave slots anyway (smpl_frame_fwd 19 -> 62 us, rigid_image
+        # 5 -> 33 us in the trace) and each cross-queue event costs more than the overlap returns.  Off by default.
+        self.defer_prior = bool(defer_prior)
         # VPoser decode (+ 6-D -> R -> axis-angle) / encode through ha_mlp_* instead of the module's ATen ops (humor_amd/mlp.py)
         self.fused_vposer = bool(fused_vposer)
         self._vposer_handle = None
@@ -130,6 +137,8 @@ class MotionOptimizer():
         self.fitting_loss = FittingLoss(loss_weights, self.init_motion_prior, self.smpl2op_map, OP_IGNORE_JOINTS, cam_f, cam_c,
                                         robust_loss_type, robust_tuning_const, joints2d_sigma=joint2d_sigma,
                                         use_chamfer=self.dense_smpl, fused=fused_loss, _lib_override=self.fit_bm._lib).to(device)
+        if motion_prior is not None and hasattr(motion_prior, 'mark_prior_grad'):
+            self.fitting_loss.prior_grad_hook = lambda g_mu, g_var: motion_prior.mark_prior_grad(g_mu, g_var) if self.defer_prior else None
 
     # ------------------------------------------------------------------------------------------------
     # small helpers
@@ -639,7 +648,8 @@ class MotionOptimizer():
         if tune_phase:
             latent_motion = latent_motion[:, :(n_init - 1)]
         rr, cam_rr = self.rollout_latent_motion(trans, root_orient, cur_body_pose, betas, local_prior_params, latent_motion,
-                                                return_prior=self.cond_prior, fit_gender=fit_gender, cam2prior=cam2prior, pre=pre)
+                                                return_prior=self.cond_prior, fit_gender=fit_gender, cam2prior=cam2prior, pre=pre,
+                                                defer_prior=self.defer_prior)
         # the reference encodes the rolled-out poses with VPoser on every evaluation (motion_optimizer.py:571) but only the pose
         # prior reads the result, and no stage-3 configuration weights it: skipped when its weight is zero (same loss value)
         pose_prior_on = self.fitting_loss.loss_weights['pose_prior'] > 0.0
@@ -666,6 +676,9 @@ class MotionOptimizer():
             self.fitting_loss.loss_weights['rgb_overlap_consist'] = 0.0
         halo = self._halo(cam_pred['verts3d'], betas, floor,
                           has_overlap and self.fitting_loss.loss_weights['rgb_overlap_consist'] > 0.0)
+        if self.defer_prior and rr.get('cond_prior') is not None:
+            # the conditional prior ran on the side stream beside the SMPL evaluations above; the loss is its first reader
+            self.motion_prior.join_prior(rr['cond_prior'][0])
         loss, stats = self.fitting_loss.motion_fit(obs, pred, cam_pred, nsteps, cond_prior=rr.get('cond_prior'),
                                                    init_motion_scale=init_motion_scale, halo=halo)
         loss = self.fitting_loss.add_next_side(loss, 'motion', cam_pred, halo)
@@ -765,7 +778,7 @@ class MotionOptimizer():
 
     def rollout_latent_motion(self, trans, root_orient, body_pose, betas, prior_opt_params, latent_motion, return_prior=False,
                               return_vel=False, fit_gender='neutral', use_mean=False, num_steps=-1, canonicalize_input=False,
-                              cam2prior=None, pre=None):
+                              cam2prior=None, pre=None, defer_prior=False):
         '''
         Initial SMPL state + latent sequence -> full SMPL sequence through the motion prior
         (motion_optimizer.py:876-1019).  Returns (prior-frame dict, camera-frame dict).
@@ -798,7 +811,8 @@ class MotionOptimizer():
             from .fit_kernels import RolloutPost
             from . import _lib as _libmod
             res = self.motion_prior.roll_out(past_in.unsqueeze(1), None, Tm1, z_seq=latent_motion, return_prior=return_prior,
-                                             canonicalize_input=canonicalize_input, return_world=True)
+                                             canonicalize_input=canonicalize_input, return_world=True,
+                                             defer_prior=defer_prior and return_prior)
             world, prior_out = res if return_prior else (res, None)
             c2p_R = cam2prior[0] if self.optim_floor else None
             c2p_t = cam2prior[1] if self.optim_floor else None

@@ -172,6 +172,9 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e =
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = hipStream_t(); return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { std::snprintf(p->gcnArchName, 64, "simt_emu"); return hipSuccess; }
 

@@ -271,3 +271,28 @@ def test_fit_pre_kernel_equals_op_chain(gpu_lib, dev, smplh_npz):
         if k != 'loss':
             e = (res[0][k] - res[1][k]).abs().max().item() / max(1.0, res[1][k].abs().max().item())
             assert e < 2e-4, (k, e)
+
+
+@pytest.mark.parametrize('B,T', [(4, 12), (32, 60)])
+def test_deferred_prior_equals_inline(gpu_lib, dev, smplh_npz, B, T):
+    """Stage-3 objective with the conditional prior on the library's side stream (ha_humor_rollout_forward_ex HA_ROLLOUT_DEFER_PRIOR,
+    ha_humor_prior_join, ha_humor_prior_grad_ready: forward beside the SMPL evaluations, adjoint beside their adjoints) against the same
+    objective with everything in stream order: the same kernels on the same data, so loss and gradients are bit-identical -- on every
+    one of several back-to-back evaluations (a missing join / a stale read would show as a difference that changes between repeats)."""
+    from oracle import closure_cases as CC
+    case = CC.make_case('rgb', B, T, seed=11)
+    ref = None
+    for defer in (False, True):
+        opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
+        opt.defer_prior = defer
+        for rep in range(1 if not defer else 6):
+            res = FC.eval_stage(opt, case, 2, dev)
+            if ref is None:
+                ref = {k: v.detach().clone() for k, v in res.items()}
+                continue
+            if defer:
+                for k in ref:
+                    assert torch.equal(ref[k], res[k].detach()), (k, rep, (ref[k] - res[k]).abs().max().item())
+    assert ref['g_latent_motion'].abs().max().item() > 0
+    n_fwd, n_bwd = opt.motion_prior.prior_side_stats(ref['loss'])
+    assert (n_fwd, n_bwd) == (6, 6), (n_fwd, n_bwd)      # the side-stream path was the one that ran

@@ -3,7 +3,12 @@
 utilisation they imply and the FLOP rate from SQ_INSTS_VALU_MFMA_MOPS_F32.   usage: pmc_mfma_summary.py <dir> [<dir> ...]
 
 MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration x shader clock).  Counter values are summed over the
-chip (all XCDs / SEs).  SQ_INSTS_VALU_MFMA_MOPS_F32 counts 512-FLOP units (MI355X_MICROARCH.md, "MFMA counters")."""
+chip (all XCDs / SEs).  SQ_INSTS_VALU_MFMA_MOPS_F32 counts 512-FLOP units (MI355X_MICROARCH.md, "MFMA counters").
+
+Effective clock (DVFS): SQ_BUSY_CYCLES is summed over the 32 shader engines; for a launch that keeps every SE busy from start to end
+(the big GEMMs, the persistent kernels) SQ_BUSY_CYCLES / 32 / duration is the shader clock the launch actually ran at, and
+MFMA-busy / SIMD / (SQ-busy / SE) is the share of ISSUED cycles the MFMA pipe was busy -- the utilisation a kernel can influence;
+`util` (against 2.4 GHz) additionally carries the clock the power management granted (MI355X_MICROARCH.md, "DVFS give-back")."""
 import collections
 import csv
 import glob
@@ -40,8 +45,10 @@ def summarise(out):
         util = busy / (SIMDS * avg * 1e-6 * CLK) if avg > 0 else 0.0
         tf = mops * 512 / (avg * 1e-6) / 1e12 if avg > 0 else 0.0
         g, w, v, a = meta[k]
+        sqb = mean('SQ_BUSY_CYCLES') / 32
+        clk = f'  eff clock {sqb / avg / 1e3:4.2f} GHz  MFMA pipe {100 * busy / SIMDS / sqb:5.1f} % of issued cycles' if sqb > 0 and avg > 100 else ''
         print(f'{k[:64]:64s} n={len(d):5d} avg {avg:9.1f} us  grid {g:>8s}/{w:>4s} vgpr {v}+{a}  MFMA insts {insts:12.0f}  busy cyc {busy:14.0f}'
-              f'  busy/inst {busy / max(insts, 1):5.1f}  util {100 * util:5.1f} %  MOPS-rate {tf:6.1f} TF = {100 * tf / PEAK_TF:5.1f} % of {PEAK_TF}')
+              f'  busy/inst {busy / max(insts, 1):5.1f}  util {100 * util:5.1f} %  MOPS-rate {tf:6.1f} TF = {100 * tf / PEAK_TF:5.1f} % of {PEAK_TF}{clk}')
 
 
 if __name__ == '__main__':
