@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, 'csrc', 'libhumor_amd.so')
 
 HA_OK = 0
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int32)
@@ -40,16 +40,21 @@ class FitArgs(C.Structure):
                 ('g_cam_jtr', C.c_void_p), ('g_cam_verts', C.c_void_p), ('g_pri_joints', C.c_void_p), ('g_ro_joints', C.c_void_p),
                 ('g_contacts_conf', C.c_void_p), ('g_latent_pose', C.c_void_p), ('g_betas', C.c_void_p), ('g_latent_motion', C.c_void_p),
                 ('g_prior_mu', C.c_void_p), ('g_prior_var', C.c_void_p), ('g_floor', C.c_void_p),
-                ('g_prev_tail', C.c_void_p), ('g_prev_betas', C.c_void_p), ('g_prev_floor', C.c_void_p), ('partial', C.c_void_p)]
+                ('g_prev_tail', C.c_void_p), ('g_prev_betas', C.c_void_p), ('g_prev_floor', C.c_void_p), ('partial', C.c_void_p),
+                ('gmm_nll', C.c_void_p), ('gmm_gx', C.c_void_p), ('gmm_w', C.c_float), ('gmm_D', C.c_int), ('gmm_nseg', C.c_int),
+                ('gmm_g', C.c_void_p * 4), ('gmm_seg_width', C.c_int * 4), ('gmm_g_stride', C.c_int * 4), ('gmm_g_acc', C.c_int * 4),
+                ('gmm_total', C.c_void_p)]
 
 
 class FitPreArgs(C.Structure):
     """ha_fit_pre_args (include/humor_amd.h)."""
-    _fields_ = [('B', C.c_int)] + [(n, C.c_void_p) for n in (
+    _fields_ = ([('B', C.c_int)] + [(n, C.c_void_p) for n in (
         'floor', 'trans0', 'root0', 'pose0', 'jcam', 'trans_vel', 'joints_vel', 'root_orient_vel',
         'past_in', 'trans_p', 'root_p', 'joints_p', 'c2p_R', 'c2p_t', 'root_height',
         'g_past_in', 'g_trans_p', 'g_root_p', 'g_joints_p', 'g_c2p_R', 'g_c2p_t', 'g_root_height',
         'g_floor', 'g_trans0', 'g_root0', 'g_pose0', 'g_jcam', 'g_trans_vel', 'g_joints_vel', 'g_root_orient_vel')]
+                + [('jcam_stride', C.c_int)] + [(n, C.c_void_p) for n in (
+                    'add_floor', 'add_pose0', 'add_trans_vel', 'add_joints_vel', 'add_root_orient_vel')])
 
 
 class RolloutPostArgs(C.Structure):
@@ -65,7 +70,7 @@ class RigidImageArgs(C.Structure):
     """ha_rigid_image_args (include/humor_amd.h)."""
     _fields_ = [('N', C.c_int), ('J', C.c_int), ('V', C.c_int)] + [(n, C.c_void_p) for n in (
         'joints', 'verts', 'root', 'trans', 'root2', 'trans2', 'joints2', 'verts2', 'g_joints2', 'g_verts2',
-        'g_joints', 'g_verts', 'g_root', 'g_trans', 'g_root2', 'g_trans2')]
+        'g_joints', 'g_verts', 'g_root', 'g_trans', 'g_root2', 'g_trans2', 'g_joints_add', 'g_verts_add')]
 
 
 class GmmArgs(C.Structure):
@@ -88,6 +93,11 @@ _SIGS = {
     'ha_smpl_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_smpl_forward_split': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3),
     'ha_smpl_backward_split': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 6),
+    'ha_smpl_forward_parts': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3),
+    'ha_smpl_backward_parts': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+                               + [C.c_void_p] * 10),
+    'ha_seq_sum_add': (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    'ha_humor_rollout_backward_ex': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p]),
     'ha_smpl_backward_dense_workspace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     'ha_smpl_backward_dense': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_void_p]),
     'ha_lbs_skin': (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),

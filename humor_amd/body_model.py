@@ -256,6 +256,19 @@ class BodyModel(nn.Module):
             self._handles[key] = _get_handle(lib, self.bm_path, self.num_betas, index)
         return self._handles[key]
 
+    def parts_config(self, device):
+        """What the stage-3 composites (humor_amd/stage3.py) need to call ha_smpl_forward_parts / _backward_parts themselves: the model
+        handle, the vertex-subset slots and the joint / vertex counts of this BodyModel's outputs (Jtr = J joints + n_sel selector
+        vertices, v = the remaining n_all - n_sel subset vertices).  None when this instance is not a vertex-subset SMPL+H model."""
+        if self._subset is None or self.model_type != 'smplh':
+            return None
+        h = self._handle_for(device)
+        if h.J != self.num_joints + 1:
+            return None
+        subset_all = self._selector + self._subset
+        return dict(handle=h, slot_all=h.subset_slot(subset_all), n_all=len(subset_all), n_sel=len(self._selector),
+                    slot_sel=h.subset_slot(self._selector) if self._selector else None, n_active=min(h.J, 22), J=h.J, NB=h.NB)
+
     def forward(self, root_orient=None, pose_body=None, pose_hand=None, pose_jaw=None, pose_eye=None, betas=None,
                 trans=None, dmpls=None, expression=None, return_dict=False, **kwargs):
         '''

@@ -241,12 +241,27 @@ __global__ __launch_bounds__(64) void fit_loss_kernel(ha_fit_args a) {
       for (int c = 0; c < 3; ++c) gr[c] += cu[c];
       for (int ch = 1; ch < 22; ++ch)
         if (SMPL_PARENTS_DEV[ch] == j) { gr[0] -= s_cu[ch * 3]; gr[1] -= s_cu[ch * 3 + 1]; gr[2] -= s_cu[ch * 3 + 2]; }
+      if (a.gmm_gx && t == 0 && a.gmm_g[0]) {     // folded init-state prior: its gradient of frame 0's joints (segment 0 of x_b)
+        const float* gx = a.gmm_gx + (size_t)b * a.gmm_D + j * 3;
+        gp[0] = fmaf(a.gmm_w, gx[0], gp[0]); gp[1] = fmaf(a.gmm_w, gx[1], gp[1]); gp[2] = fmaf(a.gmm_w, gx[2], gp[2]);
+      }
       if (a.g_pri_joints) { a.g_pri_joints[ep] = gp[0]; a.g_pri_joints[ep + 1] = gp[1]; a.g_pri_joints[ep + 2] = gp[2]; }
       if (a.g_ro_joints) { a.g_ro_joints[e] = gr[0]; a.g_ro_joints[e + 1] = gr[1]; a.g_ro_joints[e + 2] = gr[2]; }
       if (a.g_contacts_conf) a.g_contacts_conf[(size_t)f * 22 + j] = gc;
     }
     if (a.g_pri_joints)          // joints beyond the 22 body joints (hands, selected vertices) carry no prior-frame term
       for (int i = 22 * 3 + lane; i < pnj * 3; i += 64) a.g_pri_joints[(size_t)f * pnj * 3 + i] = 0.f;
+  }
+  // folded init-state prior: segments 1.. of its gradient (joint / root velocities of the initial state) to their own slots
+  if (a.gmm_gx && t == 0) {
+    int c0 = a.gmm_seg_width[0];
+    for (int sgm = 1; sgm < a.gmm_nseg; ++sgm) {
+      float* dst = a.gmm_g[sgm];
+      const int wd = a.gmm_seg_width[sgm];
+      if (dst)
+        for (int i = lane; i < wd; i += 64) dst[(size_t)b * a.gmm_g_stride[sgm] + i] = a.gmm_w * a.gmm_gx[(size_t)b * a.gmm_D + c0 + i];
+      c0 += wd;
+    }
   }
 
   // ---- pose prior (VPoser latent), motion prior (conditional Gaussian or standard normal) -----------------------------------
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(64) void fit_loss_kernel(ha_fit_args a) {
 // terms[k] = sum over frames (fixed order), loss = sum_k weff_k terms[k].  One wave per term (lane-strided partial sums, then
 // an xor-shuffle tree: a fixed association, so the value is bit-reproducible), no block barriers in the summation.
 __global__ __launch_bounds__(1024) void fit_reduce_kernel(ha_fit_args a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];     // [NT] term values
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [NT] term values | init-state prior total
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, F = a.B * a.T;
   for (int k = wave; k < NT; k += 16) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -353,6 +368,13 @@ __global__ __launch_bounds__(1024) void fit_reduce_kernel(ha_fit_args a) {
     const float s = wsum((s0 + s1) + (s2 + s3));
     if (lane == 0) smem[k] = s;
   }
+  // init-state prior total: one wave, lanes stride over the sequences (independent loads), fixed-order butterfly
+  if (a.gmm_nll && wave == 15) {
+    float v = 0.f;
+    for (int b = lane; b < a.B; b += 64) v += a.gmm_nll[b];
+    v = wsum(v);
+    if (lane == 0) smem[NT] = v;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     float loss = 0.f;
@@ -360,6 +382,11 @@ __global__ __launch_bounds__(1024) void fit_reduce_kernel(ha_fit_args a) {
       a.terms[k] = smem[k];
       const float scale = (k == HA_FIT_SHAPE_PRIOR || k == HA_FIT_FLOOR_REG) ? a.nsteps : 1.f;
       loss += a.w[k] * scale * smem[k];
+    }
+    if (a.gmm_nll) {
+      const float tot = smem[NT];
+      if (a.gmm_total) a.gmm_total[0] = tot;
+      loss += a.gmm_w * tot;
     }
     a.loss[0] = loss;
   }
@@ -379,10 +406,11 @@ extern "C" int ha_fit_loss(const ha_fit_args* args, void* stream) {
   HA_REQUIRE(!a.latent_motion || (a.S >= 1 && a.S <= a.T && a.dz >= 1), "ha_fit_loss: latent steps S must be in [1, T]");
   HA_REQUIRE((a.prior_mu == nullptr) == (a.prior_var == nullptr), "ha_fit_loss: prior_mu and prior_var go together");
   HA_REQUIRE(!a.prev_tail || (a.cam_verts && a.overlap), "ha_fit_loss: a halo tail needs cam_verts and the overlap table");
+  HA_REQUIRE(!a.gmm_gx || (a.gmm_nll && a.gmm_D >= 1 && a.gmm_nseg >= 1 && a.gmm_nseg <= 4), "ha_fit_loss: the folded init-state prior needs gmm_nll, gmm_D and 1..4 segments");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(fit_loss_kernel, dim3(a.B * a.T), dim3(64), (128 + 66) * sizeof(float), st, a);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fit_reduce_kernel, dim3(1), dim3(1024), NT * sizeof(float), st, a);
+  hipLaunchKernelGGL(fit_reduce_kernel, dim3(1), dim3(1024), (NT + 1) * sizeof(float), st, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

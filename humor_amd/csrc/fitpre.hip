@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void fit_pre_fwd_kernel(ha_fit_pre_args a) {
   const float* floor = a.floor + (size_t)b * 3;
   const float* trans = a.trans0 + (size_t)b * 3;
   const float* root = a.root0 + (size_t)b * 3;
-  const float* jc = a.jcam + (size_t)b * 22 * 3;
+  const float* jc = a.jcam + (size_t)b * (a.jcam_stride ? a.jcam_stride : 66);
   float f3[3] = {floor[0], floor[1], floor[2]}, t3[3] = {trans[0], trans[1], trans[2]}, r3[3] = {root[0], root[1], root[2]};
   C2P c;
   c2p_forward(f3, t3, r3, c);                      // (every lane: uniform, no hand-off needed)
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void fit_pre_bwd_kernel(ha_fit_pre_args a) {
   const float* floor = a.floor + (size_t)b * 3;
   const float* trans = a.trans0 + (size_t)b * 3;
   const float* root = a.root0 + (size_t)b * 3;
-  const float* jc = a.jcam + (size_t)b * 22 * 3;
+  const float* jc = a.jcam + (size_t)b * (a.jcam_stride ? a.jcam_stride : 66);
   float f3[3] = {floor[0], floor[1], floor[2]}, t3[3] = {trans[0], trans[1], trans[2]}, r3[3] = {root[0], root[1], root[2]};
   C2P c;
   c2p_forward(f3, t3, r3, c);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64) void fit_pre_bwd_kernel(ha_fit_pre_args a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       gjp[i] = gp(207 + 3 * j + i) + opt3(a.g_joints_p, ((size_t)b * 22 + j) * 3, i);
-      a.g_joints_vel[((size_t)b * 22 + j) * 3 + i] = gp(273 + 3 * j + i);
+      a.g_joints_vel[((size_t)b * 22 + j) * 3 + i] = gp(273 + 3 * j + i) + opt3(a.add_joints_vel, ((size_t)b * 22 + j) * 3, i);
     }
     const float d[3] = {jc[j * 3] - jc0[0], jc[j * 3 + 1] - jc0[1], jc[j * 3 + 2] - jc0[2]};
     mat3_tvec(c.R, gjp, gd);                      // R^T g
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void fit_pre_bwd_kernel(ha_fit_pre_args a) {
       for (int i = 0; i < 9; ++i) gRb[i] = gp(18 + 9 * (j - 1) + i);
       rodrigues_bwd(aa, gRb, gaa);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) a.g_pose0[(size_t)b * 63 + (j - 1) * 3 + i] = gaa[i];
+      for (int i = 0; i < 3; ++i) a.g_pose0[(size_t)b * 63 + (j - 1) * 3 + i] = gaa[i] + opt3(a.add_pose0, (size_t)b * 63 + (j - 1) * 3, i);
     }
   }
   // sums over the joints
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(64) void fit_pre_bwd_kernel(ha_fit_pre_args a) {
     g_tp[i] = gp(i) + opt3(a.g_trans_p, (size_t)b * 3, i) + s_gjp[i];
     g_rp[i] = opt3(a.g_root_p, (size_t)b * 3, i);
     g_t[i] = opt3(a.g_c2p_t, (size_t)b * 3, i);
-    a.g_trans_vel[(size_t)b * 3 + i] = gp(3 + i);
-    a.g_root_orient_vel[(size_t)b * 3 + i] = gp(15 + i);
+    a.g_trans_vel[(size_t)b * 3 + i] = gp(3 + i) + opt3(a.add_trans_vel, (size_t)b * 3, i);
+    a.g_root_orient_vel[(size_t)b * 3 + i] = gp(15 + i) + opt3(a.add_root_orient_vel, (size_t)b * 3, i);
   }
   if (a.g_c2p_R) {
 #pragma unroll
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(64) void fit_pre_bwd_kernel(ha_fit_pre_args a) {
     for (int i = 0; i < 3; ++i) g_nh[i] = c.sgn * g_n[i];
     const float pn = dot3(g_nh, c.nh);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) a.g_floor[(size_t)b * 3 + i] = (g_nh[i] - pn * c.nh[i]) / c.L + c.sgn * g_off * c.nh[i];
+    for (int i = 0; i < 3; ++i)
+      a.g_floor[(size_t)b * 3 + i] = (g_nh[i] - pn * c.nh[i]) / c.L + c.sgn * g_off * c.nh[i] + opt3(a.add_floor, (size_t)b * 3, i);
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {

@@ -79,7 +79,9 @@ __global__ void rigid_image_bwd_kernel(ha_rigid_image_args a) {
     float q[3];
     mat3_tvec(r.Q, g, q);                   // dL/dX = Q^T g
     float* gdst = (jt ? a.g_joints : a.g_verts) + o;
-    gdst[0] = q[0]; gdst[1] = q[1]; gdst[2] = q[2];
+    const float* gadd = jt ? a.g_joints_add : a.g_verts_add;      // the gradient another reader of the same tensor produced (or null)
+    if (gadd) { gdst[0] = q[0] + gadd[o]; gdst[1] = q[1] + gadd[o + 1]; gdst[2] = q[2] + gadd[o + 2]; }
+    else { gdst[0] = q[0]; gdst[1] = q[1]; gdst[2] = q[2]; }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       acc[3 * c + 0] = fmaf(g[c], d[0], acc[3 * c + 0]);

@@ -1625,6 +1625,7 @@ struct StashLayout {
 static thread_local int tl_groups = 1;
 // -1: make_layout decides from the live state (workspace queries); 0 / 1: the mode decided at the entry point of the call being served
 static thread_local int tl_single_mode = -1;
+static thread_local const float* tl_gz_add = nullptr;   // ha_humor_rollout_backward_ex: addend of dL/dz (rows of the group being run)
 static thread_local bool tl_prior_bwd_done = false;     // the prior's adjoint of this call already ran (on the side stream)
 
 static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, bool allow_acc = true) {
@@ -2231,7 +2232,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
       for (int l = 0; l < 3; ++l) { f.off_gn[l] = L.off_gn[l]; f.off_ht[l] = L.off_ht[l]; }
       f.off_gl = L.off_gl;
       f.t2j = stash + L.t2j;
-      f.g_past0 = g_past_in0; f.g_z = g_z_seq;
+      f.g_past0 = g_past_in0; f.g_z = g_z_seq; f.g_z_add = tl_gz_add;
       f.dz_part = stash + L.dz_part;
       f.ws = stash + L.persist_ws;
       return persist_backward(net->persist, f, g_rollout_persist >> 1, st);
@@ -2415,9 +2416,21 @@ extern "C" int ha_humor_prior_grad_ready(const ha_humor_net* net, const float* g
   return HA_OK;
 }
 
+// dst[i] += src[i] (the launch-chain path of ha_humor_rollout_backward_ex; the persistent path adds in its final reduction)
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
 extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float* z_seq, const float* g_world,
                                          const float* g_prior_mu, const float* g_prior_var, float* stash, float* g_past_in0,
                                          float* g_z_seq, void* stream) {
+  return ha_humor_rollout_backward_ex(net, B, S, z_seq, g_world, g_prior_mu, g_prior_var, stash, g_past_in0, g_z_seq, nullptr, stream);
+}
+
+extern "C" int ha_humor_rollout_backward_ex(const ha_humor_net* net, int B, int S, const float* z_seq, const float* g_world,
+                                            const float* g_prior_mu, const float* g_prior_var, float* stash, float* g_past_in0,
+                                            float* g_z_seq, const float* g_z_add, void* stream) {
   HA_REQUIRE(net && stash && g_past_in0 && g_z_seq, "ha_humor_rollout_backward: null argument");
   HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_backward: B and S must be >= 1");
   (void)z_seq;
@@ -2459,6 +2472,13 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
       }
     }
   }
+  bool add_in_kernel = false;
+  if (g_z_add && tl_single_mode == 1 && ng == 1 && g_rollout_persist_bwd != 0) {
+    StashLayout L;
+    make_layout(net, B, S, L);
+    add_in_kernel = L.single;
+  }
+  tl_gz_add = add_in_kernel ? g_z_add : nullptr;
   rc = for_each_group(net->device, B, S, true, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
     const size_t r = (size_t)r0;
     return rollout_backward_impl(net, rows, S, g_world ? g_world + r * S * D_STATE : nullptr,
@@ -2467,6 +2487,12 @@ extern "C" int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, 
   });
   tl_single_mode = -1;
   tl_prior_bwd_done = false;
+  tl_gz_add = nullptr;
+  if (rc == HA_OK && g_z_add && !add_in_kernel) {
+    const int n = B * S * ZD;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, g_z_seq, g_z_add, n);
+    HA_LAUNCH_CHECK();
+  }
   return rc;
 }
 

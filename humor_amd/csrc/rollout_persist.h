@@ -35,6 +35,7 @@ struct PersistBwd {
   const float* t2j = nullptr;
   float* g_past0 = nullptr;          // [B][339]
   float* g_z = nullptr;              // [B][S][48]
+  const float* g_z_add = nullptr;    // [B][S][48] or null: added to g_z by the final reduction (the gradient another reader of z produced)
   float* dz_part = nullptr;          // [S][persist_dz_slots()][32][48]
   float* ws = nullptr;
 };

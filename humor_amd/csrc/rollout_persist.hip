@@ -1684,13 +1684,13 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
 }
 
 // g_z[b][t][c] = sum of the DZ_SLOTS partial products, fixed order
-__global__ void dz_reduce_kernel(const float* __restrict__ part, float* __restrict__ g_z, int B, int S) {
+__global__ void dz_reduce_kernel(const float* __restrict__ part, float* __restrict__ g_z, const float* __restrict__ g_z_add, int B, int S) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * S * P_ZD) return;
   const int c = i % P_ZD, t = (i / P_ZD) % S, b = i / (P_ZD * S);
   float v = 0.f;
   for (int sl = 0; sl < DZ_SLOTS; ++sl) v += part[(((size_t)t * DZ_SLOTS + sl) * 32 + b) * P_ZD + c];
-  g_z[i] = v;
+  g_z[i] = g_z_add ? v + g_z_add[i] : v;
 }
 
 #endif  // !HA_SIMT_EMU
@@ -1945,7 +1945,7 @@ int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_
   else hipLaunchKernelGGL(rollout_persist_bwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), LB_TOTAL * 4, st, a);
   HA_LAUNCH_CHECK();
   const int n = f.B * f.S * P_ZD;
-  hipLaunchKernelGGL(dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)f.dz_part, f.g_z, f.B, f.S);
+  hipLaunchKernelGGL(dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)f.dz_part, f.g_z, f.g_z_add, f.B, f.S);
   HA_LAUNCH_CHECK();
   ++p->launches_bwd;
   return HA_OK;

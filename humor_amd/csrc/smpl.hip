@@ -68,7 +68,7 @@ extern "C" int ha_tune_set(const char* key, int value) {
   return HA_ERR_INVALID_ARG;
 }
 extern "C" const char* ha_last_error(void) { return ha::g_err; }
-extern "C" int ha_abi_version(void) { return 1; }
+extern "C" int ha_abi_version(void) { return 2; }
 extern "C" int ha_device_arch(int device, char* buf, int buflen) {
   HA_REQUIRE(buf && buflen > 0, "ha_device_arch: null buffer");
   hipDeviceProp_t prop;
@@ -412,7 +412,23 @@ struct FrameParams {
   // dense backward (ha_smpl_backward_dense): the vertex phase ran in the streaming / MFMA kernels, this kernel only consumes
   // its results: dL/dA [N][J][12], K-split partials of dL/dcoeff [gco_ks][gco_rows][gco_ld], partial vertex-gradient sums
   const float* gA_in; const float* gco_part; int gco_ks, gco_rows, gco_ld; const float* gtl_part; int gtl_np;
+  // "parts" form (ha_smpl_forward_parts / _backward_parts): the pose arrives as root [N,3] (in `pose`) + body [N,(n_active-1)*3] (no
+  // cat in front of the kernel), one shape row serves betas_div consecutive frames (no expand copy), only the first gj_rows rows of
+  // g_joints exist (row stride gj_stride), the pose gradient leaves as g_pose = root part [N,3] + g_body, and every output gradient
+  // may carry an addend (the gradient another consumer of the same input produced: no accumulation launch behind the kernel)
+  const float* pose_body; int betas_div; int gj_rows, gj_stride;
+  float* g_body;
+  const float* add_root; const float* add_body; const float* add_betas; const float* add_transl;
 };
+
+// axis-angle of joint j of frame f (J joints per frame in the packed form)
+__device__ __forceinline__ const float* pose_of(const FrameParams& p, int f, int j, int J) {
+  if (!p.pose_body) return p.pose + ((size_t)f * J + j) * 3;
+  return j == 0 ? p.pose + (size_t)f * 3 : p.pose_body + ((size_t)f * (p.n_active - 1) + (j - 1)) * 3;
+}
+__device__ __forceinline__ const float* betas_of(const FrameParams& p, int f) {
+  return p.betas + (size_t)(p.betas_div > 1 ? f / p.betas_div : f) * p.NB;
+}
 
 constexpr int FW = 4;  // waves (= frames) per block
 
@@ -466,14 +482,14 @@ __device__ __forceinline__ void joint_forward(const FrameParams& p, int f, int l
     s.parent = p.parents[j];
     s.depth = p.jdepth[j];
     if (j < p.n_active) {
-      const float* r = p.pose + ((size_t)f * p.J + j) * 3;
+      const float* r = pose_of(p, f, j, p.J);
       const float rr[3] = {r[0], r[1], r[2]};
       rodrigues(rr, s.R);
     }
     // (a block's critical path is a chain of load latencies, not bandwidth: 8 shape coefficients x 3 joint-minor rows of Js in
     // flight per trip)
     const float* js = p.Js + j;
-    const float* be = p.betas + (size_t)f * p.NB;
+    const float* be = betas_of(p, f);
     float a0 = p.Jt[j * 3], a1 = p.Jt[j * 3 + 1], a2 = p.Jt[j * 3 + 2];
     int l = 0;
     for (; l + 8 <= p.NB; l += 8) {
@@ -493,7 +509,7 @@ __device__ __forceinline__ void joint_forward(const FrameParams& p, int f, int l
     s.Jr[0] = a0; s.Jr[1] = a1; s.Jr[2] = a2;
   }
   // coefficient vector: betas | 1 | pose feature (prefix of length Kc is what the kernels iterate over)
-  for (int i = lane; i < p.NB; i += 64) coeff[i] = p.betas[(size_t)f * p.NB + i];
+  for (int i = lane; i < p.NB; i += 64) coeff[i] = betas_of(p, f)[i];
   if (lane == 0) {
     coeff[p.NB] = 1.0f;
     for (int k = p.Kc; k < ((p.Kc + 7) & ~7) && k < p.kf4; ++k) coeff[k] = 0.0f;   // pad entries read by the MFMA path's last k-pair quad
@@ -769,7 +785,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
       const int v = chunk * 64 + lane;
       float g[3] = {0.f, 0.f, 0.f};
       if (v < p.nverts) {
-        const float* src = v < p.n_head ? (p.g_joints ? p.g_joints + ((size_t)f * p.jstride + J + v) * 3 : nullptr)
+        const float* src = v < p.n_head ? ((p.g_joints && (p.gj_rows == 0 || J + v < p.gj_rows)) ? p.g_joints + ((size_t)f * (p.gj_stride ? p.gj_stride : p.jstride) + J + v) * 3 : nullptr)
                                         : (p.g_verts ? p.g_verts + ((size_t)f * (p.nverts - p.n_head) + (v - p.n_head)) * 3 : nullptr);
         if (src) { g[0] = src[0]; g[1] = src[1]; g[2] = src[2]; }
       }
@@ -914,9 +930,9 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
 #pragma unroll
     for (int i = 0; i < 12; ++i) gAj[i] = gAr[i];
     float gjt[3] = {0.f, 0.f, 0.f};
-    if (p.g_joints) {
+    if (p.g_joints && (p.gj_rows == 0 || lane < p.gj_rows)) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) gjt[c] = p.g_joints[((size_t)f * p.jstride + lane) * 3 + c];
+      for (int c = 0; c < 3; ++c) gjt[c] = p.g_joints[((size_t)f * (p.gj_stride ? p.gj_stride : p.jstride) + lane) * 3 + c];
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -1005,12 +1021,21 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
 #pragma unroll
         for (int i = 0; i < 9; ++i) gR[i] += gco[p.NB + 1 + (lane - 1) * 9 + i];
       }
-      const float* r = p.pose + ((size_t)f * J + lane) * 3;
+      const float* r = pose_of(p, f, lane, J);
       const float rr[3] = {r[0], r[1], r[2]};
       rodrigues_bwd(rr, gR, gr);
     }
+    if (!p.pose_body) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) p.g_pose[((size_t)f * J + lane) * 3 + c] = gr[c];
+      for (int c = 0; c < 3; ++c) p.g_pose[((size_t)f * J + lane) * 3 + c] = gr[c];
+    } else if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) p.g_pose[(size_t)f * 3 + c] = gr[c] + (p.add_root ? p.add_root[(size_t)f * 3 + c] : 0.f);
+    } else if (lane < p.n_active && p.g_body) {
+      const size_t o = ((size_t)f * (p.n_active - 1) + (lane - 1)) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) p.g_body[o + c] = gr[c] + (p.add_body ? p.add_body[o + c] : 0.f);
+    }
   }
   SPT(1, 8);
   // ---- betas gradient: coefficient part + rest-joint part ------------------------------------------
@@ -1032,7 +1057,8 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
 #pragma unroll
       for (int u = 1; u < 16; ++u)
         if (lane == u) mine = part[u];
-      if (lane < 16 && l0 + lane < p.NB && valid) p.g_betas[(size_t)f * p.NB + l0 + lane] = gco[l0 + lane] + mine;
+      if (lane < 16 && l0 + lane < p.NB && valid)
+        p.g_betas[(size_t)f * p.NB + l0 + lane] = gco[l0 + lane] + mine + (p.add_betas ? p.add_betas[(size_t)f * p.NB + l0 + lane] : 0.f);
     }
   }
   SPT(1, 9);
@@ -1043,7 +1069,7 @@ __global__ __launch_bounds__(FW * 64) void smpl_frame_bwd_kernel(FrameParams p) 
       float vsum = gtl[c];
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) vsum += __shfl_xor(vsum, off);
-      if (lane == 0 && valid) p.g_transl[(size_t)f * 3 + c] = vsum;
+      if (lane == 0 && valid) p.g_transl[(size_t)f * 3 + c] = vsum + (p.add_transl ? p.add_transl[(size_t)f * 3 + c] : 0.f);
     }
   }
   SPT(1, 10);
@@ -1884,6 +1910,80 @@ extern "C" int ha_smpl_backward_split(const ha_smpl_model* m, int slot, int N, i
   p.n_head = n_head; p.jstride = m->J + n_head;
   const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + kXchFloats) * sizeof(float);
   hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
+  HA_LAUNCH_CHECK();
+  return HA_OK;
+}
+
+// ---- "parts" form: split pose, shared shape rows, addends (the stage-3 composites of humor_amd/stage3.py) -------------------------
+extern "C" int ha_smpl_forward_parts(const ha_smpl_model* m, int slot, int N, int n_active, const float* root, const float* body,
+                                     const float* betas, int betas_div, const float* transl, int n_head, float* joints_ext,
+                                     float* verts_tail, void* stream) {
+  int rc = check_common("ha_smpl_forward_parts", m, slot, N, n_active);
+  if (rc != HA_OK) return rc;
+  HA_REQUIRE(root && betas && joints_ext && (body || n_active == 1), "ha_smpl_forward_parts: root, body, betas and joints_ext are required");
+  HA_REQUIRE(betas_div >= 1 && N % betas_div == 0, "ha_smpl_forward_parts: betas_div=%d must divide N=%d", betas_div, N);
+  HA_REQUIRE(n_head >= 0 && n_head <= m->sets[slot].n, "ha_smpl_forward_parts: n_head=%d out of range 0..%d", n_head, m->sets[slot].n);
+  HA_REQUIRE(verts_tail || n_head == m->sets[slot].n, "ha_smpl_forward_parts: verts_tail is required for the vertices behind the head");
+  DeviceGuard guard(m->device);
+  FrameParams p;
+  fill_model(p, m, slot);
+  p.N = N; p.n_active = n_active; p.Kc = m->NB + 1 + (n_active - 1) * 9;
+  p.pose = root; p.pose_body = body ? body : root; p.betas = betas; p.betas_div = betas_div; p.transl = transl;
+  p.joints = joints_ext; p.verts = verts_tail ? verts_tail : joints_ext;
+  p.n_head = n_head; p.jstride = m->J + n_head;
+  const size_t lds = ((size_t)FW * (((m->Kfull_pad + 3) & ~3) + m->J * 12) + kXchFloats) * sizeof(float);
+  hipLaunchKernelGGL(smpl_frame_fwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
+  HA_LAUNCH_CHECK();
+  return HA_OK;
+}
+
+extern "C" int ha_smpl_backward_parts(const ha_smpl_model* m, int slot, int N, int n_active, const float* root, const float* body,
+                                      const float* betas, int betas_div, int n_head, const float* g_joints_ext, int gj_rows,
+                                      int gj_stride, const float* g_verts_tail, const float* add_root, const float* add_body,
+                                      const float* add_betas, const float* add_transl, float* g_root, float* g_body, float* g_betas,
+                                      float* g_transl, void* stream) {
+  int rc = check_common("ha_smpl_backward_parts", m, slot, N, n_active);
+  if (rc != HA_OK) return rc;
+  HA_REQUIRE(root && betas && g_root && (body || n_active == 1), "ha_smpl_backward_parts: root, body, betas and g_root are required");
+  HA_REQUIRE(betas_div >= 1 && N % betas_div == 0, "ha_smpl_backward_parts: betas_div=%d must divide N=%d", betas_div, N);
+  HA_REQUIRE(n_head >= 0 && n_head <= m->sets[slot].n, "ha_smpl_backward_parts: n_head=%d out of range 0..%d", n_head, m->sets[slot].n);
+  HA_REQUIRE(gj_rows >= 0 && gj_rows <= m->J + n_head && gj_stride >= 0, "ha_smpl_backward_parts: gj_rows=%d out of range", gj_rows);
+  DeviceGuard guard(m->device);
+  FrameParams p;
+  fill_model(p, m, slot);
+  p.N = N; p.n_active = n_active; p.Kc = m->NB + 1 + (n_active - 1) * 9;
+  p.pose = root; p.pose_body = body ? body : root; p.betas = betas; p.betas_div = betas_div;
+  p.g_verts = g_verts_tail; p.g_joints = g_joints_ext; p.gj_rows = gj_rows; p.gj_stride = gj_stride;
+  p.g_pose = g_root; p.g_body = g_body; p.g_betas = g_betas; p.g_transl = g_transl;
+  p.add_root = add_root; p.add_body = add_body; p.add_betas = add_betas; p.add_transl = add_transl;
+  p.n_head = n_head; p.jstride = m->J + n_head;
+  const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + kXchFloats) * sizeof(float);
+  hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
+  HA_LAUNCH_CHECK();
+  return HA_OK;
+}
+
+// out[b][w] = sum_t src[b][t][w] + add1[b][w] + add2[b][w]  (the per-frame shape gradients of a [B, T] batch back to one row per
+// sequence, together with the gradients other consumers of the same shape rows produced: one launch for sum + add + add)
+__global__ __launch_bounds__(256) void seq_sum_add_kernel(const float* __restrict__ src, const float* __restrict__ add1,
+                                                          const float* __restrict__ add2, float* __restrict__ out, int T, int W) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [4][64] partial sums of the four frame slices
+  const int b = blockIdx.x, w = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (w < W)
+    for (int t = sl; t < T; t += 4) acc += src[((size_t)b * T + t) * W + w];
+  smem[sl * 64 + w] = acc;
+  __syncthreads();
+  if (sl != 0 || w >= W) return;
+  acc = (smem[w] + smem[64 + w]) + (smem[128 + w] + smem[192 + w]);
+  if (add1) acc += add1[(size_t)b * W + w];
+  if (add2) acc += add2[(size_t)b * W + w];
+  out[(size_t)b * W + w] = acc;
+}
+
+extern "C" int ha_seq_sum_add(int B, int T, int W, const float* src, const float* add1, const float* add2, float* out, void* stream) {
+  HA_REQUIRE(src && out && B >= 1 && T >= 1 && W >= 1 && W <= 64, "ha_seq_sum_add: need src, out, B, T >= 1 and 1 <= W <= 64");
+  hipLaunchKernelGGL(seq_sum_add_kernel, dim3(B), dim3(256), 256 * sizeof(float), (hipStream_t)stream, src, add1, add2, out, T, W);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

@@ -22,8 +22,24 @@ TERM_NAMES = ['joints2d', 'joints3d', 'verts3d', 'joints3d_rollout', 'pose_prior
 DIFF_INPUTS = [('cam_jtr', 'g_cam_jtr'), ('cam_verts', 'g_cam_verts'), ('pri_joints', 'g_pri_joints'), ('ro_joints', 'g_ro_joints'),
                ('contacts_conf', 'g_contacts_conf'), ('latent_pose', 'g_latent_pose'), ('betas', 'g_betas'),
                ('latent_motion', 'g_latent_motion'), ('prior_mu', 'g_prior_mu'), ('prior_var', 'g_prior_var'), ('floor', 'g_floor'),
-               ('prev_tail', 'g_prev_tail'), ('prev_betas', 'g_prev_betas'), ('prev_floor', 'g_prev_floor')]
+               ('prev_tail', 'g_prev_tail'), ('prev_betas', 'g_prev_betas'), ('prev_floor', 'g_prev_floor'),
+               # inputs of the folded init-state prior only (spec['gmm']): their gradients come from ha_gmm_nll through ha_fit_loss
+               ('joints_vel', None), ('trans_vel', None), ('root_orient_vel', None)]
+GMM_INPUTS = ('joints_vel', 'trans_vel', 'root_orient_vel')
 CONST_INPUTS = ['obs_j2d', 'smpl2op', 'op_mask', 'cam_f', 'cam_c', 'obs_j3d', 'obs_v3d', 'obs_floor', 'overlap']
+
+
+_UNIT = {}
+
+
+def unit_seed(ref):
+    """The constant 1.0 the closure seeds loss.backward() with, one cached 0-dim tensor per device: backward(gradient=unit_seed(loss))
+    saves autograd's ones_like launch, and FusedFit.backward recognises the tensor (by address) and skips its multiply-by-one launch."""
+    key = (ref.device, ref.dtype)
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones((), dtype=ref.dtype, device=ref.device)
+    return t
 
 
 class FusedFit(torch.autograd.Function):
@@ -39,6 +55,7 @@ class FusedFit(torch.autograd.Function):
         a.B, a.T = spec['B'], spec['T']
         keep = []
         sizes = []
+        named = {}
         for (name, _), t in zip(DIFF_INPUTS, tensors):
             if t is None:
                 sizes.append(0)
@@ -47,7 +64,9 @@ class FusedFit(torch.autograd.Function):
             if not t.is_contiguous() or t.dtype != torch.float32:
                 t = t.contiguous().float()
             keep.append(t)
-            setattr(a, name, t.data_ptr())
+            named[name] = t
+            if name not in GMM_INPUTS:
+                setattr(a, name, t.data_ptr())
             sizes.append(t.numel())
         for name in CONST_INPUTS:
             t = spec.get(name)
@@ -60,32 +79,61 @@ class FusedFit(torch.autograd.Function):
         for k in range(NT):
             a.w[k] = float(spec['w'][k])
         F = a.B * a.T
-        # one flat buffer: [gradients of every present input | terms NT | loss 1 | per-frame partial sums F*NT]
+        # one flat buffer: [gradients of every present input | terms NT | loss 1 | init-state prior total 1 | per-frame partial sums F*NT]
         ng = sum(sizes)
-        flat = torch.empty(ng + NT + 1 + F * NT, dtype=torch.float32, device=dev)
+        flat = torch.empty(ng + NT + 2 + F * NT, dtype=torch.float32, device=dev)
         base, esz, o = flat.data_ptr(), 4, 0
-        views = []
-        for (_, gname), t, n in zip(DIFF_INPUTS, tensors, sizes):
+        views, goff = [], {}
+        for (name, gname), t, n in zip(DIFF_INPUTS, tensors, sizes):
             if n == 0:
                 views.append(None)
                 continue
-            setattr(a, gname, base + o * esz)
+            if gname is not None:
+                setattr(a, gname, base + o * esz)
+            goff[name] = base + o * esz
             views.append((o, n, tuple(t.shape)))
             o += n
-        a.terms, a.loss, a.partial = base + ng * esz, base + (ng + NT) * esz, base + (ng + NT + 1) * esz
+        a.terms, a.loss, a.partial = base + ng * esz, base + (ng + NT) * esz, base + (ng + NT + 2) * esz
+        gmm = spec.get('gmm')
+        if gmm is not None:
+            # init-state prior (FittingLoss.init_motion_prior_loss): ha_gmm_nll on [frame 0 of the prior-frame joints | joints_vel |
+            # trans_vel | root_orient_vel], its value and gradient folded into the objective by ha_fit_loss's reduction kernel
+            pj = named['pri_joints']
+            segs = [(pj, 66, a.T * a.pri_nj * 3)] + [(named[k], named[k][0].numel(), named[k][0].numel()) for k in GMM_INPUTS]
+            g = gmm['gmm']
+            K, D = g.means.shape
+            lp, gpart, nll, g_x = (torch.empty(sh, dtype=torch.float32, device=dev) for sh in ((a.B, K), (a.B, K, D), (a.B,), (a.B, D)))
+            ga = _lib.GmmArgs()
+            ga.B, ga.K, ga.D, ga.nseg = a.B, K, D, len(segs)
+            for i, (sgt, w_, st_) in enumerate(segs):
+                ga.seg[i], ga.seg_width[i], ga.seg_stride[i] = sgt.data_ptr(), w_, st_
+            tb = g.device_tables(dev)
+            for k, v in dict(means=tb['means'], Linv=tb['Linv'], LinvT=tb['LinvT'], cst=tb['const'], lp=lp, gpart=gpart, nll=nll, g_x=g_x).items():
+                setattr(ga, k, v.data_ptr())
+            lib.call('ha_gmm_nll', C.byref(ga), _lib.stream_ptr(ref))
+            keep += [lp, gpart, nll, g_x]
+            a.gmm_nll, a.gmm_gx, a.gmm_w, a.gmm_D, a.gmm_nseg = nll.data_ptr(), g_x.data_ptr(), float(gmm['w']), D, len(segs)
+            a.gmm_g[0], a.gmm_seg_width[0], a.gmm_g_stride[0], a.gmm_g_acc[0] = goff['pri_joints'], 66, a.T * a.pri_nj * 3, 1
+            for i, k in enumerate(GMM_INPUTS):
+                a.gmm_g[i + 1], a.gmm_seg_width[i + 1], a.gmm_g_stride[i + 1], a.gmm_g_acc[i + 1] = goff[k], segs[i + 1][1], segs[i + 1][1], 0
+            a.gmm_total = base + (ng + NT + 1) * esz
         lib.call('ha_fit_loss', C.byref(a), _lib.stream_ptr(ref))
         ctx.flat, ctx.views, ctx.ng = flat, views, ng
         ctx.prior_grad_hook = spec.get('prior_grad_hook')
         ctx.set_materialize_grads(False)
-        loss, terms = flat[ng + NT], flat[ng:ng + NT]
-        ctx.mark_non_differentiable(terms)
-        return loss, terms
+        loss, terms, gmm_total = flat[ng + NT], flat[ng:ng + NT], flat[ng + NT + 1]
+        ctx.mark_non_differentiable(terms, gmm_total)
+        return loss, terms, gmm_total
 
     @staticmethod
-    def backward(ctx, g_loss, _g_terms):
+    def backward(ctx, g_loss, _g_terms, _g_gmm=None):
         if g_loss is None:
             return (None, None) + (None,) * len(DIFF_INPUTS)
-        scaled = ctx.flat[:ctx.ng] * g_loss           # one launch for all inputs
+        unit = _UNIT.get((g_loss.device, g_loss.dtype))
+        if unit is not None and g_loss.dim() == 0 and g_loss.data_ptr() == unit.data_ptr():
+            scaled = ctx.flat[:ctx.ng]                # seeded with the cached 1.0 (MotionOptimizer._finish_closure): nothing to scale
+        else:
+            scaled = ctx.flat[:ctx.ng] * g_loss       # one launch for all inputs
         out = [None if v is None else scaled[v[0]:v[0] + v[1]].view(v[2]) for v in ctx.views]
         if ctx.prior_grad_hook is not None:
             # dL/d(prior_mu, prior_var) are complete here: the prior network's adjoint may start (HumorModel.mark_prior_grad)

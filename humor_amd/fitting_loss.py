@@ -109,6 +109,7 @@ class FittingLoss(nn.Module):
         # (humor_amd/csrc/fitloss.hip, fit_kernels.FusedFit) whenever the predictions live on the GPU; the term-by-term
         # PyTorch evaluation below remains for the cases the kernel does not cover (cross-batch `prev_batch_overlap_res`).
         self.fused = fused
+        self.fold_init_prior = True        # stage 3: the init-state GMM term inside the fused loss launches (see _fused_fit)
         self.prior_grad_hook = None        # callable(g_prior_mu, g_prior_var) run when the fused loss has produced them (MotionOptimizer)
         self._lib = _lib_override
         self.all_stage_loss_weights = loss_weights
@@ -257,14 +258,25 @@ class FittingLoss(nn.Module):
                 spec['S'], spec['dz'] = lm.shape[1], lm.shape[2]
                 if cond_prior is not None:
                     t['prior_mu'], t['prior_var'] = c(cond_prior[0]), c(cond_prior[1])
-            if all(k in pred for k in ('joints3d', 'joints_vel', 'trans_vel', 'root_orient_vel')) and W['init_motion_prior'] > 0.0:
-                cur = self.init_motion_prior_loss(pred['joints3d'][:, 0:1], pred['joints_vel'], pred['trans_vel'], pred['root_orient_vel'])
-                extra = W['init_motion_prior'] * init_motion_scale * cur
-                stats_extra['init_motion_prior'] = cur
             pj = pred.get('jtr')
             if pj is None and 'joints3d' in pred:
                 pj = pred['joints3d']
             want_pj = False
+            fold_gmm = False
+            if all(k in pred for k in ('joints3d', 'joints_vel', 'trans_vel', 'root_orient_vel')) and W['init_motion_prior'] > 0.0:
+                gmm = self.init_motion_prior['gmm']
+                # folded into the fused kernel's launches (fit_kernels.FusedFit, spec['gmm']) when it can read frame 0 of the joints in
+                # place: no separate autograd node, no accumulation launches for the gradients of the joints and the velocities
+                fold_gmm = (self.fold_init_prior and pj is not None and gmm.means.shape[0] <= 64 and gmm.means.shape[1] == 138
+                            and pj.dtype == torch.float32 and all(pred[k].dtype == torch.float32 for k in ('joints_vel', 'trans_vel', 'root_orient_vel')))
+                if fold_gmm:
+                    spec['gmm'] = dict(gmm=gmm, w=W['init_motion_prior'] * init_motion_scale)
+                    t['joints_vel'], t['trans_vel'], t['root_orient_vel'] = (c(pred[k]) for k in ('joints_vel', 'trans_vel', 'root_orient_vel'))
+                    want_pj = True
+                else:
+                    cur = self.init_motion_prior_loss(pred['joints3d'][:, 0:1], pred['joints_vel'], pred['trans_vel'], pred['root_orient_vel'])
+                    extra = W['init_motion_prior'] * init_motion_scale * cur
+                    stats_extra['init_motion_prior'] = cur
             if 'joints3d_rollout' in pred:
                 ro = pred['joints3d_rollout']
                 use_ro = False
@@ -303,8 +315,10 @@ class FittingLoss(nn.Module):
         spec['w'] = w
         if cond_prior is not None and self.prior_grad_hook is not None:
             spec['prior_grad_hook'] = self.prior_grad_hook
-        loss, terms = FK.FusedFit.apply(lib, spec, *[t[n] for n, _ in FK.DIFF_INPUTS])
+        loss, terms, gmm_total = FK.FusedFit.apply(lib, spec, *[t[n] for n, _ in FK.DIFF_INPUTS])
         stats = {FK.TERM_NAMES[k]: terms[k] for k in range(FK.NT) if w[k] != 0.0}
+        if 'gmm' in spec:
+            stats_extra['init_motion_prior'] = gmm_total
         stats.update(stats_extra)
         if extra is not None:
             loss = loss + extra

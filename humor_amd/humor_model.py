@@ -129,8 +129,9 @@ class _RolloutFunction(torch.autograd.Function):
     """(past_in0 [B,339], z_seq [B,S,48]) -> (world [B,S,348], prior_mu [B,S,48], prior_var [B,S,48])."""
 
     @staticmethod
-    def forward(ctx, past_in0, z_seq, handle, want_prior, defer_prior=False):
+    def forward(ctx, past_in0, z_seq, handle, want_prior, defer_prior=False, z_thru=False):
         lib = handle.lib
+        z_in = z_seq
         past_in0, z_seq = past_in0.contiguous().float(), z_seq.contiguous().float()
         B, S = z_seq.shape[0], z_seq.shape[1]
         dev = past_in0.device
@@ -146,23 +147,23 @@ class _RolloutFunction(torch.autograd.Function):
         ctx.handle, ctx.stash, ctx.dims, ctx.want_prior = handle, stash, (B, S), want_prior
         ctx.save_for_backward(z_seq)
         ctx.set_materialize_grads(False)
-        if want_prior:
-            return world, pm, pv
-        return world, None, None
+        # z_thru: the latent sequence handed through as a fourth output -- a later reader of it (the motion-prior loss term) then sends
+        # its gradient here, where it is added inside the adjoint's last kernel (ha_humor_rollout_backward_ex) instead of by autograd
+        return world, pm, pv, (z_in if z_thru else None)
 
     @staticmethod
-    def backward(ctx, g_world, g_pm, g_pv):
+    def backward(ctx, g_world, g_pm, g_pv, g_z_thru=None):
         handle, (B, S) = ctx.handle, ctx.dims
         lib = handle.lib
         z_seq, = ctx.saved_tensors
         dev = z_seq.device
         c = lambda t: None if t is None else t.contiguous().float()
-        g_world, g_pm, g_pv = c(g_world), c(g_pm), c(g_pv)
+        g_world, g_pm, g_pv, g_z_thru = c(g_world), c(g_pm), c(g_pv), c(g_z_thru)
         g_past = torch.empty(B, 339, dtype=torch.float32, device=dev)
         g_z = torch.empty(B, S, 48, dtype=torch.float32, device=dev)
-        lib.call('ha_humor_rollout_backward', handle.ptr, B, S, _lib.ptr(z_seq), _lib.ptr(g_world), _lib.ptr(g_pm), _lib.ptr(g_pv),
-                 _lib.ptr(ctx.stash), _lib.ptr(g_past), _lib.ptr(g_z), _lib.stream_ptr(z_seq))
-        return g_past, g_z, None, None, None
+        lib.call('ha_humor_rollout_backward_ex', handle.ptr, B, S, _lib.ptr(z_seq), _lib.ptr(g_world), _lib.ptr(g_pm), _lib.ptr(g_pv),
+                 _lib.ptr(ctx.stash), _lib.ptr(g_past), _lib.ptr(g_z), _lib.ptr(g_z_thru), _lib.stream_ptr(z_seq))
+        return g_past, g_z, None, None, None, None
 
 
 def _rollout_sample(handle, past_in, eps, S):
@@ -502,13 +503,17 @@ class HumorModel(nn.Module):
             world, pm, pv, z_out = _rollout_sample(handle, past_in.detach(), eps, num_steps)
         else:
             z_seq = z_seq[:, :num_steps]
-            world, pm, pv = _RolloutFunction.apply(past_in, z_seq, handle, bool(return_prior), bool(defer_prior))
-            z_out = z_seq
+            world, pm, pv, z_t = _RolloutFunction.apply(past_in, z_seq, handle, bool(return_prior), bool(defer_prior), bool(return_world and return_z))
+            z_out = z_seq if z_t is None else z_t
         if canonicalize_input and uncanonicalize_output:
             from .frames import uncanonicalize_world
             world = uncanonicalize_world(world, *uncanon)
         if return_world:
             # the undivided [B, S, 348] world-frame state (what the fused post-processing kernel reads) instead of the dict
+            if return_z:
+                # (extension) the latent sequence handed through the roll-out node: read THIS tensor in later loss terms instead of the one
+                # passed in, and its gradient joins the roll-out's inside the adjoint kernel (no accumulation launch)
+                return (world, (pm, pv), z_out) if return_prior else (world, z_out)
             return (world, (pm, pv)) if return_prior else world
         # one split (views forward, a single cat backward) instead of one slice + zero-fill + add per output
         dims = list(self.delta_output_dim_list)

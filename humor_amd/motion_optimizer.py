@@ -36,7 +36,7 @@ class MotionOptimizer():
                  robust_tuning_const=4.6851, joint2d_sigma=100, stage3_tune_init_state=True, stage3_tune_init_num_frames=15,
                  stage3_tune_init_freeze_start=30, stage3_tune_init_freeze_end=50, stage3_contact_refine_only=False,
                  use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs='auto', fused_loss=True, lbfgs='fused', fused_post=True, fused_pre=True, fused_vposer=True,
-                 rigid_cam_body=True, defer_prior=False):
+                 rigid_cam_body=True, defer_prior=False, fused_stage3=True):
         B, T = batch_size, seq_len
         self.device = device
         self.batch_size, self.seq_len = B, T
@@ -72,6 +72,8 @@ class MotionOptimizer():
         # stage 3 evaluates the body model on the same pose and shape under two root trajectories (prior frame, camera frame):
         # the second evaluation as the rigid image of the first (ha_rigid_image_*) instead of a second SMPL forward + backward
         self.rigid_cam_body = bool(rigid_cam_body)
+        # stage 3 as three composite autograd nodes (humor_amd/stage3.py): no accumulation / cat / expand launches between the kernels
+        self.fused_stage3 = bool(fused_stage3)
         # stage 3, opt-in: the conditional prior's batched GEMMs (forward and adjoint, ~0.27 ms of a 1.8 ms evaluation at 32 x 60) on the
         # library's side stream beside the SMPL evaluations and their adjoints (HumorModel.roll_out(defer_prior=True) / join_prior /
         # mark_prior_grad) instead of in line between the decoder chain and them.  Bit-identical results, but MEASURED SLOWER on one
@@ -311,7 +313,11 @@ class MotionOptimizer():
         self.stage_profile['_last'] = (now, self.closure_evals)
 
     def _finish_closure(self, loss, params, stats=None):
-        loss.backward()
+        if loss.dim() == 0 and loss.dtype == torch.float32:
+            from .fit_kernels import unit_seed
+            loss.backward(gradient=unit_seed(loss))      # (a cached 1.0: no ones_like launch, see fit_kernels.unit_seed)
+        else:
+            loss.backward()
         self.closure_evals += 1
         if self.shard is not None:
             from .distributed import allreduce_loss_and_grads
@@ -616,9 +622,72 @@ class MotionOptimizer():
                          joints_vel.reshape(B, 22, 3), root_orient_vel.reshape(B, 3))
         return (cur_body_pose,) + tuple(o)
 
+    def _stage3_nodes_config(self, ref):
+        """cfg of the stage-3 composite nodes (humor_amd/stage3.py) when every piece they group is available, else None."""
+        lib = self.fit_bm._lib
+        if not (self.fused_stage3 and self.optim_floor and self.fused_pre and self.fused_post and self.rigid_cam_body and self.fitting_loss.fused
+                and not self.dense_smpl and (ref.is_cuda or (lib is not None and lib.emulator)) and getattr(self.motion_prior, 'pred_contacts', False)):
+            return None
+        fv = self._fused_vposer(ref)
+        sm = self.fit_bm.parts_config(ref.device)
+        if fv is None or sm is None or fv.dec.out_dim != 2 * J_BODY * 3:
+            return None
+        if lib is None:
+            from . import _lib as _libmod
+            lib = _libmod.get_lib()
+        return dict(lib=lib, smpl=sm, vposer=fv.dec)
+
+    def _stage3_objective_nodes(self, cfg, obs_local, obs_init, prior_opt_params, tune_phase, n_init, init_motion_scale, og_overlap_w,
+                                has_overlap):
+        """_stage3_objective as three composite autograd nodes + the fused loss (humor_amd/stage3.py): the same library calls in the same
+        order, but no tensor with two readers crosses a node boundary, so autograd launches no accumulation kernels between them."""
+        from .stage3 import Stage3Body, Stage3Head
+        L = self._local
+        trans, root_orient, betas, floor = L(self.trans), L(self.root_orient), L(self.betas), L(self.floor_plane)
+        tv, jv, rv = (L(p) for p in prior_opt_params)
+        B = trans.size(0)
+        (pose0, past_in, trans_p, root_p, joints_p, c2p_R, c2p_t, root_h, floor_t, tv_t, jv_t, rv_t, betas_t) = Stage3Head.apply(
+            cfg, L(self.latent_pose).reshape(B, -1), trans.reshape(B, 3), root_orient.reshape(B, 3), betas, floor, tv.reshape(B, 3),
+            jv.reshape(B, 22, 3), rv.reshape(B, 3))
+        if self.shard is None:
+            self.cam2prior_R, self.cam2prior_t, self.cam2prior_root_height = c2p_R, c2p_t, root_h
+        latent_motion = L(self.latent_motion)
+        if tune_phase:
+            latent_motion = latent_motion[:, :(n_init - 1)]
+        res = self.motion_prior.roll_out(past_in.unsqueeze(1), None, latent_motion.size(1), z_seq=latent_motion, return_prior=self.cond_prior,
+                                         return_world=True, return_z=True, defer_prior=self.defer_prior and self.cond_prior)
+        world, prior_out, z_t = res if self.cond_prior else (res[0], None, res[1])
+        (pri_jtr, pri_verts, cam_jtr, cam_verts, r_trans, r_root, r_pose, ro_joints, conf, contacts, _cam_trans, _cam_root, betas_t) = Stage3Body.apply(
+            cfg, world, trans_p, root_p, pose0, joints_p, c2p_R, c2p_t, betas_t)
+        nj = len(SMPL_JOINTS)
+        faces = self.fit_bm.bm.faces_tensor
+        pred = {'joints3d': pri_jtr[:, :, :nj], 'joints3d_extra': pri_jtr[:, :, nj:], 'jtr': pri_jtr, 'verts3d': pri_verts, 'faces': faces,
+                'betas': betas_t, 'latent_motion': z_t, 'joints_vel': jv_t, 'trans_vel': tv_t, 'root_orient_vel': rv_t,
+                'joints3d_rollout': ro_joints, 'contacts': contacts, 'contacts_conf': conf}
+        cam_pred = {'joints3d': cam_jtr[:, :, :nj], 'joints3d_extra': cam_jtr[:, :, nj:], 'jtr': cam_jtr, 'verts3d': cam_verts, 'faces': faces,
+                    'betas': betas_t, 'floor_plane': floor_t}
+        if self.fitting_loss.loss_weights['pose_prior'] > 0.0:
+            pred['latent_pose'] = cam_pred['latent_pose'] = self.pose2latent(r_pose)
+        nsteps, obs = self.seq_len, obs_local
+        if tune_phase:
+            nsteps, obs = n_init, obs_init
+            self.fitting_loss.loss_weights['rgb_overlap_consist'] = 0.0
+        halo = self._halo(cam_verts, betas_t, floor_t, has_overlap and self.fitting_loss.loss_weights['rgb_overlap_consist'] > 0.0)
+        if self.defer_prior and prior_out is not None:
+            self.motion_prior.join_prior(prior_out[0])
+        loss, stats = self.fitting_loss.motion_fit(obs, pred, cam_pred, nsteps, cond_prior=prior_out, init_motion_scale=init_motion_scale, halo=halo)
+        loss = self.fitting_loss.add_next_side(loss, 'motion', cam_pred, halo)
+        if tune_phase:
+            self.fitting_loss.loss_weights['rgb_overlap_consist'] = og_overlap_w
+        return loss, stats
+
     def _stage3_objective(self, obs_local, obs_init, prior_opt_params, tune_phase, n_init, init_motion_scale, og_overlap_w,
                           has_overlap, fit_gender):
         """One stage-3 objective evaluation on this rank's sequences (motion_optimizer.py:514-605)."""
+        cfg = self._stage3_nodes_config(self.trans)
+        if cfg is not None:
+            return self._stage3_objective_nodes(cfg, obs_local, obs_init, prior_opt_params, tune_phase, n_init, init_motion_scale, og_overlap_w,
+                                                has_overlap)
         L = self._local
         trans, root_orient, betas = L(self.trans), L(self.root_orient), L(self.betas)
         floor = L(self.floor_plane) if self.optim_floor else None

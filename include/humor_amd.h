@@ -104,6 +104,28 @@ int ha_smpl_backward_split(const ha_smpl_model* m, int slot, int N, int n_active
                            int n_head, const float* g_joints_ext, const float* g_verts_tail, float* g_pose, float* g_betas,
                            float* g_transl, void* stream);
 
+/* "Parts" form of the split evaluation (ABI 2; what the stage-3 composites of humor_amd/stage3.py call, so that no ATen launch sits
+ * between the kernels of an objective evaluation):
+ *   - the pose arrives as root [N,3] + body [N,(n_active-1)*3] (BodyModel.forward's arguments, humor/body_model/body_model.py:72-80,
+ *     without the cat in front of the kernel); joints >= n_active rest;
+ *   - one shape row serves betas_div consecutive frames: betas [N / betas_div, NB] (the reference expands betas over the frames,
+ *     humor/fitting/motion_optimizer.py:1087; here neither the expanded copy nor its summed gradient's expand node exist -- g_betas is
+ *     still per frame [N, NB], ha_seq_sum_add folds it);
+ *   - backward: only the first gj_rows rows of g_joints_ext exist (0 = all J + n_head), row stride gj_stride joints per frame (0 = J +
+ *     n_head); the pose gradient leaves as g_root [N,3] + g_body [N,(n_active-1)*3]; add_root / add_body / add_betas [N,NB] /
+ *     add_transl (each may be NULL) are added to the corresponding output in the kernel: the gradient another reader of the same
+ *     input produced, instead of an accumulation launch behind the call. */
+int ha_smpl_forward_parts(const ha_smpl_model* m, int slot, int N, int n_active, const float* root, const float* body,
+                          const float* betas, int betas_div, const float* transl, int n_head, float* joints_ext, float* verts_tail,
+                          void* stream);
+int ha_smpl_backward_parts(const ha_smpl_model* m, int slot, int N, int n_active, const float* root, const float* body,
+                           const float* betas, int betas_div, int n_head, const float* g_joints_ext, int gj_rows, int gj_stride,
+                           const float* g_verts_tail, const float* add_root, const float* add_body, const float* add_betas,
+                           const float* add_transl, float* g_root, float* g_body, float* g_betas, float* g_transl, void* stream);
+/* out [B,W] = sum_t src [B,T,W] + add1 [B,W] + add2 [B,W] (addends may be NULL; W <= 64): per-frame shape gradients back to one row
+ * per sequence together with the gradients the other readers of the shape rows produced, in one launch. */
+int ha_seq_sum_add(int B, int T, int W, const float* src, const float* add1, const float* add2, float* out, void* stream);
+
 /* Backward of the DENSE forward (slot 0, every vertex carries a gradient: the point-cloud / chamfer term of
  * humor/fitting/fitting_loss.py:378-396 back through BodyModel): g_verts [N, V, 3] is required; v_posed [N, V, 3] and
  * A [N, J, 12] are the forward's `ws_vposed` / `A_out`.  The vertex phase runs as batched kernels over all frames
@@ -214,6 +236,12 @@ int ha_humor_rollout_backward(const ha_humor_net* net, int B, int S, const float
                               const float* g_world, const float* g_prior_mu, const float* g_prior_var,
                               float* stash, float* g_past_in0, float* g_z_seq, void* stream);
 
+/* ha_humor_rollout_backward with an addend: g_z_add [B,S,48] (or NULL) is added to g_z_seq -- the gradient another reader of z_seq (the
+ * motion-prior loss term) produced -- inside the adjoint's last kernel instead of by an accumulation launch behind the call. */
+int ha_humor_rollout_backward_ex(const ha_humor_net* net, int B, int S, const float* z_seq,
+                                 const float* g_world, const float* g_prior_mu, const float* g_prior_var,
+                                 float* stash, float* g_past_in0, float* g_z_seq, const float* g_z_add, void* stream);
+
 /* Per-network options.  "output_delta" (default 1): the decoder emits residuals that are composed with the input state
  * (HumorModel(output_delta=True), humor/models/humor_model.py:460-494); 0: it emits the next state itself and only its rotations are
  * converted (humor_model.py:331-347).  Networks with output_delta = 0 run the launch chain. */
@@ -309,6 +337,14 @@ typedef struct ha_fit_args {
   float* g_latent_pose; float* g_betas; float* g_latent_motion; float* g_prior_mu; float* g_prior_var; float* g_floor;
   float* g_prev_tail; float* g_prev_betas; float* g_prev_floor;
   float* partial;                      /* workspace [B*T, HA_FIT_NTERMS] */
+  /* optional (ABI 2): the stage-3 init-state prior (ha_gmm_nll run by the caller just before, on the same stream) folded into the
+   * objective: loss += gmm_w * sum_b gmm_nll[b]; gmm_total[0] = sum_b gmm_nll[b]; and gmm_w * gmm_gx [B, gmm_D] is handed out segment
+   * by segment (as ha_gmm_args lays x_b out): segment 0 (66 floats: the 22 joints of frame 0 of pri_joints) is added to frame 0 of
+   * g_pri_joints by the loss kernel itself when gmm_g[0] != NULL; segment s >= 1 of row b is stored to gmm_g[s] + b * gmm_g_stride[s]
+   * (gmm_g_acc is reserved, pass 0). */
+  const float* gmm_nll; const float* gmm_gx; float gmm_w; int gmm_D; int gmm_nseg;
+  float* gmm_g[4]; int gmm_seg_width[4]; int gmm_g_stride[4]; int gmm_g_acc[4];
+  float* gmm_total;
 } ha_fit_args;
 
 int ha_fit_loss(const ha_fit_args* args, void* stream);
@@ -331,6 +367,11 @@ typedef struct ha_fit_pre_args {
   const float* g_c2p_t; const float* g_root_height;
   float* g_floor; float* g_trans0; float* g_root0; float* g_pose0; float* g_jcam; float* g_trans_vel; float* g_joints_vel;
   float* g_root_orient_vel;
+  /* optional (ABI 2).  jcam_stride: floats between the sequences' rows of jcam (0 = 66; 219 reads the first 22 rows of a [B,73,3] joint
+   * tensor in place).  Backward addends (each may be NULL): the gradient another reader of floor / pose0 / the velocities produced,
+   * added to the corresponding output in the kernel instead of by an accumulation launch behind it. */
+  int jcam_stride;
+  const float* add_floor; const float* add_pose0; const float* add_trans_vel; const float* add_joints_vel; const float* add_root_orient_vel;
 } ha_fit_pre_args;
 int ha_fit_pre_forward(const ha_fit_pre_args* args, void* stream);
 int ha_fit_pre_backward(const ha_fit_pre_args* args, void* stream);
@@ -378,6 +419,9 @@ typedef struct ha_rigid_image_args {
   float* joints2; float* verts2;
   const float* g_joints2; const float* g_verts2;
   float* g_joints; float* g_verts; float* g_root; float* g_trans; float* g_root2; float* g_trans2;
+  /* backward, optional (ABI 2): addends of g_joints / g_verts -- the gradient another reader of joints / verts produced, added in
+   * the kernel instead of by an accumulation launch behind it */
+  const float* g_joints_add; const float* g_verts_add;
 } ha_rigid_image_args;
 int ha_rigid_image_forward(const ha_rigid_image_args* args, void* stream);
 int ha_rigid_image_backward(const ha_rigid_image_args* args, void* stream);

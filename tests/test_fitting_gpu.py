@@ -296,3 +296,24 @@ def test_deferred_prior_equals_inline(gpu_lib, dev, smplh_npz, B, T):
     assert ref['g_latent_motion'].abs().max().item() > 0
     n_fwd, n_bwd = opt.motion_prior.prior_side_stats(ref['loss'])
     assert (n_fwd, n_bwd) == (6, 6), (n_fwd, n_bwd)      # the side-stream path was the one that ran
+
+
+@pytest.mark.parametrize('B,T', [(4, 12), (32, 60)])
+def test_stage3_nodes_equal_separate_functions(gpu_lib, dev, smplh_npz, B, T):
+    """The stage-3 objective as three composite autograd nodes with in-kernel gradient addends (humor_amd/stage3.py, the init-state GMM
+    term folded into the fused loss) against the same objective built from the separate Functions + autograd's accumulation launches:
+    same kernels, same arithmetic, only the order in which gradient contributions are summed differs (fp32 rounding)."""
+    from oracle import closure_cases as CC
+    case = CC.make_case('rgb', B, T, seed=13)
+    res = []
+    for nodes in (True, False):
+        opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
+        opt.fused_stage3 = nodes
+        opt.fitting_loss.fold_init_prior = nodes
+        assert (opt._stage3_nodes_config(torch.zeros(1, device=dev)) is not None) == nodes
+        res.append(FC.eval_stage(opt, case, 2, dev))
+    assert abs(res[0]['loss'].item() - res[1]['loss'].item()) <= 1e-6 * abs(res[1]['loss'].item())
+    for k in res[0]:
+        if k != 'loss':
+            e = (res[0][k] - res[1][k]).abs().max().item() / max(1.0, res[1][k].abs().max().item())
+            assert e < 2e-5, (k, e)
