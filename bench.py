@@ -378,7 +378,8 @@ def lbfgs_profile(dev, npz, k=5):
     obs, _ = make_problem(B_SEQ, T_SEQ, seed=100, device=dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    opt.run(obs, data_fps=30, lr=1.0, num_iter=[k, k, 3 * k], lbfgs_max_iter=20)
+    # (stages 1-2: 3 k iterations each -- their evaluations are 0.3 ms, and a phase's wall time includes the one-off capture of its graph)
+    opt.run(obs, data_fps=30, lr=1.0, num_iter=[3 * k, 3 * k, 3 * k], lbfgs_max_iter=20)
     torch.cuda.synchronize()
     total = time.perf_counter() - t0
     prof = {n: v for n, v in opt.stage_profile.items() if not n.startswith('_')}

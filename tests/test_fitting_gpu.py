@@ -317,3 +317,29 @@ def test_stage3_nodes_equal_separate_functions(gpu_lib, dev, smplh_npz, B, T):
         if k != 'loss':
             e = (res[0][k] - res[1][k]).abs().max().item() / max(1.0, res[1][k].abs().max().item())
             assert e < 2e-5, (k, e)
+
+
+def test_stage3_nodes_with_frozen_initial_state(gpu_lib, dev, smplh_npz):
+    """The frozen-init phase of stage 3 (motion_optimizer.py:451-458: the initial state does not require gradients, init_motion_scale 4):
+    composite nodes against the separate Functions, gradients of the variables that phase optimises."""
+    from oracle import closure_cases as CC
+    B, T = 8, 20
+    case = CC.make_case('rgb', B, T, seed=3)
+    out = []
+    for nodes in (True, False):
+        opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
+        opt.fused_stage3 = nodes
+        opt.fitting_loss.fold_init_prior = nodes
+        var = {k: v.clone().to(dev) for k, v in case['var'].items()}
+        obs = {k: v.clone().to(dev) for k, v in case['obs'].items()}
+        opt.fitting_loss.set_stage(2)
+        opt.trans, opt.root_orient, opt.latent_pose = var['trans'][:, :1].clone(), var['root_orient'][:, :1].clone(), var['latent_pose'][:, :1].clone()
+        opt.betas, opt.latent_motion = var['betas'].requires_grad_(True), var['latent_motion'].requires_grad_(True)
+        opt.trans_vel, opt.joints_vel, opt.root_orient_vel = var['trans_vel'], var['joints_vel'], var['root_orient_vel']
+        opt.floor_plane = var['floor_plane'].requires_grad_(True)
+        loss, _ = opt._stage3_objective(opt._local_obs(obs), None, [opt.trans_vel, opt.joints_vel, opt.root_orient_vel], False, 15, 4.0,
+                                        opt.fitting_loss.loss_weights['rgb_overlap_consist'], True, 'neutral')
+        out.append((loss.item(), torch.autograd.grad(loss, [opt.latent_motion, opt.betas, opt.floor_plane])))
+    assert abs(out[0][0] - out[1][0]) <= 1e-6 * abs(out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
