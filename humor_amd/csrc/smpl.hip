@@ -1963,6 +1963,7 @@ extern "C" int ha_smpl_backward_parts(const ha_smpl_model* m, int slot, int N, i
   return HA_OK;
 }
 
+namespace ha {
 // out[b][w] = sum_t src[b][t][w] + add1[b][w] + add2[b][w]  (the per-frame shape gradients of a [B, T] batch back to one row per
 // sequence, together with the gradients other consumers of the same shape rows produced: one launch for sum + add + add)
 __global__ __launch_bounds__(256) void seq_sum_add_kernel(const float* __restrict__ src, const float* __restrict__ add1,
@@ -1980,6 +1981,7 @@ __global__ __launch_bounds__(256) void seq_sum_add_kernel(const float* __restric
   if (add2) acc += add2[(size_t)b * W + w];
   out[(size_t)b * W + w] = acc;
 }
+}  // namespace ha
 
 extern "C" int ha_seq_sum_add(int B, int T, int W, const float* src, const float* add1, const float* add2, float* out, void* stream) {
   HA_REQUIRE(src && out && B >= 1 && T >= 1 && W >= 1 && W <= 64, "ha_seq_sum_add: need src, out, B, T >= 1 and 1 <= W <= 64");
