@@ -41,6 +41,19 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
 #endif
 }
 
+// Zero-fill as a KERNEL (4-byte words).  Not hipMemsetAsync: inside a captured hipGraph a memset node followed by a kernel node was
+// observed (ROCm 7.0 / gfx950, round 4) to let the kernel start on the previous replay's contents -- the persistent roll-out kernel then
+// found its team counters already full (error word 0x100) -- while kernel -> kernel edges are ordered exactly as in a stream.
+static __global__ void zero_words_kernel(unsigned* __restrict__ p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+static inline void zero_async(void* p, size_t bytes, hipStream_t st) {
+  const size_t n = bytes / 4;       // (every caller clears whole floats)
+  if (n == 0) return;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(p), n);
+}
+
 #define HA_CHECK_HIP(expr)                                                                        \
   do {                                                                                            \
     hipError_t _e = (expr);                                                                       \

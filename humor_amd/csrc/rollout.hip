@@ -2025,7 +2025,7 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
     if (phase == PH_STEP) return HA_OK;
   }
   if (phase == PH_BEGIN) {
-    if (L.acc) HA_CHECK_HIP(hipMemsetAsync(stash + L.steps, 0, (size_t)(S + 1) * L.per_step * sizeof(float), st));
+    if (L.acc) zero_async(stash + L.steps, (size_t)(S + 1) * L.per_step * sizeof(float), st);
     hipLaunchKernelGGL(transpose_in_kernel, dim3(256), dim3(256), 0, st, z_seq, stash + L.zT, B, S, ZD, ZD, RT);
     HA_LAUNCH_CHECK();
     hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, x_ptr(0), B, 1, D_IN, D_INP, RT);
@@ -2182,7 +2182,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
   const int gxp_pad = net->pri[0].Nin_pad;
   // adjoint scratch of decoder layer l at step t (accumulate policy: one pre-zeroed set per step; else one set reused by every step)
   auto bd = [&](int l, int t) { return stash + L.bwd_dec[l] + (size_t)(t < 0 ? 0 : (t >= S ? S - 1 : t)) * L.bwd_set; };
-  if (L.acc && phase == PH_BEGIN) HA_CHECK_HIP(hipMemsetAsync(stash + L.bwd_begin, 0, L.bwd_floats * sizeof(float), st));
+  if (L.acc && phase == PH_BEGIN) zero_async(stash + L.bwd_begin, L.bwd_floats * sizeof(float), st);
 
   // the prior's contribution to dL/dx_t for every step, before the reverse scan (it does not depend on the scan)
   if (with_prior && phase == PH_BEGIN && !tl_prior_bwd_done) {

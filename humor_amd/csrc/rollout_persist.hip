@@ -1896,7 +1896,8 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
 #else
   HA_REQUIRE(p && f.B >= 1 && f.B <= NTEAMS * ROWS && f.S >= 1, "persistent roll-out: needs 1 <= B <= 32 sequences");
   HA_REQUIRE(f.S < (1 << 28), "persistent roll-out: too many steps");
-  HA_CHECK_HIP(hipMemsetAsync(f.ws, 0, XCH_BYTES, st));        // tags, team counters (tag 0 never matches)
+  zero_async(f.ws, XCH_BYTES, st);        // tags, team counters (tag 0 never matches); a kernel, not a memset node: common.h
+  HA_LAUNCH_CHECK();
   PersistArgs a;
   memset(&a, 0, sizeof(a));
   a.B = f.B; a.S = f.S;
@@ -1927,7 +1928,8 @@ int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_
   return HA_ERR_INVALID_ARG;
 #else
   HA_REQUIRE(p && f.B >= 1 && f.B <= NTEAMS * ROWS && f.S >= 1, "persistent roll-out adjoint: needs 1 <= B <= 32 sequences");
-  HA_CHECK_HIP(hipMemsetAsync(f.ws, 0, XCH_BYTES, st));
+  zero_async(f.ws, XCH_BYTES, st);
+  HA_LAUNCH_CHECK();
   PersistBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.B = f.B; a.S = f.S;

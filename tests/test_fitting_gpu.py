@@ -55,10 +55,13 @@ def test_lbfgs_kernels_against_two_loop_recursion(gpu_lib, dev, n, h, k):
     print('direction rel. error', LC.check_direction(gpu_lib, dev, n=n, h=h, k=k, seed=k))
 
 
-def test_graphed_closure_equals_eager(gpu_lib, dev, smplh_npz):
-    """hipGraph replay of the stage-3 closure returns the eager loss and gradients bit-for-bit, call after call."""
+@pytest.mark.parametrize('B,T,reps', [(4, 8, 3), (32, 60, 8)])
+def test_graphed_closure_equals_eager(gpu_lib, dev, smplh_npz, B, T, reps):
+    """hipGraph replay of the stage-3 closure returns the eager loss and gradients, call after call, while every variable changes in
+    place between the calls; at the metric's batch the persistent roll-out kernels are inside the graph and must not report a failed
+    launch (round 4: with hipMemsetAsync in front of them they started on the previous replay's team counters -- error word 0x100 --
+    as soon as the values changed; the exchange space is now cleared by a kernel, csrc/common.h zero_async)."""
     from oracle import closure_cases as CC
-    B, T = 4, 8
     case = CC.make_case('rgb', B, T, seed=1)
     res = {}
     for graphs in (False, True):
@@ -77,16 +80,21 @@ def test_graphed_closure_equals_eager(gpu_lib, dev, smplh_npz):
         ol = opt._local_obs(obs)
         closure = opt.make_closure(lambda: opt._stage3_objective(ol, None, prior, False, 15, 1.0, 200.0, True, 'neutral'), params, None)
         out = []
-        for it in range(3):
+        for it in range(reps):
             loss = closure()
             out.append((loss.item(), [p.grad.clone() for p in params]))
             with torch.no_grad():
                 opt.latent_motion.add_(0.01)          # the optimiser updates variables in place between evaluations
+                for p in params:
+                    p.mul_(1.0 + 2.0 ** -20)
+            torch.cuda.synchronize()
         res[graphs] = out
+        available, err, _ = opt.motion_prior.persistent_rollout_status(dev)
+        assert err == 0 and available == 1, (graphs, available, hex(err))
     for (l0, g0), (l1, g1) in zip(res[False], res[True]):
         assert abs(l0 - l1) <= 1e-5 * abs(l0)
         for a, b in zip(g0, g1):
-            assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())
+            assert (a - b).abs().max().item() <= 2e-4 * max(1.0, a.abs().max().item())
 
 
 def _sharded_gpu_worker(rank, world, port, npz, out):
