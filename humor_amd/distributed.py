@@ -74,3 +74,83 @@ def allreduce_loss_and_grads(loss, params, group=None):
             p.grad.copy_(g)
         o += n
     return packed[-1].clone()
+
+
+class GradArena:
+    """Packed [gradients of the live parameters | loss] buffer of a sharded closure, persistent across evaluations.
+
+    Without it an evaluation pays, per parameter, autograd's slice_backward (a full-size zero fill + a copy of the rank's rows), a `cat` into
+    the packed vector and a copy back out of it after the all-reduce: ~35 small launches (0.09 ms of a 1.75 ms evaluation on one MI355X).
+    With it: `begin()` zero-fills the arena once, `rows(p)` hands the closure this rank's rows of p through an autograd node whose backward
+    drops the incoming gradient into the arena's rows (one copy) and returns the arena's full-size view, the all-reduce runs in place on
+    the arena, and `p.grad` of every live parameter is left as a view of it (no copies out).  A parameter's rows are handed out ONCE per
+    evaluation (later calls return the same tensor), so autograd sums its readers' gradients before the one backward call.
+    The arena is overwritten by the next evaluation: callers that keep a gradient across evaluations clone it (the L-BFGS implementations do)."""
+
+    def __init__(self, params, shard):
+        self.shard = shard
+        self.live = [p for p in params if p.requires_grad]
+        self.sizes = [p.numel() for p in self.live]
+        ref = self.live[0]
+        self.buf = torch.zeros(sum(self.sizes) + 1, dtype=ref.dtype, device=ref.device)
+        self.views, o = {}, 0
+        for p, n in zip(self.live, self.sizes):
+            self.views[id(p)] = self.buf[o:o + n].view_as(p)
+            o += n
+        self._rows = {}
+
+    def matches(self, params):
+        live = [p for p in params if p.requires_grad]
+        return len(live) == len(self.live) and all(a is b for a, b in zip(live, self.live))
+
+    def begin(self):
+        self.buf.zero_()
+        self._rows = {}
+
+    def rows(self, p):
+        """This rank's rows of parameter p (None: p is not one of the arena's parameters)."""
+        view = self.views.get(id(p))
+        if view is None:
+            return None
+        out = self._rows.get(id(p))
+        if out is None:
+            out = self._rows[id(p)] = _ShardRows.apply(p, self.shard.b0, self.shard.b1, view)
+        return out
+
+    def rows_buffer(self, p):
+        """The arena's rows b0:b1 of parameter p (where a kernel may write dL/d(rows of p) directly), or None."""
+        view = self.views.get(id(p))
+        return None if view is None else view[self.shard.b0:self.shard.b1]
+
+    def allreduce(self, loss, group=None):
+        """Sums the arena (and the loss) over the ranks in place; leaves p.grad = the arena's view for every live parameter."""
+        for p in self.live:
+            view = self.views[id(p)]
+            g = p.grad
+            if g is None:
+                continue                                   # no gradient reached p: its rows are still zero
+            if g.data_ptr() != view.data_ptr():
+                view.copy_(g)                              # (a gradient that did not come through rows())
+        self.buf[-1:].copy_(loss.detach().reshape(1))
+        dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
+        for p in self.live:
+            p.grad = self.views[id(p)]
+        return self.buf[-1].clone()
+
+
+class _ShardRows(torch.autograd.Function):
+    """x [B, ...] -> x[b0:b1]; backward: the incoming gradient goes into rows b0:b1 of `full` (a view of the GradArena, zero elsewhere) and
+    `full` is returned -- what SliceBackward computes, without allocating and zero-filling a full-size tensor per evaluation."""
+
+    @staticmethod
+    def forward(ctx, x, b0, b1, full):
+        ctx.b0, ctx.b1, ctx.full = b0, b1, full
+        return x[b0:b1]
+
+    @staticmethod
+    def backward(ctx, g):
+        rows = ctx.full[ctx.b0:ctx.b1]
+        if g.data_ptr() != rows.data_ptr():
+            rows.copy_(g)
+        # a fresh view object: AccumulateGrad takes a gradient over without cloning it only when nobody else holds the tensor object
+        return ctx.full.view_as(ctx.full), None, None, None

@@ -74,6 +74,8 @@ class MotionOptimizer():
         self.rigid_cam_body = bool(rigid_cam_body)
         # stage 3 as three composite autograd nodes (humor_amd/stage3.py): no accumulation / cat / expand launches between the kernels
         self.fused_stage3 = bool(fused_stage3)
+        # sharded closures: gradients of the variables land in one persistent packed arena that is all-reduced in place (distributed.GradArena)
+        self.grad_arena = True
         # stage 3, opt-in: the conditional prior's batched GEMMs (forward and adjoint, ~0.27 ms of a 1.8 ms evaluation at 32 x 60) on the
         # library's side stream beside the SMPL evaluations and their adjoints (HumorModel.roll_out(defer_prior=True) / join_prior /
         # mark_prior_grad) instead of in line between the decoder chain and them.  Bit-identical results, but MEASURED SLOWER on one
@@ -146,8 +148,16 @@ class MotionOptimizer():
     # small helpers
     # ------------------------------------------------------------------------------------------------
     def _local(self, x):
-        """This rank's slice of a per-sequence tensor (identity without sharding)."""
-        return x if self.shard is None else self.shard.sl(x)
+        """This rank's slice of a per-sequence tensor (identity without sharding).  Inside a sharded closure the optimisation variables
+        come through the gradient arena (distributed.GradArena): same rows, no slice_backward fill + copy per variable."""
+        if self.shard is None:
+            return x
+        arena = getattr(self, '_arena', None)
+        if arena is not None and x.requires_grad and x.is_leaf:
+            r = arena.rows(x)
+            if r is not None:
+                return r
+        return self.shard.sl(x)
 
     def _local_obs(self, observed_data, nsteps=None):
         out = {}
@@ -219,8 +229,17 @@ class MotionOptimizer():
             def closure():
                 for p in params:          # = optim.zero_grad(set_to_none=True) of the reference closures
                     p.grad = None
-                loss, stats = objective()
-                return self._finish_closure(loss, params, stats)
+                if self.shard is not None and self.grad_arena:
+                    from .distributed import GradArena
+                    if getattr(self, '_arena', None) is None or not self._arena.matches(params):
+                        self._arena = GradArena(params, self.shard)
+                    self._arena.begin()
+                try:
+                    loss, stats = objective()
+                    return self._finish_closure(loss, params, stats)
+                finally:
+                    if self.shard is not None and getattr(self, '_arena', None) is not None:
+                        self._arena._rows = {}
             closure.discard_last = self._discard_last_eval
             return closure
         state = {'graph': None, 'loss': None, 'grads': None, 'failed': False}
@@ -320,8 +339,12 @@ class MotionOptimizer():
             loss.backward()
         self.closure_evals += 1
         if self.shard is not None:
-            from .distributed import allreduce_loss_and_grads
-            loss = allreduce_loss_and_grads(loss, params, self.shard.group)
+            arena = getattr(self, '_arena', None)
+            if self.grad_arena and arena is not None and arena.matches(params):
+                loss = arena.allreduce(loss, self.shard.group)
+            else:
+                from .distributed import allreduce_loss_and_grads
+                loss = allreduce_loss_and_grads(loss, params, self.shard.group)
         if self.loss_trace is not None:
             self.loss_trace.append((self.fitting_loss.cur_stage_idx, float(loss.detach())))
         if self.verbose and stats is not None:
@@ -652,6 +675,18 @@ class MotionOptimizer():
         trans, root_orient, betas, floor = L(self.trans), L(self.root_orient), L(self.betas), L(self.floor_plane)
         tv, jv, rv = (L(p) for p in prior_opt_params)
         B = trans.size(0)
+        arena = getattr(self, '_arena', None) if self.shard is not None else None
+        if arena is not None:
+            # sharded closure: the head's adjoint writes the variables' gradients straight into this rank's rows of the gradient arena
+            named = dict(latent_pose=self.latent_pose, trans=self.trans, root_orient=self.root_orient, betas=self.betas, floor=self.floor_plane,
+                         trans_vel=prior_opt_params[0], joints_vel=prior_opt_params[1], root_orient_vel=prior_opt_params[2])
+            shapes = dict(latent_pose=(B, -1), trans=(B, 3), root_orient=(B, 3), joints_vel=(B, 22, 3), trans_vel=(B, 3), root_orient_vel=(B, 3))
+            place = {}
+            for k, p_ in named.items():
+                r = arena.rows_buffer(p_)
+                if r is not None:
+                    place[k] = r.reshape(shapes[k]) if k in shapes else r
+            cfg = dict(cfg, grad_out=place)
         (pose0, past_in, trans_p, root_p, joints_p, c2p_R, c2p_t, root_h, floor_t, tv_t, jv_t, rv_t, betas_t) = Stage3Head.apply(
             cfg, L(self.latent_pose).reshape(B, -1), trans.reshape(B, 3), root_orient.reshape(B, 3), betas, floor, tv.reshape(B, 3),
             jv.reshape(B, 22, 3), rv.reshape(B, 3))

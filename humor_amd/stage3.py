@@ -29,6 +29,15 @@ def _new(dev, *sh):
     return torch.empty(sh, dtype=torch.float32, device=dev)
 
 
+def _out(cfg, name, dev, *shape):
+    """Buffer for a gradient the node returns: the place the caller reserved for it (cfg['grad_out'], e.g. the rows of the sharded
+    closure's gradient arena -- the kernel then writes the variable's gradient where the all-reduce reads it) or a new tensor."""
+    t = cfg.get('grad_out', {}).get(name) if cfg.get('grad_out') else None
+    if t is not None and tuple(t.shape) == tuple(shape) and t.is_contiguous() and t.dtype == torch.float32 and t.device == dev:
+        return t
+    return _new(dev, *shape)
+
+
 def _c(x):
     return None if x is None else x.detach().contiguous().float()
 
@@ -100,8 +109,9 @@ class Stage3Head(torch.autograd.Function):
                                 g_jv_t, g_rv_t, g_betas_t)]
         (g_pose0, g_past_in, g_trans_p, g_root_p, g_joints_p, g_c2p_R, g_c2p_t, g_root_height, g_floor_t, g_tv_t, g_jv_t, g_rv_t, g_betas_t) = keep
         # ha_fit_pre adjoint; the gradients of the handed-through floor / velocities and RolloutPost's dL/dpose0 ride along as addends
-        o = dict(g_floor=_new(dev, B, 3), g_trans0=_new(dev, B, 3), g_root0=_new(dev, B, 3), g_pose0=_new(dev, B, 63), g_jcam=_new(dev, B, 22, 3),
-                 g_trans_vel=_new(dev, B, 3), g_joints_vel=_new(dev, B, 22, 3), g_root_orient_vel=_new(dev, B, 3))
+        o = dict(g_floor=_out(cfg, 'floor', dev, B, 3), g_trans0=_new(dev, B, 3), g_root0=_new(dev, B, 3), g_pose0=_new(dev, B, 63), g_jcam=_new(dev, B, 22, 3),
+                 g_trans_vel=_out(cfg, 'trans_vel', dev, B, 3), g_joints_vel=_out(cfg, 'joints_vel', dev, B, 22, 3),
+                 g_root_orient_vel=_out(cfg, 'root_orient_vel', dev, B, 3))
         a = _lib.FitPreArgs()
         a.B = B
         fields = dict(floor=fl, trans0=tr, root0=ro, pose0=pose0, jcam=joints, trans_vel=tv, joints_vel=jv, root_orient_vel=rv,
@@ -114,11 +124,12 @@ class Stage3Head(torch.autograd.Function):
         a.jcam_stride = ctx.jrows * 3
         lib.call('ha_fit_pre_backward', C.byref(a), st)
         # frame-0 SMPL adjoint: joint gradients = dL/djcam (22 rows), ha_fit_pre's direct gradients of trans / root / pose as addends
-        g_root, g_body, g_betas, g_transl = _new(dev, B, 3), _new(dev, B, 63), _new(dev, B, be.shape[1]), _new(dev, B, 3)
+        g_root, g_body = _out(cfg, 'root_orient', dev, B, 3), _new(dev, B, 63)
+        g_betas, g_transl = _out(cfg, 'betas', dev, B, be.shape[1]), _out(cfg, 'trans', dev, B, 3)
         lib.call('ha_smpl_backward_parts', sm['handle'].ptr, ctx.slot, B, sm['n_active'], _p(ro), _p(pose0), _p(be), 1, ctx.n_head,
                  _p(o['g_jcam']), 22, 22, None, _p(o['g_root0']), _p(o['g_pose0']), _p(g_betas_t), _p(o['g_trans0']),
                  _p(g_root), _p(g_body), _p(g_betas), _p(g_transl), st)
-        g_z = _new(dev, B, vp.in_dim)
+        g_z = _out(cfg, 'latent_pose', dev, B, vp.in_dim)
         lib.call('ha_mlp_backward', vp.ptr, B, _p(g_body), 1, _p(ctx.vws), _p(g_z), st)
         return None, g_z, g_transl, g_root, g_betas, o['g_floor'], o['g_trans_vel'], o['g_joints_vel'], o['g_root_orient_vel']
 

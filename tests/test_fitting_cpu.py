@@ -255,3 +255,59 @@ def test_lbfgs_failed_curvature_test_keeps_the_oldest_pair(emu_lib):
     s6 = opt._alloc_slot()
     assert s6 == slots[0] and H['order'] == [slots[2], s5, s6] and H['evicted'] == slots[1]
 
+
+
+def _arena_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from humor_amd.distributed import GradArena, Shard, allreduce_loss_and_grads
+    torch.manual_seed(0)
+    B = 5
+    a = torch.randn(B, 3, requires_grad=True)
+    b = torch.randn(B, 1, 4, requires_grad=True)
+    frozen = torch.randn(B, 2)                     # a parameter that does not require gradients this phase
+    w = torch.arange(1, B + 1, dtype=torch.float32).reshape(B, 1)
+    sh = Shard(B)
+    params = [a, frozen, b]
+
+    def objective(get):
+        ra, rb = get(a), get(b)
+        rb2 = get(b)                               # a second reader of the same variable
+        return ((ra * sh.sl(w)) ** 2).sum() + (rb.reshape(rb.shape[0], -1) * sh.sl(w)).sum() * 3.0 + (rb2 ** 3).sum() + (sh.sl(frozen) ** 2).sum()
+
+    results = []
+    for use_arena in (False, True, True):          # (twice with the arena: it is reused across evaluations)
+        for p in params:
+            p.grad = None
+        if use_arena:
+            if len(results) == 1:
+                arena = GradArena(params, sh)
+            assert arena.matches(params)
+            arena.begin()
+            loss = objective(lambda p: arena.rows(p))
+            loss.backward()
+            total = arena.allreduce(loss, None)
+        else:
+            loss = objective(sh.sl)
+            loss.backward()
+            total = allreduce_loss_and_grads(loss, params, None)
+        results.append((total.item(), a.grad.clone(), b.grad.clone()))
+    if rank == 0:
+        torch.save(results, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_grad_arena_equals_packed_allreduce(tmp_path, world):
+    """distributed.GradArena (the sharded closure's persistent packed gradient buffer: rows of a variable handed out once per evaluation,
+    gradients dropped into the arena by the backward of that node, all-reduce in place, p.grad left as views) against the slice +
+    cat + all-reduce + copy-back form it replaces: same loss and gradients, also on the arena's second evaluation, with a variable read
+    twice and a frozen parameter in the list."""
+    out = str(tmp_path / 'arena.pt')
+    port = 29500 + (os.getpid() % 2000) + 31 * world
+    mp.spawn(_arena_worker, args=(world, port, out), nprocs=world, join=True)
+    res = torch.load(out)
+    for r in res[1:]:
+        assert abs(r[0] - res[0][0]) <= 1e-6 * abs(res[0][0])
+        assert torch.allclose(r[1], res[0][1], rtol=1e-6, atol=1e-6) and torch.allclose(r[2], res[0][2], rtol=1e-6, atol=1e-6)
