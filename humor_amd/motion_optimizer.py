@@ -662,7 +662,7 @@ class MotionOptimizer():
             if lib is None:
                 from . import _lib as _libmod
                 lib = _libmod.get_lib()
-            cfg = dict(lib=lib, smpl=sm, vposer=fv.dec)
+            cfg = dict(lib=lib, smpl=sm, vposer=fv.dec, _vposer_ws={})
         self._stage3_cfg = (key, cfg)
         return cfg
 

@@ -39,7 +39,11 @@ def _out(cfg, name, dev, *shape):
 
 
 def _c(x):
-    return None if x is None else x.detach().contiguous().float()
+    # (the common case -- a contiguous fp32 tensor -- costs one check: these run ~40 times per evaluation, between L-BFGS's host read and
+    # the first launch of the next one)
+    if x is None or (x.dtype is torch.float32 and x.is_contiguous()):
+        return x
+    return x.detach().contiguous().float()
 
 
 def _p(x):
@@ -69,9 +73,12 @@ class Stage3Head(torch.autograd.Function):
         B, dev = z.shape[0], z.device
         st = _lib.stream_ptr(z)
         # VPoser decode (+ 6-D -> R -> axis-angle)
-        n = C.c_int64()
-        lib.call('ha_mlp_workspace', vp.ptr, B, C.byref(n))
-        vws = _new(dev, n.value)
+        nws = cfg.setdefault('_vposer_ws', {}).get(B)
+        if nws is None:
+            n = C.c_int64()
+            lib.call('ha_mlp_workspace', vp.ptr, B, C.byref(n))
+            nws = cfg['_vposer_ws'][B] = n.value
+        vws = _new(dev, nws)
         pose0 = _new(dev, B, vp.out_dim // 2)
         lib.call('ha_mlp_forward', vp.ptr, B, _p(z), 1, _p(pose0), _p(vws), st)
         # frame-0 body in the camera frame: joints (+ the selector vertices: only the first 22 rows are read)
