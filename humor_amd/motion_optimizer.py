@@ -197,7 +197,7 @@ class MotionOptimizer():
         from .distributed import all_gather_flat
         T, nb = pred_verts3d.size(1), self.num_betas
         ovm = min(self._pair_info['ovm'], T)
-        zf = pred_verts3d.new_zeros(3)
+        zf = pred_verts3d.new_zeros(3) if floor_plane is None else None      # (placeholder of the floor slot: one fill launch, only when needed)
         with torch.no_grad():
             packed = torch.cat([pred_verts3d[-1, T - ovm:].reshape(-1), betas[-1].reshape(-1), floor_plane[-1].reshape(-1) if floor_plane is not None else zf,
                                 pred_verts3d[0, :ovm].reshape(-1), betas[0].reshape(-1), floor_plane[0].reshape(-1) if floor_plane is not None else zf])
