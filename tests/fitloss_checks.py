@@ -285,3 +285,61 @@ def check_gmm_nll(lib, device, B=5, seed=0):
             assert e < 2e-5, e
     return worst
 
+
+
+def check_backward_addends(lib, device, B=3, seed=0):
+    """The optional addends of ha_rigid_image_backward (g_joints_add / g_verts_add) and ha_fit_pre_backward (add_floor / add_pose0 / add_*_vel,
+    jcam read with a row stride): out = adjoint + addend -- compared with the same call without addends plus the additions."""
+    import ctypes as C
+    from humor_amd import _lib
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(device).contiguous()
+    st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
+    worst = 0.0
+    # ---- rigid image ----
+    N, J, V = B * 2, 73, 43
+    t = dict(joints=r(N, J, 3), verts=r(N, V, 3), root=r(N, 3, sc=0.8), trans=r(N, 3), root2=r(N, 3, sc=0.8), trans2=r(N, 3),
+             g_joints2=r(N, J, 3), g_verts2=r(N, V, 3))
+    outs = []
+    adds = dict(g_joints_add=r(N, J, 3), g_verts_add=r(N, V, 3))
+    for with_add in (False, True):
+        o = {k: torch.empty_like(t[s]) for k, s in (('g_joints', 'joints'), ('g_verts', 'verts'), ('g_root', 'root'), ('g_trans', 'trans'),
+                                                    ('g_root2', 'root2'), ('g_trans2', 'trans2'))}
+        a = _lib.RigidImageArgs()
+        a.N, a.J, a.V = N, J, V
+        for k, v in dict(**t, **o, **(adds if with_add else {})).items():
+            setattr(a, k, v.data_ptr())
+        lib.call('ha_rigid_image_backward', C.byref(a), st)
+        outs.append(o)
+    for k in outs[0]:
+        want = outs[0][k] + (adds['g_joints_add'] if k == 'g_joints' else adds['g_verts_add'] if k == 'g_verts' else 0.0)
+        e = (outs[1][k] - want).abs().max().item() / max(1.0, want.abs().max().item())
+        worst = max(worst, e)
+        assert e < 1e-6, ('rigid', k, e)
+    # ---- fit_pre: jcam as the first 22 rows of a [B,73,3] joint tensor (stride 219), five addends ----
+    jfull = r(B, 73, 3)
+    ins = dict(floor=torch.tensor([[0.05, -1.0, 0.1]]).repeat(B, 1).to(device) * (1.0 + 0.1 * r(B, 1).abs()), trans0=r(B, 3), root0=r(B, 3, sc=0.5), pose0=r(B, 63, sc=0.3),
+               trans_vel=r(B, 3), joints_vel=r(B, 22, 3), root_orient_vel=r(B, 3))
+    gin = dict(g_past_in=r(B, 339), g_trans_p=r(B, 3), g_root_p=r(B, 3), g_joints_p=r(B, 22, 3), g_c2p_R=r(B, 3, 3), g_c2p_t=r(B, 3), g_root_height=r(B, 1))
+    adds = dict(add_floor=r(B, 3), add_pose0=r(B, 63), add_trans_vel=r(B, 3), add_joints_vel=r(B, 22, 3), add_root_orient_vel=r(B, 3))
+    names = ('g_floor', 'g_trans0', 'g_root0', 'g_pose0', 'g_jcam', 'g_trans_vel', 'g_joints_vel', 'g_root_orient_vel')
+    shapes = dict(g_floor=(B, 3), g_trans0=(B, 3), g_root0=(B, 3), g_pose0=(B, 63), g_jcam=(B, 22, 3), g_trans_vel=(B, 3), g_joints_vel=(B, 22, 3), g_root_orient_vel=(B, 3))
+    outs = []
+    for mode in ('compact', 'strided', 'strided+add'):
+        o = {k: torch.empty(shapes[k], dtype=torch.float32, device=device) for k in names}
+        a = _lib.FitPreArgs()
+        a.B = B
+        jc = jfull[:, :22].contiguous() if mode == 'compact' else jfull
+        a.jcam_stride = 0 if mode == 'compact' else 73 * 3
+        for k, v in dict(jcam=jc, **ins, **gin, **o, **(adds if mode.endswith('add') else {})).items():
+            setattr(a, k, v.data_ptr())
+        lib.call('ha_fit_pre_backward', C.byref(a), st)
+        outs.append(o)
+    for k in names:
+        assert torch.equal(outs[0][k], outs[1][k]), ('fit_pre stride', k)
+        ak = {'g_floor': 'add_floor', 'g_pose0': 'add_pose0', 'g_trans_vel': 'add_trans_vel', 'g_joints_vel': 'add_joints_vel', 'g_root_orient_vel': 'add_root_orient_vel'}.get(k)
+        want = outs[0][k] + (adds[ak] if ak else 0.0)
+        e = (outs[2][k] - want).abs().max().item() / max(1.0, want.abs().max().item())
+        worst = max(worst, e)
+        assert e < 1e-6, ('fit_pre', k, e)
+    return worst

@@ -134,3 +134,48 @@ def check_fused_forward(lib, npz, ds, N, device, seed=0, hands=False):
     dv = (fused.v.cpu() - ref.vertices.detach()).abs().max().item()
     assert dv < FWD_TOL, dv
     return dv
+
+
+def check_parts_api(lib, npz, device, B=2, T=3, seed=0):
+    """ha_smpl_forward_parts / ha_smpl_backward_parts / ha_seq_sum_add (split pose pointers, one shape row per sequence, a reduced number of
+    joint-gradient rows, addends on every output gradient) against BodyModel's split path on the expanded inputs + the additions autograd
+    would launch: same kernels, so forward bit-identical and gradients to rounding of the addend sums."""
+    import ctypes as C
+    from humor_amd import _lib
+    N = B * T
+    bm = BodyModel(npz, num_betas=16, batch_size=N, use_vtx_selector=True, vertex_subset=KEYPT_VERTS, _lib_override=lib)
+    sm = bm.parts_config(device)
+    assert sm is not None
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(device)
+    root, body, betas, trans = rnd(N, 3, sc=0.5), rnd(N, 63, sc=0.4), rnd(B, 16), rnd(N, 3)
+    betas_x = betas.reshape(B, 1, 16).expand(B, T, 16).reshape(N, 16).clone()
+    leaf = [t.clone().requires_grad_(True) for t in (root, body, betas_x, trans)]
+    out = bm(root_orient=leaf[0], pose_body=leaf[1], betas=leaf[2], trans=leaf[3])
+    h, st = sm['handle'], C.c_void_p(torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
+    jx, nv = sm['J'] + sm['n_sel'], sm['n_all'] - sm['n_sel']
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+    joints, verts = new(N, jx, 3), new(N, nv, 3)
+    p = _lib.ptr
+    lib.call('ha_smpl_forward_parts', h.ptr, sm['slot_all'], N, sm['n_active'], p(root), p(body), p(betas), T, p(trans), sm['n_sel'], p(joints), p(verts), st)
+    assert torch.equal(joints, out.Jtr.detach()) and torch.equal(verts, out.v.detach())
+    # backward: only the first 22 joint rows carry a gradient (a [N,22,3] tensor), every output gradient has an addend
+    gj22, gv = rnd(N, 22, 3), rnd(N, nv, 3)
+    add_root, add_body, add_betas, add_tr = rnd(N, 3), rnd(N, 63), rnd(N, 16), rnd(N, 3)
+    loss = (out.Jtr[:, :22] * gj22).sum() + (out.v * gv).sum()
+    ref = torch.autograd.grad(loss, leaf)
+    g_root, g_body, g_bf, g_tr = new(N, 3), new(N, 63), new(N, 16), new(N, 3)
+    lib.call('ha_smpl_backward_parts', h.ptr, sm['slot_all'], N, sm['n_active'], p(root), p(body), p(betas), T, sm['n_sel'], p(gj22), 22, 22, p(gv),
+             p(add_root), p(add_body), p(add_betas), p(add_tr), p(g_root), p(g_body), p(g_bf), p(g_tr), st)
+    worst = 0.0
+    for got, want in ((g_root, ref[0] + add_root), (g_body, ref[1] + add_body), (g_bf, ref[2] + add_betas), (g_tr, ref[3] + add_tr)):
+        e = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+        worst = max(worst, e)
+        assert e < 1e-5, e
+    # per-frame shape gradients back to one row per sequence, with two addends
+    a1, a2 = rnd(B, 16), rnd(B, 16)
+    g_betas = new(B, 16)
+    lib.call('ha_seq_sum_add', B, T, 16, p(g_bf), p(a1), p(a2), p(g_betas), st)
+    want = g_bf.reshape(B, T, 16).sum(1) + a1 + a2
+    assert (g_betas - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    return worst

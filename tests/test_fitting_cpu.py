@@ -181,6 +181,13 @@ def test_emu_rigid_image_equals_second_smpl_evaluation(emu_lib, smplh_npz):
     print('rigid image: worst relative gradient difference', FL.check_rigid_image(emu_lib, CPU, smplh_npz, N=3, seed=2))
 
 
+def test_emu_backward_addends(emu_lib):
+    """In-kernel gradient addends of ha_rigid_image_backward / ha_fit_pre_backward and the strided jcam read (ABI 2; the stage-3 composite
+    nodes) on the emulator."""
+    import fitloss_checks as FL
+    print('addends: worst relative difference', FL.check_backward_addends(emu_lib, CPU, B=2, seed=1))
+
+
 def test_emu_gmm_nll_kernel(emu_lib):
     """ha_gmm_nll on the SIMT emulator against the op-by-op mixture log-density (strided frame-0 rows, B = 1)."""
     import fitloss_checks as FL

@@ -351,3 +351,9 @@ def test_stage3_nodes_with_frozen_initial_state(gpu_lib, dev, smplh_npz):
     assert abs(out[0][0] - out[1][0]) <= 1e-6 * abs(out[1][0])
     for a, b in zip(out[0][1], out[1][1]):
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+
+
+def test_backward_addends(gpu_lib, dev):
+    """In-kernel gradient addends of ha_rigid_image_backward / ha_fit_pre_backward and the strided jcam read (ABI 2)."""
+    import fitloss_checks as FL
+    print('addends: worst relative difference', FL.check_backward_addends(gpu_lib, dev, B=32, seed=2))

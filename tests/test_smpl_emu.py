@@ -24,6 +24,11 @@ def test_emu_subset_two_chunks_split_outputs(emu_lib, smplh_npz, smplh_struct):
     SC.check_forward_backward(emu_lib, smplh_npz, smplh_struct, N=2, device=CPU, subset=sub[:30], selector=False, seed=8)
 
 
+def test_emu_parts_api(emu_lib, smplh_npz):
+    """ha_smpl_forward_parts / _backward_parts / ha_seq_sum_add on the emulator (what the stage-3 composite nodes call)."""
+    SC.check_parts_api(emu_lib, smplh_npz, CPU, B=2, T=2)
+
+
 def test_emu_hands_dense_grad(emu_lib, smplh_npz, smplh_struct):
     SC.check_forward_backward(emu_lib, smplh_npz, smplh_struct, N=3, device=CPU, hands=True, selector=False, algo=1, dense_grad=True)
 

@@ -117,3 +117,11 @@ def test_chamfer_kernels(gpu_lib):
     dev = torch.device('cuda:0')
     for b, n, m, seed in ((2, 1024, 6890, 0), (3, 37, 1100, 1), (1, 4096, 6890, 2), (5, 300, 29, 3)):
         print('chamfer', b, n, m, CC.check_chamfer(gpu_lib, dev, b, n, m, seed))
+
+
+@pytest.mark.gpu
+def test_parts_api_equals_split_path(gpu_lib, dev, smplh_npz):
+    """ha_smpl_forward_parts / _backward_parts / ha_seq_sum_add against the split path + autograd's additions, at a toy size and at the
+    metric's batch (32 x 60)."""
+    for B, T in ((2, 3), (32, 60)):
+        print('parts api', B, T, SC.check_parts_api(gpu_lib, smplh_npz, dev, B=B, T=T, seed=B))
