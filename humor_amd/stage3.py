@@ -22,8 +22,6 @@ import torch
 
 from . import _lib
 
-J_BODY = 21
-
 
 def _new(dev, *sh):
     return torch.empty(sh, dtype=torch.float32, device=dev)
