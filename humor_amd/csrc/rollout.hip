@@ -2178,7 +2178,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
   auto x_ptr = [&](int t) { return stash + L.xT + (size_t)t * RT * D_INP * 32; };
   const bool with_prior = g_prior_mu != nullptr || g_prior_var != nullptr;
   const PackedLayer& DL = net->dec[net->n_dec - 1];
-  const int nd = net->n_dec, np = net->n_pri;
+  const int nd = net->n_dec;
   const int gxp_pad = net->pri[0].Nin_pad;
   // adjoint scratch of decoder layer l at step t (accumulate policy: one pre-zeroed set per step; else one set reused by every step)
   auto bd = [&](int l, int t) { return stash + L.bwd_dec[l] + (size_t)(t < 0 ? 0 : (t >= S ? S - 1 : t)) * L.bwd_set; };
