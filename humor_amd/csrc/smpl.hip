@@ -1923,10 +1923,12 @@ extern "C" int ha_smpl_forward_parts(const ha_smpl_model* m, int slot, int N, in
   HA_REQUIRE(root && betas && joints_ext && (body || n_active == 1), "ha_smpl_forward_parts: root, body, betas and joints_ext are required");
   HA_REQUIRE(betas_div >= 1 && N % betas_div == 0, "ha_smpl_forward_parts: betas_div=%d must divide N=%d", betas_div, N);
   HA_REQUIRE(n_head >= 0 && n_head <= m->sets[slot].n, "ha_smpl_forward_parts: n_head=%d out of range 0..%d", n_head, m->sets[slot].n);
-  HA_REQUIRE(verts_tail || n_head == m->sets[slot].n, "ha_smpl_forward_parts: verts_tail is required for the vertices behind the head");
+  const bool joints_only = !verts_tail && n_head == 0;      // no vertex of the subset is wanted: the J joints alone (no blend, no skinning)
+  HA_REQUIRE(verts_tail || n_head == m->sets[slot].n || joints_only, "ha_smpl_forward_parts: verts_tail is required for the vertices behind the head");
   DeviceGuard guard(m->device);
   FrameParams p;
   fill_model(p, m, slot);
+  if (joints_only) { p.nverts = 0; p.nchunks = 0; }
   p.N = N; p.n_active = n_active; p.Kc = m->NB + 1 + (n_active - 1) * 9;
   p.pose = root; p.pose_body = body ? body : root; p.betas = betas; p.betas_div = betas_div; p.transl = transl;
   p.joints = joints_ext; p.verts = verts_tail ? verts_tail : joints_ext;
@@ -1953,6 +1955,7 @@ extern "C" int ha_smpl_backward_parts(const ha_smpl_model* m, int slot, int N, i
   fill_model(p, m, slot);
   p.N = N; p.n_active = n_active; p.Kc = m->NB + 1 + (n_active - 1) * 9;
   p.pose = root; p.pose_body = body ? body : root; p.betas = betas; p.betas_div = betas_div;
+  if (!g_verts_tail && (n_head == 0 || !g_joints_ext || (gj_rows != 0 && gj_rows <= m->J))) { p.nverts = 0; p.nchunks = 0; }   // no vertex carries a gradient
   p.g_verts = g_verts_tail; p.g_joints = g_joints_ext; p.gj_rows = gj_rows; p.gj_stride = gj_stride;
   p.g_pose = g_root; p.g_body = g_body; p.g_betas = g_betas; p.g_transl = g_transl;
   p.add_root = add_root; p.add_body = add_body; p.add_betas = add_betas; p.add_transl = add_transl;

@@ -79,13 +79,10 @@ class Stage3Head(torch.autograd.Function):
         vws = _new(dev, nws)
         pose0 = _new(dev, B, vp.out_dim // 2)
         lib.call('ha_mlp_forward', vp.ptr, B, _p(z), 1, _p(pose0), _p(vws), st)
-        # frame-0 body in the camera frame: joints (+ the selector vertices: only the first 22 rows are read)
+        # frame-0 body in the camera frame: the joints alone (ha_fit_pre reads the first 22; no vertex is evaluated)
         h = sm['handle']
-        if sm['n_sel'] > 0:
-            slot, n_head, tail = sm['slot_sel'], sm['n_sel'], None
-        else:
-            slot, n_head, tail = sm['slot_all'], 0, _new(dev, B, sm['n_all'], 3)
-        jrows = sm['J'] + n_head
+        slot, n_head, tail = sm['slot_all'], 0, None
+        jrows = sm['J']
         joints = _new(dev, B, jrows, 3)
         lib.call('ha_smpl_forward_parts', h.ptr, slot, B, sm['n_active'], _p(ro), _p(pose0), _p(be), 1, _p(tr), n_head, _p(joints), _p(tail), st)
         out = dict(past_in=_new(dev, B, 339), trans_p=_new(dev, B, 3), root_p=_new(dev, B, 3), joints_p=_new(dev, B, 22, 3),

@@ -111,6 +111,8 @@ int ha_smpl_backward_split(const ha_smpl_model* m, int slot, int N, int n_active
  *   - one shape row serves betas_div consecutive frames: betas [N / betas_div, NB] (the reference expands betas over the frames,
  *     humor/fitting/motion_optimizer.py:1087; here neither the expanded copy nor its summed gradient's expand node exist -- g_betas is
  *     still per frame [N, NB], ha_seq_sum_add folds it);
+ *   - forward with n_head == 0 and verts_tail == NULL evaluates the J joints alone (no vertex is blended or skinned); the backward call
+ *     skips the vertex phase whenever no vertex can carry a gradient (g_verts_tail NULL and no head row inside gj_rows);
  *   - backward: only the first gj_rows rows of g_joints_ext exist (0 = all J + n_head), row stride gj_stride joints per frame (0 = J +
  *     n_head); the pose gradient leaves as g_root [N,3] + g_body [N,(n_active-1)*3]; add_root / add_body / add_betas [N,NB] /
  *     add_transl (each may be NULL) are added to the corresponding output in the kernel: the gradient another reader of the same

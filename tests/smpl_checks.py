@@ -172,6 +172,17 @@ def check_parts_api(lib, npz, device, B=2, T=3, seed=0):
         e = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
         worst = max(worst, e)
         assert e < 1e-5, e
+    # joints only (n_head = 0, no vertex tensor): the first J rows of the full evaluation; its adjoint = the full adjoint with zero vertex gradients
+    jo = new(N, sm['J'], 3)
+    lib.call('ha_smpl_forward_parts', h.ptr, sm['slot_all'], N, sm['n_active'], p(root), p(body), p(betas), T, p(trans), 0, p(jo), None, st)
+    assert torch.equal(jo, joints[:, :sm['J']].contiguous())
+    out2 = bm(root_orient=leaf[0], pose_body=leaf[1], betas=leaf[2], trans=leaf[3])
+    ref_j = torch.autograd.grad((out2.Jtr[:, :22] * gj22).sum(), leaf)
+    r2, b2, f2, t2 = new(N, 3), new(N, 63), new(N, 16), new(N, 3)
+    lib.call('ha_smpl_backward_parts', h.ptr, sm['slot_all'], N, sm['n_active'], p(root), p(body), p(betas), T, 0, p(gj22), 22, 22, None,
+             None, None, None, None, p(r2), p(b2), p(f2), p(t2), st)
+    for got, want in ((r2, ref_j[0]), (b2, ref_j[1]), (f2, ref_j[2]), (t2, ref_j[3])):
+        assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
     # per-frame shape gradients back to one row per sequence, with two addends
     a1, a2 = rnd(B, 16), rnd(B, 16)
     g_betas = new(B, 16)
