@@ -181,6 +181,21 @@ def test_emu_rigid_image_equals_second_smpl_evaluation(emu_lib, smplh_npz):
     print('rigid image: worst relative gradient difference', FL.check_rigid_image(emu_lib, CPU, smplh_npz, N=3, seed=2))
 
 
+@pytest.mark.slow          # (two stage-3 evaluations on the emulator: ~15 minutes; the GPU tier runs the same check at 4 x 12 and 32 x 60)
+def test_emu_stage3_nodes_equal_separate_functions(emu_lib, smplh_npz):
+    """The stage-3 objective as composite autograd nodes (humor_amd/stage3.py) against the separate Functions on the emulator, 1 x 3: same
+    kernels in the same order, so at this size even the gradient sums agree to the last bit."""
+    case = CC.make_case('rgb', 1, 3, seed=3)
+    res = []
+    for nodes in (True, False):
+        opt = FC.build(emu_lib, CPU, 'rgb', 1, 3, smplh_npz)
+        opt.fused_stage3 = nodes
+        opt.fitting_loss.fold_init_prior = nodes
+        res.append(FC.eval_stage(opt, case, 2, CPU))
+    for k in res[0]:
+        assert (res[0][k] - res[1][k]).abs().max().item() <= 1e-6 * max(1.0, res[1][k].abs().max().item()), k
+
+
 def test_emu_backward_addends(emu_lib):
     """In-kernel gradient addends of ha_rigid_image_backward / ha_fit_pre_backward and the strided jcam read (ABI 2; the stage-3 composite
     nodes) on the emulator."""
