@@ -56,3 +56,16 @@ def make_case(kind, B, T, seed=0, ov=3):
         var['floor_plane'] = torch.tensor([[0.02, 0.5, 0.03]]) + r(B, 3, sc=0.02)
     case['obs'], case['var'] = obs, var
     return case
+
+
+def perturb_obs(obs, seed, eps=1e-6):
+    """Every finite fp32 observation moved by `eps` relative, random sign (seeded): the size of an fp32 gradient's rounding error.
+    Shared by the reference-side branch generator (oracle/make_golden_branches.py) and the short-run check of the tests, so both
+    sides see the SAME perturbed problems."""
+    g = torch.Generator().manual_seed(seed)
+    out = dict(obs)
+    for k in obs:
+        if obs[k].dtype == torch.float32:
+            sign = (torch.rand(obs[k].shape, generator=g) > 0.5).float() * 2 - 1
+            out[k] = torch.where(torch.isfinite(obs[k]), obs[k] * (1.0 + sign * eps), obs[k])
+    return out

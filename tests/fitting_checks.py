@@ -153,72 +153,60 @@ def check_lbfgs_trajectory(lib, device, npz, kind, long_name=None, rtol=1e-4):
     return rel.max()
 
 
-# Which fixtures' reference trajectories this implementation follows without any perturbation of the observations (measured on MI355X;
-# where it does, the strict assertion applies; where a bracketing tie puts the reference on the other branch, see check_short_run)
-ON_REFERENCE_PATH = {'amass': True, 'rgb': True, 'c2': False, 'c3': True, 'c4': True}
+def _reference_branches(name, gd):
+    """The reference-reachable trajectories of a short-run fixture: the fixture's own `run_trace` and, where the generator
+    oracle/make_golden_branches.py has been run (closure_<name>_branches.npz), every distinct line-search branch the UNMODIFIED
+    reference lands on when the observations move by 1e-6 (c2: two branches, 19 / 6 of 25 reference runs)."""
+    import os
+    from conftest import GOLDEN
+    out = [(gd['run_trace'], gd['run_stage2_joints3d'])]
+    path = os.path.join(GOLDEN, f'closure_{name}_branches.npz')
+    if os.path.exists(path):
+        br = np.load(path)
+        out = [(br['trace'][b, :int(br['len'][b])], br['stage2_joints3d'][b]) for b in range(len(br['len']))]
+    return out
 
 
 def check_short_run(lib, device, npz, kind, long_name=None):
-    """The reference's run() for a few L-BFGS iterations vs ours on the same problem (fixture `run_trace`).
-    What is asserted, always, on the UNPERTURBED run: the first evaluations of stage 1 (identical variables: the closure-level check in
-    situ, 1e-4), a proper fit (stage 3 makes the reference's kind of progress, finite results of the right shapes), and -- for the
-    fixtures recorded in ON_REFERENCE_PATH -- that the whole run follows the reference's trajectory.
+    """The reference's run() for a few L-BFGS iterations vs ours on the same problem.
+    Asserted on the UNPERTURBED run: the first evaluations of stage 1 (identical variables: the closure-level check in situ, 1e-4),
+    that the WHOLE run follows a trajectory the unmodified reference itself takes, and a proper fit (finite results of the right shapes).
     L-BFGS with a strong-Wolfe line search is piecewise continuous in its inputs: at a bracketing decision that is a tie to fp32
-    rounding two correct closures take different trial steps and the runs separate for good.  The optimiser itself is pinned
-    deterministically (check_lbfgs_trajectory: same closure, both optimisers) and the closures are pinned at fixed variables
-    (check_objectives_long), so for a fixture that sits on such a tie the trajectory comparison is informational: the number of
-    1e-6 perturbations of the observations (out of 6) that put this implementation on the reference's branch is reported with a
-    warning, not asserted."""
-    import warnings
+    rounding two correct closures take different trial steps and the runs separate for good.  Such a tie is a property of the PROBLEM
+    and shows on the reference side too: oracle/make_golden_branches.py runs the reference with the observations moved by 1e-6 and
+    stores every distinct branch it reaches (c2: the fixture's branch in 19 of 25 runs, a second one in 6; all other fixtures: one).
+    This implementation's unperturbed run must be ON ONE OF THEM -- same evaluation sequence, losses and stage-2 joints within the
+    tolerances below, first stage-3 evaluations to 2e-4 -- there is no warning path."""
     name = long_name or kind
-    gd0 = golden(f'closure_{name}.npz')
-    B, T = int(gd0['B']), int(gd0['T'])
-    ref_trace = gd0['run_trace']
-    n12 = int((ref_trace[:, 0] < 2).sum())
-
-    def run_once(perturb_seed=None):
-        gd, opt, obs = _short_run_problem(lib, device, npz, kind, long_name)
-        if perturb_seed is not None:      # observations moved by 1e-6 (relative): the size of an fp32 gradient's rounding error
-            g = torch.Generator().manual_seed(perturb_seed)
-            for k in obs:
-                if obs[k].dtype == torch.float32:
-                    sign = (torch.rand(obs[k].shape, generator=g) > 0.5).float() * 2 - 1
-                    obs[k] = torch.where(torch.isfinite(obs[k]), obs[k] * (1.0 + sign * 1e-6), obs[k])
-        obs = {k: v.clone().to(device) for k, v in obs.items()}
-        opt.loss_trace = []
-        final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[int(x) for x in gd['run_num_iter']], lbfgs_max_iter=5)
-        ours = np.array(opt.loss_trace, dtype=np.float64)
-        same_seq = len(ours) >= n12 and (ours[:n12, 0] == ref_trace[:n12, 0]).all()
+    gd, opt, obs = _short_run_problem(lib, device, npz, kind, long_name)
+    B, T = int(gd['B']), int(gd['T'])
+    obs = {k: v.clone().to(device) for k, v in obs.items()}
+    opt.loss_trace = []
+    final, stages = opt.run(obs, data_fps=30, lr=1.0, num_iter=[int(x) for x in gd['run_num_iter']], lbfgs_max_iter=5)
+    ours = np.array(opt.loss_trace, dtype=np.float64)
+    j2 = stages['stage2']['joints3d'].cpu().numpy()
+    # 8-frame problems: 1e-4 along the whole run; 60 / 90-frame problems: the strong-Wolfe line search amplifies rounding within a few
+    # evaluations -- the first evaluations are the closure-level check, the rest must stay on the branch to within a per cent
+    tol12, tolj = (1e-4, 1e-3) if long_name is None else (2e-2, 2e-2)
+    report = []
+    hit = None
+    for b, (ref_trace, ref_j2) in enumerate(_reference_branches(name, gd)):
+        n12 = int((ref_trace[:, 0] < 2).sum())
+        same_seq = len(ours) >= n12 and (ours[:n12, 0] == ref_trace[:n12, 0]).all() and int((ours[:, 0] < 2).sum()) == n12
         rel = np.abs(ours[:n12, 1] - ref_trace[:n12, 1]) / np.abs(ref_trace[:n12, 1]) if same_seq else np.full(n12, np.inf)
         s3_ours, s3_ref = ours[ours[:, 0] == 2][:, 1], ref_trace[ref_trace[:, 0] == 2][:, 1]
         rel3 = np.abs(s3_ours[:3] - s3_ref[:3]) / np.abs(s3_ref[:3])
-        d2 = np.abs(stages['stage2']['joints3d'].cpu().numpy() - gd['run_stage2_joints3d']).max()
-        return dict(ours=ours, rel=rel, rel3=rel3, d2=d2, s3_ours=s3_ours, s3_ref=s3_ref, final=final, same_seq=same_seq)
-
-    def on_reference_path(r):
-        if long_name is None:
-            return r['same_seq'] and r['rel'].max() < 1e-4 and r['d2'] < 1e-3 and r['rel3'].max() < 2e-4
-        # 60 / 90-frame problems: the strong-Wolfe line search amplifies rounding within a few evaluations; the first evaluations are
-        # the closure-level check, the rest must stay on the reference's path to within a per cent
-        return r['same_seq'] and r['rel'].max() < 2e-2 and r['d2'] < 2e-2 and r['rel3'].max() < 2e-4
-
-    base = run_once()
-    print('short run', name, 'stage-1/2 closure losses rel dev', np.array2string(base['rel'], precision=1), 'stage-3 first evals', base['rel3'],
-          'stage-2 joints', base['d2'])
-    # always: the first two evaluations of the run (same variables on both sides)
-    assert base['ours'][0, 0] == ref_trace[0, 0] and base['rel'][:2].max() < 1e-4, (name, base['rel'][:2])
-    on_path = on_reference_path(base)
-    if ON_REFERENCE_PATH.get(name, False):
-        assert on_path, (name, 'expected to follow the reference trajectory unperturbed', base['rel'].max(), base['d2'], base['rel3'])
-    elif not on_path:
-        hits = [seed for seed in range(1, 7) if on_reference_path(run_once(seed))]
-        msg = (f'short run {name}: the unperturbed run leaves the reference trajectory at a line-search tie (stage-1/2 deviation '
-               f'{base["rel"].max():.1e}); {len(hits)} of 6 runs with the observations perturbed by 1e-6 follow it (seeds {hits})')
-        print(msg)
-        warnings.warn(msg)
-    s3_ours, s3_ref, final = base['s3_ours'], base['s3_ref'], base['final']
+        d2 = np.abs(j2 - ref_j2).max()
+        report.append((b, bool(same_seq), float(rel.max()), float(d2), [float('%.1e' % x) for x in rel3]))
+        if b == 0:        # the first two evaluations of the run see the same variables on every branch
+            assert ours[0, 0] == ref_trace[0, 0] and rel[:2].max() < 1e-4, (name, rel[:2])
+        if hit is None and same_seq and rel.max() < tol12 and d2 < tolj and rel3.max() < 2e-4:
+            hit = (b, s3_ours, s3_ref, d2)
+    print('short run', name, '(branch, same sequence, stage-1/2 loss deviation, stage-2 joints, first stage-3 evaluations):', report)
+    assert hit is not None, (name, 'the unperturbed run is on none of the trajectories the reference reaches', report)
+    b, s3_ours, s3_ref, d2 = hit
     assert s3_ours[-1] < s3_ours[0] and abs(np.log(s3_ours.min() / s3_ref.min())) < 0.7
     assert set(final.keys()) >= {'trans', 'root_orient', 'pose_body', 'betas', 'latent_pose', 'latent_motion'}
     assert final['latent_motion'].shape == (B, T - 1, 48) and final['trans'].shape == (B, T, 3)
     assert all(torch.isfinite(v).all() for v in final.values())
-    return base['d2']
+    return d2
