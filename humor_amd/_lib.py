@@ -113,10 +113,6 @@ _SIGS = {
     'ha_humor_net_destroy': (C.c_int, [C.c_void_p]),
     'ha_humor_rollout_workspace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     'ha_humor_rollout_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p]),
-    'ha_humor_rollout_forward_ex': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p, C.c_int]),
-    'ha_humor_prior_join': (C.c_int, [C.c_void_p, C.c_void_p]),
-    'ha_humor_prior_grad_ready': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'ha_humor_prior_side_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'ha_humor_rollout_sample': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_humor_rollout_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_humor_net_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),

@@ -103,20 +103,6 @@ struct ha_humor_net {
   // knob, the asynchronous error word).  A forward call decides ONCE and records the decision for the stash it fills; every later
   // phase of that call and the backward over the same stash use the recorded mode (one host thread per device: no lock).
   mutable std::unordered_map<const void*, int> stash_mode;
-  // The prior network of a roll-out only consumes the decoder chain's states and only the loss consumes its output: on request
-  // (ha_humor_rollout_forward_ex, HA_ROLLOUT_DEFER_PRIOR) its batched GEMMs run on a side stream beside whatever the caller queues next
-  // (the SMPL evaluations of the rolled-out poses), and its adjoint starts at the event ha_humor_prior_grad_ready recorded instead of
-  // at the tail of the caller's stream.  One host thread per device (no lock).
-  struct PriorSide {
-    bool ready = false;
-    hipStream_t stream{};
-    hipEvent_t roll{}, fwd_done{}, grad{}, bwd_done{};
-    bool pending = false;                  // a deferred forward has not been joined into a caller stream yet
-    bool grad_marked = false;              // `grad` was recorded for the gradient buffers below
-    const void* grad_mu = nullptr; const void* grad_var = nullptr;
-    int64_t n_fwd = 0, n_bwd = 0;          // forwards deferred / adjoints started at a mark so far (ha_humor_prior_side_stats)
-  };
-  mutable PriorSide ps;
 };
 
 namespace ha {
@@ -1626,7 +1612,6 @@ static thread_local int tl_groups = 1;
 // -1: make_layout decides from the live state (workspace queries); 0 / 1: the mode decided at the entry point of the call being served
 static thread_local int tl_single_mode = -1;
 static thread_local const float* tl_gz_add = nullptr;   // ha_humor_rollout_backward_ex: addend of dL/dz (rows of the group being run)
-static thread_local bool tl_prior_bwd_done = false;     // the prior's adjoint of this call already ran (on the side stream)
 
 static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, bool allow_acc = true) {
   L.RT = ceil_div(B, 32);
@@ -1869,24 +1854,6 @@ static size_t group_stash_floats(const ha_humor_net* net, int rows, int S) {
 
 using namespace ha;
 
-static int prior_side_init(const ha_humor_net* net) {
-  ha_humor_net::PriorSide& P = net->ps;
-  if (P.ready) return HA_OK;
-  HA_CHECK_HIP(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&P.roll, &P.fwd_done, &P.grad, &P.bwd_done}) HA_CHECK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-  P.ready = true;
-  return HA_OK;
-}
-
-// a deferred prior forward that nobody joined: the stream of the next call into this network waits for it
-static int prior_side_join(const ha_humor_net* net, hipStream_t st) {
-  ha_humor_net::PriorSide& P = net->ps;
-  if (!P.pending) return HA_OK;
-  HA_CHECK_HIP(hipStreamWaitEvent(st, P.fwd_done, 0));
-  P.pending = false;
-  return HA_OK;
-}
-
 extern "C" int ha_humor_net_create(ha_humor_net** out, int device, const ha_mlp_desc* decoder, const ha_mlp_desc* prior) {
   HA_REQUIRE(out && decoder && prior, "ha_humor_net_create: null argument");
   const int raw = decoder->out_dims[decoder->n_linear - 1];
@@ -1919,12 +1886,6 @@ extern "C" int ha_humor_net_destroy(ha_humor_net* net) {
   DeviceGuard guard(net->device);
   persist_destroy(net->persist);
   net->persist = nullptr;
-  if (net->ps.ready) {
-    (void)hipStreamSynchronize(net->ps.stream);
-    (void)hipStreamDestroy(net->ps.stream);
-    for (hipEvent_t e : {net->ps.roll, net->ps.fwd_done, net->ps.grad, net->ps.bwd_done}) (void)hipEventDestroy(e);
-    net->ps.ready = false;
-  }
   for (PackedLayer* arr : {net->dec, net->pri})
     for (int i = 0; i < MAXL; ++i) {
       void* ptrs[] = {arr[i].Wf, arr[i].Wb, arr[i].bias, arr[i].gamma, arr[i].beta};
@@ -2020,7 +1981,7 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
       f.off_gl = L.off_gl;
       f.t2j = stash + L.t2j;
       f.ws = stash + L.persist_ws;
-      return persist_forward(net->persist, f, (g_rollout_persist >> 1) | (g_rollout_persist_inject ? 2 : 0), st);
+      return persist_forward(net->persist, f, ((g_rollout_persist >> 1) & 1) | (g_rollout_persist_inject ? 2 : 0), st);
     }
     if (phase == PH_STEP) return HA_OK;
   }
@@ -2089,10 +2050,6 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
   HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_sample: B and S must be >= 1");
   DeviceGuard guard(net->device);
   hipStream_t st = (hipStream_t)stream;
-  {
-    const int rcj = prior_side_join(net, st);
-    if (rcj != HA_OK) return rcj;
-  }
   StashLayout L;
   make_layout(net, B, S, L, false);
   const int RT = L.RT, rows = RT * 32;
@@ -2185,7 +2142,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
   if (L.acc && phase == PH_BEGIN) zero_async(stash + L.bwd_begin, L.bwd_floats * sizeof(float), st);
 
   // the prior's contribution to dL/dx_t for every step, before the reverse scan (it does not depend on the scan)
-  if (with_prior && phase == PH_BEGIN && !tl_prior_bwd_done) {
+  if (with_prior && phase == PH_BEGIN) {
     int rc = prior_adjoint_all(net, L, B, S, g_prior_mu, g_prior_var, stash, st);
     if (rc != HA_OK) return rc;
   }
@@ -2235,7 +2192,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
       f.g_past0 = g_past_in0; f.g_z = g_z_seq; f.g_z_add = tl_gz_add;
       f.dz_part = stash + L.dz_part;
       f.ws = stash + L.persist_ws;
-      return persist_backward(net->persist, f, g_rollout_persist >> 1, st);
+      return persist_backward(net->persist, f, (g_rollout_persist >> 1) & 1, st);
     }
     return HA_OK;
   }
@@ -2337,11 +2294,6 @@ static int for_each_group(int device, int B, int S, bool reverse, hipStream_t st
 
 extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, const float* past_in0, const float* z_seq,
                                         float* world, float* prior_mu, float* prior_var, float* stash, void* stream) {
-  return ha_humor_rollout_forward_ex(net, B, S, past_in0, z_seq, world, prior_mu, prior_var, stash, stream, 0);
-}
-
-extern "C" int ha_humor_rollout_forward_ex(const ha_humor_net* net, int B, int S, const float* past_in0, const float* z_seq,
-                                           float* world, float* prior_mu, float* prior_var, float* stash, void* stream, int flags) {
   HA_REQUIRE(net && past_in0 && z_seq && world && stash, "ha_humor_rollout_forward: null argument");
   HA_REQUIRE(B >= 1 && S >= 1, "ha_humor_rollout_forward: B and S must be >= 1");
   HA_REQUIRE((prior_mu == nullptr) == (prior_var == nullptr), "ha_humor_rollout_forward: prior_mu and prior_var go together");
@@ -2359,29 +2311,12 @@ extern "C" int ha_humor_rollout_forward_ex(const ha_humor_net* net, int B, int S
   tl_groups = 1;
   // the roll-out mode of this call, decided once (see ha_humor_net::stash_mode)
   const int mode = (g_rollout_persist != 0 && persist_usable(net->persist)) ? 1 : 0;
-  if (net->stash_mode.size() > 256) net->stash_mode.clear();
+  // (one entry per distinct stash address ever seen -- the allocator recycles them, a forward overwrites its entry -- so the map stays
+  // small; the wholesale clear is a backstop that a process would need 64 k live stashes to reach)
+  if (net->stash_mode.size() > 65536) net->stash_mode.clear();
   net->stash_mode[stash] = mode;
   tl_single_mode = mode;
-  int rc = prior_side_join(net, (hipStream_t)stream);
-  if (rc != HA_OK) { tl_single_mode = -1; return rc; }
-  if ((flags & HA_ROLLOUT_DEFER_PRIOR) && mode == 1 && ng == 1 && prior_mu) {
-    // one launch for the decoder chain on the caller's stream; the prior network (batched over all steps) on the side stream, joined
-    // by ha_humor_prior_join (or by the next call into this network)
-    hipStream_t st = (hipStream_t)stream;
-    rc = prior_side_init(net);
-    if (rc == HA_OK) rc = rollout_forward_impl(net, B, S, past_in0, z_seq, world, prior_mu, prior_var, stash, st, PH_BEGIN, 0);
-    if (rc == HA_OK) {
-      ha_humor_net::PriorSide& P = net->ps;
-      HA_CHECK_HIP(hipEventRecord(P.roll, st));
-      HA_CHECK_HIP(hipStreamWaitEvent(P.stream, P.roll, 0));
-      rc = rollout_forward_impl(net, B, S, past_in0, z_seq, world, prior_mu, prior_var, stash, P.stream, PH_END, 0);
-      HA_CHECK_HIP(hipEventRecord(P.fwd_done, P.stream));
-      P.pending = true;
-      ++P.n_fwd;
-    }
-    tl_single_mode = -1;
-    return rc;
-  }
+  int rc;
   rc = for_each_group(net->device, B, S, false, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
     const size_t r = (size_t)r0;
     return rollout_forward_impl(net, rows, S, past_in0 + r * D_IN, z_seq + r * S * ZD, world + r * S * D_STATE,
@@ -2390,30 +2325,6 @@ extern "C" int ha_humor_rollout_forward_ex(const ha_humor_net* net, int B, int S
   });
   tl_single_mode = -1;
   return rc;
-}
-
-extern "C" int ha_humor_prior_join(const ha_humor_net* net, void* stream) {
-  HA_REQUIRE(net, "ha_humor_prior_join: null argument");
-  DeviceGuard guard(net->device);
-  return prior_side_join(net, (hipStream_t)stream);
-}
-
-extern "C" int ha_humor_prior_side_stats(const ha_humor_net* net, int64_t* out) {
-  HA_REQUIRE(net && out, "ha_humor_prior_side_stats: null argument");
-  out[0] = net->ps.n_fwd; out[1] = net->ps.n_bwd;
-  return HA_OK;
-}
-
-extern "C" int ha_humor_prior_grad_ready(const ha_humor_net* net, const float* g_prior_mu, const float* g_prior_var, void* stream) {
-  HA_REQUIRE(net, "ha_humor_prior_grad_ready: null argument");
-  DeviceGuard guard(net->device);
-  int rc = prior_side_init(net);
-  if (rc != HA_OK) return rc;
-  ha_humor_net::PriorSide& P = net->ps;
-  HA_CHECK_HIP(hipEventRecord(P.grad, (hipStream_t)stream));
-  P.grad_marked = true;
-  P.grad_mu = g_prior_mu; P.grad_var = g_prior_var;
-  return HA_OK;
 }
 
 // dst[i] += src[i] (the launch-chain path of ha_humor_rollout_backward_ex; the persistent path adds in its final reduction)
@@ -2448,30 +2359,7 @@ extern "C" int ha_humor_rollout_backward_ex(const ha_humor_net* net, int B, int 
   // the mode the forward over this stash recorded (a stash this library has not seen: decided from the live state, as before)
   const auto it = net->stash_mode.find(stash);
   tl_single_mode = it != net->stash_mode.end() ? it->second : -1;
-  int rc = prior_side_join(net, (hipStream_t)stream);
-  if (rc != HA_OK) { tl_single_mode = -1; return rc; }
-  {
-    // The prior's adjoint needs only dL/d(prior_mu, prior_var): when the caller marked the point of its stream at which exactly these
-    // buffers were complete (ha_humor_prior_grad_ready), the five batched GEMMs start there on the side stream -- beside the SMPL and
-    // post-processing adjoints queued after that point -- and the decoder chain's adjoint waits for them.
-    ha_humor_net::PriorSide& P = net->ps;
-    const bool marked = P.ready && P.grad_marked && (g_prior_mu || g_prior_var) && P.grad_mu == g_prior_mu && P.grad_var == g_prior_var;
-    P.grad_marked = false;
-    if (marked && tl_single_mode == 1 && ng == 1) {
-      StashLayout L;
-      make_layout(net, B, S, L);
-      if (L.single) {
-        hipStream_t st = (hipStream_t)stream;
-        HA_CHECK_HIP(hipStreamWaitEvent(P.stream, P.grad, 0));
-        rc = prior_adjoint_all(net, L, B, S, g_prior_mu, g_prior_var, stash, P.stream);
-        if (rc != HA_OK) { tl_single_mode = -1; return rc; }
-        HA_CHECK_HIP(hipEventRecord(P.bwd_done, P.stream));
-        HA_CHECK_HIP(hipStreamWaitEvent(st, P.bwd_done, 0));
-        tl_prior_bwd_done = true;
-        ++P.n_bwd;
-      }
-    }
-  }
+  int rc;
   bool add_in_kernel = false;
   if (g_z_add && tl_single_mode == 1 && ng == 1 && g_rollout_persist_bwd != 0) {
     StashLayout L;
@@ -2486,7 +2374,6 @@ extern "C" int ha_humor_rollout_backward_ex(const ha_humor_net* net, int B, int 
                                  stash + (size_t)g * gs, g_past_in0 + r * D_IN, g_z_seq + r * S * ZD, st, phase, t);
   });
   tl_single_mode = -1;
-  tl_prior_bwd_done = false;
   tl_gz_add = nullptr;
   if (rc == HA_OK && g_z_add && !add_in_kernel) {
     const int n = B * S * ZD;

@@ -1835,10 +1835,10 @@ extern "C" int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_ac
       const int n_groups = ceil_div(n_vt, kFusedTilesPerBlock);
       const size_t lds_f = (size_t)(32 * m->J * 12 + 128) * sizeof(float);
 #ifndef HA_SIMT_EMU
-      static bool attr_set = false;          // (more than the default 64 KB of dynamic LDS)
-      if (!attr_set) {
+      // more than the default 64 KB of dynamic LDS: a per-DEVICE function attribute, remembered in the model handle (one handle per device)
+      if (!m->fused_lds_attr_set) {
         HA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pose_blend_skin_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr_set = true;
+        m->fused_lds_attr_set = true;
       }
 #endif
       HA_REQUIRE(lds_f <= 80 * 1024, "ha_smpl_forward: algo 3 keeps the A matrices of 32 frames in LDS (J <= 53)");

@@ -33,6 +33,7 @@ struct VertexSet {
 
 struct ha_smpl_model {
   int device = 0;
+  mutable bool fused_lds_attr_set = false;   // pose_blend_skin_kernel's 80 KB dynamic-LDS attribute has been set on this handle's device
   int V = 0, J = 0, NB = 0, P = 0;
   int Kfull = 0;      // NB + 1 + P
   int Kfull_pad = 0;  // even

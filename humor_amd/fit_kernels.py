@@ -119,7 +119,6 @@ class FusedFit(torch.autograd.Function):
             a.gmm_total = base + (ng + NT + 1) * esz
         lib.call('ha_fit_loss', C.byref(a), _lib.stream_ptr(ref))
         ctx.flat, ctx.views, ctx.ng = flat, views, ng
-        ctx.prior_grad_hook = spec.get('prior_grad_hook')
         ctx.set_materialize_grads(False)
         loss, terms, gmm_total = flat[ng + NT], flat[ng:ng + NT], flat[ng + NT + 1]
         ctx.mark_non_differentiable(terms, gmm_total)
@@ -131,14 +130,13 @@ class FusedFit(torch.autograd.Function):
             return (None, None) + (None,) * len(DIFF_INPUTS)
         unit = _UNIT.get((g_loss.device, g_loss.dtype))
         if unit is not None and g_loss.dim() == 0 and g_loss.data_ptr() == unit.data_ptr():
+            # (the cached seed is shared by every closure of the process: an in-place write to it would mis-scale all gradients silently;
+            # its version counter -- host side, no device read -- says whether anybody has written to it since it was made)
+            assert unit._version == 0, 'fit_kernels.unit_seed(): the cached 1.0 was modified in place'
             scaled = ctx.flat[:ctx.ng]                # seeded with the cached 1.0 (MotionOptimizer._finish_closure): nothing to scale
         else:
             scaled = ctx.flat[:ctx.ng] * g_loss       # one launch for all inputs
         out = [None if v is None else scaled[v[0]:v[0] + v[1]].view(v[2]) for v in ctx.views]
-        if ctx.prior_grad_hook is not None:
-            # dL/d(prior_mu, prior_var) are complete here: the prior network's adjoint may start (HumorModel.mark_prior_grad)
-            names = [n for n, _ in DIFF_INPUTS]
-            ctx.prior_grad_hook(out[names.index('prior_mu')], out[names.index('prior_var')])
         return (None, None) + tuple(out)
 
 

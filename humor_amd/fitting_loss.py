@@ -110,7 +110,6 @@ class FittingLoss(nn.Module):
         # PyTorch evaluation below remains for the cases the kernel does not cover (cross-batch `prev_batch_overlap_res`).
         self.fused = fused
         self.fold_init_prior = True        # stage 3: the init-state GMM term inside the fused loss launches (see _fused_fit)
-        self.prior_grad_hook = None        # callable(g_prior_mu, g_prior_var) run when the fused loss has produced them (MotionOptimizer)
         self._lib = _lib_override
         self.all_stage_loss_weights = loss_weights
         self.cur_stage_idx = 0
@@ -313,8 +312,6 @@ class FittingLoss(nn.Module):
                 if use_f:
                     t['floor'] = c(cam['floor_plane'])
         spec['w'] = w
-        if cond_prior is not None and self.prior_grad_hook is not None:
-            spec['prior_grad_hook'] = self.prior_grad_hook
         loss, terms, gmm_total = FK.FusedFit.apply(lib, spec, *[t[n] for n, _ in FK.DIFF_INPUTS])
         stats = {FK.TERM_NAMES[k]: terms[k] for k in range(FK.NT) if w[k] != 0.0}
         if 'gmm' in spec:

@@ -129,7 +129,7 @@ class _RolloutFunction(torch.autograd.Function):
     """(past_in0 [B,339], z_seq [B,S,48]) -> (world [B,S,348], prior_mu [B,S,48], prior_var [B,S,48])."""
 
     @staticmethod
-    def forward(ctx, past_in0, z_seq, handle, want_prior, defer_prior=False, z_thru=False):
+    def forward(ctx, past_in0, z_seq, handle, want_prior, z_thru=False):
         lib = handle.lib
         z_in = z_seq
         past_in0, z_seq = past_in0.contiguous().float(), z_seq.contiguous().float()
@@ -141,9 +141,8 @@ class _RolloutFunction(torch.autograd.Function):
         world = torch.empty(B, S, 348, dtype=torch.float32, device=dev)
         pm = torch.empty(B, S, 48, dtype=torch.float32, device=dev) if want_prior else None
         pv = torch.empty(B, S, 48, dtype=torch.float32, device=dev) if want_prior else None
-        # defer_prior: the prior network runs on the library's side stream; pm / pv are valid after HumorModel.join_prior()
-        lib.call('ha_humor_rollout_forward_ex', handle.ptr, B, S, _lib.ptr(past_in0), _lib.ptr(z_seq), _lib.ptr(world),
-                 _lib.ptr(pm), _lib.ptr(pv), _lib.ptr(stash), _lib.stream_ptr(past_in0), 1 if (defer_prior and want_prior) else 0)
+        lib.call('ha_humor_rollout_forward', handle.ptr, B, S, _lib.ptr(past_in0), _lib.ptr(z_seq), _lib.ptr(world),
+                 _lib.ptr(pm), _lib.ptr(pv), _lib.ptr(stash), _lib.stream_ptr(past_in0))
         ctx.handle, ctx.stash, ctx.dims, ctx.want_prior = handle, stash, (B, S), want_prior
         ctx.save_for_backward(z_seq)
         ctx.set_materialize_grads(False)
@@ -163,7 +162,7 @@ class _RolloutFunction(torch.autograd.Function):
         g_z = torch.empty(B, S, 48, dtype=torch.float32, device=dev)
         lib.call('ha_humor_rollout_backward_ex', handle.ptr, B, S, _lib.ptr(z_seq), _lib.ptr(g_world), _lib.ptr(g_pm), _lib.ptr(g_pv),
                  _lib.ptr(ctx.stash), _lib.ptr(g_past), _lib.ptr(g_z), _lib.ptr(g_z_thru), _lib.stream_ptr(z_seq))
-        return g_past, g_z, None, None, None, None
+        return g_past, g_z, None, None, None
 
 
 def _rollout_sample(handle, past_in, eps, S):
@@ -437,29 +436,6 @@ class HumorModel(nn.Module):
         h.lib.call('ha_humor_persist_status', h.ptr, C.byref(av), C.byref(err), C.byref(n))
         return av.value, err.value, n.value
 
-    def join_prior(self, ref):
-        """The current stream of tensor `ref`'s device waits for a prior network deferred by roll_out(defer_prior=True)
-        (ha_humor_prior_join; a no-op when nothing is pending)."""
-        h = self._cached_handle(ref)
-        if h is not None:
-            h.lib.call('ha_humor_prior_join', h.ptr, _lib.stream_ptr(ref))
-
-    def mark_prior_grad(self, g_mu, g_var):
-        """Tells the library that the gradient buffers g_mu / g_var (what roll_out's backward will receive for the prior outputs) are
-        complete at this point of the current stream (ha_humor_prior_grad_ready): the prior's adjoint then overlaps what follows."""
-        ref = g_mu if g_mu is not None else g_var
-        h = self._cached_handle(ref) if ref is not None else None
-        if h is not None:
-            h.lib.call('ha_humor_prior_grad_ready', h.ptr, _lib.ptr(g_mu), _lib.ptr(g_var), _lib.stream_ptr(ref))
-
-    def prior_side_stats(self, ref):
-        """(deferred prior forwards, prior adjoints started at a mark) so far on the device of tensor `ref`."""
-        h = self._cached_handle(ref)
-        out = (C.c_int64 * 2)()
-        if h is not None:
-            h.lib.call('ha_humor_prior_side_stats', h.ptr, out)
-        return out[0], out[1]
-
     def _cached_handle(self, ref):
         dev = ref.device
         index = (dev.index if dev.index is not None else torch.cuda.current_device()) if dev.type == 'cuda' else 0
@@ -467,15 +443,12 @@ class HumorModel(nn.Module):
         return None if cached is None else cached[1]
 
     def roll_out(self, x_past, init_input_dict, num_steps, use_mean=False, z_seq=None, return_prior=False, gender=None,
-                 betas=None, return_z=False, canonicalize_input=False, uncanonicalize_output=False, eps_seq=None, return_world=False,
-                 defer_prior=False):
+                 betas=None, return_z=False, canonicalize_input=False, uncanonicalize_output=False, eps_seq=None, return_world=False):
         '''
         Rolls the model out from the initial state (humor_model.py:785-1017): with the given latent sequence (differentiable,
         the fitting path) or, with z_seq=None, sampling z_t = mu_t + eps_t * sigma_t from the conditional prior at every step
         (use_mean: z_t = mu_t; forward only).  eps_seq [B,S,48] is an extension for reproducible sampling (default: randn).
         Returns a dict of world-frame [B, num_steps, D] tensors (rotations as matrices), optionally (prior mean, var).
-        defer_prior (extension, with z_seq and return_prior): the prior network runs on the library's side stream beside whatever the
-        caller queues next; the returned (prior mean, var) may only be read after join_prior().
         '''
         self._check_rollout_config()
         if x_past is not None:
@@ -503,7 +476,7 @@ class HumorModel(nn.Module):
             world, pm, pv, z_out = _rollout_sample(handle, past_in.detach(), eps, num_steps)
         else:
             z_seq = z_seq[:, :num_steps]
-            world, pm, pv, z_t = _RolloutFunction.apply(past_in, z_seq, handle, bool(return_prior), bool(defer_prior), bool(return_world and return_z))
+            world, pm, pv, z_t = _RolloutFunction.apply(past_in, z_seq, handle, bool(return_prior), bool(return_world and return_z))
             z_out = z_seq if z_t is None else z_t
         if canonicalize_input and uncanonicalize_output:
             from .frames import uncanonicalize_world

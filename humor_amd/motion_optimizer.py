@@ -36,7 +36,7 @@ class MotionOptimizer():
                  robust_tuning_const=4.6851, joint2d_sigma=100, stage3_tune_init_state=True, stage3_tune_init_num_frames=15,
                  stage3_tune_init_freeze_start=30, stage3_tune_init_freeze_end=50, stage3_contact_refine_only=False,
                  use_chamfer=False, im_dim=(1080, 1080), shard=None, verbose=False, use_graphs='auto', fused_loss=True, lbfgs='fused', fused_post=True, fused_pre=True, fused_vposer=True,
-                 rigid_cam_body=True, defer_prior=False, fused_stage3=True):
+                 rigid_cam_body=True, fused_stage3=True):
         B, T = batch_size, seq_len
         self.device = device
         self.batch_size, self.seq_len = B, T
@@ -75,14 +75,9 @@ class MotionOptimizer():
         # stage 3 as three composite autograd nodes (humor_amd/stage3.py): no accumulation / cat / expand launches between the kernels
         self.fused_stage3 = bool(fused_stage3)
         # sharded closures: gradients of the variables land in one persistent packed arena that is all-reduced in place (distributed.GradArena)
+        # (p.grad is then a VIEW of the arena, which the next closure evaluation zero-fills: an optimiser that keeps p.grad across
+        # evaluations must clone it -- humor_amd.lbfgs.LBFGS and torch.optim.LBFGS both copy the flat gradient -- or set this to False)
         self.grad_arena = True
-        # stage 3, opt-in: the conditional prior's batched GEMMs (forward and adjoint, ~0.27 ms of a 1.8 ms evaluation at 32 x 60) on the
-        # library's side stream beside the SMPL evaluations and their adjoints (HumorModel.roll_out(defer_prior=True) / join_prior /
-        # mark_prior_grad) instead of in line between the decoder chain and them.  Bit-identical results, but MEASURED SLOWER on one
-        # MI355X (tools/defer_prior_ab.py: 1.823 ms in stream order, 1.908 forward on the side stream, 1.863 adjoint, 1.877 both): the
-        # GEMMs fill every CU, so the small kernels beside them wait for wave slots anyway (smpl_frame_fwd 19 -> 62 us, rigid_image
-        # 5 -> 33 us in the trace) and each cross-queue event costs more than the overlap returns.  Off by default.
-        self.defer_prior = bool(defer_prior)
         # VPoser decode (+ 6-D -> R -> axis-angle) / encode through ha_mlp_* instead of the module's ATen ops (humor_amd/mlp.py)
         self.fused_vposer = bool(fused_vposer)
         self._vposer_handle = None
@@ -141,8 +136,6 @@ class MotionOptimizer():
         self.fitting_loss = FittingLoss(loss_weights, self.init_motion_prior, self.smpl2op_map, OP_IGNORE_JOINTS, cam_f, cam_c,
                                         robust_loss_type, robust_tuning_const, joints2d_sigma=joint2d_sigma,
                                         use_chamfer=self.dense_smpl, fused=fused_loss, _lib_override=self.fit_bm._lib).to(device)
-        if motion_prior is not None and hasattr(motion_prior, 'mark_prior_grad'):
-            self.fitting_loss.prior_grad_hook = lambda g_mu, g_var: motion_prior.mark_prior_grad(g_mu, g_var) if self.defer_prior else None
 
     # ------------------------------------------------------------------------------------------------
     # small helpers
@@ -293,19 +286,27 @@ class MotionOptimizer():
         closure.discard_last = self._discard_last_eval
         return closure
 
+    def _rollout_error_word(self):
+        """The persistent roll-out's host-mapped error word on this fit's device (0: no failure reported so far; also 0 without a GPU)."""
+        if self.motion_prior is None or self.device is None or torch.device(self.device).type != 'cuda':
+            return 0
+        status = getattr(self.motion_prior, 'persistent_rollout_status', None)
+        if status is None:
+            return 0
+        return status(torch.device(self.device))[1]
+
     def _check_rollout_health(self):
         """Called after every stage-3 outer iteration (L-BFGS has just read its scalars: the stream is drained).  The persistent roll-out
         kernels report a team that did not complete -- another process's kernel held part of the chip, say -- only through NaN results
-        and a host-mapped error word; closures replayed from a hipGraph never pass an entry point that returns it.  On a reported
-        failure: the captured graphs (they contain the persistent launches) are dropped, the network serves later calls through the
-        launch chain, and this fit is aborted with an error (run_fitting.py:437-439 skips the batch)."""
-        if self.motion_prior is None or self.device is None or torch.device(self.device).type != 'cuda':
-            return
-        status = getattr(self.motion_prior, 'persistent_rollout_status', None)
-        if status is None:
-            return
-        _, err, _ = status(torch.device(self.device))
-        if err != 0:
+        and a host-mapped error word; closures replayed from a hipGraph never pass an entry point that returns it.  On a failure reported
+        DURING this fit: the captured graphs (they contain the persistent launches) are dropped, the network serves later calls through
+        the launch chain, and this fit is aborted with an error (run_fitting.py:437-439 skips the batch).  The word is sticky for the
+        lifetime of the network handle, which outlives a fit (run_fitting.py makes one MotionOptimizer per batch around one HumorModel):
+        a failure an EARLIER fit already reported must not abort this one -- its evaluations ran on the launch chain and are valid --
+        so run() records the word it starts with and only a change counts."""
+        err = self._rollout_error_word()
+        if err != getattr(self, '_rollout_err0', 0):
+            self._rollout_err0 = err
             for st in self._graph_states:
                 st['graph'], st['failed'] = None, True
             raise RuntimeError('humor_amd: the persistent roll-out reported an incomplete launch (error word 0x%x): the objective values of '
@@ -394,6 +395,7 @@ class MotionOptimizer():
             raise ValueError('Must have num iters for 3 stages! But %d stages were given!' % len(num_iter))
         per_stage_outputs = {}
         T = self.seq_len
+        self._rollout_err0 = self._rollout_error_word()      # (sticky per network handle: only a change during THIS fit aborts it)
         self.initialize(observed_data)
         obs_local = self._local_obs(observed_data)
         has_overlap = 'seq_interval' in observed_data
@@ -696,7 +698,7 @@ class MotionOptimizer():
         if tune_phase:
             latent_motion = latent_motion[:, :(n_init - 1)]
         res = self.motion_prior.roll_out(past_in.unsqueeze(1), None, latent_motion.size(1), z_seq=latent_motion, return_prior=self.cond_prior,
-                                         return_world=True, return_z=True, defer_prior=self.defer_prior and self.cond_prior)
+                                         return_world=True, return_z=True)
         world, prior_out, z_t = res if self.cond_prior else (res[0], None, res[1])
         (pri_jtr, pri_verts, cam_jtr, cam_verts, r_trans, r_root, r_pose, ro_joints, conf, contacts, _cam_trans, _cam_root, betas_t) = Stage3Body.apply(
             cfg, world, trans_p, root_p, pose0, joints_p, c2p_R, c2p_t, betas_t)
@@ -714,8 +716,6 @@ class MotionOptimizer():
             nsteps, obs = n_init, obs_init
             self.fitting_loss.loss_weights['rgb_overlap_consist'] = 0.0
         halo = self._halo(cam_verts, betas_t, floor_t, has_overlap and self.fitting_loss.loss_weights['rgb_overlap_consist'] > 0.0)
-        if self.defer_prior and prior_out is not None:
-            self.motion_prior.join_prior(prior_out[0])
         loss, stats = self.fitting_loss.motion_fit(obs, pred, cam_pred, nsteps, cond_prior=prior_out, init_motion_scale=init_motion_scale, halo=halo)
         loss = self.fitting_loss.add_next_side(loss, 'motion', cam_pred, halo)
         if tune_phase:
@@ -758,8 +758,7 @@ class MotionOptimizer():
         if tune_phase:
             latent_motion = latent_motion[:, :(n_init - 1)]
         rr, cam_rr = self.rollout_latent_motion(trans, root_orient, cur_body_pose, betas, local_prior_params, latent_motion,
-                                                return_prior=self.cond_prior, fit_gender=fit_gender, cam2prior=cam2prior, pre=pre,
-                                                defer_prior=self.defer_prior)
+                                                return_prior=self.cond_prior, fit_gender=fit_gender, cam2prior=cam2prior, pre=pre)
         # the reference encodes the rolled-out poses with VPoser on every evaluation (motion_optimizer.py:571) but only the pose
         # prior reads the result, and no stage-3 configuration weights it: skipped when its weight is zero (same loss value)
         pose_prior_on = self.fitting_loss.loss_weights['pose_prior'] > 0.0
@@ -786,9 +785,6 @@ class MotionOptimizer():
             self.fitting_loss.loss_weights['rgb_overlap_consist'] = 0.0
         halo = self._halo(cam_pred['verts3d'], betas, floor,
                           has_overlap and self.fitting_loss.loss_weights['rgb_overlap_consist'] > 0.0)
-        if self.defer_prior and rr.get('cond_prior') is not None:
-            # the conditional prior ran on the side stream beside the SMPL evaluations above; the loss is its first reader
-            self.motion_prior.join_prior(rr['cond_prior'][0])
         loss, stats = self.fitting_loss.motion_fit(obs, pred, cam_pred, nsteps, cond_prior=rr.get('cond_prior'),
                                                    init_motion_scale=init_motion_scale, halo=halo)
         loss = self.fitting_loss.add_next_side(loss, 'motion', cam_pred, halo)
@@ -888,7 +884,7 @@ class MotionOptimizer():
 
     def rollout_latent_motion(self, trans, root_orient, body_pose, betas, prior_opt_params, latent_motion, return_prior=False,
                               return_vel=False, fit_gender='neutral', use_mean=False, num_steps=-1, canonicalize_input=False,
-                              cam2prior=None, pre=None, defer_prior=False):
+                              cam2prior=None, pre=None):
         '''
         Initial SMPL state + latent sequence -> full SMPL sequence through the motion prior
         (motion_optimizer.py:876-1019).  Returns (prior-frame dict, camera-frame dict).
@@ -921,8 +917,7 @@ class MotionOptimizer():
             from .fit_kernels import RolloutPost
             from . import _lib as _libmod
             res = self.motion_prior.roll_out(past_in.unsqueeze(1), None, Tm1, z_seq=latent_motion, return_prior=return_prior,
-                                             canonicalize_input=canonicalize_input, return_world=True,
-                                             defer_prior=defer_prior and return_prior)
+                                             canonicalize_input=canonicalize_input, return_world=True)
             world, prior_out = res if return_prior else (res, None)
             c2p_R = cam2prior[0] if self.optim_floor else None
             c2p_t = cam2prior[1] if self.optim_floor else None

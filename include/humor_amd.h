@@ -203,27 +203,6 @@ int ha_humor_rollout_workspace(const ha_humor_net* net, int B, int S, int64_t* s
 int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, const float* past_in0, const float* z_seq,
                              float* world, float* prior_mu, float* prior_var, float* stash, void* stream);
 
-/* ha_humor_rollout_forward with flags.  HA_ROLLOUT_DEFER_PRIOR: the conditional prior of a roll-out only reads the decoder chain's states
- * and only the loss reads its output (humor/fitting/motion_optimizer.py:944-948 -> fitting_loss.py:504), so when the persistent one-
- * launch chain serves the call (B <= 32) the prior's batched GEMMs are queued on a library-owned side stream behind the chain and the
- * caller's stream does NOT wait for them: prior_mu / prior_var are valid on `stream` only after ha_humor_prior_join(net, stream).
- * (Whatever the caller queues in between -- the SMPL evaluation of the rolled-out poses -- runs beside the GEMMs.)  A deferred prior
- * nobody joined is joined by the next call into this network.  Calls the flag does not apply to (launch chain, no prior outputs)
- * behave as ha_humor_rollout_forward; ha_humor_prior_join is then a no-op. */
-#define HA_ROLLOUT_DEFER_PRIOR 1
-int ha_humor_rollout_forward_ex(const ha_humor_net* net, int B, int S, const float* past_in0, const float* z_seq,
-                                float* world, float* prior_mu, float* prior_var, float* stash, void* stream, int flags);
-int ha_humor_prior_join(const ha_humor_net* net, void* stream);
-
-/* Marks the point of `stream` at which the buffers g_prior_mu / g_prior_var (the arguments a following ha_humor_rollout_backward will
- * receive) are complete.  A backward call that gets exactly these pointers starts the prior network's adjoint at that point on the
- * side stream -- beside the work queued on `stream` after the mark -- instead of at the stream's tail; the decoder chain's adjoint
- * waits for it.  Without a matching mark the backward call runs everything in stream order.  The mark is consumed by the next
- * ha_humor_rollout_backward on this network. */
-int ha_humor_prior_grad_ready(const ha_humor_net* net, const float* g_prior_mu, const float* g_prior_var, void* stream);
-/* out[0] = forward calls whose prior ran deferred on the side stream, out[1] = backward calls whose prior adjoint started at a mark */
-int ha_humor_prior_side_stats(const ha_humor_net* net, int64_t* out);
-
 /* Sampling roll-out (HumorModel.roll_out with z_seq=None, humor_model.py:1029-1047; test_humor.py:224): at every step
  * z_t = prior_mu_t + eps_t * sqrt(prior_var_t) (eps_seq [B,S,48]; NULL = use the prior mean, `use_mean=True`).
  * Outputs as ha_humor_rollout_forward plus the sampled latents z_out [B,S,48].  Forward only. */

@@ -11,15 +11,16 @@ from humor_amd.motion_optimizer import MotionOptimizer
 from oracle import closure_cases as CC
 
 
-def build(lib, device, kind, B, T, npz, shard=None, state_dict=None, lbfgs='fused'):
+def build(lib, device, kind, B, T, npz, shard=None, state_dict=None, lbfgs='fused', hm=None):
     rgb = kind == 'rgb'
     bm = BodyModel(npz, num_betas=16, batch_size=B * T, use_vtx_selector=rgb, _lib_override=lib)
-    hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1,
-                    _lib_override=lib)
-    hm.load_state_dict(synth.humor_state_dict(seed=0) if state_dict is None else state_dict)
-    hm = hm.to(device).eval()
-    for p in hm.parameters():
-        p.requires_grad_(False)
+    if hm is None:
+        hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=1,
+                        _lib_override=lib)
+        hm.load_state_dict(synth.humor_state_dict(seed=0) if state_dict is None else state_dict)
+        hm = hm.to(device).eval()
+        for p in hm.parameters():
+            p.requires_grad_(False)
     vp = synth.SynthVPoser(seed=0).to(device).eval()      # run_fitting.py:232-234 puts the pose prior in eval mode
     w, mu, cov = synth.make_gmm(seed=0)
     weights = CC.RGB_WEIGHTS if rgb else CC.AMASS_WEIGHTS

@@ -282,31 +282,6 @@ def test_fit_pre_kernel_equals_op_chain(gpu_lib, dev, smplh_npz):
 
 
 @pytest.mark.parametrize('B,T', [(4, 12), (32, 60)])
-def test_deferred_prior_equals_inline(gpu_lib, dev, smplh_npz, B, T):
-    """Stage-3 objective with the conditional prior on the library's side stream (ha_humor_rollout_forward_ex HA_ROLLOUT_DEFER_PRIOR,
-    ha_humor_prior_join, ha_humor_prior_grad_ready: forward beside the SMPL evaluations, adjoint beside their adjoints) against the same
-    objective with everything in stream order: the same kernels on the same data, so loss and gradients are bit-identical -- on every
-    one of several back-to-back evaluations (a missing join / a stale read would show as a difference that changes between repeats)."""
-    from oracle import closure_cases as CC
-    case = CC.make_case('rgb', B, T, seed=11)
-    ref = None
-    for defer in (False, True):
-        opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
-        opt.defer_prior = defer
-        for rep in range(1 if not defer else 6):
-            res = FC.eval_stage(opt, case, 2, dev)
-            if ref is None:
-                ref = {k: v.detach().clone() for k, v in res.items()}
-                continue
-            if defer:
-                for k in ref:
-                    assert torch.equal(ref[k], res[k].detach()), (k, rep, (ref[k] - res[k]).abs().max().item())
-    assert ref['g_latent_motion'].abs().max().item() > 0
-    n_fwd, n_bwd = opt.motion_prior.prior_side_stats(ref['loss'])
-    assert (n_fwd, n_bwd) == (6, 6), (n_fwd, n_bwd)      # the side-stream path was the one that ran
-
-
-@pytest.mark.parametrize('B,T', [(4, 12), (32, 60)])
 def test_stage3_nodes_equal_separate_functions(gpu_lib, dev, smplh_npz, B, T):
     """The stage-3 objective as three composite autograd nodes with in-kernel gradient addends (humor_amd/stage3.py, the init-state GMM
     term folded into the fused loss) against the same objective built from the separate Functions + autograd's accumulation launches:
@@ -357,3 +332,36 @@ def test_backward_addends(gpu_lib, dev):
     """In-kernel gradient addends of ha_rigid_image_backward / ha_fit_pre_backward and the strided jcam read (ABI 2)."""
     import fitloss_checks as FL
     print('addends: worst relative difference', FL.check_backward_addends(gpu_lib, dev, B=32, seed=2))
+
+
+def test_fit_after_an_earlier_persistent_failure_completes_on_the_launch_chain(gpu_lib, dev, smplh_npz):
+    """the persistent roll-out's error word is sticky for the lifetime of the network handle, and run_fitting.py makes a
+    new MotionOptimizer per batch around ONE HumorModel.  A fit that starts after a failure has already been reported (its evaluations run
+    on the launch chain: valid) must complete -- only a failure DURING a fit aborts that fit."""
+    from humor_amd import _lib
+    from oracle import closure_cases as CC
+    B, T = 4, 8
+    opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
+    hm = opt.motion_prior
+    g = torch.Generator().manual_seed(5)
+    import rollout_checks as RC
+    past, z = RC.canonical_state(B, g).to(dev), torch.randn(B, 3, 48, generator=g).to(dev)
+    with torch.no_grad():
+        hm.roll_out(past, None, 3, z_seq=z)
+        if hm.persistent_rollout_status(dev)[0] != 1:
+            pytest.skip('the persistent roll-out is not available on this device')
+        gpu_lib.call('ha_tune_set', b'rollout_persist_inject', 1)
+        try:
+            hm.roll_out(past, None, 3, z_seq=z)
+            torch.cuda.synchronize()
+        finally:
+            gpu_lib.call('ha_tune_set', b'rollout_persist_inject', 0)
+        with pytest.raises(_lib.HumorAmdError):
+            hm.roll_out(past, None, 3, z_seq=z)                 # the failure is reported once
+    av, err, _ = hm.persistent_rollout_status(dev)
+    assert av == 0 and err != 0
+    obs = {k: v.clone().to(dev) for k, v in CC.make_case('rgb', B, T, seed=2)['obs'].items()}
+    for _ in range(2):                                           # two "batches" around the same HumorModel
+        opt2 = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz, hm=hm)
+        final, _stages = opt2.run(obs, data_fps=30, lr=1.0, num_iter=[1, 1, 2], lbfgs_max_iter=3)
+        assert all(torch.isfinite(v).all() for v in final.values())
