@@ -16,7 +16,7 @@ def sources():
 
 def _deps():
     inc = os.path.join(os.path.dirname(HERE), 'include', 'humor_amd.h')
-    return sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [inc]
+    return sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc'))] + [inc]
 
 
 def is_stale():

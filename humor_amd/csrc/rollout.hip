@@ -74,6 +74,11 @@ int g_rollout_persist = 1;
 // ha_tune_set "rollout_persist_bwd": 1 (default) = behind a persistent forward the adjoint is ONE persistent launch too (reverse scan,
 // transposed weights resident, rollout_persist.hip); 0 = the launch-chain adjoint reads the persistent forward's stash.
 int g_rollout_persist_bwd = 1;
+// ha_tune_set "rollout_pipe": 1 (default) = 32 < B <= 256 sequences run the layer-parallel pipelined persistent kernels (rollout_pipe.inc);
+// 0 = the launch chain (A/B runs, tests)
+int g_rollout_pipe = 1;
+// ha_tune_set "rollout_pipe_bwd": 1 = behind a pipelined forward the adjoint is the pipelined persistent launch too; 0 = the launch chain's adjoint
+int g_rollout_pipe_bwd = 0;
 // ha_tune_set "rollout_persist_inject": test hook -- 1 = the persistent forward drops one CU of team 0, so that the team's bounded waits run
 // out and the failure path (NaN results, host-mapped error word, fall-back to the launch chain) can be exercised on a healthy GPU
 int g_rollout_persist_inject = 0;
@@ -1595,6 +1600,7 @@ struct StashLayout {
   // persistent forward (rollout_persist.hip): every decoder activation is ONE complete slab (bias included), written by the
   // persistent kernel; the adjoint reads it like a one-split partial slab
   bool single = false;
+  bool pipe = false;             // single, 32 < B <= 256: the layer-parallel pipelined kernels (rollout_pipe.inc), one set of records per row tile
   size_t persist_ws = 0;         // exchange space of the persistent kernel
   size_t off_gn[3] = {0, 0, 0}, off_gl = 0;   // single: per step GroupNorm statistics [16][32][2] x 3, glue record [32][32]
   size_t off_ht[3] = {0, 0, 0};               // single: per step the hidden pre-activations again, team layout [8][channel][4 rows]
@@ -1627,8 +1633,12 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, b
   for (int i = 0; i < net->n_dec; ++i) { L.nsf_dec[i] = ceil_div(net->dec[i].nslices_f, L.spb); L.nsb_dec[i] = ceil_div(net->dec[i].nslices_b, L.spb); }
   // GroupNorm prologues once per activation in gn_finish_kernel (see there and the policy note above)
   L.finish = (L.RT >= 2 && g_layer_finish != 0) || g_layer_finish == 2;     // 0: never, 2: always (A/B runs)
+  const bool want_single = tl_single_mode >= 0 ? tl_single_mode == 1 : (g_rollout_persist != 0 && persist_usable(net->persist));
   const bool may_single = allow_acc && !L.finish && B <= 32 && tl_groups == 1;
-  L.single = may_single && (tl_single_mode >= 0 ? tl_single_mode == 1 : (g_rollout_persist != 0 && persist_usable(net->persist)));
+  // 32 < B <= 256: the pipelined persistent kernels; the launch-chain adjoint behind them keeps its finishing-pass policy (it reads the
+  // forward's pre-activations as ONE complete slab per activation and row tile, like behind the B <= 32 kernel)
+  L.pipe = allow_acc && B > 32 && B <= 256 && tl_groups == 1 && g_rollout_pipe != 0 && g_layer_finish != 2 && want_single;
+  L.single = (may_single && want_single) || L.pipe;
   L.acc = allow_acc && !L.finish && !L.single && g_layer_acc != 0;
   L.hsum = !L.finish && !L.acc && !L.single && g_layer_hsum != 0;
   size_t o = 0;
@@ -1643,9 +1653,9 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, b
   for (int i = 0; i < net->n_dec; ++i) L.off_dec[i] = ptake((size_t)L.rd_f(i) * RT * net->dec[i].Nout_pad * 32);
   for (int i = 0; i + 1 < net->n_dec; ++i) L.off_hsum[i] = L.hsum ? ptake(RT * net->dec[i].Nout_pad * 32) : 0;
   if (L.single) {
-    for (int i = 0; i < 3; ++i) L.off_gn[i] = ptake(16 * 32 * 2);
-    L.off_gl = ptake(32 * 32);
-    for (int i = 0; i < 3; ++i) L.off_ht[i] = ptake(32 * (size_t)net->dec[i].Nout);
+    for (int i = 0; i < 3; ++i) L.off_gn[i] = ptake(RT * 16 * 32 * 2);
+    L.off_gl = ptake(RT * 32 * 32);
+    for (int i = 0; i < 3; ++i) L.off_ht[i] = ptake(RT * 32 * (size_t)net->dec[i].Nout);
   }
   L.per_step = p;
   L.steps = take(p * (size_t)(S + 1));
@@ -1674,8 +1684,8 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, b
   if (L.finish)
     L.fin[0] = take(RT * 1280 * 32);     // widest operand: K <= 1280 (checked at pack time)
   if (L.single) {
-    L.persist_ws = take(persist_ws_floats());
-    L.dz_part = take((size_t)S * persist_dz_slots() * 32 * ZD);
+    L.persist_ws = take(L.pipe ? pipe_ws_floats() : persist_ws_floats());
+    L.dz_part = take((size_t)S * (L.pipe ? pipe_dz_slots() : persist_dz_slots()) * RT * 32 * ZD);
   }
   L.total = o;
 }
@@ -1826,7 +1836,14 @@ static int prior_backward_batched(const ha_humor_net* net, const StashLayout& L,
 constexpr int MAX_GROUPS = 8;
 
 // rows per group (whole 32-row tiles) and the group count for a batch of B sequences
-static void group_plan(int B, int& ngroups, int& rows_per_group) {
+// pipelined: the call runs on the pipelined persistent kernels -- chunks of up to 256 sequences one after another on the caller's stream
+// (a persistent launch owns every CU: nothing runs beside it)
+static void group_plan(int B, int& ngroups, int& rows_per_group, bool pipelined = false) {
+  if (pipelined) {
+    rows_per_group = 256;
+    ngroups = ceil_div(B, 256);
+    return;
+  }
   const int RT = ceil_div(B, 32);
   int n = g_rollout_groups > 0 ? g_rollout_groups : (RT == 2 ? 2 : 1);
   if (n > MAX_GROUPS) n = MAX_GROUPS;
@@ -1834,6 +1851,8 @@ static void group_plan(int B, int& ngroups, int& rows_per_group) {
   rows_per_group = ceil_div(RT, n) * 32;
   ngroups = ceil_div(B, rows_per_group);
 }
+
+static bool pipelined_call(int B, int mode) { return mode == 1 && B > 32 && g_rollout_pipe != 0 && g_layer_finish != 2; }
 
 static size_t group_stash_floats(const ha_humor_net* net, int rows, int S) {
   // the largest of: persistent mode, launch-chain mode, sampling roll-out (the mode may change between the query and the call)
@@ -1950,8 +1969,12 @@ extern "C" int ha_humor_rollout_workspace(const ha_humor_net* net, int B, int S,
   group_plan(B, ng, rpg);
   const size_t whole = group_stash_floats(net, B, S);
   tl_groups = ng;
-  const size_t grouped = ng > 1 ? (size_t)ng * group_stash_floats(net, rpg, S) : 0;
+  size_t grouped = ng > 1 ? (size_t)ng * group_stash_floats(net, rpg, S) : 0;
   tl_groups = 1;
+  if (B > 256) {       // chunks of the pipelined kernels, one after another
+    group_plan(B, ng, rpg, true);
+    grouped = std::max(grouped, (size_t)ng * group_stash_floats(net, rpg, S));
+  }
   *stash_floats = (int64_t)(whole > grouped ? whole : grouped);
   return HA_OK;
 }
@@ -1979,6 +2002,7 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
       for (int l = 0; l < 4; ++l) f.off_dec[l] = L.off_dec[l];
       for (int l = 0; l < 3; ++l) { f.off_gn[l] = L.off_gn[l]; f.off_ht[l] = L.off_ht[l]; }
       f.off_gl = L.off_gl;
+      for (int l = 0; l < 4; ++l) f.dec_pad[l] = net->dec[l].Nout_pad;
       f.t2j = stash + L.t2j;
       f.ws = stash + L.persist_ws;
       return persist_forward(net->persist, f, ((g_rollout_persist >> 1) & 1) | (g_rollout_persist_inject ? 2 : 0), st);
@@ -2177,7 +2201,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
     }
   };
 
-  const bool persist_bwd = L.single && g_rollout_persist_bwd != 0;
+  const bool persist_bwd = L.single && g_rollout_persist_bwd != 0 && (!L.pipe || g_rollout_pipe_bwd != 0);
   if (persist_bwd) {
     if (phase == PH_BEGIN) {
       PersistBwd f;
@@ -2188,6 +2212,7 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
       for (int l = 0; l < 4; ++l) f.off_dec[l] = L.off_dec[l];
       for (int l = 0; l < 3; ++l) { f.off_gn[l] = L.off_gn[l]; f.off_ht[l] = L.off_ht[l]; }
       f.off_gl = L.off_gl;
+      for (int l = 0; l < 4; ++l) f.dec_pad[l] = net->dec[l].Nout_pad;
       f.t2j = stash + L.t2j;
       f.g_past0 = g_past_in0; f.g_z = g_z_seq; f.g_z_add = tl_gz_add;
       f.dz_part = stash + L.dz_part;
@@ -2260,9 +2285,21 @@ static int side_pool(int device, SidePool** out) {
 // round-robin over the groups (the host issues ~3 us per launch, a chain advances one launch per ~6 us: issuing one group's
 // whole chain first would leave the others waiting for the host).
 template <typename F>
-static int for_each_group(int device, int B, int S, bool reverse, hipStream_t st, F&& fn) {
+static int for_each_group(int device, int B, int S, bool reverse, hipStream_t st, bool pipelined, F&& fn) {
   int ng, rpg;
-  group_plan(B, ng, rpg);
+  group_plan(B, ng, rpg, pipelined);
+  if (pipelined) {
+    // one persistent launch (per direction) per chunk of <= 256 sequences, in stream order
+    for (int g = 0; g < ng; ++g) {
+      const int r0 = g * rpg, rows = (B - r0) < rpg ? (B - r0) : rpg;
+      int rc = fn(g, r0, rows, st, PH_BEGIN, 0);
+      // (the step phases are no-ops behind a persistent launch; the launch-chain adjoint behind a pipelined forward walks them)
+      for (int i = 0; i < S && rc == HA_OK; ++i) rc = fn(g, r0, rows, st, PH_STEP, reverse ? S - 1 - i : i);
+      if (rc == HA_OK) rc = fn(g, r0, rows, st, PH_END, 0);
+      if (rc != HA_OK) return rc;
+    }
+    return HA_OK;
+  }
   struct GroupScope { int prev; explicit GroupScope(int n) : prev(tl_groups) { tl_groups = n; } ~GroupScope() { tl_groups = prev; } } scope(ng);
   SidePool* P = nullptr;
   if (ng > 1) {
@@ -2304,20 +2341,21 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
     return HA_ERR_HIP;
   }
   DeviceGuard guard(net->device);
-  int ng, rpg;
-  group_plan(B, ng, rpg);
-  tl_groups = ng;
-  const size_t gs = ng > 1 ? group_stash_floats(net, rpg, S) : 0;
-  tl_groups = 1;
   // the roll-out mode of this call, decided once (see ha_humor_net::stash_mode)
   const int mode = (g_rollout_persist != 0 && persist_usable(net->persist)) ? 1 : 0;
+  const bool piped = pipelined_call(B, mode);
+  int ng, rpg;
+  group_plan(B, ng, rpg, piped);
+  tl_groups = piped ? 1 : ng;
+  const size_t gs = ng > 1 ? group_stash_floats(net, rpg, S) : 0;
+  tl_groups = 1;
   // (one entry per distinct stash address ever seen -- the allocator recycles them, a forward overwrites its entry -- so the map stays
   // small; the wholesale clear is a backstop that a process would need 64 k live stashes to reach)
   if (net->stash_mode.size() > 65536) net->stash_mode.clear();
   net->stash_mode[stash] = mode;
   tl_single_mode = mode;
   int rc;
-  rc = for_each_group(net->device, B, S, false, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
+  rc = for_each_group(net->device, B, S, false, (hipStream_t)stream, piped, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
     const size_t r = (size_t)r0;
     return rollout_forward_impl(net, rows, S, past_in0 + r * D_IN, z_seq + r * S * ZD, world + r * S * D_STATE,
                                 prior_mu ? prior_mu + r * S * ZD : nullptr, prior_var ? prior_var + r * S * ZD : nullptr,
@@ -2351,23 +2389,24 @@ extern "C" int ha_humor_rollout_backward_ex(const ha_humor_net* net, int B, int 
     return HA_ERR_HIP;
   }
   DeviceGuard guard(net->device);
-  int ng, rpg;
-  group_plan(B, ng, rpg);
-  tl_groups = ng;
-  const size_t gs = ng > 1 ? group_stash_floats(net, rpg, S) : 0;
-  tl_groups = 1;
   // the mode the forward over this stash recorded (a stash this library has not seen: decided from the live state, as before)
   const auto it = net->stash_mode.find(stash);
   tl_single_mode = it != net->stash_mode.end() ? it->second : -1;
+  const bool piped = pipelined_call(B, tl_single_mode >= 0 ? tl_single_mode : ((g_rollout_persist != 0 && persist_usable(net->persist)) ? 1 : 0));
+  int ng, rpg;
+  group_plan(B, ng, rpg, piped);
+  tl_groups = piped ? 1 : ng;
+  const size_t gs = ng > 1 ? group_stash_floats(net, rpg, S) : 0;
+  tl_groups = 1;
   int rc;
   bool add_in_kernel = false;
   if (g_z_add && tl_single_mode == 1 && ng == 1 && g_rollout_persist_bwd != 0) {
     StashLayout L;
     make_layout(net, B, S, L);
-    add_in_kernel = L.single;
+    add_in_kernel = L.single && (!L.pipe || g_rollout_pipe_bwd != 0);
   }
   tl_gz_add = add_in_kernel ? g_z_add : nullptr;
-  rc = for_each_group(net->device, B, S, true, (hipStream_t)stream, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
+  rc = for_each_group(net->device, B, S, true, (hipStream_t)stream, piped, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
     const size_t r = (size_t)r0;
     return rollout_backward_impl(net, rows, S, g_world ? g_world + r * S * D_STATE : nullptr,
                                  g_prior_mu ? g_prior_mu + r * S * ZD : nullptr, g_prior_var ? g_prior_var + r * S * ZD : nullptr,

@@ -18,6 +18,7 @@ struct PersistFwd {
   size_t per_step = 0, off_G = 0, off_dec[4] = {0, 0, 0, 0};
   size_t off_gn[3] = {0, 0, 0}, off_gl = 0;   // per step: GroupNorm statistics of the hidden activations; glue record (for the persistent adjoint)
   size_t off_ht[3] = {0, 0, 0};               // per step: the hidden pre-activations in team layout [8][channel][4 rows]
+  int dec_pad[4] = {0, 0, 0, 0};              // B > 32 (pipelined kernels): slab widths of the decoder layers, one slab per 32-row tile
   float* t2j = nullptr;              // [32][3]
   float* ws = nullptr;               // persist_ws_floats() floats of exchange space (zeroed by persist_forward before the launch)
 };
@@ -32,6 +33,7 @@ struct PersistBwd {
   const float* xT = nullptr;
   const float* steps = nullptr;
   size_t per_step = 0, off_G = 0, off_dec[4] = {0, 0, 0, 0}, off_gn[3] = {0, 0, 0}, off_gl = 0, off_ht[3] = {0, 0, 0};
+  int dec_pad[4] = {0, 0, 0, 0};
   const float* t2j = nullptr;
   float* g_past0 = nullptr;          // [B][339]
   float* g_z = nullptr;              // [B][S][48]
@@ -41,6 +43,8 @@ struct PersistBwd {
 };
 
 size_t persist_ws_floats();
+size_t pipe_ws_floats();      // exchange space of the pipelined kernels (32 < B <= 256)
+int pipe_dz_slots();
 int persist_dz_slots();      // partial dL/dz products per (step, sequence) written by the persistent adjoint
 // *out stays null (and HA_OK is returned) when the network or the device does not have the shape this path is built for
 int persist_create(PersistNet** out, int device, const ha_mlp_desc* decoder);

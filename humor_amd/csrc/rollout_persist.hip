@@ -143,6 +143,8 @@ struct PersistNet {
   int device = 0;
   float* Wreg = nullptr;
   float* Wreg_b = nullptr;          // transposed layers for the adjoint
+  float* Wreg_pf = nullptr;         // pipelined forward (32 < B <= 256): role-ordered packing, rollout_pipe.inc
+  float* Wreg_pb = nullptr;         // pipelined adjoint
   float* bias[4] = {nullptr, nullptr, nullptr, nullptr};
   float* gamma[3] = {nullptr, nullptr, nullptr};
   float* beta[3] = {nullptr, nullptr, nullptr};
@@ -1695,6 +1697,8 @@ __global__ void dz_reduce_kernel(const float* __restrict__ part, float* __restri
 
 #endif  // !HA_SIMT_EMU
 
+#include "rollout_pipe.inc"
+
 #ifdef HA_PERSIST_TIMING
 }  // namespace ha
 extern "C" int ha_debug_persist_timing(unsigned long long* out /* [2][8][24] */) {
@@ -1745,6 +1749,8 @@ void persist_destroy(PersistNet* p) {
   DeviceGuard guard(p->device);
   if (p->Wreg) (void)hipFree(p->Wreg);
   if (p->Wreg_b) (void)hipFree(p->Wreg_b);
+  if (p->Wreg_pf) (void)hipFree(p->Wreg_pf);
+  if (p->Wreg_pb) (void)hipFree(p->Wreg_pb);
   for (float* q : p->bias)
     if (q) (void)hipFree(q);
   for (float* q : p->gamma)
@@ -1837,6 +1843,29 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
       }
     rc = p_upload(&p->Wreg_b, wb);
   }
+  if (rc == HA_OK) {
+    // pipelined forward: wave g = 4 m + w of a team belongs to the role of CU m; register c * NCGW + cg = K chunk c of column group cg
+    std::vector<float> wp((size_t)NWAVES_TEAM * PF_NREG * 64, 0.f);
+    for (int g = 0; g < NWAVES_TEAM; ++g) {
+      const int m = g / 4;
+      const int l = m < PR1_M0 ? 0 : (m < PR2_M0 ? 1 : (m < PR3_M0 ? 2 : 3));
+      const int m0[4] = {PR0_M0, PR1_M0, PR2_M0, PR3_M0}, ncgw[4] = {PF0_CG, PF1_CG, PF2_CG, PF3_CG};
+      const int gw = g - 4 * m0[l];
+      for (int c = 0; c < NCm[l] + NCZ; ++c)
+        for (int cg = 0; cg < ncgw[l]; ++cg)
+          for (int ln = 0; ln < 64; ++ln) {
+            const int b = ln >> 2, j = ln & 3;
+            const int col = 4 * (ncgw[l] * gw + cg) + j;
+            int k;
+            if (c < NCm[l]) { k = 16 * c + b; if (k >= Cmain[l]) k = -1; }
+            else k = Cmain[l] + 16 * (c - NCm[l]) + b;
+            float v = 0.f;
+            if (col < Nout[l] && k >= 0) v = d->w[l][(size_t)col * Kin[l] + k];
+            wp[((size_t)g * PF_NREG + c * ncgw[l] + cg) * 64 + ln] = v;
+          }
+    }
+    rc = p_upload(&p->Wreg_pf, wp);
+  }
   const int bpad[4] = {P_H0, P_H1, P_H2, P_RAWPAD};
   for (int l = 0; l < 4 && rc == HA_OK; ++l) {
     std::vector<float> bv(bpad[l], 0.f);
@@ -1860,6 +1889,8 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_persist_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_persist_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_TOTAL * 4);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_persist_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_TOTAL * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_pipe_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PL_TOTAL * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_pipe_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PL_TOTAL * 4);
     if (e != hipSuccess) { set_error("persist_create: LDS attribute: %s", hipGetErrorString(e)); rc = HA_ERR_HIP; }
   }
   if (rc == HA_OK) {
@@ -1894,8 +1925,29 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
   set_error("persistent roll-out: not available on the host emulator");
   return HA_ERR_INVALID_ARG;
 #else
-  HA_REQUIRE(p && f.B >= 1 && f.B <= NTEAMS * ROWS && f.S >= 1, "persistent roll-out: needs 1 <= B <= 32 sequences");
+  HA_REQUIRE(p && f.B >= 1 && f.B <= 32 * PG_MAX && f.S >= 1, "persistent roll-out: needs 1 <= B <= 256 sequences");
   HA_REQUIRE(f.S < (1 << 28), "persistent roll-out: too many steps");
+  if (f.B > NTEAMS * ROWS) {
+    // 32 < B <= 256: the layer-parallel pipeline (rollout_pipe.inc), one group of 4 sequences per team and 32-row tile
+    zero_async(f.ws, PX_BYTES, st);
+    HA_LAUNCH_CHECK();
+    PipeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = f.B; a.S = f.S; a.NG = (f.B + 31) / 32;
+    a.Wreg = p->Wreg_pf;
+    for (int l = 0; l < 4; ++l) { a.bias[l] = p->bias[l]; a.off_dec[l] = f.off_dec[l]; a.dec_pad[l] = f.dec_pad[l]; }
+    for (int l = 0; l < 3; ++l) { a.gamma[l] = p->gamma[l]; a.beta[l] = p->beta[l]; a.off_gn[l] = f.off_gn[l]; a.off_ht[l] = f.off_ht[l]; }
+    a.past_in0 = f.past_in0; a.z_seq = f.z_seq; a.world = f.world; a.xT = f.xT; a.steps = f.steps;
+    a.per_step = f.per_step; a.off_G = f.off_G; a.off_gl = f.off_gl;
+    a.t2j = f.t2j;
+    a.xch = reinterpret_cast<unsigned char*>(f.ws);
+    a.err = p->err_dev;
+    if (variant & 1) hipLaunchKernelGGL(rollout_pipe_fwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), PL_TOTAL * 4, st, a);
+    else hipLaunchKernelGGL(rollout_pipe_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), PL_TOTAL * 4, st, a);
+    HA_LAUNCH_CHECK();
+    ++p->launches;
+    return HA_OK;
+  }
   zero_async(f.ws, XCH_BYTES, st);        // tags, team counters (tag 0 never matches); a kernel, not a memset node: common.h
   HA_LAUNCH_CHECK();
   PersistArgs a;

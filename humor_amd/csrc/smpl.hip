@@ -46,7 +46,7 @@ int g_skin_variant = -1;
 int g_dense_gA_sparse = 1;   // ha_tune_set("dense_gA_sparse"): 1 = dL/dA of the dense backward by joint lists (default), 0 = dense MFMA product,
                              // 2 = MFMA product over the joints each 64-vertex chunk touches (experiment, unmeasured)
 int g_dense_bwd_waves = 0;   // ha_tune_set("dense_bwd_waves"): wave-count target of the dense backward's K split (0 = default)
-extern int g_layer_spb, g_layer_nw, g_layer_finish, g_gemm_rm, g_layer_hsum, g_layer_acc, g_rollout_groups, g_gemm_ks, g_rollout_persist, g_rollout_persist_bwd, g_rollout_persist_inject;   // rollout.hip
+extern int g_layer_spb, g_layer_nw, g_layer_finish, g_gemm_rm, g_layer_hsum, g_layer_acc, g_rollout_groups, g_gemm_ks, g_rollout_persist, g_rollout_persist_bwd, g_rollout_persist_inject, g_rollout_pipe, g_rollout_pipe_bwd;   // rollout.hip
 }
 extern "C" int ha_tune_set(const char* key, int value) {
   HA_REQUIRE(key, "ha_tune_set: null key");
@@ -63,6 +63,8 @@ extern "C" int ha_tune_set(const char* key, int value) {
   if (strcmp(key, "gemm_ks") == 0) { ha::g_gemm_ks = value; return HA_OK; }
   if (strcmp(key, "rollout_persist") == 0) { ha::g_rollout_persist = value; return HA_OK; }
   if (strcmp(key, "rollout_persist_bwd") == 0) { ha::g_rollout_persist_bwd = value; return HA_OK; }
+  if (strcmp(key, "rollout_pipe") == 0) { ha::g_rollout_pipe = value; return HA_OK; }
+  if (strcmp(key, "rollout_pipe_bwd") == 0) { ha::g_rollout_pipe_bwd = value; return HA_OK; }
   if (strcmp(key, "rollout_persist_inject") == 0) { ha::g_rollout_persist_inject = value; return HA_OK; }
   ha::set_error("ha_tune_set: unknown key '%s'", key);
   return HA_ERR_INVALID_ARG;

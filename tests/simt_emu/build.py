@@ -19,7 +19,7 @@ def sources():
 def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     srcs = sources() + [os.path.join(HERE, 'simt_emu.cpp')]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + \
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc'))] + \
         [os.path.join(HERE, 'include', 'hip', 'hip_runtime.h'), os.path.join(ROOT, 'include', 'humor_amd.h')]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
