@@ -1724,6 +1724,11 @@ extern "C" int ha_debug_persist_timing_glue(unsigned long long* out /* [2][8][8]
   HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_ptc), sizeof(unsigned long long) * 2 * 8 * 8));
   return HA_OK;
 }
+extern "C" int ha_debug_pipe_timing(unsigned long long* out /* [2][4][4][8][12] */) {
+  HA_CHECK_HIP(hipDeviceSynchronize());
+  HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_ppt), sizeof(unsigned long long) * 2 * 4 * 4 * 8 * 12));
+  return HA_OK;
+}
 extern "C" int ha_debug_persist_timing_bwd(unsigned long long* out /* [8][24] */) {
   HA_CHECK_HIP(hipDeviceSynchronize());
   HA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(ha::g_ptb), sizeof(unsigned long long) * 8 * 24));
