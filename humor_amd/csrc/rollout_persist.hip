@@ -1871,6 +1871,46 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
     }
     rc = p_upload(&p->Wreg_pf, wp);
   }
+  if (rc == HA_OK) {
+    // pipelined adjoint: register c * NCGW + cg = K chunk c (forward output channels 16 c .. 16 c + 15 of the layer) of column group cg
+    // (forward input columns) of the role's transposed layer; behind them the wave's LDS-resident dL/dz vectors
+    auto W = [&](int l, int k, int col) -> float { return (k >= 0 && k < Nout[l] && col >= 0 && col < Kin[l]) ? d->w[l][(size_t)k * Kin[l] + col] : 0.f; };
+    const size_t stride = (size_t)(QB_NREG + QB_NLW) * 64;
+    std::vector<float> wq((size_t)NWAVES_TEAM * stride, 0.f);
+    for (int g = 0; g < NWAVES_TEAM; ++g) {
+      const int m = g / 4;
+      if (m >= PRG_M0 && m < PR1_M0) continue;       // the glue CU holds no weights
+      const int l = m < PRG_M0 ? 0 : (m < PR2_M0 ? 1 : (m < PR3_M0 ? 2 : 3));
+      const int m0[4] = {PR0_M0, PR1_M0, PR2_M0, PR3_M0}, ncgw[4] = {QB0_CG, QB1_CG, QB2_CG, QB3_CG}, nch[4] = {BC0, BC1, BC2, BC3};
+      const int gw = g - 4 * m0[l];
+      for (int ln = 0; ln < 64; ++ln) {
+        const int b = ln >> 2, j = ln & 3;
+        float* dst = wq.data() + (size_t)g * stride + ln;
+        for (int c = 0; c < nch[l]; ++c)
+          for (int cg = 0; cg < ncgw[l]; ++cg) {
+            const int col = 4 * (ncgw[l] * gw + cg) + j;
+            dst[(size_t)(c * ncgw[l] + cg) * 64] = col < Cmain[l] ? W(l, 16 * c + b, col) : 0.f;
+          }
+        float* dz = dst + (size_t)QB_NREG * 64;
+        if (l == 3 && gw < 6) {
+          for (int k = 0; k < 2; ++k)
+            for (int i = 0; i < BC3; ++i) dz[(size_t)(k * BC3 + i) * 64] = W(3, 16 * i + b, Cmain[3] + 4 * (2 * gw + k) + j);
+        } else if (l == 2 && gw < 24) {
+          for (int i = 0; i < 16; ++i) dz[(size_t)i * 64] = W(2, 16 * (16 * (gw % 2) + i) + b, Cmain[2] + 4 * (gw / 2) + j);
+        } else if (l == 1 && gw < 48) {
+          for (int i = 0; i < 16; ++i) dz[(size_t)i * 64] = W(1, 16 * (16 * (gw % 4) + i) + b, Cmain[1] + 4 * (gw / 4) + j);
+        } else if (l == 0) {
+          const int zks = gw >> 2, zc0 = 3 * (gw & 3);
+          for (int k = 0; k < 3; ++k)
+            for (int i = 0; i < QZ0_CH; ++i) {
+              const int c = QZ0_CH * zks + i;      // (the 65th chunk of the last K fifth does not exist: zero vector)
+              dz[(size_t)(k * QZ0_CH + i) * 64] = c < BC0 ? W(0, 16 * c + b, Cmain[0] + 4 * (zc0 + k) + j) : 0.f;
+            }
+        }
+      }
+    }
+    rc = p_upload(&p->Wreg_pb, wq);
+  }
   const int bpad[4] = {P_H0, P_H1, P_H2, P_RAWPAD};
   for (int l = 0; l < 4 && rc == HA_OK; ++l) {
     std::vector<float> bv(bpad[l], 0.f);
@@ -1896,6 +1936,8 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_persist_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LB_TOTAL * 4);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_pipe_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PL_TOTAL * 4);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_pipe_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PL_TOTAL * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_pipe_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QL_TOTAL * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_pipe_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QL_TOTAL * 4);
     if (e != hipSuccess) { set_error("persist_create: LDS attribute: %s", hipGetErrorString(e)); rc = HA_ERR_HIP; }
   }
   if (rc == HA_OK) {
@@ -1984,7 +2026,31 @@ int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_
   set_error("persistent roll-out: not available on the host emulator");
   return HA_ERR_INVALID_ARG;
 #else
-  HA_REQUIRE(p && f.B >= 1 && f.B <= NTEAMS * ROWS && f.S >= 1, "persistent roll-out adjoint: needs 1 <= B <= 32 sequences");
+  HA_REQUIRE(p && f.B >= 1 && f.B <= 32 * PG_MAX && f.S >= 1, "persistent roll-out adjoint: needs 1 <= B <= 256 sequences");
+  if (f.B > NTEAMS * ROWS) {
+    // 32 < B <= 256: the layer-parallel pipelined adjoint (rollout_pipe.inc)
+    zero_async(f.ws, PX_BYTES, st);
+    HA_LAUNCH_CHECK();
+    PipeBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = f.B; a.S = f.S; a.NG = (f.B + 31) / 32;
+    a.Wreg = p->Wreg_pb;
+    for (int l = 0; l < 3; ++l) { a.gamma[l] = p->gamma[l]; a.beta[l] = p->beta[l]; a.off_gn[l] = f.off_gn[l]; a.off_ht[l] = f.off_ht[l]; }
+    for (int l = 0; l < 4; ++l) { a.off_dec[l] = f.off_dec[l]; a.dec_pad[l] = f.dec_pad[l]; }
+    a.g_world = f.g_world; a.gx_pri = f.gx_pri; a.gxp_pad = f.gxp_pad;
+    a.xT = f.xT; a.steps = f.steps; a.per_step = f.per_step; a.off_G = f.off_G; a.off_gl = f.off_gl;
+    a.t2j = f.t2j; a.g_past0 = f.g_past0; a.dz_part = f.dz_part;
+    a.xch = reinterpret_cast<unsigned char*>(f.ws);
+    a.err = p->err_dev;
+    if (variant & 1) hipLaunchKernelGGL(rollout_pipe_bwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), QL_TOTAL * 4, st, a);
+    else hipLaunchKernelGGL(rollout_pipe_bwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), QL_TOTAL * 4, st, a);
+    HA_LAUNCH_CHECK();
+    const int n = f.B * f.S * P_ZD;
+    hipLaunchKernelGGL(pipe_dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)f.dz_part, f.g_z, f.g_z_add, f.B, f.S, a.NG * 32);
+    HA_LAUNCH_CHECK();
+    ++p->launches_bwd;
+    return HA_OK;
+  }
   zero_async(f.ws, XCH_BYTES, st);
   HA_LAUNCH_CHECK();
   PersistBwdArgs a;
