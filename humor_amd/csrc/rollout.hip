@@ -78,7 +78,7 @@ int g_rollout_persist_bwd = 1;
 // 0 = the launch chain (A/B runs, tests)
 int g_rollout_pipe = 1;
 // ha_tune_set "rollout_pipe_bwd": 1 = behind a pipelined forward the adjoint is the pipelined persistent launch too; 0 = the launch chain's adjoint
-int g_rollout_pipe_bwd = 0;
+int g_rollout_pipe_bwd = 1;
 // ha_tune_set "rollout_persist_inject": test hook -- 1 = the persistent forward drops one CU of team 0, so that the team's bounded waits run
 // out and the failure path (NaN results, host-mapped error word, fall-back to the launch chain) can be exercised on a healthy GPU
 int g_rollout_persist_inject = 0;
@@ -1633,7 +1633,7 @@ static void make_layout(const ha_humor_net* net, int B, int S, StashLayout& L, b
   for (int i = 0; i < net->n_dec; ++i) { L.nsf_dec[i] = ceil_div(net->dec[i].nslices_f, L.spb); L.nsb_dec[i] = ceil_div(net->dec[i].nslices_b, L.spb); }
   // GroupNorm prologues once per activation in gn_finish_kernel (see there and the policy note above)
   L.finish = (L.RT >= 2 && g_layer_finish != 0) || g_layer_finish == 2;     // 0: never, 2: always (A/B runs)
-  const bool want_single = tl_single_mode >= 0 ? tl_single_mode == 1 : (g_rollout_persist != 0 && persist_usable(net->persist));
+  const bool want_single = tl_single_mode >= 0 ? tl_single_mode >= 1 : (g_rollout_persist != 0 && persist_usable(net->persist));
   const bool may_single = allow_acc && !L.finish && B <= 32 && tl_groups == 1;
   // 32 < B <= 256: the pipelined persistent kernels; the launch-chain adjoint behind them keeps its finishing-pass policy (it reads the
   // forward's pre-activations as ONE complete slab per activation and row tile, like behind the B <= 32 kernel)
@@ -1852,7 +1852,7 @@ static void group_plan(int B, int& ngroups, int& rows_per_group, bool pipelined 
   ngroups = ceil_div(B, rows_per_group);
 }
 
-static bool pipelined_call(int B, int mode) { return mode == 1 && B > 32 && g_rollout_pipe != 0 && g_layer_finish != 2; }
+static bool pipelined_call(int B, int mode) { return mode >= 1 && B > 32 && g_rollout_pipe != 0 && g_layer_finish != 2; }
 
 static size_t group_stash_floats(const ha_humor_net* net, int rows, int S) {
   // the largest of: persistent mode, launch-chain mode, sampling roll-out (the mode may change between the query and the call)
@@ -2003,6 +2003,7 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
       for (int l = 0; l < 3; ++l) { f.off_gn[l] = L.off_gn[l]; f.off_ht[l] = L.off_ht[l]; }
       f.off_gl = L.off_gl;
       for (int l = 0; l < 4; ++l) f.dec_pad[l] = net->dec[l].Nout_pad;
+      f.hidden_slabs = tl_single_mode != 2;
       f.t2j = stash + L.t2j;
       f.ws = stash + L.persist_ws;
       return persist_forward(net->persist, f, ((g_rollout_persist >> 1) & 1) | (g_rollout_persist_inject ? 2 : 0), st);
@@ -2202,6 +2203,9 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
   };
 
   const bool persist_bwd = L.single && g_rollout_persist_bwd != 0 && (!L.pipe || g_rollout_pipe_bwd != 0);
+  HA_REQUIRE(!(L.pipe && !persist_bwd && tl_single_mode == 2),
+             "ha_humor_rollout_backward: this stash was filled by a pipelined forward without launch-chain slabs (the adjoint knobs said the "
+             "pipelined adjoint would follow) and the adjoint knobs changed since -- set them before the forward call");
   if (persist_bwd) {
     if (phase == PH_BEGIN) {
       PersistBwd f;
@@ -2342,8 +2346,11 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
   }
   DeviceGuard guard(net->device);
   // the roll-out mode of this call, decided once (see ha_humor_net::stash_mode)
-  const int mode = (g_rollout_persist != 0 && persist_usable(net->persist)) ? 1 : 0;
+  int mode = (g_rollout_persist != 0 && persist_usable(net->persist)) ? 1 : 0;
   const bool piped = pipelined_call(B, mode);
+  // mode 2: a pipelined forward whose adjoint will be the pipelined launch too writes the hidden pre-activations in the teams' layout only
+  // (no launch-chain slabs: a third of its stores); only the pipelined adjoint can read such a stash, and the backward entry checks that
+  if (piped && g_rollout_persist_bwd != 0 && g_rollout_pipe_bwd != 0) mode = 2;
   int ng, rpg;
   group_plan(B, ng, rpg, piped);
   tl_groups = piped ? 1 : ng;
@@ -2400,7 +2407,7 @@ extern "C" int ha_humor_rollout_backward_ex(const ha_humor_net* net, int B, int 
   tl_groups = 1;
   int rc;
   bool add_in_kernel = false;
-  if (g_z_add && tl_single_mode == 1 && ng == 1 && g_rollout_persist_bwd != 0) {
+  if (g_z_add && tl_single_mode >= 1 && ng == 1 && g_rollout_persist_bwd != 0) {
     StashLayout L;
     make_layout(net, B, S, L);
     add_in_kernel = L.single && (!L.pipe || g_rollout_pipe_bwd != 0);

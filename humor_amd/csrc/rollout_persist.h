@@ -19,6 +19,7 @@ struct PersistFwd {
   size_t off_gn[3] = {0, 0, 0}, off_gl = 0;   // per step: GroupNorm statistics of the hidden activations; glue record (for the persistent adjoint)
   size_t off_ht[3] = {0, 0, 0};               // per step: the hidden pre-activations in team layout [8][channel][4 rows]
   int dec_pad[4] = {0, 0, 0, 0};              // B > 32 (pipelined kernels): slab widths of the decoder layers, one slab per 32-row tile
+  bool hidden_slabs = true;                   // B > 32: also write the hidden pre-activations as launch-chain slabs (for the launch-chain adjoint)
   float* t2j = nullptr;              // [32][3]
   float* ws = nullptr;               // persist_ws_floats() floats of exchange space (zeroed by persist_forward before the launch)
 };

@@ -533,7 +533,7 @@ def persist_status(lib, hm, device):
     return av.value, err.value, n.value
 
 
-def check_persistent_vs_chain(lib, device, B, S, seed=0, variant=1, contractive=True):
+def check_persistent_vs_chain(lib, device, B, S, seed=0, variant=1, contractive=True, launches_per_call=1):
     """The one-launch persistent forward and adjoint (ha_tune_set "rollout_persist" / "rollout_persist_bwd") against the launch chain on
     the same inputs: world states, prior outputs and every gradient, for (i) persistent forward + launch-chain adjoint reading its
     stash and (ii) persistent forward + persistent adjoint."""
@@ -578,7 +578,7 @@ def check_persistent_vs_chain(lib, device, B, S, seed=0, variant=1, contractive=
     av, err, n1 = persist_status(lib, hm, device)
     assert err == 0, hex(err)
     # the persistent kernels really ran (no silent fall-back): two forwards (low word), one adjoint (high word)
-    assert av == 1 and (n1 & 0xffffffff) == (n0 & 0xffffffff) + 2 and (n1 >> 32) == (n0 >> 32) + 1, (av, n0, n1)
+    assert av == 1 and (n1 & 0xffffffff) == (n0 & 0xffffffff) + 2 * launches_per_call and (n1 >> 32) == (n0 >> 32) + launches_per_call, (av, n0, n1)
     errs = []
     for k in (1, 2):
         for name, a, b, tol in zip(('world', 'prior_mu', 'prior_var', 'g_past', 'g_z'), res[0], res[k], (2e-5, 2e-5, 2e-5, 3e-4, 3e-4)):

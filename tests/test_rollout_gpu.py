@@ -15,8 +15,9 @@ def dev():
 
 @pytest.fixture(params=[(1, 1), (1, 0), (0, 0)], ids=['persistent', 'persistent_fwd_chain_bwd', 'chain'])
 def fwd_path(request, gpu_lib):
-    """The paths of a roll-out of <= 32 sequences: one persistent launch per direction (default), persistent forward with the
-    launch-chain adjoint, and the launch chain in both directions."""
+    """The paths of a roll-out: one persistent launch per direction (default: the weight-stationary kernels of rollout_persist.hip for
+    <= 32 sequences, the layer-parallel pipelined kernels of rollout_pipe.inc for 33 .. 256, chunks of 256 beyond), persistent forward
+    with the launch-chain adjoint reading its stash, and the launch chain in both directions."""
     gpu_lib.call('ha_tune_set', b'rollout_persist', request.param[0])
     gpu_lib.call('ha_tune_set', b'rollout_persist_bwd', request.param[1])
     yield request.param
@@ -114,6 +115,7 @@ def test_rollout_row_groups(gpu_lib, dev, B, groups):
     past = RC.canonical_state(B, g).to(dev)
     z = torch.randn(B, 12, 48, generator=g).to(dev)
     res = []
+    gpu_lib.call('ha_tune_set', b'rollout_pipe', 0)          # (row groups on side streams are a launch-chain policy)
     try:
         for n in (1, groups):
             gpu_lib.call('ha_tune_set', b'rollout_groups', n)
@@ -124,6 +126,7 @@ def test_rollout_row_groups(gpu_lib, dev, B, groups):
             res.append((w.detach(), pm.detach(), pv.detach(), p.grad.clone(), zz.grad.clone()))
     finally:
         gpu_lib.call('ha_tune_set', b'rollout_groups', 0)
+        gpu_lib.call('ha_tune_set', b'rollout_pipe', 1)
     for a, b in zip(*res):
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item())
 
@@ -204,6 +207,34 @@ def test_persistent_forward_matches_launch_chain(gpu_lib, dev, variant):
     4 sequences; variant 3 publishes write-through) against the 5-launches-per-step chain -- outputs and gradients."""
     for B, S in ((32, 59), (5, 7), (1, 3), (32, 1), (17, 20), (4, 119)):
         print('persistent vs chain', B, S, variant, RC.check_persistent_vs_chain(gpu_lib, dev, B, S, seed=B, variant=variant))
+
+
+@pytest.mark.parametrize('B,S', [(64, 12), (40, 5), (100, 7), (256, 20), (300, 4)])
+def test_pipelined_rollout_matches_launch_chain(gpu_lib, dev, B, S):
+    """roll-outs of more than 32 sequences on the layer-parallel pipelined persistent kernels (rollout_pipe.inc: forward and
+    adjoint, one launch each per chunk of <= 256 sequences) against the 5-launches-per-step chain on the same inputs -- world states,
+    prior outputs and every gradient, for the pipelined forward + launch-chain adjoint and for pipelined forward + pipelined adjoint;
+    partial last tiles (40, 100), full tiles (64, 256) and two chunks (300)."""
+    print('pipelined vs chain', B, S, RC.check_persistent_vs_chain(gpu_lib, dev, B, S, seed=B, variant=1, launches_per_call=(B + 255) // 256))
+
+
+def test_pipelined_rollout_determinism_and_reuse(gpu_lib, dev):
+    """Back-to-back pipelined launches on one network (fresh stash each): bit-identical results in both directions, no stale granules."""
+    hm, _ = RC.make_model(gpu_lib, dev, contractive=True)
+    g = torch.Generator().manual_seed(6)
+    past, z = RC.canonical_state(96, g).to(dev), torch.randn(96, 30, 48, generator=g).to(dev)
+    outs = []
+    for _ in range(5):
+        p, zz = past.clone().requires_grad_(True), z.clone().requires_grad_(True)
+        out, (pm, pv) = hm.roll_out(p, None, 30, z_seq=zz, return_prior=True)
+        w = RC.world_of(out)
+        (w.square().sum() + pm.sum() + pv.square().sum()).backward()
+        outs.append((w.detach(), p.grad.clone(), zz.grad.clone()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+    av, err, n = RC.persist_status(gpu_lib, hm, dev)
+    assert av == 1 and err == 0 and (n & 0xffffffff) >= 5 and (n >> 32) >= 5, (av, err, n)
 
 
 def test_persistent_forward_determinism_and_reuse(gpu_lib, dev):
