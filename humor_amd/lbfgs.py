@@ -13,7 +13,13 @@ humor/fitting/motion_optimizer.py:233-254, 284-310, 461-512), restructured for t
     direction, and the first trial evaluation of an iteration is issued right behind the direction kernels: ONE host read per inner
     iteration; the interpolation arithmetic is plain Python floats (torch runs it as 0-dim GPU tensor ops with a host sync per
     comparison).  A closure whose owner wants exact evaluation counters may carry a `discard_last` attribute: it is called in the
-    rare cases where torch would have stopped before the trial evaluation that was already issued.
+    rare cases where torch would have stopped before the trial evaluation that was already issued;
+  * the host read itself is taken off the critical path (`speculate`, default on): the common outcome of an inner iteration is "first
+    trial step t = lr accepted", and everything the NEXT iteration issues in that case -- pair (y = g_trial - g, s = lr d), direction,
+    first trial evaluation -- needs no host value.  It is issued BEFORE the current iteration's scalars are read, so the GPU works on
+    iteration k + 1 while the host decides on k.  Any other outcome (line search continues, curvature test fails, a stopping test
+    fires) rolls the speculative iteration back: its pair is dropped from the history, the retired oldest pair restored, the gradient
+    row reset, its evaluation reported through `discard_last`; the iterates are bit-identical to the non-speculative run.
 
 Measured at C4 (32 x 60): 4.9 ms per closure evaluation inside torch.optim.LBFGS.step for a 0.64 ms stage-1 closure; here 0.37 ms
 (stage 1) / 0.46 ms (stage 2) per evaluation including the closure.
@@ -126,14 +132,17 @@ class LBFGS:
             max_eval = max_iter * 5 // 4
         if line_search_fn not in (None, 'strong_wolfe'):
             raise RuntimeError("only 'strong_wolfe' is supported")
-        if history_size > 127:
-            raise ValueError('history_size must be <= 127 (ha_lbfgs_coeffs holds history_size + 1 slots, at most 128)')
+        if history_size > 126:
+            raise ValueError('history_size must be <= 126 (ha_lbfgs_coeffs holds history_size + 2 slots, at most 128)')
         self.param_groups = [dict(params=self._params, lr=lr, max_iter=max_iter, max_eval=max_eval, tolerance_grad=tolerance_grad,
                                   tolerance_change=tolerance_change, history_size=history_size, line_search_fn=line_search_fn)]
         self.state = {'func_evals': 0, 'n_iter': 0}
         self._lib = _lib_override
         self._flat = None
         self._hist = None
+        # issue the next inner iteration before the current one's scalars are read (see the module docstring); False: one iteration at a time
+        self.speculate = True
+        self.spec_stats = {'issued': 0, 'rolled_back': 0}
         # optional host-side timeline (tools/lbfgs_eval_breakdown.py): set to a dict to accumulate seconds per phase
         self.profile = None
 
@@ -175,34 +184,40 @@ class LBFGS:
 
     # ---- history (device Gram matrix) ------------------------------------------------------------------------------------------
     def _init_history(self, n, device):
-        # one slot more than the history holds: with a full history the speculative pair goes to the spare slot, and the oldest pair is
-        # retired only by the NEXT allocation -- a failed curvature test restores it (torch.optim.LBFGS keeps it in that case)
+        # two slots more than the history holds: with a full history a new pair goes to a spare slot and the oldest pair it retires stays
+        # intact until that allocation can no longer be undone -- a failed curvature test restores it (torch.optim.LBFGS keeps it in that
+        # case), and so does the roll-back of a speculatively issued iteration: two allocations can be open at a time
         hmax = self.param_groups[0]['history_size']
-        h = hmax + 1
+        h = hmax + 2
         lib = self._lib if self._lib is not None else _lib.get_lib()
         npart = C.c_int64()
         lib.call('ha_lbfgs_gram_workspace', n, 2 * h, C.byref(npart))
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
         # M: rows 0..h-1 the s slots, h..2h-1 the y slots, row 2h the current gradient (it doubles as torch's prev_flat_grad)
         self._hist = {'M': z(2 * h + 1, n), 'G': z(2 * h, 2 * h), 'order': [], 'coef': z(2 * h + 1), 'h': h, 'Mg': z(2 * h),
-                      'P': z(2 * h, 3), 'part': z(npart.value), 'scal': z(12), 'hmax': hmax, 'evicted': None}
+                      'P': z(2 * h, 3), 'part': z(npart.value), 'scal': z(2, 12), 'hmax': hmax, 'evicted': []}
 
     def _pop_pair(self, undo):
-        """Drops the pair stored by the matching _alloc_slot (its slot's Gram entries become dead: slots outside `order` are ignored) and
-        puts back the oldest pair that allocation had retired from a full history (its slot was not touched), as torch.optim.LBFGS
-        keeps it when the curvature test fails."""
+        """Drops the pair stored by the matching _alloc_slot -- the most recent one still open -- (its slot's Gram entries become dead:
+        slots outside `order` are ignored) and puts back the oldest pair that allocation had retired from a full history (its slot was
+        not touched), as torch.optim.LBFGS keeps it when the curvature test fails."""
         H = self._hist
+        slot, evicted = H['evicted'].pop()
+        assert slot == undo, 'allocations are undone in reverse order'
         H['order'].remove(undo)
-        if H['evicted'] is not None:
-            H['order'].insert(0, H['evicted'])
-            H['evicted'] = None
+        if evicted is not None:
+            H['order'].insert(0, evicted)
 
     def _alloc_slot(self):
         H = self._hist
-        h, order = H['h'], H['order']
-        H['evicted'] = order.pop(0) if len(order) == H['hmax'] else None       # (its rows stay intact until the slot is handed out again)
-        slot = next(i for i in range(h) if i not in order and i != H['evicted'])
+        h, order, open_ = H['h'], H['order'], H['evicted']
+        if len(open_) == 2:            # the older of two open allocations can no longer be undone: the pair it retired is gone for good
+            open_.pop(0)
+        evicted = order.pop(0) if len(order) == H['hmax'] else None       # (its rows stay intact while the allocation is open)
+        reserved = {e for _, e in open_ if e is not None}
+        slot = next(i for i in range(h) if i not in order and i != evicted and i not in reserved)
         order.append(slot)
+        open_.append((slot, evicted))
         return slot
 
     def _direction(self, g, h_diag):
@@ -228,7 +243,7 @@ class LBFGS:
                  _lib.stream_ptr(a))
         return out
 
-    def _pair_direction(self, slot):
+    def _pair_direction(self, slot, scal):
         """Installs the pair already written to rows slot / h + slot of M (gradient in row 2h) and returns the new direction
         d = M^T coef (coef[2h] = -y.s / y.y); scal[4:6] = (y.s, y.y).  Four launches: Gram pass, its reduction, coefficients, GEMV."""
         H = self._hist
@@ -238,10 +253,45 @@ class LBFGS:
         lib.call('ha_lbfgs_gram', M.shape[1], 2 * h, _lib.ptr(M), slot, h + slot, 2 * h, _lib.ptr(H['part']), _lib.ptr(H['P']), st)
         order = (C.c_int32 * len(H['order']))(*H['order'])
         lib.call('ha_lbfgs_pair_coeffs', h, len(H['order']), order, slot, _lib.ptr(H['P']), _lib.ptr(H['G']), _lib.ptr(H['Mg']),
-                 _lib.ptr(H['coef']), _lib.ptr(H['scal'][4:]), st)
+                 _lib.ptr(H['coef']), _lib.ptr(scal[4:]), st)
         return torch.mv(M.t(), H['coef'])
 
     # ---- step ------------------------------------------------------------------------------------------------------------------
+    def _issue_iteration(self, closure, x, flat_grad, d_prev, t_prev, lr, scal):
+        """Everything an inner iteration (from the second one on, with a line search) issues before it needs a host value: the pair
+        y = g - g_prev, s = t d of the step that led here, the new direction with its scalars (scal[0:2] = g.d, max|d|; scal[4:6] =
+        y.s, y.y) and the first trial evaluation at t = lr (scal[8:12] = g_new.d, max|g_new|, sum|g_new|, loss)."""
+        Hh = self._hist
+        M, hsz = Hh['M'], Hh['h']
+        g_row = M[2 * hsz]
+        pushed = self._alloc_slot()
+        torch.sub(flat_grad, g_row, out=M[hsz + pushed])             # y = g - g_prev
+        torch.mul(d_prev, t_prev, out=M[pushed])                     # s = t d
+        g_row.copy_(flat_grad)
+        d = self._pair_direction(pushed, scal)
+        self._scalars(d, flat_grad, None, scal[:4])
+        x_init = x.clone()
+        torch.add(x_init, d, alpha=lr, out=x)
+        l = closure()
+        g_new = self._gather_flat_grad()
+        self._scalars(g_new, d, l.detach().reshape(1).float(), scal[8:12])
+        return {'pushed': pushed, 'd': d, 'x_init': x_init, 'g_new': g_new, 'scal': scal, 'g_in': flat_grad}
+
+    def _roll_back(self, it, g_row_value, discard):
+        """Undoes a speculatively issued iteration (see the module docstring): its pair leaves the history (the oldest pair it retired
+        returns), the gradient row gets the gradient it held before, the evaluation is reported as discarded.  The caller restores x
+        (every continuation writes x from the current iteration's x_init)."""
+        self._pop_pair(it['pushed'])
+        H = self._hist
+        H['M'][2 * H['h']].copy_(g_row_value)
+        # (a speculative iteration may have been built on a direction the host then rejects -- curvature test failed: H = y.s / y.y of a
+        # vanishing pair -- and hold non-finite rows; dead rows are multiplied by zero coefficients in d = M^T coef, so they must be finite)
+        H['M'][it['pushed']].zero_()
+        H['M'][H['h'] + it['pushed']].zero_()
+        if discard is not None:
+            discard()
+        self.spec_stats['rolled_back'] += 1
+
     @torch.no_grad()
     def step(self, closure):
         group = self.param_groups[0]
@@ -260,8 +310,10 @@ class LBFGS:
             self._init_history(x.numel(), x.device)
             state['n_iter'] = 0          # a new variable vector: the stored pairs (and torch's persistent direction) no longer apply
         Hh = self._hist
-        M, hsz, scal = Hh['M'], Hh['h'], Hh['scal']
+        M, hsz = Hh['M'], Hh['h']
         g_row = M[2 * hsz]               # the previous gradient (torch's prev_flat_grad) until it is overwritten below
+        n_issued = 0                     # iterations issued through _issue_iteration so far (they alternate between the two scalar buffers)
+        scal = Hh['scal'][0]
         loss_t = orig_loss.detach().reshape(1).float()
         gg, gmax, gsum, loss = self._scalars(flat_grad, flat_grad, loss_t, scal[:4]).tolist()
         current_evals = 1
@@ -273,35 +325,43 @@ class LBFGS:
         prev_loss = state.get('prev_loss')
 
         n_iter = 0
+        pending = None                   # the next iteration, issued speculatively
         tp = time.perf_counter()
         while n_iter < max_iter:
             n_iter += 1
             state['n_iter'] += 1
             pushed = None
+            it = None
             tp = self._tick('other', tp)
-            if state['n_iter'] == 1:
-                d = flat_grad.neg()
-                Hh['order'] = []
-                Hh['evicted'] = None
-                H_diag = 1.0
-                g_row.copy_(flat_grad)
-            else:
-                # Speculative update: the pair is stored and the direction built with H = ys / yy computed on the device, and the
-                # curvature test ys > 1e-10 is read back together with g.d and max|d| -- ONE host read per iteration.  When the
-                # test fails (rare) the pair is dropped and the direction rebuilt with the previous scaling, as torch does.
-                pushed = self._alloc_slot()
-                torch.sub(flat_grad, g_row, out=M[hsz + pushed])             # y = g - g_prev
-                torch.mul(d, t, out=M[pushed])                                # s = t d
-                g_row.copy_(flat_grad)
-                d = self._pair_direction(pushed)
-                self._scalars(d, flat_grad, None, scal[:4])                   # g.d, max|d|
-            prev_loss = loss
-
-            tp = self._tick('direction_issue', tp)
             # From the second iteration on the first trial step is always t = lr, and the direction's scalars are only needed for two
             # rare decisions (curvature test failed / directional derivative ~ 0): with a line search the first trial evaluation is
             # issued right behind the direction kernels and ONE read returns both sets of scalars -- one host round trip per iteration.
             deferred = state['n_iter'] > 1 and line_search_fn is not None
+            if state['n_iter'] == 1:
+                d = flat_grad.neg()
+                Hh['order'] = []
+                Hh['evicted'] = []
+                H_diag = 1.0
+                g_row.copy_(flat_grad)
+            elif deferred:
+                if pending is not None:
+                    it, pending = pending, None          # issued while the previous iteration's scalars were on their way
+                else:
+                    it = self._issue_iteration(closure, x, flat_grad, d, t, lr, Hh['scal'][n_issued & 1])
+                    n_issued += 1
+                pushed, d, scal = it['pushed'], it['d'], it['scal']
+            else:
+                # (no line search) speculative update: the pair is stored and the direction built with H = ys / yy computed on the device
+                scal = Hh['scal'][0]
+                pushed = self._alloc_slot()
+                torch.sub(flat_grad, g_row, out=M[hsz + pushed])             # y = g - g_prev
+                torch.mul(d, t, out=M[pushed])                                # s = t d
+                g_row.copy_(flat_grad)
+                d = self._pair_direction(pushed, scal)
+                self._scalars(d, flat_grad, None, scal[:4])                   # g.d, max|d|
+            prev_loss = loss
+
+            tp = self._tick('direction_issue', tp)
             if state['n_iter'] == 1:
                 gtd, d_norm = -gg, gmax              # d = -g: g.d, max|d| and sum|g| came with the first evaluation's read
                 t = min(1.0, 1.0 / gsum) * lr
@@ -323,8 +383,9 @@ class LBFGS:
                 break
 
             ls_func_evals = 0
+            stop = False
             if line_search_fn is not None:
-                x_init = x.clone()
+                x_init = x.clone() if it is None else it['x_init']
                 gmax_of = {}
 
                 def issue(tt, out=None):
@@ -345,7 +406,14 @@ class LBFGS:
                 g_in = flat_grad
                 first = None
                 if deferred:
-                    g_new, _ = issue(t, scal[8:12])
+                    g_new = it['g_new']
+                    # the NEXT iteration, for the common outcome "first trial accepted": issued before this iteration's scalars are read.
+                    # (Not behind the last iteration of this call, and not when accepting the trial exhausts the evaluation budget.)
+                    spec = None
+                    if self.speculate and n_iter < max_iter and current_evals + 1 < max_eval:
+                        spec = self._issue_iteration(closure, x, g_new, d, lr, lr, Hh['scal'][n_issued & 1])
+                        n_issued += 1
+                        self.spec_stats['issued'] += 1
                     tp = self._tick('closure_issue', tp)
                     vals = scal.tolist()
                     self._tp = tp = self._tick('closure_wait', tp)
@@ -357,6 +425,9 @@ class LBFGS:
                     else:
                         # curvature test failed: torch keeps the old pairs and scaling -- drop the pair, rebuild the direction, and let
                         # the line search start over from x_init (the trial evaluation along the discarded direction is not counted)
+                        if spec is not None:
+                            self._roll_back(spec, flat_grad, discard)
+                            spec = None
                         x.copy_(x_init)
                         if discard is not None:
                             discard()
@@ -364,16 +435,37 @@ class LBFGS:
                         d = self._direction(flat_grad, H_diag)
                         gtd, d_norm = self._scalars(d, flat_grad).tolist()[:2]
                     if gtd > -tolerance_change:
+                        if spec is not None:
+                            self._roll_back(spec, flat_grad, discard)
+                            spec = None
                         if first is not None:
                             x.copy_(x_init)              # torch stops before the line search: the trial step is discarded
                             if discard is not None:
                                 discard()
                         break
+                    if spec is not None:
+                        # does the first trial end the line search?  (_strong_wolfe's first tests, on the scalars just read)
+                        f_new, gtd_new = first[0], first[2]
+                        accepted = not (f_new > (loss + 1e-4 * t * gtd)) and abs(gtd_new) <= -0.9 * gtd
+                        if not accepted:
+                            self._roll_back(spec, flat_grad, discard)
+                            spec = None
                 loss, flat_grad, t, ls_func_evals = _strong_wolfe(obj_func, t, d_norm, loss, flat_grad, gtd, max_ls=max_eval - current_evals,
                                                                   first=first)
                 tp = self._tp
-                torch.add(x_init, d, alpha=t, out=x)
                 gmax = gmax_of[id(flat_grad)] if id(flat_grad) in gmax_of else (gmax if flat_grad is g_in else flat_grad.abs().max().item())
+                if deferred and spec is not None:
+                    # the speculative iteration stands unless a stopping test fires now (x already holds ITS trial point)
+                    assert ls_func_evals == 1 and t == lr and flat_grad is it['g_new']
+                    stop = (current_evals + 1 >= max_eval or gmax <= tolerance_grad or d_norm * abs(t) <= tolerance_change or
+                            abs(loss - prev_loss) < tolerance_change)
+                    if stop:
+                        self._roll_back(spec, g_in, discard)
+                        torch.add(x_init, d, alpha=t, out=x)
+                    else:
+                        pending = spec
+                else:
+                    torch.add(x_init, d, alpha=t, out=x)
             else:
                 x.add_(d, alpha=t)
                 if n_iter != max_iter:
@@ -395,6 +487,7 @@ class LBFGS:
             if abs(loss - prev_loss) < tolerance_change:
                 break
 
+        assert pending is None
         state['d'], state['t'], state['H_diag'] = d, t, H_diag
         state['prev_loss'] = prev_loss
         return orig_loss

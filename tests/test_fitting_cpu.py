@@ -217,12 +217,15 @@ def test_emu_lbfgs_kernels_long_history(emu_lib):
     print('direction rel. error (k = 128)', LC.check_direction(emu_lib, CPU, n=200, h=128, k=128, seed=1))
 
 
-def test_emu_fused_lbfgs_follows_torch_lbfgs(emu_lib):
+@pytest.mark.parametrize('speculate', [True, False])
+def test_emu_fused_lbfgs_follows_torch_lbfgs(emu_lib, speculate):
     """humor_amd.lbfgs.LBFGS (flat buffer, one Gram pass + coefficient-form two-loop recursion + one GEMV per direction, every scalar
-    of an evaluation in one read) against torch.optim.LBFGS on a smooth non-quadratic problem with a short history (pairs get evicted):
-    the same number of closure evaluations in every step() call (state carried over), loss trace equal to fp32 rounding.  The problem
-    is sized so that three steps stay clear of the fp32 noise floor -- at the floor the stopping tests flip on the last bit and the
-    evaluation counts of ANY two implementations drift apart."""
+    of an evaluation in one read; the next inner iteration issued speculatively before that read, or -- speculate=False -- one iteration
+    at a time) against torch.optim.LBFGS on a smooth non-quadratic problem with a short history (pairs get evicted): the same number of
+    closure evaluations in every step() call (state carried over; speculative evaluations that were rolled back are reported through
+    the closure's `discard_last` and do not count), loss trace equal to fp32 rounding.  The problem is sized so that three steps stay
+    clear of the fp32 noise floor -- at the floor the stopping tests flip on the last bit and the evaluation counts of ANY two
+    implementations drift apart."""
     from humor_amd.lbfgs import LBFGS
     torch.manual_seed(0)
     n = 120
@@ -238,6 +241,8 @@ def test_emu_fused_lbfgs_follows_torch_lbfgs(emu_lib):
         ps = [torch.zeros(70, requires_grad=True), torch.zeros(50, requires_grad=True)]
         kw = dict(max_iter=8, lr=1.0, line_search_fn='strong_wolfe', history_size=7)
         opt = torch.optim.LBFGS(ps, **kw) if name == 'torch' else LBFGS(ps, _lib_override=emu_lib, **kw)
+        if name == 'ours':
+            opt.speculate = speculate
         trace, counts = [], []
 
         def closure():
@@ -247,36 +252,84 @@ def test_emu_fused_lbfgs_follows_torch_lbfgs(emu_lib):
             l.backward()
             trace.append(l.item())
             return l
+        closure.discard_last = lambda: trace.pop()
         for _ in range(3):
             opt.step(closure)
             counts.append(len(trace))
         res[name] = (trace, counts, torch.cat([p.detach() for p in ps]))
+        if name == 'ours':
+            print('speculative iterations issued / rolled back:', opt.spec_stats)
+            assert (opt.spec_stats['issued'] > 0) == speculate
     (t0, c0, x0), (t1, c1, x1) = res['torch'], res['ours']
     assert c0 == c1, (c0, c1)
     assert max(abs(a - c) / max(1.0, abs(a)) for a, c in zip(t0, t1)) < 1e-5
     assert (x0 - x1).abs().max().item() < 1e-3 and t1[-1] < t1[0] - 1.0
 
 
+def test_emu_speculative_lbfgs_is_bit_identical_to_sequential(emu_lib):
+    """The speculative issue of the next inner iteration changes WHEN kernels are issued, never what they compute: on a problem whose line
+    search regularly needs more than one trial (so speculative iterations ARE rolled back: pair dropped, retired pair restored, gradient
+    row reset, x rewritten) iterates, evaluation counts and the final history order equal the one-iteration-at-a-time run bit for bit."""
+    from humor_amd.lbfgs import LBFGS
+    torch.manual_seed(3)
+    n = 90
+    A = torch.randn(n, n)
+    A = A @ A.t() / n + 0.05 * torch.eye(n)
+    b = torch.randn(n)
+
+    def f(x):
+        return 0.5 * x @ A @ x - b @ x + 2.0 * torch.sum(torch.sin(2.5 * x) ** 2) + 0.01 * (x ** 4).sum()
+    out = {}
+    for spec in (False, True):
+        p = torch.full((n,), 0.3, requires_grad=True)
+        opt = LBFGS([p], max_iter=12, lr=1.0, line_search_fn='strong_wolfe', history_size=4, _lib_override=emu_lib)
+        opt.speculate = spec
+        trace = []
+
+        def closure():
+            p.grad = None
+            l = f(p)
+            l.backward()
+            trace.append(l.item())
+            return l
+        closure.discard_last = lambda: trace.pop()
+        for _ in range(4):
+            opt.step(closure)
+        out[spec] = (list(trace), p.detach().clone(), list(opt._hist['order']), dict(opt.spec_stats))
+    assert out[True][3]['issued'] > 0 and out[True][3]['rolled_back'] > 0, out[True][3]
+    assert out[False][0] == out[True][0]
+    assert torch.equal(out[False][1], out[True][1])
+    assert out[False][2] == out[True][2]
+
+
 def test_lbfgs_failed_curvature_test_keeps_the_oldest_pair(emu_lib):
-    """With a full history the speculative pair goes to the spare slot: dropping it (curvature test failed) puts the retired oldest pair
-    back, untouched, as torch.optim.LBFGS keeps it; its slot is handed out again only after a pair has been accepted."""
+    """With a full history a new pair goes to a spare slot: dropping it (curvature test failed, or a speculative iteration rolled back)
+    puts the retired oldest pair back, untouched, as torch.optim.LBFGS keeps it; two allocations can be open at a time and are undone in
+    reverse order; a retired pair's slot is handed out again only when its allocation can no longer be undone."""
     from humor_amd.lbfgs import LBFGS
     p = torch.zeros(40, requires_grad=True)
     opt = LBFGS([p], history_size=3, line_search_fn='strong_wolfe', _lib_override=emu_lib)
     opt._init_history(40, CPU)
     H = opt._hist
     slots = [opt._alloc_slot() for _ in range(3)]
-    assert H['order'] == slots and H['evicted'] is None and len(set(slots)) == 3
+    assert H['order'] == slots and len(set(slots)) == 3 and all(e is None for _, e in H['evicted'])
     H['M'][slots[0]].fill_(7.0)                       # the oldest pair's s row
+    H['M'][slots[1]].fill_(8.0)
     s4 = opt._alloc_slot()
-    assert s4 not in slots and H['order'] == slots[1:] + [s4] and H['evicted'] == slots[0]
+    assert s4 not in slots and H['order'] == slots[1:] + [s4] and H['evicted'][-1] == (s4, slots[0])
     opt._pop_pair(s4)                                 # curvature test failed
-    assert H['order'] == slots and H['evicted'] is None and bool((H['M'][slots[0]] == 7.0).all())
-    s5 = opt._alloc_slot()                            # accepted this time
-    assert s5 == s4 and H['order'] == slots[1:] + [s5]
-    s6 = opt._alloc_slot()
-    assert s6 == slots[0] and H['order'] == [slots[2], s5, s6] and H['evicted'] == slots[1]
-
+    assert H['order'] == slots and bool((H['M'][slots[0]] == 7.0).all())
+    s5 = opt._alloc_slot()                            # the current iteration's pair ...
+    s6 = opt._alloc_slot()                            # ... and the speculatively issued next iteration's: both retire a pair, both rows intact
+    assert len({s5, s6} | set(slots)) == 5 and H['order'] == [slots[2], s5, s6]
+    assert bool((H['M'][slots[0]] == 7.0).all()) and bool((H['M'][slots[1]] == 8.0).all())
+    opt._pop_pair(s6)                                 # roll the speculative one back, then the current one (curvature test failed)
+    opt._pop_pair(s5)
+    assert H['order'] == slots and H['evicted'] in ([], [(slots[2], None)])
+    s7 = opt._alloc_slot()                            # accepted this time
+    s8 = opt._alloc_slot()
+    s9 = opt._alloc_slot()                            # the allocation of s7 can no longer be undone: the pair it retired may be overwritten
+    assert H['order'] == [s7, s8, s9] and s9 == slots[0]
 
 
 def _arena_worker(rank, world, port, out):
