@@ -1564,15 +1564,10 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     PTB(4);
     // ---- transposed layer 3: dL/d(decoder output) [216] -> dL/da3 [512] (+ dz) ------------------------------------------------
     GnbRegs<2> gr2;
-#ifndef HA_GNB_LATE
     gnb_issue<2, 32>(sp + a.off_ht[2] + (size_t)team * P_H2 * 4, sp + a.off_gn[2], row0, tid, gr2);
-#endif
     {
       float acc[4];
       mma_layer<BC3, 0, 1, BR3>(sD3, sD3, wa, wv, lane, acc);
-#ifdef HA_GNB_LATE
-      gnb_issue<2, 32>(sp + a.off_ht[2] + (size_t)team * P_H2 * 4, sp + a.off_gn[2], row0, tid, gr2);
-#endif
       PTB(5);
       publish<1, SC1, 32>(acc, 0.f, 4 * g, team_xch, rs, GA_OFF3, tag + 1, nullptr, row0, lane);
       if (g < DZ3_WAVES) {
@@ -1592,15 +1587,10 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     if (misc[2]) break;
     PTB(9);
     GnbRegs<4> gr1;
-#ifndef HA_GNB_LATE
     gnb_issue<4, 64>(sp + a.off_ht[1] + (size_t)team * P_H1 * 4, sp + a.off_gn[1], row0, tid, gr1);
-#endif
     {
       float acc[8];
       mma_layer<BC2, 0, 2, BR2>(sD2, sD2, wa, wv, lane, acc);
-#ifdef HA_GNB_LATE
-      gnb_issue<4, 64>(sp + a.off_ht[1] + (size_t)team * P_H1 * 4, sp + a.off_gn[1], row0, tid, gr1);
-#endif
       PTB(10);
       publish<2, SC1, 64>(acc, 0.f, 8 * g, team_xch, rs, GA_OFF2, tag + 2, nullptr, row0, lane);
       if (g < DZ2_WAVES) {
@@ -1618,15 +1608,10 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     if (misc[2]) break;
     PTB(14);
     GnbRegs<4> gr0;
-#ifndef HA_GNB_LATE
     gnb_issue<4, 64>(sp + a.off_ht[0] + (size_t)team * P_H0 * 4, sp + a.off_gn[0], row0, tid, gr0);
-#endif
     {
       float acc[8];
       mma_layer<BC1, 0, 2, BR1>(sD1, sD1, wa, wv, lane, acc);
-#ifdef HA_GNB_LATE
-      gnb_issue<4, 64>(sp + a.off_ht[0] + (size_t)team * P_H0 * 4, sp + a.off_gn[0], row0, tid, gr0);
-#endif
       PTB(15);
       publish<2, SC1, 64>(acc, 0.f, 8 * g, team_xch, rs, GA_OFF1, tag + 3, nullptr, row0, lane);
       if (g < DZ1_WAVES) {

@@ -14,12 +14,16 @@ humor/fitting/motion_optimizer.py:233-254, 284-310, 461-512), restructured for t
     iteration; the interpolation arithmetic is plain Python floats (torch runs it as 0-dim GPU tensor ops with a host sync per
     comparison).  A closure whose owner wants exact evaluation counters may carry a `discard_last` attribute: it is called in the
     rare cases where torch would have stopped before the trial evaluation that was already issued;
-  * the host read itself is taken off the critical path (`speculate`, default on): the common outcome of an inner iteration is "first
+  * optionally (`speculate`, default OFF) the host read itself is taken off the critical path: the common outcome of an inner iteration is "first
     trial step t = lr accepted", and everything the NEXT iteration issues in that case -- pair (y = g_trial - g, s = lr d), direction,
     first trial evaluation -- needs no host value.  It is issued BEFORE the current iteration's scalars are read, so the GPU works on
     iteration k + 1 while the host decides on k.  Any other outcome (line search continues, curvature test fails, a stopping test
     fires) rolls the speculative iteration back: its pair is dropped from the history, the retired oldest pair restored, the gradient
-    row reset, its evaluation reported through `discard_last`; the iterates are bit-identical to the non-speculative run.
+    row reset, its evaluation reported through `discard_last`; the iterates are bit-identical to the non-speculative run.  Measured on
+    MI355X at C4 (tools/lbfgs_phase_profile.py, profiles/r05_lbfgs): no gain -- 2.13-2.17 ms per stage-3 evaluation against 2.02-2.06
+    without (94 speculative iterations, none rolled back): since round 4 an evaluation inside step() is GPU-bound (1.73 ms closure +
+    ~0.3 ms of the optimiser's own kernels: two passes over the 78 MB history, the coefficient kernel, ten small launches), the host's
+    decision latency is no longer on the critical path -- hence off by default.
 
 Measured at C4 (32 x 60): 4.9 ms per closure evaluation inside torch.optim.LBFGS.step for a 0.64 ms stage-1 closure; here 0.37 ms
 (stage 1) / 0.46 ms (stage 2) per evaluation including the closure.
@@ -123,6 +127,8 @@ def flat_arena(shapes, device, dtype=torch.float32):
 
 
 class LBFGS:
+    _SPARE = 2          # slots beyond the history size (two allocations can be open at a time)
+
     def __init__(self, params, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100,
                  line_search_fn=None, _lib_override=None):
         self._params = list(params)
@@ -140,8 +146,8 @@ class LBFGS:
         self._lib = _lib_override
         self._flat = None
         self._hist = None
-        # issue the next inner iteration before the current one's scalars are read (see the module docstring); False: one iteration at a time
-        self.speculate = True
+        # True: issue the next inner iteration before the current one's scalars are read (see the module docstring: no gain measured)
+        self.speculate = False
         self.spec_stats = {'issued': 0, 'rolled_back': 0}
         # optional host-side timeline (tools/lbfgs_eval_breakdown.py): set to a dict to accumulate seconds per phase
         self.profile = None
@@ -188,7 +194,7 @@ class LBFGS:
         # intact until that allocation can no longer be undone -- a failed curvature test restores it (torch.optim.LBFGS keeps it in that
         # case), and so does the roll-back of a speculatively issued iteration: two allocations can be open at a time
         hmax = self.param_groups[0]['history_size']
-        h = hmax + 2
+        h = hmax + self._SPARE
         lib = self._lib if self._lib is not None else _lib.get_lib()
         npart = C.c_int64()
         lib.call('ha_lbfgs_gram_workspace', n, 2 * h, C.byref(npart))

@@ -85,6 +85,7 @@ class MotionOptimizer():
         self._graph_states = []     # capture states of the closures made so far (invalidated when the persistent roll-out reports a failure)
         self.stage_profile = None   # set to {} before run(): wall time / closure evaluations / outer iterations per stage (3 syncs per phase)
         self.loss_trace = None      # set to a list to record (stage, loss) of every closure evaluation (host sync per eval)
+        self.iter_log = None        # set to a list to record (phase, wall clock, closure evaluations so far) after every stage-3 outer iteration
         if motion_prior is None:
             raise ValueError('Need the motion prior to use all-implicit parameterization!')
         # the body model evaluates only what the losses consume (43 key vertices + 21 selector vertices) unless a point-cloud term
@@ -507,6 +508,9 @@ class MotionOptimizer():
                     motion_params, None, short=tune_phase)
             motion_optim.step(closures3[phase])
             self._check_rollout_health()
+            if self.iter_log is not None:          # (tools/lbfgs_phase_profile.py: a device synchronise per outer iteration)
+                torch.cuda.synchronize()
+                self.iter_log.append((phase_name, time.perf_counter(), self.closure_evals))
         if last_phase_name is not None:
             self._mark(last_phase_name, phase_iters)
 

@@ -35,11 +35,17 @@ OUT = os.path.join(ROOT, 'tests', 'golden')
 BRANCH_RTOL = 2e-2
 
 
-def reference_run(R, gd, npz, seed):
-    kind, B, T, ov = str(gd['kind']), int(gd['B']), int(gd['T']), int(gd['ov'])
+def reference_run(R, gd, npz, seed, name):
+    B, T = int(gd['B']), int(gd['T'])
     torch.manual_seed(0)
-    opt = MGC.build_reference(R, kind, B, T, npz, state_dict=synth.contractive_state_dict(int(gd['weight_seed'])))
-    obs = CC.make_case(kind, B, T, seed=2, ov=None if ov < 0 else ov)['obs']
+    if 'kind' in gd.files:        # BASELINE-length fixtures (oracle/make_golden_long.py)
+        kind, ov = str(gd['kind']), int(gd['ov'])
+        opt = MGC.build_reference(R, kind, B, T, npz, state_dict=synth.contractive_state_dict(int(gd['weight_seed'])))
+        obs = CC.make_case(kind, B, T, seed=2, ov=None if ov < 0 else ov)['obs']
+    else:                         # the 8-frame fixtures of oracle/make_golden_closures.py: closure_amass.npz / closure_rgb.npz
+        kind = name
+        opt = MGC.build_reference(R, kind, B, T, npz)
+        obs = CC.make_case(kind, B, T, seed=2)['obs']
     if 'run_obs_joints3d' in gd.files:
         obs['joints3d'] = torch.from_numpy(gd['run_obs_joints3d'])
     if seed >= 0:
@@ -77,7 +83,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         npz = synth.write_smplh_npz(os.path.join(td, 'model.npz'), seed=0)
         for seed in [-1] + list(range(1, n_seeds + 1)):
-            tr, j2 = reference_run(R, gd, npz, seed)
+            tr, j2 = reference_run(R, gd, npz, seed, name)
             if seed == -1:
                 assert same_branch(tr, gd['run_trace']), 'the unperturbed reference run must reproduce the fixture trace'
             for b, ref in enumerate(branches):
