@@ -141,6 +141,45 @@ __device__ __forceinline__ void half_sum8(float (&v)[8]) {
   }
 }
 
+// The last two stages of block_sum8 / block_sum4 (sum over the four k-blocks b' of a 16-lane row: row_ror 4, then row_ror 8) for FOUR (TWO)
+// independent values in one asm block: a value's second add reads its first add's result three (two, with the s_nop) instructions
+// later, so the block needs one leading s_nop instead of one per add -- and the four dependent chains overlap instead of running one
+// after the other (a wave that owns a SIMD alone has nobody else to hide the DPP latency behind).
+__device__ __forceinline__ void kblock_sum4(float (&t)[4]) {
+#define HA_LR_KB4(ROR)                                                                \
+  "v_add_f32_dpp %0, %0, %0 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %1, %1, %1 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %2, %2, %2 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %3, %3, %3 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" HA_LR_KB4(4) HA_LR_KB4(8) : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+#undef HA_LR_KB4
+}
+__device__ __forceinline__ void kblock_sum2(float (&t)[2]) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 0\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               : "+v"(t[0]), "+v"(t[1]));
+}
+// block_sum8 without its last two stages: afterwards out[0], out[1] still have to be summed over the row's four k-blocks (kblock_sum*)
+__device__ __forceinline__ void block_sum8_head(const float (&v)[8], float (&out)[2]) {
+  float u[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a = v[i], b = v[i + 4];
+    swap32(a, b);
+    u[i] = a + b;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float a = u[i], b = u[i + 2];
+    swap16(a, b);
+    out[i] = a + b;
+  }
+}
+
 // MFMA 4x4x1 accumulators: lane = 16 r + 4 b' + j holds the partial of k-block b = 4 r + b' for column j.  Sums over the 16
 // k-blocks, reduce-scatter form: 8 values in (two column groups x 4 rows), afterwards lane (half h, row parity p, column j, any b')
 // holds in out[0], out[1] the totals of values 4 h + 2 p and 4 h + 2 p + 1 (column group h, rows 2 p and 2 p + 1).

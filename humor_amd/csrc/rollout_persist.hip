@@ -1988,6 +1988,7 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
     a.per_step = f.per_step; a.off_G = f.off_G; a.off_gl = f.off_gl;
     a.t2j = f.t2j;
     a.hidden_slabs = f.hidden_slabs ? 1 : 0;
+    a.inject = (variant >> 1) & 1;
     a.xch = reinterpret_cast<unsigned char*>(f.ws);
     a.err = p->err_dev;
     if (variant & 1) hipLaunchKernelGGL(rollout_pipe_fwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), PL_TOTAL * 4, st, a);

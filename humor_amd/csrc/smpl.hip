@@ -43,8 +43,8 @@ namespace ha {
 // ha_tune_set("skin_variant"): -1 = auto; else bits 0-1: waves per block 4 << b; +4: non-temporal stores;
 // +8 / +16: profiling modes of the streaming kernel (LDS-transposed copy only / every lane gathers bone 0)
 int g_skin_variant = -1;
-int g_dense_gA_sparse = 1;   // ha_tune_set("dense_gA_sparse"): 1 = dL/dA of the dense backward by joint lists (default), 0 = dense MFMA product,
-                             // 2 = MFMA product over the joints each 64-vertex chunk touches (experiment, unmeasured)
+int g_dense_gA_sparse = 2;   // ha_tune_set("dense_gA_sparse"): dL/dA of the dense backward -- 2 (default) = MFMA product over the joints each 64-vertex
+                             // chunk touches (205 us at N = 1920), 1 = by joint lists (255 us), 0 = dense 64-column MFMA product (417 us)
 int g_dense_bwd_waves = 0;   // ha_tune_set("dense_bwd_waves"): wave-count target of the dense backward's K split (0 = default)
 extern int g_layer_spb, g_layer_nw, g_layer_finish, g_gemm_rm, g_layer_hsum, g_layer_acc, g_rollout_groups, g_gemm_ks, g_rollout_persist, g_rollout_persist_bwd, g_rollout_persist_inject, g_rollout_pipe, g_rollout_pipe_bwd;   // rollout.hip
 }
@@ -1519,7 +1519,8 @@ __global__ __launch_bounds__(256) void sparse_gA_kernel(const float* __restrict_
   }
 }
 
-// Experiment (ha_tune_set("dense_gA_sparse", 2); correct on the emulator tier, not measured on the GPU yet): the dense product below
+// Default since round 5 (ha_tune_set("dense_gA_sparse", 2); measured 205 us against 255 us for the joint lists at N = 1920, 8.5 against
+// 9.2 ms for the whole dense backward at N = 30 720, profiles/r05_dense_bwd.txt): the dense product below
 // restricted, per 64-vertex chunk, to the joints the chunk touches, 16 slots per MFMA tile (one tile for 105 of the 108 chunks of the
 // synthetic model, two for the rest) instead of four tiles over all 64 joint columns, an 8 KB weight operand per chunk instead of 16 KB,
 // every vertex record read once.  A wave takes the chunks w, w + 4, ...; after a tile's 16 MFMAs lane (a = l >> 4, slot = l & 15) adds

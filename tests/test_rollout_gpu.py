@@ -279,3 +279,35 @@ def test_persistent_failure_poisons_results_and_is_reported(gpu_lib, dev):
             hm.roll_out(past, None, S, z_seq=z)                               # reported once
         again = RC.world_of(hm.roll_out(past, None, S, z_seq=z))             # the launch chain from now on
         assert torch.isfinite(again).all() and (again - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_pipelined_failure_poisons_results_and_is_reported(gpu_lib, dev):
+    """The failure protocol of the B <= 32 kernels on the pipelined ones (rollout_pipe.inc): with ha_tune_set("rollout_persist_inject") one
+    CU of team 0 (a layer-0 CU) leaves at once, the team's bounded waits run out: every row the team owns -- rows 0..3 of EVERY 32-row tile --
+    is NaN, the other teams' rows are untouched, the host-mapped error word is set, the next entry point returns the error once, and from
+    then on the launch chain serves the network with correct results."""
+    from humor_amd import _lib
+    hm, _ = RC.make_model(gpu_lib, dev, seed=4, contractive=True)          # its own network handle (the failure is sticky per handle)
+    g = torch.Generator().manual_seed(12)
+    B, S = 70, 3
+    past, z = RC.canonical_state(B, g).to(dev), torch.randn(B, S, 48, generator=g).to(dev)
+    with torch.no_grad():
+        ref = RC.world_of(hm.roll_out(past, None, S, z_seq=z))                # healthy pipelined launch
+        assert hm.persistent_rollout_status(dev)[:2] == (1, 0)
+        gpu_lib.call('ha_tune_set', b'rollout_persist_inject', 1)
+        try:
+            bad = RC.world_of(hm.roll_out(past, None, S, z_seq=z))
+            torch.cuda.synchronize()
+        finally:
+            gpu_lib.call('ha_tune_set', b'rollout_persist_inject', 0)
+        team0 = torch.zeros(B, dtype=torch.bool)
+        for tile in range(3):
+            team0[32 * tile: min(32 * tile + 4, B)] = True
+        assert torch.isnan(bad[team0]).all(), 'the incomplete team\'s rows must be NaN'
+        assert torch.equal(bad[~team0], ref[~team0]), 'the other teams are unaffected'
+        av, err, _ = hm.persistent_rollout_status(dev)
+        assert av == 0 and (err & 0xf00) == 0x600, (av, hex(err))
+        with pytest.raises(_lib.HumorAmdError):
+            hm.roll_out(past, None, S, z_seq=z)                               # reported once
+        again = RC.world_of(hm.roll_out(past, None, S, z_seq=z))             # the launch chain from now on
+        assert torch.isfinite(again).all() and (again - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())

@@ -98,17 +98,17 @@ def test_emu_dense_backward_kernels(emu_lib, tmp_path):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize('variant', [0, 2])
+@pytest.mark.parametrize('variant', [0, 1])
 def test_emu_dense_backward_dA_variants(emu_lib, tmp_path, variant):
-    """dL/dA of the dense backward behind ha_tune_set("dense_gA_sparse"): the dense 64-column MFMA product (0) and the chunk-local compressed
-    product (2, experiment: the 1100-vertex model has chunks with one and with two 16-slot groups); the default (1, joint lists) is
+    """dL/dA of the dense backward behind ha_tune_set("dense_gA_sparse"): the dense 64-column MFMA product (0) and the joint lists (1); the
+    default (2: the chunk-local compressed product -- the 1100-vertex model has chunks with one and with two 16-slot groups) is
     test_emu_dense_backward_kernels."""
     npz, ds = _small_model(tmp_path, 1100)
     emu_lib.call('ha_tune_set', b'dense_gA_sparse', variant)
     try:
         SC.check_forward_backward(emu_lib, npz, ds, N=2, device=CPU, hands=True, selector=False, algo=2, dense_grad=True, seed=4 + variant)
     finally:
-        emu_lib.call('ha_tune_set', b'dense_gA_sparse', 1)
+        emu_lib.call('ha_tune_set', b'dense_gA_sparse', 2)
 
 
 @pytest.mark.slow

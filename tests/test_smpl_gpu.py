@@ -35,11 +35,16 @@ def test_hands_and_dense_gradient(gpu_lib, smplh_npz, smplh_struct, dev):
     SC.check_forward_backward(gpu_lib, smplh_npz, smplh_struct, N=9, device=dev, hands=True, selector=True, algo=2, dense_grad=True)
 
 
-@pytest.mark.parametrize('N,hands', [(70, False), (130, True)])
-def test_dense_backward_kernels(gpu_lib, smplh_npz, smplh_struct, dev, N, hands):
+@pytest.mark.parametrize('N,hands,dA', [(70, False, 2), (130, True, 2), (70, True, 1), (33, False, 0)])
+def test_dense_backward_kernels(gpu_lib, smplh_npz, smplh_struct, dev, N, hands, dA):
     """Every vertex carries a gradient (point-cloud / chamfer term): ha_smpl_backward_dense (streaming dL/dv_posed, MFMA dL/dA and
-    dL/dcoeff with K split, chain adjoint) against the oracle's autograd; frame counts that leave a ragged 64-frame row pair."""
-    SC.check_forward_backward(gpu_lib, smplh_npz, smplh_struct, N=N, device=dev, seed=N, hands=hands, selector=not hands, algo=2, dense_grad=True)
+    dL/dcoeff with K split, chain adjoint) against the oracle's autograd; frame counts that leave a ragged 64-frame row pair.  dA: the
+    dL/dA variant (ha_tune_set "dense_gA_sparse": 2 = the default chunk-compressed MFMA product, 1 = joint lists, 0 = dense product)."""
+    gpu_lib.call('ha_tune_set', b'dense_gA_sparse', dA)
+    try:
+        SC.check_forward_backward(gpu_lib, smplh_npz, smplh_struct, N=N, device=dev, seed=N, hands=hands, selector=not hands, algo=2, dense_grad=True)
+    finally:
+        gpu_lib.call('ha_tune_set', b'dense_gA_sparse', 2)
 
 
 def test_golden_vectors(gpu_lib, smplh_npz, dev):

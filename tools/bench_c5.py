@@ -92,9 +92,25 @@ def measure(B=256, T=120, dev=None):
         out, (pm, pv) = hm.roll_out(past, None, T - 1, z_seq=z, return_prior=True)
         (out['trans'].sum() + pm.sum()).backward()
     ms_f, ms_fb = ev(fwd, iters=3, warm=1), ev(fwdbwd, iters=3, warm=1)
+
+    def fwd_chain_only():
+        with torch.no_grad():
+            hm.roll_out(past, None, T - 1, z_seq=z, return_prior=False)
+    ms_chain = ev(fwd_chain_only, iters=3, warm=1)
     mlp_flops = 11.55e6 * B * (T - 1)                  # 11.55 MFLOP per row-step (prior + decoder)
-    res['rollout'] = {'fwd_ms': round(ms_f, 2), 'fwd_bwd_ms': round(ms_fb, 2), 'steps_per_sec_fwd': round(B * (T - 1) / (ms_f * 1e-3), 1),
-                      'mlp_TFLOPs_fwd': round(mlp_flops / ms_f / 1e9, 2), 'frac_fp32_mfma_fwd': round(mlp_flops / ms_f / 1e9 / MFMA_F32_PEAK, 4)}
+    dec_flops = 2 * 2171736.0 * B * (T - 1)            # the decoder chain's share (the recurrence: what the pipelined kernels run)
+    res['rollout'] = {'path': 'pipelined persistent kernels (rollout_pipe.inc), one launch per direction' if 32 < B <= 256 else
+                              ('persistent kernels (rollout_persist.hip)' if B <= 32 else 'pipelined persistent kernels, chunks of 256'),
+                      'fwd_ms': round(ms_f, 2), 'fwd_bwd_ms': round(ms_fb, 2), 'steps_per_sec_fwd': round(B * (T - 1) / (ms_f * 1e-3), 1),
+                      'mlp_TFLOPs_fwd': round(mlp_flops / ms_f / 1e9, 2), 'frac_fp32_mfma_fwd': round(mlp_flops / ms_f / 1e9 / MFMA_F32_PEAK, 4),
+                      'decoder_chain_fwd_ms': round(ms_chain, 2), 'decoder_chain_frac_fp32_mfma': round(dec_flops / ms_chain / 1e9 / MFMA_F32_PEAK, 4)}
+    # the launch chain on the same inputs (what rounds 1-4 ran at this size), for the record
+    lib.call('ha_tune_set', b'rollout_persist', 0)
+    try:
+        ms_f0, ms_fb0 = ev(fwd, iters=2, warm=1), ev(fwdbwd, iters=2, warm=1)
+        res['rollout']['launch_chain'] = {'fwd_ms': round(ms_f0, 2), 'fwd_bwd_ms': round(ms_fb0, 2), 'frac_fp32_mfma_fwd': round(mlp_flops / ms_f0 / 1e9 / MFMA_F32_PEAK, 4)}
+    finally:
+        lib.call('ha_tune_set', b'rollout_persist', 1)
     return res
 
 
