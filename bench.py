@@ -372,19 +372,27 @@ def lbfgs_profile(dev, npz, k=5):
     per stage and per stage-3 phase (tune-init on the first 15 frames / frozen-init / refine); wall time per phase from
     MotionOptimizer.stage_profile (a device synchronise at every phase boundary)."""
     from humor_amd.configs import NUM_ITER_RGB, STAGE3_TUNE_INIT_FREEZE
-    opt = build_optimizer(dev, npz, B_SEQ, use_graphs='auto')      # MotionOptimizer's default: hipGraph replay for the short closures
-    opt.stage3_tune_init_freeze_start, opt.stage3_tune_init_freeze_end = k, 2 * k
-    opt.stage_profile = {}
-    obs, _ = make_problem(B_SEQ, T_SEQ, seed=100, device=dev)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    # (stages 1-2: 3 k iterations each -- their evaluations are 0.3 ms, and a phase's wall time includes the one-off capture of its graph)
-    opt.run(obs, data_fps=30, lr=1.0, num_iter=[3 * k, 3 * k, 3 * k], lbfgs_max_iter=20)
-    torch.cuda.synchronize()
-    total = time.perf_counter() - t0
+    totals = []
+    for rep in range(2):
+        # Two fits, each with a NEW MotionOptimizer (its own optimisers, histories and hipGraph captures); the SECOND one is reported: the
+        # first also pays what a process pays once -- code-object loads, the caching allocator growing back after the 256 x 120 closure
+        # measured before (empty_cache) -- and with 15 outer iterations per stage that one-off cost moved the stage-2 figure by 50 %
+        # between two otherwise identical runs (profiles/r05_mid vs the steady-state A/B of tools/stage_lbfgs_n.py).
+        opt = build_optimizer(dev, npz, B_SEQ, use_graphs='auto')      # MotionOptimizer's default: hipGraph replay for the short closures
+        opt.stage3_tune_init_freeze_start, opt.stage3_tune_init_freeze_end = k, 2 * k
+        opt.stage_profile = {}
+        obs, _ = make_problem(B_SEQ, T_SEQ, seed=100, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        # (stages 1-2: 3 k iterations each -- their evaluations are 0.3 ms, and a phase's wall time includes the one-off capture of its graph)
+        opt.run(obs, data_fps=30, lr=1.0, num_iter=[3 * k, 3 * k, 3 * k], lbfgs_max_iter=20)
+        torch.cuda.synchronize()
+        totals.append(time.perf_counter() - t0)
+    total = totals[-1]
     prof = {n: v for n, v in opt.stage_profile.items() if not n.startswith('_')}
-    out = {'k_outer_iters_per_phase': k, 'lbfgs_max_iter': 20, 'measured_run_seconds': round(total, 3), 'phases': {},
-           'note': 'each phase includes the one-off hipGraph capture of its closure where use_graphs=auto captures it (stages 1-2, tune-init)'}
+    out = {'k_outer_iters_per_phase': k, 'lbfgs_max_iter': 20, 'measured_run_seconds': round(total, 3), 'first_run_seconds': round(totals[0], 3), 'phases': {},
+           'note': 'second of two fits in this process (new MotionOptimizer each); each phase includes the one-off hipGraph capture of its closure '
+                   'where use_graphs=auto captures it (stages 1-2, tune-init) and the first step of its optimiser'}
     f0, f1 = STAGE3_TUNE_INIT_FREEZE
     sched = {'stage1': NUM_ITER_RGB[0], 'stage2': NUM_ITER_RGB[1], 'stage3_tune_init': f0, 'stage3_frozen_init': f1 - f0,
              'stage3_refine': NUM_ITER_RGB[2] - f1}
