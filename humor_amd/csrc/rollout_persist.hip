@@ -315,12 +315,17 @@ __device__ __forceinline__ void load_a(const float* xs, const float* zs, int lan
 // compiler-written accumulator is read), and mma_layer ends with s_nop 7 before the VALU reads the results.
 template <class F, int... I>
 __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int R, bool FIRST, int NWAS, int NWVS>
+template <int R, bool FIRST, bool VNOP = true, int NWAS = 1, int NWVS = 1>
 __device__ __forceinline__ void mfma_w(pvf4& acc, float av, const float (&wa)[NWAS], const float (&wv)[NWVS]) {
   constexpr int NWA = NWAS;
   if constexpr (R < NWA) {
     if constexpr (FIRST) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&" HA_ACC(acc) : "v"(av), "a"(wa[R]));
     else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+" HA_ACC(acc) : "v"(av), "a"(wa[R]));
+  } else if constexpr (!VNOP) {
+    // (kernels whose VGPR-class weights demonstrably never leave their registers -- tools/isa_census_pipe.py / tests/test_build.py hold
+    // the pipelined kernels to zero v_accvgpr traffic -- need no wait states in front of the MFMA)
+    if constexpr (FIRST) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&" HA_ACC(acc) : "v"(av), "v"(wv[R - NWA]));
+    else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+" HA_ACC(acc) : "v"(av), "v"(wv[R - NWA]));
   } else {
     // (a VGPR-class weight may be parked in an AGPR by the register allocator and copied back right in front of the asm: that copy
     // is a VALU write the MFMA must not read within two wait states, and the hazard recogniser does not look inside the asm)

@@ -32,3 +32,23 @@ def test_persistent_step_loops_have_no_agpr_copies_or_scratch():
         assert n_scratch == 0, (head, 'scratch traffic in the step loop', n_scratch)
         n_inst = int(head.split(':')[1].split()[0])
         assert 2000 < n_inst < 6000, head          # the loop was found (a changed code shape would make the census meaningless)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='needs hipcc')
+def test_pipelined_kernels_have_no_agpr_traffic_or_scratch():
+    """rollout_pipe.inc (the layer-parallel kernels for more than 32 sequences): every role loop of both kernels keeps all 256 AGPRs as
+    MFMA weight operands and never touches them otherwise -- no v_accvgpr_write (a copy into an AGPR in front of an inline-asm MFMA is an
+    unguarded hazard), no v_accvgpr_read, no v_mov (the VGPR-class weights carry no wait states in front of their MFMAs, which is only
+    correct while nothing rewrites them), no scratch, no spills."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_census_pipe.py')], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    heads = [l for l in out.stdout.split('\n') if l.startswith('pipe ')]
+    assert len(heads) == 4 and all('spills 0' in h for h in heads), out.stdout
+    loops = [l for l in out.stdout.split('\n') if 'role loop' in l]
+    assert len(loops) >= 8, out.stdout
+    num = lambda l, key: int(l.split(key)[1].split()[0].rstrip(','))
+    for l in loops:
+        assert num(l, 'v_accvgpr_write INTO WEIGHT AGPRS IN THE LOOP') == 0 and num(l, 'v_accvgpr_write (any)') == 0, l
+        assert num(l, 'v_accvgpr_read') == 0 and num(l, 'scratch ops') == 0 and num(l, 'v_mov') == 0, l
+        assert num(l, 'v_mfma') >= 250, l
+    assert any(num(l, 'weight AGPRs read by MFMAs') == 256 for l in loops)
