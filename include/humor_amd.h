@@ -34,7 +34,7 @@ const char* ha_last_error(void);
 int ha_abi_version(void);
 /* Writes the device's gcnArchName (e.g. "gfx950:sramecc+:xnack-") into buf. */
 int ha_device_arch(int device, char* buf, int buflen);
-/* Development knobs for kernel launch variants (A/B measurements), process-wide: "skin_variant" (-1 = auto), "layer_spb" (K-slices per block of the roll-out layer kernel, 0 = default), "layer_finish" (0 never / 1 auto / 2 always use the GroupNorm finishing pass), "gemm_rm" (row tiles per wave of the batched prior GEMM: 0 by size / 1 / 2), "rollout_persist" / "rollout_persist_bwd" (0 = launch chain; 1 = persistent kernels, 3 = with write-through publishes), "rollout_persist_inject" (test hook: 1 = the next persistent forwards drop one CU of team 0, so that the failure path -- NaN results, error word -- can be exercised). */
+/* Development knobs for kernel launch variants (A/B measurements), process-wide: "skin_variant" (-1 = auto), "layer_spb" (K-slices per block of the roll-out layer kernel, 0 = default), "layer_finish" (0 never / 1 auto / 2 always use the GroupNorm finishing pass), "gemm_rm" (row tiles per wave of the batched prior GEMM: 0 by size / 1 / 2), "rollout_persist" / "rollout_persist_bwd" (0 = launch chain; 1 = persistent kernels, 3 = with write-through publishes), "rollout_pipe" / "rollout_pipe_bwd" (batches of more than 32 sequences: 1 = the layer-parallel pipelined persistent kernels, 0 = launch chain; set the adjoint knobs before the forward call), "rollout_persist_inject" (test hook: 1 = the next persistent forwards drop one CU of team 0, so that the failure path -- NaN results, error word -- can be exercised). */
 int ha_tune_set(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------------
@@ -228,10 +228,10 @@ int ha_humor_rollout_backward_ex(const ha_humor_net* net, int B, int S, const fl
  * converted (humor_model.py:331-347).  Networks with output_delta = 0 run the launch chain. */
 int ha_humor_net_set_option(ha_humor_net* net, const char* key, int value);
 
-/* Persistent forward (ha_tune_set "rollout_persist" != 0, B <= 32): state of the weight-stationary one-launch forward of this
+/* Persistent roll-out (ha_tune_set "rollout_persist" != 0; B <= 32: weight-stationary kernels, 32 < B: pipelined kernels): state of the one-launch path of this
  * network.  *available = 1 when the network / device qualify and no launch has reported a failure; *error_word = the kernel's
- * host-mapped error word (0 = none; 0x1xx / 0x3xx an XCD received more than its 32 blocks (forward / adjoint), 0x2xx / 0x4xx a team's
- * bounded wait ran out (forward / adjoint): that team's output rows -- world states; dL/dpast_in0 and dL/dz -- are filled with NaN),
+ * host-mapped error word (0 = none; 0x1xx / 0x3xx an XCD received more than its 32 blocks (forward / adjoint; pipelined kernels: 0x5xx / 0x7xx),
+ * 0x2xx / 0x4xx a team's bounded wait ran out (forward / adjoint; pipelined kernels: 0x6xx / 0x8xx): that team's output rows -- world states; dL/dpast_in0 and dL/dz -- are filled with NaN),
  * meaningful once the stream of the last roll-out has been synchronised; *launches = persistent forwards issued so far for this
  * network in the low 32 bits, persistent adjoints in the high 32 bits.  After a failure the library uses the launch chain. */
 int ha_humor_persist_status(const ha_humor_net* net, int* available, unsigned int* error_word, int64_t* launches);

@@ -58,7 +58,7 @@ def measure(B=256, T=120, dev=None):
 
     def chain_only():
         lib.call('ha_smpl_forward', h.ptr, 0, N, 22, p(pose), p(betas), p(tr), None, p(joints), p(A), p(ws_v), p(ws_c), 2, st)
-    # sustained figures: the first ~20 launches at this size ride a power-management transient (tools/skin_jitter.py)
+    # sustained figures: the first ~20 launches at this size ride a power-management transient (profiles/r02_run20_skin_jitter.txt)
     def fused():          # forward-only callers: blend + skin in one kernel, v_posed never written (ha_smpl_forward algo 3)
         lib.call('ha_smpl_forward', h.ptr, 0, N, 22, p(pose), p(betas), p(tr), p(verts), p(joints), p(A), None, p(ws_c), 3, st)
     ms_dense, ms_skin, ms_chain = ev(dense, 10, 10), ev(skin, 20, 20), ev(chain_only, 10, 3)
