@@ -721,9 +721,9 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   for (int t = 0; t < a.S; ++t) {
     const unsigned tag = 4u * (unsigned)t;
     float* sp = a.steps + (size_t)t * a.per_step;
-    // latent of the next step: issued now, written to LDS in the glue phase
+    // latent of the next step: requested behind the first sweep of the step (in front of it, the sweep's in-order vmcnt wait would include
+    // this load's latency), written to LDS in the glue phase
     float z_next = 0.f;
-    if (zlive && t + 1 < a.S) z_next = a.z_seq[((size_t)(row0 + zi) * a.S + (t + 1)) * P_ZD + zc];
     __syncthreads();                                   // xs0 / zs of this step are complete
     PT(0);
     // ---- layer 0: [x_t | z_t] (raw) -> 1024 ---------------------------------------------------------------------------
@@ -737,6 +737,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     if (t > 0) deferred(t - 1);       // (in the shadow of the layer-1 sweep)
     // ---- layer 1 ----------------------------------------------------------------------------------------------------------
     if (!gather_norm<4, 64, 3>(rs, ACT_OFF0, tag + 1, gam1, bet1, xs1, tid, m == 1 ? sp + a.off_gn[0] : nullptr, row0 PT_PASS)) fail = true;
+    if (zlive && t + 1 < a.S) z_next = a.z_seq[((size_t)(row0 + zi) * a.S + (t + 1)) * P_ZD + zc];
     PT(4);
     if (fail) misc[2] = 1;
     __syncthreads();
@@ -1215,8 +1216,8 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
   // ---- per-step inputs: (channel quad, row) per thread, 16-byte loads, one step ahead ---------------------------------------
   // x_t (state slab), decoder output (slab 3), dL/dworld_t, glue record, accumulated transform, dL/dx_{t+1} through the prior
   const int pq_q = tid >> 2, pq_i = tid & 3;                  // first pass: quads 0..63; second pass: quads 64..127
-  // two halves, each live in four 16-byte registers only while one sweep spins: A = state, decoder output, glue record, transform
-  // (issued before the dL/dx sweep at the top of a step); B = dL/dworld and the prior part (issued before the first layer sweep)
+  // two halves, each in four 16-byte registers: A = state, decoder output, glue record, transform (requested behind the dL/dx sweep at the
+  // top of a step, live across the glue adjoint); B = dL/dworld and the prior part (requested behind the first layer sweep, live across the layer-2 product)
   pvf4 pf[4];
   const pvf4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto prefetch_a_issue = [&](int tp) {
@@ -1285,7 +1286,6 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     const float* sp = a.steps + (size_t)t * a.per_step;
     const float* cur = smem + LB_PF + (t & 1) * PF_SIZE;
     // ---- total adjoint of x_{t+1}: own direct part + prior part + the team's layer-0 input gradient of step t+1 ----------------
-    prefetch_a_issue(t - 1);
     __syncthreads();                                   // the prefetched buffer of this step and sGXD of step t+1 are complete
     PTB(0);
     {
@@ -1305,7 +1305,9 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       }
     }
     PTB(1);
-    prefetch_a_store(t - 1);
+    // the next step's state / decoder output / glue record: requested BEHIND the sweep (vmcnt counts in order: a sweep issued after these
+    // loads waits for their HBM / Infinity-Cache latency too), written to LDS behind the glue adjoint (round 5: -0.8 % per roll-out)
+    prefetch_a_issue(t - 1);
     if (fail) misc[2] = 1;
     __syncthreads();
     if (misc[2]) break;
@@ -1565,6 +1567,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     }
     PTC(0, 3);
     PTB(3);
+    prefetch_a_store(t - 1);
     __syncthreads();
     PTB(4);
     // ---- transposed layer 3: dL/d(decoder output) [216] -> dL/da3 [512] (+ dz) ------------------------------------------------
@@ -1583,9 +1586,8 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     }
     // ---- layer 2 ------------------------------------------------------------------------------------------------------------
     PTB(6);
-    prefetch_b_issue(t - 1);
     if (!gather_norm_bwd<2, 32, 7>(rs, GA_OFF3, tag + 1, sGam3, sBet3, gr2, sD2, tid PTB_PASS)) fail = true;
-    prefetch_b_store(t - 1);
+    prefetch_b_issue(t - 1);          // (dL/dworld and the prior's dL/dx of the next step: behind the sweep, stored behind the layer-2 product)
     PTB(8);
     if (fail) misc[2] = 1;
     __syncthreads();
@@ -1604,6 +1606,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
         dz_store(accz, a.dz_part, t, DZ_S2 + g % (BC2 / DZ2_CH), g / (BC2 / DZ2_CH), row0, lane);
       }
     }
+    prefetch_b_store(t - 1);
     // ---- layer 1 ------------------------------------------------------------------------------------------------------------
     PTB(11);
     if (!gather_norm_bwd<4, 64, 12>(rs, GA_OFF2, tag + 2, sGam2, sBet2, gr1, sD1, tid PTB_PASS)) fail = true;
