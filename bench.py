@@ -696,6 +696,15 @@ def run(args):
             d = t.item()
         return d
     dt = timed(fc)
+    roof_early = None
+    if rank == 0:
+        # the roofline kernel at the metric's batch, measured right behind the headline timing: behind the 256 x 120 closure / the C5 sizes the
+        # chip sits in a power-management transient (MI355X_MICROARCH.md, DVFS give-back; profiles/r02_run20_skin_jitter.txt) that cost this
+        # HBM-bound kernel 5-10 % in the round-5 runs (0.59-0.62 measured there against 0.63-0.65 of the rounds that measured it first)
+        roof_early = skin_roofline(dev, npz, rotate=4)
+        roof_early['cache_warm_single_set'] = {k: v for k, v in skin_roofline(dev, npz, rotate=1).items() if k in ('achieved', 'frac', 'avg_launch_us')}
+        roof_early['ceilings'] = skin_ceilings(dev, npz, roof_early)
+        roof_early['measured'] = 'right behind the headline closure timing, before the 32 x 120 / 256 x 120 closures'
     # Two more jobs beside the headline (SCALE runs: make the curves unambiguous).
     #   strong  -- the ONE 32-sequence job BASELINE.json / north_star name ("batch=32 sub-seqs of 60 frames sharded over 8 MI355X": 4 per GPU
     #              at N = 8).  Chain-bound: a rank's closure is a 59-step dependent chain whatever its share is.
@@ -767,9 +776,7 @@ def run(args):
             gpu_eval['gpu_unstable'] = fc.gradient_sensitivity()
         # the roofline kernel at the metric's batch, HBM figure: launches rotate over 4 operand sets (1.27 GB: > 256 MiB of other
         # lines between two uses of any line); the single-set (Infinity-Cache-assisted) figure of rounds 1-2 is kept beside it
-        roof = skin_roofline(dev, npz, rotate=4)
-        roof['cache_warm_single_set'] = {k: v for k, v in skin_roofline(dev, npz, rotate=1).items() if k in ('achieved', 'frac', 'avg_launch_us')}
-        roof['ceilings'] = skin_ceilings(dev, npz, roof)
+        roof = roof_early
         ms_dense, ms_dense_fb = dense_smpl_ms(dev, npz)
         res = {
             'metric': 'fitting closure evaluations/s (stage-3 objective fwd+bwd), batch=32 seq=60 per GPU',

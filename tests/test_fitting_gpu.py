@@ -8,6 +8,7 @@ import torch
 
 import fitting_checks as FC
 from conftest import ROOT
+from humor_amd import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -55,12 +56,13 @@ def test_lbfgs_kernels_against_two_loop_recursion(gpu_lib, dev, n, h, k):
     print('direction rel. error', LC.check_direction(gpu_lib, dev, n=n, h=h, k=k, seed=k))
 
 
-@pytest.mark.parametrize('B,T,reps', [(4, 8, 3), (32, 60, 8)])
+@pytest.mark.parametrize('B,T,reps', [(4, 8, 3), (32, 60, 8), (40, 16, 4)])
 def test_graphed_closure_equals_eager(gpu_lib, dev, smplh_npz, B, T, reps):
     """hipGraph replay of the stage-3 closure returns the eager loss and gradients, call after call, while every variable changes in
     place between the calls; at the metric's batch the persistent roll-out kernels are inside the graph and must not report a failed
     launch (round 4: with hipMemsetAsync in front of them they started on the previous replay's team counters -- error word 0x100 --
-    as soon as the values changed; the exchange space is now cleared by a kernel, csrc/common.h zero_async)."""
+    as soon as the values changed; the exchange space is now cleared by a kernel, csrc/common.h zero_async).  40 x 16: the pipelined
+    kernels of rollout_pipe.inc (more than 32 sequences) inside the graph."""
     from oracle import closure_cases as CC
     case = CC.make_case('rgb', B, T, seed=1)
     res = {}
@@ -365,3 +367,28 @@ def test_fit_after_an_earlier_persistent_failure_completes_on_the_launch_chain(g
         opt2 = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz, hm=hm)
         final, _stages = opt2.run(obs, data_fps=30, lr=1.0, num_iter=[1, 1, 2], lbfgs_max_iter=3)
         assert all(torch.isfinite(v).all() for v in final.values())
+
+
+def test_stage3_closure_beyond_32_sequences_pipelined_equals_launch_chain(gpu_lib, dev, smplh_npz):
+    """A stage-3 objective of 40 overlapping sub-sequences (roll-out on the pipelined persistent kernels, rollout_pipe.inc) against the same
+    objective with the roll-out on the launch chain (ha_tune_set "rollout_persist" 0): loss and every gradient."""
+    from oracle import closure_cases as CC
+    B, T = 40, 14
+    case = CC.make_case('rgb', B, T, seed=21)
+    res = {}
+    try:
+        for knob in (0, 1):
+            gpu_lib.call('ha_tune_set', b'rollout_persist', knob)
+            opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz, state_dict=synth.contractive_state_dict(0))
+            res[knob] = {k: v.detach().clone() for k, v in FC.eval_stage(opt, case, 2, dev).items()}
+            if knob == 1:
+                av, err, n = opt.motion_prior.persistent_rollout_status(dev)
+                assert av == 1 and err == 0 and (n & 0xffffffff) >= 1 and (n >> 32) >= 1, (av, hex(err), n)
+    finally:
+        gpu_lib.call('ha_tune_set', b'rollout_persist', 1)
+    assert abs(res[0]['loss'].item() - res[1]['loss'].item()) <= 1e-5 * abs(res[0]['loss'].item())
+    for k in res[0]:
+        if k != 'loss':
+            e = (res[0][k] - res[1][k]).abs().reshape(res[0][k].shape[0], -1).amax(1) / max(1.0, res[0][k].abs().max().item())
+            # (per sub-sequence; a ReLU kink within fp32 rounding moves one sequence's gradient by a per cent between two correct evaluations)
+            assert (e > 1e-3).sum().item() <= 2 and e.max().item() <= 5e-2, (k, e.max().item(), int((e > 1e-3).sum()))
