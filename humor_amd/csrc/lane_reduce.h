@@ -73,6 +73,26 @@ __device__ __forceinline__ void row_sum8(float (&t)[8]) {
 #undef HA_LR_STAGE8
 }
 
+// Two (four) values, each summed over the EIGHT lanes of equal parity of its 16-lane row (rotations by 8, 4, 2 keep the parity): the
+// GroupNorm reduction of the half-granule sweeps (rollout_persist.hip: lane parity = row pair of the exchange granule).  Two values:
+// a result is read by DPP two instructions after it was written, hence the s_nop 0 between the stages.
+__device__ __forceinline__ void parity_sum2(float (&t)[2]) {
+#define HA_LR_PS2(ROR)                                                                \
+  "v_add_f32_dpp %0, %0, %0 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %1, %1, %1 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" HA_LR_PS2(8) "s_nop 0\n\t" HA_LR_PS2(4) "s_nop 0\n\t" HA_LR_PS2(2) : "+v"(t[0]), "+v"(t[1]));
+#undef HA_LR_PS2
+}
+__device__ __forceinline__ void parity_sum4(float (&t)[4]) {
+#define HA_LR_PS4(ROR)                                                                \
+  "v_add_f32_dpp %0, %0, %0 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %1, %1, %1 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %2, %2, %2 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %3, %3, %3 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" HA_LR_PS4(8) HA_LR_PS4(4) HA_LR_PS4(2) : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+#undef HA_LR_PS4
+}
+
 template <int N>
 __device__ __forceinline__ void row_sum(float (&t)[N]) {
   if constexpr (N == 4) row_sum4(t);

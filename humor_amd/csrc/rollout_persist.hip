@@ -75,7 +75,7 @@ constexpr int L_XS0 = 0, L_XS1 = L_XS0 + P_XPAD * 4, L_XS2 = L_XS1 + P_H0 * 4, L
 // waves of a CU can work on the same sequence side by side -- see the glue)
 constexpr int L_SX = L_ZS + P_ZD * 4, L_SRAW = L_SX + 2 * ROWS * P_XPAD, L_SW = L_SRAW + ROWS * P_RAWPAD, L_SG = L_SW + ROWS * P_XPAD;
 constexpr int L_GSZ = ROWS * 12 + 16;
-constexpr int L_SGL = L_SG + 2 * L_GSZ, L_T2J = L_SGL + ROWS * 32, L_ZERO = L_T2J + 16, L_MISC = L_ZERO + 16, L_TOTAL = L_MISC + 64;
+constexpr int L_SGL = L_SG + 2 * L_GSZ, L_T2J = L_SGL + ROWS * 32, L_ZERO = L_T2J + 16, L_MISC = L_ZERO + 16, L_GB = L_MISC + 64, L_TOTAL = L_GB + 4 * (P_H0 + P_H1 + P_H2);   // L_GB: GroupNorm affine, gamma | beta of the three activations
 // per-step results of a team (world states, next state slab, accumulated transforms) leave through all 32 CUs, COPY_PER_CU floats each
 constexpr int COPY_WORLD = ROWS * P_STATE, COPY_XT = ROWS * P_DINP, COPY_G = ROWS * 12, COPY_GL = ROWS * 32;
 constexpr int COPY_TOTAL = COPY_WORLD + COPY_XT + COPY_G + COPY_GL;
@@ -232,64 +232,112 @@ __device__ __forceinline__ bool sweep(__amdgpu_buffer_rsrc_t rs, unsigned off, u
   }
 }
 
-// Exchange slots of a GroupNorm'ed activation.  The consumer sweeps slot tid + 256 q (coalesced: one wave = 2 KB per load) and wants
-// its NQ = GW / 16 values of a row to belong to ONE normalisation group, the group spread over exactly one 16-lane DPP row:
-//     slot (tid, q)  <->  channel GW (tid / 16) + 16 q + (tid % 16)
-// so a group's statistics are NQ - 1 lane-local adds + one 4-stage DPP row reduction (lr::row_sum4: every lane of the row gets the
-// bitwise identical total) -- no v_permlane swaps, no operand copies (round 3: channel = tid + 256 q, a group = a whole wave,
-// 2 x wave_sum16 per layer = the issue-bound 2.1 k cycles of the phase tables).  GW = 0: identity (no GroupNorm on the consumer side).
+// The same wait for a GroupNorm'ed hidden activation, in HALF granules: the thread's k-th load is piece tid + 256 k (16 bytes: one row
+// pair of slot (tid >> 1) + 128 k), so a wave's load instruction covers 1 KB of contiguous exchange space -- every 128-byte line is
+// requested by ONE instruction.  (sweep() above reads bytes 0-15 and 16-31 of a 32-byte slot with two instructions: the same number of
+// instructions, but each touches twice the lines, half of every line unused; the texture path processes a 64 x 16-byte request line by
+// line, and it is shared by everything a CU loads.)  The lane's row pair is its parity: rows 2 (tid & 1), 2 (tid & 1) + 1.
+template <int NK>
+__device__ __forceinline__ bool sweep_pairs(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, int tid, float (&x)[NK][2]) {
+  for (int spins = 0;; ++spins) {
+    unsigned diff = 0;
+    puv4 v[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)(tid + 256 * k) * 16u, 0, 16);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      diff |= (v[k].y ^ tag) | (v[k].w ^ tag);
+      x[k][0] = as_f(v[k].x); x[k][1] = as_f(v[k].z);
+    }
+    if (__all(diff == 0)) { PT_SPINS(spins); return true; }
+    if (spins > SPIN_LIMIT) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// Exchange slots of a GroupNorm'ed activation.  The consumer's k-th load covers slot (tid >> 1) + 128 k (sweep_pairs) and wants its
+// NK = GW / 8 values of a row to belong to ONE normalisation group, the group spread over exactly one 16-lane DPP row (8 slots x 2 row
+// pairs):
+//     slot (tid, k)  <->  channel GW (tid / 16) + 8 k + ((tid / 2) % 8)
+// so a group's statistics are NK - 1 lane-local adds + one 3-stage DPP reduction over the row's lanes of equal parity
+// (lr::parity_sum2: every such lane gets the bitwise identical total) -- no v_permlane swaps, no operand copies (round 3: channel =
+// tid + 256 q, a group = a whole wave, 2 x wave_sum16 per layer = the issue-bound 2.1 k cycles of the phase tables).
+// GW = 0: identity (no GroupNorm on the consumer side; swept with sweep()).
 template <int GW>
 __device__ __forceinline__ int xslot(int col) {
   if constexpr (GW == 0) return col;
-  else return 16 * (col / GW) + (col & 15) + 256 * ((col >> 4) & (GW / 16 - 1));
+  else return 8 * (col / GW) + (col & 7) + 128 * ((col >> 3) & (GW / 8 - 1));
 }
 template <int GW>
-__device__ __forceinline__ int xchan(int tid, int q) { return GW * (tid >> 4) + 16 * q + (tid & 15); }
+__device__ __forceinline__ int xchan(int tid, int k) { return GW * (tid >> 4) + 8 * k + ((tid >> 1) & 7); }
 
-// consumer side of a hidden activation: sweep, GroupNorm (two-pass statistics per row and group of GROUP = 16 NQ channels) + ReLU, the
-// finished A operand to LDS as [channel][4 rows]
+typedef float pvf2 __attribute__((ext_vector_type(2)));
+template <int NK>
+__device__ __forceinline__ float sum_k(const float (&v)[NK][2], int i) {
+  if constexpr (NK == 8) return ((v[0][i] + v[1][i]) + (v[2][i] + v[3][i])) + ((v[4][i] + v[5][i]) + (v[6][i] + v[7][i]));
+  else return (v[0][i] + v[1][i]) + (v[2][i] + v[3][i]);
+}
+// GroupNorm (two-pass statistics per row and group of GROUP = 8 NK channels) + ReLU of the thread's NK channels x 2 rows, the finished A
+// operand to LDS as [channel][4 rows]
 // stats (or null): the (mean, rstd) of every (group, row) go to stats[group][32 rows][2] for the adjoint (one CU of the team writes)
-template <int NQ, int GROUP, int PTI = 0>
-__device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float (&gam)[NQ], const float (&bet)[NQ],
-                                            float* xs, int tid, float* stats, int row0 PT_ARGS) {
-  static_assert(GROUP == 16 * NQ, "a 16-lane row holds one group");
-  float x[NQ][4];
-  if (!sweep<NQ>(rs, off, tag, NQ * 256, tid, x)) return false;
-  PT(PTI);
+template <int NK, int GROUP>
+__device__ __forceinline__ void norm_pairs(const float (&x)[NK][2], const float (&gam)[NK], const float (&bet)[NK], float* xs, int tid, float* stats, int row0) {
+  static_assert(GROUP == 8 * NK && (NK == 4 || NK == 8), "a 16-lane row holds one group");
   const float inv_n = 1.0f / (float)GROUP;
-  float mu[4], var[4];
+  float mu[2] = {sum_k<NK>(x, 0), sum_k<NK>(x, 1)};
+  lr::parity_sum2(mu);
+  float d[NK][2], sq[NK][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if constexpr (NQ == 4) mu[i] = (x[0][i] + x[1][i]) + (x[2][i] + x[3][i]);
-    else mu[i] = x[0][i] + x[1][i];
-  }
-  lr::row_sum4(mu);
-  float d[NQ][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 2; ++i) {
     mu[i] *= inv_n;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) d[q][i] = x[q][i] - mu[i];
-    if constexpr (NQ == 4) var[i] = (d[0][i] * d[0][i] + d[1][i] * d[1][i]) + (d[2][i] * d[2][i] + d[3][i] * d[3][i]);
-    else var[i] = d[0][i] * d[0][i] + d[1][i] * d[1][i];
+    for (int k = 0; k < NK; ++k) { d[k][i] = x[k][i] - mu[i]; sq[k][i] = d[k][i] * d[k][i]; }
   }
-  lr::row_sum4(var);
-  float rs4[4];
+  float var[2] = {sum_k<NK>(sq, 0), sum_k<NK>(sq, 1)};
+  lr::parity_sum2(var);
   // (v_rsq_f32 itself: the argument is >= 1e-5, so rsqrtf's denormal pre-scaling never applies and the result is the same)
+  const float rs2[2] = {__builtin_amdgcn_rsqf(var[0] * inv_n + 1e-5f), __builtin_amdgcn_rsqf(var[1] * inv_n + 1e-5f)};
+  const int hp = tid & 1;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) rs4[i] = __builtin_amdgcn_rsqf(var[i] * inv_n + 1e-5f);
+  for (int k = 0; k < NK; ++k) {
+    pvf2 o;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    pvf4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = fmaxf(d[q][i] * rs4[i] * gam[q] + bet[q], 0.f);
-    *reinterpret_cast<pvf4*>(xs + (size_t)xchan<GROUP>(tid, q) * 4) = o;
+    for (int i = 0; i < 2; ++i) o[i] = fmaxf(d[k][i] * rs2[i] * gam[k] + bet[k], 0.f);
+    *reinterpret_cast<pvf2*>(xs + (size_t)xchan<GROUP>(tid, k) * 4 + 2 * hp) = o;
   }
-  if (stats && (tid & 15) == 0) {        // one lane per group (= 16-lane row)
-    pvf4* sp = reinterpret_cast<pvf4*>(stats + ((size_t)(tid >> 4) * 32 + row0) * 2);
-    sp[0] = pvf4{mu[0], rs4[0], mu[1], rs4[1]};
-    sp[1] = pvf4{mu[2], rs4[2], mu[3], rs4[3]};
+  if (stats && (tid & 14) == 0)          // two lanes per group (= 16-lane row): one per row pair
+    *reinterpret_cast<pvf4*>(stats + ((size_t)(tid >> 4) * 32 + row0 + 2 * hp) * 2) = pvf4{mu[0], rs2[0], mu[1], rs2[1]};
+}
+// GroupNorm affine in LDS.  Forward (DUP): {gamma, beta, gamma, beta} per channel, so that a thread reads its channel's pair at the very
+// index it stores the channel's row pair at ([channel][4 rows] + 2 (tid & 1)): one address register serves both.  Adjoint (LDS is
+// short there): {gamma, beta} per channel.
+template <bool DUP>
+__device__ __forceinline__ void gb_fill(float* gb_lds, const float* gamma, const float* beta, int n, int tid) {
+  for (int c = tid; c < n; c += 256) {
+    if constexpr (DUP) *reinterpret_cast<pvf4*>(gb_lds + (size_t)c * 4) = pvf4{gamma[c], beta[c], gamma[c], beta[c]};
+    else *reinterpret_cast<pvf2*>(gb_lds + (size_t)c * 2) = pvf2{gamma[c], beta[c]};
   }
+}
+template <int GROUP, bool DUP>
+__device__ __forceinline__ pvf2 gb_at(const float* gb_lds, int tid, int k) {
+  if constexpr (DUP) return *reinterpret_cast<const pvf2*>(gb_lds + (size_t)xchan<GROUP>(tid, k) * 4 + 2 * (tid & 1));
+  else return *reinterpret_cast<const pvf2*>(gb_lds + (size_t)xchan<GROUP>(tid, k) * 2);
+}
+// consumer side of a hidden activation: sweep, GroupNorm + ReLU
+template <int NQ, int GROUP, int PTI = 0>
+__device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float* gb_lds,
+                                            float* xs, int tid, float* stats, int row0 PT_ARGS) {
+  constexpr int NK = 2 * NQ;
+  float x[NK][2];
+  if (!sweep_pairs<NK>(rs, off, tag, tid, x)) return false;
+  PT(PTI);
+  float gam[NK], bet[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const pvf2 gb = gb_at<GROUP, true>(gb_lds, tid, k);
+    gam[k] = gb[0]; bet[k] = gb[1];
+  }
+  norm_pairs<NK, GROUP>(x, gam, bet, xs, tid, stats, row0);
   return true;
 }
 
@@ -423,7 +471,6 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
         sp[4] = v1;
       }
       if (ht) {
-        typedef float pvf2 __attribute__((ext_vector_type(2)));
         *reinterpret_cast<pvf2*>(ht + (size_t)col * 4 + 2 * p) = pvf2{v0, v1};
       }
     }
@@ -593,14 +640,12 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   const int j4 = lane & 3, h4 = 4 * (lane >> 5);
   const float b0 = a.bias[0][8 * g + h4 + j4], b1 = a.bias[1][8 * g + h4 + j4], b2 = a.bias[2][4 * g + j4];
   const float b3 = g < L3_WAVES ? a.bias[3][4 * g + j4] : 0.f;
-  float gam1[4], bet1[4], gam2[4], bet2[4], gam3[2], bet3[2];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    gam1[q] = a.gamma[0][xchan<64>(tid, q)]; bet1[q] = a.beta[0][xchan<64>(tid, q)];
-    gam2[q] = a.gamma[1][xchan<64>(tid, q)]; bet2[q] = a.beta[1][xchan<64>(tid, q)];
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) { gam3[q] = a.gamma[2][xchan<32>(tid, q)]; bet3[q] = a.beta[2][xchan<32>(tid, q)]; }
+  float* sGb1 = smem + L_GB;
+  float* sGb2 = sGb1 + 4 * P_H0;
+  float* sGb3 = sGb2 + 4 * P_H1;
+  gb_fill<true>(sGb1, a.gamma[0], a.beta[0], P_H0, tid);
+  gb_fill<true>(sGb2, a.gamma[1], a.beta[1], P_H1, tid);
+  gb_fill<true>(sGb3, a.gamma[2], a.beta[2], P_H2, tid);
 
   // ---- initial state: x_0 (row-major copy for the glue, [channel][row] copy as the A operand), z_0, world transform ---------
   for (int e = tid; e < ROWS * P_XPAD; e += 256) {
@@ -736,7 +781,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     }
     if (t > 0) deferred(t - 1);       // (in the shadow of the layer-1 sweep)
     // ---- layer 1 ----------------------------------------------------------------------------------------------------------
-    if (!gather_norm<4, 64, 3>(rs, ACT_OFF0, tag + 1, gam1, bet1, xs1, tid, m == 1 ? sp + a.off_gn[0] : nullptr, row0 PT_PASS)) fail = true;
+    if (!gather_norm<4, 64, 3>(rs, ACT_OFF0, tag + 1, sGb1, xs1, tid, m == 1 ? sp + a.off_gn[0] : nullptr, row0 PT_PASS)) fail = true;
     if (zlive && t + 1 < a.S) z_next = a.z_seq[((size_t)(row0 + zi) * a.S + (t + 1)) * P_ZD + zc];
     PT(4);
     if (fail) misc[2] = 1;
@@ -753,7 +798,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     if (t > 0) copy_out(t - 1);       // the previous step's results leave in the shadow of the layer-2 sweep (stores only; the deferred
                                       // tasks' LDS writes are one barrier back)
     // ---- layer 2 ----------------------------------------------------------------------------------------------------------
-    if (!gather_norm<4, 64, 8>(rs, ACT_OFF1, tag + 2, gam2, bet2, xs2, tid, m == 2 ? sp + a.off_gn[1] : nullptr, row0 PT_PASS)) fail = true;
+    if (!gather_norm<4, 64, 8>(rs, ACT_OFF1, tag + 2, sGb2, xs2, tid, m == 2 ? sp + a.off_gn[1] : nullptr, row0 PT_PASS)) fail = true;
     PT(9);
     if (fail) misc[2] = 1;
     __syncthreads();
@@ -767,7 +812,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       PT(12);
     }
     // ---- layer 3 (GroupNorm groups of 32) -------------------------------------------------------------------------------
-    if (!gather_norm<2, 32, 13>(rs, ACT_OFF2, tag + 3, gam3, bet3, xs3, tid, m == 3 ? sp + a.off_gn[2] : nullptr, row0 PT_PASS)) fail = true;
+    if (!gather_norm<2, 32, 13>(rs, ACT_OFF2, tag + 3, sGb3, xs3, tid, m == 3 ? sp + a.off_gn[2] : nullptr, row0 PT_PASS)) fail = true;
     PT(14);
     if (fail) misc[2] = 1;
     __syncthreads();
@@ -1103,59 +1148,54 @@ __device__ __forceinline__ void head_adj(const HeadPrep& o, const RodPrep& p, co
 // (gnb_issue, before the previous layer's MFMAs) so that the sweep's loads do not queue behind them.
 template <int NQ>
 struct GnbRegs {
-  pvf4 h[NQ];                 // the channel's four rows
-  pvf4 s0, s1;                // (mean, rstd) of rows 0-1 and 2-3 of the thread's group (one group per 16-lane row: xchan)
+  pvf2 h[2 * NQ];             // the thread's row pair of its 2 NQ channels (xchan)
+  pvf4 s;                     // (mean, rstd) of the two rows in the thread's group (one group per 16-lane row)
 };
 // ht: the team's copy of the pre-activations, [channel][4 rows]
 template <int NQ, int GROUP>
 __device__ __forceinline__ void gnb_issue(const float* ht, const float* stats, int row0, int tid, GnbRegs<NQ>& r) {
+  const int hp = tid & 1;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) r.h[q] = *reinterpret_cast<const pvf4*>(ht + (size_t)xchan<GROUP>(tid, q) * 4);
-  const pvf4* sp = reinterpret_cast<const pvf4*>(stats + ((size_t)(tid >> 4) * 32 + row0) * 2);
-  r.s0 = sp[0];
-  r.s1 = sp[1];
+  for (int k = 0; k < 2 * NQ; ++k) r.h[k] = *reinterpret_cast<const pvf2*>(ht + (size_t)xchan<GROUP>(tid, k) * 4 + 2 * hp);
+  r.s = *reinterpret_cast<const pvf4*>(stats + ((size_t)(tid >> 4) * 32 + row0 + 2 * hp) * 2);
 }
 template <int NQ, int GROUP, int PTI = 0>
-__device__ __forceinline__ bool gather_norm_bwd(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float* gam_lds, const float* bet_lds,
+__device__ __forceinline__ bool gather_norm_bwd(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, const float* gb_lds,
                                                 const GnbRegs<NQ>& r, float* ds, int tid PTB_ARGS) {
-  static_assert(GROUP == 16 * NQ, "a 16-lane row holds one group");
-  const float mean[4] = {r.s0.x, r.s0.z, r.s1.x, r.s1.z}, rstd[4] = {r.s0.y, r.s0.w, r.s1.y, r.s1.w};
-  float xh[NQ][4];
+  constexpr int NK = 2 * NQ;
+  static_assert(GROUP == 8 * NK, "a 16-lane row holds one group");
+  const float mean[2] = {r.s.x, r.s.z}, rstd[2] = {r.s.y, r.s.w};
+  float xh[NK][2];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
+  for (int k = 0; k < NK; ++k)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xh[q][i] = (r.h[q][i] - mean[i]) * rstd[i];
-  float ga[NQ][4];
-  if (!sweep<NQ>(rs, off, tag, NQ * 256, tid, ga)) return false;
+    for (int i = 0; i < 2; ++i) xh[k][i] = (r.h[k][i] - mean[i]) * rstd[i];
+  float ga[NK][2];
+  if (!sweep_pairs<NK>(rs, off, tag, tid, ga)) return false;
   PTB(PTI);
   const float inv_n = 1.0f / (float)GROUP;
-  float dxh[NQ][4], m[8];           // m[0..3] = sum of dxh, m[4..7] = sum of dxh xh over the group, per row
+  float dxh[NK][2], dx2[NK][2];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const float gam = gam_lds[xchan<GROUP>(tid, q)], bet = bet_lds[xchan<GROUP>(tid, q)];
+  for (int k = 0; k < NK; ++k) {
+    const pvf2 gb = gb_at<GROUP, false>(gb_lds, tid, k);
+    const float gam = gb[0], bet = gb[1];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float y = xh[q][i] * gam + bet;
-      dxh[q][i] = (y > 0.f ? ga[q][i] : 0.f) * gam;
+    for (int i = 0; i < 2; ++i) {
+      const float y = xh[k][i] * gam + bet;
+      dxh[k][i] = (y > 0.f ? ga[k][i] : 0.f) * gam;
+      dx2[k][i] = dxh[k][i] * xh[k][i];
     }
   }
+  // m[0..1] = sum of dxh, m[2..3] = sum of dxh xh over the group, per row
+  float m[4] = {sum_k<NK>(dxh, 0), sum_k<NK>(dxh, 1), sum_k<NK>(dx2, 0), sum_k<NK>(dx2, 1)};
+  lr::parity_sum4(m);
+  const int hp = tid & 1;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if constexpr (NQ == 4) {
-      m[i] = (dxh[0][i] + dxh[1][i]) + (dxh[2][i] + dxh[3][i]);
-      m[4 + i] = (dxh[0][i] * xh[0][i] + dxh[1][i] * xh[1][i]) + (dxh[2][i] * xh[2][i] + dxh[3][i] * xh[3][i]);
-    } else {
-      m[i] = dxh[0][i] + dxh[1][i];
-      m[4 + i] = dxh[0][i] * xh[0][i] + dxh[1][i] * xh[1][i];
-    }
-  }
-  lr::row_sum8(m);
+  for (int k = 0; k < NK; ++k) {
+    pvf2 o;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    pvf4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = rstd[i] * (dxh[q][i] - m[i] * inv_n - xh[q][i] * (m[4 + i] * inv_n));
-    *reinterpret_cast<pvf4*>(ds + (size_t)xchan<GROUP>(tid, q) * 4) = o;
+    for (int i = 0; i < 2; ++i) o[i] = rstd[i] * (dxh[k][i] - m[i] * inv_n - xh[k][i] * (m[2 + i] * inv_n));
+    *reinterpret_cast<pvf2*>(ds + (size_t)xchan<GROUP>(tid, k) * 4 + 2 * hp) = o;
   }
   return true;
 }
@@ -1204,14 +1244,12 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     for (int r = 0; r < NLW; ++r) sWz[r * 64 + lane] = wp[(size_t)(NREG_B + r) * 64];
   }
   // GroupNorm affine of the three hidden activations in LDS (register budget: 292 weight registers per wave)
-  float* sGam1 = smem + LB_GB;
-  float* sBet1 = sGam1 + P_H0;
-  float* sGam2 = sBet1 + P_H0;
-  float* sBet2 = sGam2 + P_H1;
-  float* sGam3 = sBet2 + P_H1;
-  float* sBet3 = sGam3 + P_H2;
-  for (int c = tid; c < P_H0; c += 256) { sGam1[c] = a.gamma[0][c]; sBet1[c] = a.beta[0][c]; sGam2[c] = a.gamma[1][c]; sBet2[c] = a.beta[1][c]; }
-  for (int c = tid; c < P_H2; c += 256) { sGam3[c] = a.gamma[2][c]; sBet3[c] = a.beta[2][c]; }
+  float* sGb1 = smem + LB_GB;
+  float* sGb2 = sGb1 + 2 * P_H0;
+  float* sGb3 = sGb2 + 2 * P_H1;
+  gb_fill<false>(sGb1, a.gamma[0], a.beta[0], P_H0, tid);
+  gb_fill<false>(sGb2, a.gamma[1], a.beta[1], P_H1, tid);
+  gb_fill<false>(sGb3, a.gamma[2], a.beta[2], P_H2, tid);
 
   // ---- per-step inputs: (channel quad, row) per thread, 16-byte loads, one step ahead ---------------------------------------
   // x_t (state slab), decoder output (slab 3), dL/dworld_t, glue record, accumulated transform, dL/dx_{t+1} through the prior
@@ -1586,7 +1624,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     }
     // ---- layer 2 ------------------------------------------------------------------------------------------------------------
     PTB(6);
-    if (!gather_norm_bwd<2, 32, 7>(rs, GA_OFF3, tag + 1, sGam3, sBet3, gr2, sD2, tid PTB_PASS)) fail = true;
+    if (!gather_norm_bwd<2, 32, 7>(rs, GA_OFF3, tag + 1, sGb3, gr2, sD2, tid PTB_PASS)) fail = true;
     prefetch_b_issue(t - 1);          // (dL/dworld and the prior's dL/dx of the next step: behind the sweep, stored behind the layer-2 product)
     PTB(8);
     if (fail) misc[2] = 1;
@@ -1609,7 +1647,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     prefetch_b_store(t - 1);
     // ---- layer 1 ------------------------------------------------------------------------------------------------------------
     PTB(11);
-    if (!gather_norm_bwd<4, 64, 12>(rs, GA_OFF2, tag + 2, sGam2, sBet2, gr1, sD1, tid PTB_PASS)) fail = true;
+    if (!gather_norm_bwd<4, 64, 12>(rs, GA_OFF2, tag + 2, sGb2, gr1, sD1, tid PTB_PASS)) fail = true;
     PTB(13);
     if (fail) misc[2] = 1;
     __syncthreads();
@@ -1630,7 +1668,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     }
     // ---- layer 0 ------------------------------------------------------------------------------------------------------------
     PTB(16);
-    if (!gather_norm_bwd<4, 64, 17>(rs, GA_OFF1, tag + 3, sGam1, sBet1, gr0, sD0, tid PTB_PASS)) fail = true;
+    if (!gather_norm_bwd<4, 64, 17>(rs, GA_OFF1, tag + 3, sGb1, gr0, sD0, tid PTB_PASS)) fail = true;
     PTB(18);
     if (fail) misc[2] = 1;
     __syncthreads();

@@ -34,7 +34,15 @@ def chain_only(gpu_lib):
 
 @pytest.mark.parametrize('B,S', [(1, 1), (2, 3), (4, 10), (32, 12), (33, 5), (70, 3), (130, 2)])   # 130 rows: full-K launch policy
 def test_rollout_forward_backward(gpu_lib, dev, fwd_path, B, S):
-    RC.check_rollout(gpu_lib, dev, B=B, S=S, seed=B)
+    # Every case is judged against an fp64 evaluation with the fp32 oracle's own distance from it as the yardstick (cond_aware): the random,
+    # non-contractive test network sits on ReLU kinks, and a unit that flips between two fp32 evaluations moves single gradient entries by
+    # ~1e-3 of the largest one after as few as 5 steps (measured, profiles/r05_final/accuracy_ab.txt: at 32 x 12 the ORACLE is 1.8e-3 away
+    # from fp64 for seed 1 where the kernels are 4e-6 away, and the other way round for seed 32).  From 10 steps on the chain also amplifies
+    # plain rounding to the order of the base tolerances (see test_rollout_full_length): those cases get its bounds.
+    if S >= 10:
+        RC.check_rollout(gpu_lib, dev, B=B, S=S, seed=B, fwd_tol=1e-3, grad_rtol=1e-2, cond_aware=True)
+    else:
+        RC.check_rollout(gpu_lib, dev, B=B, S=S, seed=B, cond_aware=True)
 
 
 def test_rollout_without_prior(gpu_lib, dev, fwd_path):
