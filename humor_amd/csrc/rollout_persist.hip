@@ -277,6 +277,12 @@ __device__ __forceinline__ float sum_k(const float (&v)[NK][2], int i) {
   if constexpr (NK == 8) return ((v[0][i] + v[1][i]) + (v[2][i] + v[3][i])) + ((v[4][i] + v[5][i]) + (v[6][i] + v[7][i]));
   else return (v[0][i] + v[1][i]) + (v[2][i] + v[3][i]);
 }
+// (the same tree on row pairs: the two rows of a lane are the two halves of packed fp32 instructions, v_pk_add / v_pk_mul)
+template <int NK>
+__device__ __forceinline__ pvf2 sum_kv(const pvf2 (&v)[NK]) {
+  if constexpr (NK == 8) return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  else return (v[0] + v[1]) + (v[2] + v[3]);
+}
 // GroupNorm (two-pass statistics per row and group of GROUP = 8 NK channels) + ReLU of the thread's NK channels x 2 rows, the finished A
 // operand to LDS as [channel][4 rows]
 // stats (or null): the (mean, rstd) of every (group, row) go to stats[group][32 rows][2] for the adjoint (one CU of the team writes)
@@ -284,29 +290,30 @@ template <int NK, int GROUP>
 __device__ __forceinline__ void norm_pairs(const float (&x)[NK][2], const float (&gam)[NK], const float (&bet)[NK], float* xs, int tid, float* stats, int row0) {
   static_assert(GROUP == 8 * NK && (NK == 4 || NK == 8), "a 16-lane row holds one group");
   const float inv_n = 1.0f / (float)GROUP;
-  float mu[2] = {sum_k<NK>(x, 0), sum_k<NK>(x, 1)};
+  pvf2 xv[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) xv[k] = pvf2{x[k][0], x[k][1]};
+  const pvf2 s1 = sum_kv<NK>(xv);
+  float mu[2] = {s1[0], s1[1]};
   lr::parity_sum2(mu);
-  float d[NK][2], sq[NK][2];
+  const pvf2 muv = pvf2{mu[0], mu[1]} * inv_n;
+  pvf2 d[NK], sq[NK];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    mu[i] *= inv_n;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) { d[k][i] = x[k][i] - mu[i]; sq[k][i] = d[k][i] * d[k][i]; }
-  }
-  float var[2] = {sum_k<NK>(sq, 0), sum_k<NK>(sq, 1)};
+  for (int k = 0; k < NK; ++k) { d[k] = xv[k] - muv; sq[k] = d[k] * d[k]; }
+  const pvf2 s2 = sum_kv<NK>(sq);
+  float var[2] = {s2[0], s2[1]};
   lr::parity_sum2(var);
   // (v_rsq_f32 itself: the argument is >= 1e-5, so rsqrtf's denormal pre-scaling never applies and the result is the same)
-  const float rs2[2] = {__builtin_amdgcn_rsqf(var[0] * inv_n + 1e-5f), __builtin_amdgcn_rsqf(var[1] * inv_n + 1e-5f)};
+  const pvf2 rs2 = {__builtin_amdgcn_rsqf(var[0] * inv_n + 1e-5f), __builtin_amdgcn_rsqf(var[1] * inv_n + 1e-5f)};
   const int hp = tid & 1;
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    pvf2 o;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) o[i] = fmaxf(d[k][i] * rs2[i] * gam[k] + bet[k], 0.f);
+    pvf2 o = d[k] * rs2 * gam[k] + bet[k];
+    o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f);
     *reinterpret_cast<pvf2*>(xs + (size_t)xchan<GROUP>(tid, k) * 4 + 2 * hp) = o;
   }
   if (stats && (tid & 14) == 0)          // two lanes per group (= 16-lane row): one per row pair
-    *reinterpret_cast<pvf4*>(stats + ((size_t)(tid >> 4) * 32 + row0 + 2 * hp) * 2) = pvf4{mu[0], rs2[0], mu[1], rs2[1]};
+    *reinterpret_cast<pvf4*>(stats + ((size_t)(tid >> 4) * 32 + row0 + 2 * hp) * 2) = pvf4{muv[0], rs2[0], muv[1], rs2[1]};
 }
 // GroupNorm affine in LDS.  Forward (DUP): {gamma, beta, gamma, beta} per channel, so that a thread reads its channel's pair at the very
 // index it stores the channel's row pair at ([channel][4 rows] + 2 (tid & 1)): one address register serves both.  Adjoint (LDS is
@@ -1187,6 +1194,7 @@ __device__ __forceinline__ bool gather_norm_bwd(__amdgpu_buffer_rsrc_t rs, unsig
     }
   }
   // m[0..1] = sum of dxh, m[2..3] = sum of dxh xh over the group, per row
+  // (scalar form: the packed-fp32 form of norm_pairs measured 1 % slower here -- the pairs have to be assembled with copies first)
   float m[4] = {sum_k<NK>(dxh, 0), sum_k<NK>(dxh, 1), sum_k<NK>(dx2, 0), sum_k<NK>(dx2, 1)};
   lr::parity_sum4(m);
   const int hp = tid & 1;
