@@ -2203,9 +2203,10 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
   };
 
   const bool persist_bwd = L.single && g_rollout_persist_bwd != 0 && (!L.pipe || g_rollout_pipe_bwd != 0);
-  HA_REQUIRE(!(L.pipe && !persist_bwd && tl_single_mode == 2),
-             "ha_humor_rollout_backward: this stash was filled by a pipelined forward without launch-chain slabs (the adjoint knobs said the "
-             "pipelined adjoint would follow) and the adjoint knobs changed since -- set them before the forward call");
+  HA_REQUIRE(!(!persist_bwd && tl_single_mode == 2),
+             "ha_humor_rollout_backward: this stash was filled by a persistent / pipelined forward without launch-chain slabs (the adjoint knobs said "
+             "the one-launch adjoint would follow) and the adjoint knobs changed since, or the persistent path was disabled by a failure in between "
+             "-- set the knobs before the forward call");
   if (persist_bwd) {
     if (phase == PH_BEGIN) {
       PersistBwd f;
@@ -2350,7 +2351,9 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
   const bool piped = pipelined_call(B, mode);
   // mode 2: a pipelined forward whose adjoint will be the pipelined launch too writes the hidden pre-activations in the teams' layout only
   // (no launch-chain slabs: a third of its stores); only the pipelined adjoint can read such a stash, and the backward entry checks that
+  // (the same for the B <= 32 kernels)
   if (piped && g_rollout_persist_bwd != 0 && g_rollout_pipe_bwd != 0) mode = 2;
+  if (!piped && mode == 1 && B <= 32 && g_layer_finish != 2 && g_rollout_persist_bwd != 0) mode = 2;
   int ng, rpg;
   group_plan(B, ng, rpg, piped);
   tl_groups = piped ? 1 : ng;

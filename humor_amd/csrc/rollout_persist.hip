@@ -137,6 +137,7 @@ struct PersistArgs {
   unsigned char* xch;
   unsigned* err;            // host-mapped error word
   int inject;               // test hook (ha_tune_set "rollout_persist_inject"): member 3 of team 0 leaves at once -> the team's bounded waits run out
+  int hidden_slabs;         // 1: the hidden pre-activations also as launch-chain slabs (off_dec[0..2]); 0: team layout (off_ht) only
 };
 
 struct PersistNet {
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float acc[8];
       mma_layer<NC0, NCZ, 2, R0>(xs0, zs, wa, wv, lane, acc);
       PT(1);
-      publish<2, SC1, 64>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, sp + a.off_dec[0], row0, lane, sp + a.off_ht[0] + (size_t)team * P_H0 * 4);
+      publish<2, SC1, 64>(acc, b0, 8 * g, team_xch, rs, ACT_OFF0, tag + 1, a.hidden_slabs ? sp + a.off_dec[0] : nullptr, row0, lane, sp + a.off_ht[0] + (size_t)team * P_H0 * 4);
       PT(2);
     }
     if (t > 0) deferred(t - 1);       // (in the shadow of the layer-1 sweep)
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float acc[8];
       mma_layer<NC1, NCZ, 2, R1>(xs1, zs, wa, wv, lane, acc);
       PT(6);
-      publish<2, SC1, 64>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, sp + a.off_dec[1], row0, lane, sp + a.off_ht[1] + (size_t)team * P_H1 * 4);
+      publish<2, SC1, 64>(acc, b1, 8 * g, team_xch, rs, ACT_OFF1, tag + 2, a.hidden_slabs ? sp + a.off_dec[1] : nullptr, row0, lane, sp + a.off_ht[1] + (size_t)team * P_H1 * 4);
       PT(7);
     }
     if (t > 0) copy_out(t - 1);       // the previous step's results leave in the shadow of the layer-2 sweep (stores only; the deferred
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       float acc[4];
       mma_layer<NC2, NCZ, 1, R2>(xs2, zs, wa, wv, lane, acc);
       PT(11);
-      publish<1, SC1, 32>(acc, b2, 4 * g, team_xch, rs, ACT_OFF2, tag + 3, sp + a.off_dec[2], row0, lane, sp + a.off_ht[2] + (size_t)team * P_H2 * 4);
+      publish<1, SC1, 32>(acc, b2, 4 * g, team_xch, rs, ACT_OFF2, tag + 3, a.hidden_slabs ? sp + a.off_dec[2] : nullptr, row0, lane, sp + a.off_ht[2] + (size_t)team * P_H2 * 4);
       PT(12);
     }
     // ---- layer 3 (GroupNorm groups of 32) -------------------------------------------------------------------------------
@@ -2068,6 +2069,7 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
   a.xch = reinterpret_cast<unsigned char*>(f.ws);
   a.err = p->err_dev;
   a.inject = (variant >> 1) & 1;
+  a.hidden_slabs = f.hidden_slabs ? 1 : 0;
   if (variant & 1) hipLaunchKernelGGL(rollout_persist_fwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
   else hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
   HA_LAUNCH_CHECK();
