@@ -118,7 +118,8 @@ def _sharded_worker(rank, world, port, npz, emu_path, out, B=4):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,B', [(2, 4), (3, 4), (2, 6)])
+# (the default CPU tier keeps the 2-rank case; three ranks / ragged shards run with HUMOR_AMD_SLOW=1 -- about a minute each on the emulator)
+@pytest.mark.parametrize('world,B', [(2, 4), pytest.param(3, 4, marks=pytest.mark.slow), pytest.param(2, 6, marks=pytest.mark.slow)])
 def test_sharded_closure_equals_single_process(emu_lib, smplh_npz, tmp_path, world, B):
     """world_size-2/3 gloo: replicated variables, closure on the local slice, packed all-reduce, forward-only halo (option B: both
     neighbours evaluate the boundary pair; with 3 ranks over 4 sequences the middle ranks own ONE sequence that is both the
@@ -217,7 +218,8 @@ def test_emu_lbfgs_kernels_long_history(emu_lib):
     print('direction rel. error (k = 128)', LC.check_direction(emu_lib, CPU, n=200, h=128, k=128, seed=1))
 
 
-@pytest.mark.parametrize('speculate', [True, False])
+# (speculation is opt-in and off by default: its two tests run with HUMOR_AMD_SLOW=1)
+@pytest.mark.parametrize('speculate', [pytest.param(True, marks=pytest.mark.slow), False])
 def test_emu_fused_lbfgs_follows_torch_lbfgs(emu_lib, speculate):
     """humor_amd.lbfgs.LBFGS (flat buffer, one Gram pass + coefficient-form two-loop recursion + one GEMV per direction, every scalar
     of an evaluation in one read; the next inner iteration issued speculatively before that read, or -- speculate=False -- one iteration
@@ -266,6 +268,7 @@ def test_emu_fused_lbfgs_follows_torch_lbfgs(emu_lib, speculate):
     assert (x0 - x1).abs().max().item() < 1e-3 and t1[-1] < t1[0] - 1.0
 
 
+@pytest.mark.slow
 def test_emu_speculative_lbfgs_is_bit_identical_to_sequential(emu_lib):
     """The speculative issue of the next inner iteration changes WHEN kernels are issued, never what they compute: on a problem whose line
     search regularly needs more than one trial (so speculative iterations ARE rolled back: pair dropped, retired pair restored, gradient

@@ -108,6 +108,7 @@ def test_emu_fused_vposer_k_split(emu_lib):
         emu_lib.call('ha_tune_set', b'gemm_ks', 2)
 
 
+@pytest.mark.slow          # (a minute on the emulator: the same GEMM kernel as test_emu_fused_vposer_matches_module with the GroupNorm epilogues; GPU tier: test_fused_posterior_encoder_matches_module)
 def test_emu_fused_posterior_encoder_matches_module(emu_lib):
     # one 32-row tile here (the two-tile, ragged-tile geometry of the same GEMM kernel is test_emu_fused_vposer_matches_module above)
     MC.check_posterior(emu_lib, CPU, N=7)
@@ -118,6 +119,7 @@ def test_infer_global_seq_fixture_module_path():
     print('infer_global_seq (module path) vs fixture', MC.check_infer_global_seq_golden(None, CPU))
 
 
+@pytest.mark.slow          # (GPU tier: test_posterior_gives_parameter_gradients)
 def test_emu_posterior_gives_parameter_gradients(emu_lib):
     """a training-mode infer_step must leave gradients on the encoder / prior weights (module forward), frozen nets run fused."""
     MC.check_posterior_param_grads(emu_lib, CPU, N=3)

@@ -84,6 +84,7 @@ def _small_model(tmp_path, num_verts):
     return npz, ds
 
 
+@pytest.mark.slow          # (a minute and a half on the emulator; the GPU tier runs the dense backward at five sizes against the oracle)
 def test_emu_dense_backward_kernels(emu_lib, tmp_path):
     """ha_smpl_backward_dense (streaming dL/dv_posed, 16x16x4 MFMA dL/dA, 32x32x2 MFMA dL/dcoeff with K split, chain adjoint) behind the
     MFMA forward: every vertex carries a gradient.  1100-vertex model (ragged last chunk), hands on (52 active joints, 476 blend
