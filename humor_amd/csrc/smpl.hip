@@ -324,7 +324,8 @@ extern "C" int ha_smpl_model_create(ha_smpl_model** out, int device, int V, int 
             slot = used++;
             gcj[(size_t)c * 32 + slot] = j;
           }
-          gcw[((size_t)c * 64 + vl) * 32 + slot] += wv;
+          // packed for the kernel's lanes: [chunk][slot group][k-quarter = vl & 3][slot & 15][e = vl >> 2]
+          gcw[((((size_t)c * 2 + (slot >> 4)) * 4 + (vl & 3)) * 16 + (slot & 15)) * 16 + (vl >> 2)] += wv;
         }
       }
       gng[c] = used > 16 ? 2 : 1;
@@ -1525,44 +1526,114 @@ __global__ __launch_bounds__(256) void sparse_gA_kernel(const float* __restrict_
 // synthetic model, two for the rest) instead of four tiles over all 64 joint columns, an 8 KB weight operand per chunk instead of 16 KB,
 // every vertex record read once.  A wave takes the chunks w, w + 4, ...; after a tile's 16 MFMAs lane (a = l >> 4, slot = l & 15) adds
 // its four values into the wave's own [joint][12] table in LDS (two slots of a chunk never share a joint: no conflicts, fixed order).
+// Round 5, late: the first form read its operands straight from global memory -- per chunk 32 dword loads of which a wave used 48 bytes
+// each (lane (k-quarter, a, b) wants g[v][a] and p[v][b]: 12 distinct floats per instruction) plus 16 strided dword loads of the weights:
+// 48 load instructions per 16 MFMAs, the kernel sat on the CU's address path (205 us against a 63 us HBM bound).  Now a chunk's 192 + 192
+// floats arrive with four 8-byte loads per lane (issued two chunks ahead, pinned behind the chunk's weight loads), go through the wave's LDS slice, and the weights are packed
+// [chunk][group][lane][16] so that a lane's 16 B operands are four 16-byte loads: 8 load instructions per chunk.
+constexpr int GA_STAGE = 2 * 192;      // floats of LDS per wave: the chunk's g and p records
+template <bool PAIR>      // PAIR: V is even, a frame's records are 8-byte aligned
 __global__ __launch_bounds__(256) void compressed_gA_kernel(const float* __restrict__ g_verts, const float* __restrict__ v_posed,
                                                             const int32_t* __restrict__ gcj, const float* __restrict__ gcw,
                                                             const int32_t* __restrict__ gng, float* __restrict__ gA_out, int V, int Vpad, int J) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];      // [4 waves][64 joints][12]
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [4 waves][64 joints][12] | [4 waves][GA_STAGE]
   const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int row = lane & 15, kq = lane >> 4, a = row >> 2, b = row & 3, col = lane & 15;
   const float* gf = g_verts + (size_t)f * V * 3;
   const float* vf = v_posed + (size_t)f * V * 3;
   float* tab = smem + wave * 768;
+  float* stg = smem + 4 * 768 + wave * GA_STAGE;
   for (int i = lane; i < 768; i += 64) tab[i] = 0.f;
-  wave_sync();
-  for (int c = wave; c < Vpad / 64; c += 4) {
+  const int nch = Vpad / 64, nfl = V * 3;
+  // a chunk's records: floats [192 c, 192 c + 192) of the frame, two per lane and load (8-byte aligned whenever V is even; odd V: scalar
+  // loads).  Branch-free: every lane loads from a clamped address, elements beyond the frame are zeroed by a select.
+  // (the loaded value is not touched here -- a select right behind the load would make the wave wait for it on the spot; `keep` zeroes
+  // it when the chunk goes to LDS, one iteration later)
+  auto ld2 = [&](const float* src, int e) -> vf2 {
+    vf2 u;
+    if constexpr (PAIR) {
+      u = *reinterpret_cast<const vf2*>(src + (e < nfl ? e : nfl - 2));
+    } else {
+      u[0] = src[e < nfl ? e : nfl - 1];
+      u[1] = src[e + 1 < nfl ? e + 1 : nfl - 1];
+    }
+    return u;
+  };
+  auto keep = [&](vf2 u, int e) -> vf2 { return vf2{e < nfl ? u[0] : 0.f, e + 1 < nfl ? u[1] : 0.f}; };
+  auto fetch = [&](int c, vf2 (&r)[4]) {
+    const int e0 = 192 * c + 2 * lane, e1 = 192 * c + 128 + 2 * (lane & 31);
+    r[0] = ld2(gf, e0); r[1] = ld2(gf, e1);
+    r[2] = ld2(vf, e0); r[3] = ld2(vf, e1);
+  };
+  // the lane's operand addresses inside the staged chunk (rows a = 3 / b = 3 of the 16 x 4 operand tile are the constants 0 / 1)
+  const float ga = a < 3 ? 1.f : 0.f;
+  const int ia = (a < 3 ? a : 0) + 3 * kq, ib = 192 + (b < 3 ? b : 0) + 3 * kq;
+  // two chunks ahead: an iteration (~1 k cycles) is shorter than the memory latency under load
+  vf2 nxt[4], nx2[4];
+#ifdef HA_SIMT_EMU
+  const int w0 = wave;
+#else
+  const int w0 = __builtin_amdgcn_readfirstlane(wave);      // (wave-uniform: the chunk index and its table loads stay scalar)
+#endif
+  if (w0 < nch) {
+    fetch(w0, nxt);
+    fetch(w0 + 4 < nch ? w0 + 4 : w0, nx2);
+  }
+  for (int c = w0; c < nch; c += 4) {
+    wave_sync();                                  // (the previous chunk's operand reads are done)
+    {
+      const int e0 = 192 * c + 2 * lane, e1 = 192 * c + 128 + 2 * (lane & 31);
+      *reinterpret_cast<vf2*>(stg + 2 * lane) = keep(nxt[0], e0);
+      *reinterpret_cast<vf2*>(stg + 192 + 2 * lane) = keep(nxt[2], e0);
+      if (lane < 32) {
+        *reinterpret_cast<vf2*>(stg + 128 + 2 * lane) = keep(nxt[1], e1);
+        *reinterpret_cast<vf2*>(stg + 192 + 128 + 2 * lane) = keep(nxt[3], e1);
+      }
+    }
+    const int ng = gng[c];
+    vf4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const vf4*>(gcw + (((size_t)c * 2 + 0) * 64 + lane) * 16 + 4 * q);
+    int joint = gcj[(size_t)c * 32 + col];
+    // the next chunk's records are requested BEHIND this chunk's weights and the order is pinned: vmcnt counts in order, so the MFMAs' wait
+    // for the weights would otherwise also wait for the (HBM) prefetch the compiler had moved in front of them (measured: 31 % MFMA-busy,
+    // every chunk exposed to the memory latency).  Unconditional (the last iteration re-reads its own chunk): straight-line code keeps the
+    // waits counted instead of vmcnt(0).
+    HA_SCHED_FENCE();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nxt[i] = nx2[i];
+    fetch(c + 8 < nch ? c + 8 : c, nx2);
+    HA_SCHED_FENCE();
+    wave_sync();
     float av[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int v = c * 64 + 4 * e + kq;
-      const bool live = v < V && a < 3;
-      const float gval = live ? gf[(size_t)v * 3 + a] : 0.f;
-      const float pval = (live && b < 3) ? vf[(size_t)v * 3 + b] : 1.f;
-      av[e] = gval * pval;
+      const float gval = stg[ia + 12 * e] * ga;            // (vertices beyond V were staged as zeros)
+      const float pv = stg[ib + 12 * e];
+      av[e] = gval * (b < 3 ? pv : 1.f);
     }
-    const int ng = gng[c];
-    for (int grp = 0; grp < ng; ++grp) {
+    // slot group 0 in the same basic block as the loads above (a loop over the groups lets the compiler sink the weight loads into it, behind the
+    // prefetch); the second group (3 of the synthetic model's 108 chunks) under its own uniform branch
+    auto product = [&](const vf4 (&w)[4], int jnt) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      float bw[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) bw[e] = gcw[((size_t)c * 64 + 4 * e + kq) * 32 + 16 * grp + col];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e], acc, 0, 0, 0);
+      for (int e = 0; e < 16; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], w[e >> 2][e & 3], acc, 0, 0, 0);
+      // (two accumulator chains of 8 instead of one of 16: measured, no change -- 7.5 waves per SIMD cover the dependent accumulate)
       // accumulator register r of lane l: row 4 (l >> 4) + r = (a = l >> 4, b = r), slot l & 15
-      const int joint = gcj[(size_t)c * 32 + 16 * grp + col];
-      if (joint >= 0 && kq < 3) {
-        float* d = tab + joint * 12;
+      if (jnt >= 0 && kq < 3) {
+        float* d = tab + jnt * 12;
 #pragma unroll
         for (int r = 0; r < 3; ++r) d[kq * 3 + r] += acc[r];
         d[9 + kq] += acc[3];
       }
       wave_sync();
+    };
+    product(bq, joint);
+    if (ng > 1) {
+      vf4 b1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b1[q] = *reinterpret_cast<const vf4*>(gcw + (((size_t)c * 2 + 1) * 64 + lane) * 16 + 4 * q);
+      product(b1, gcj[(size_t)c * 32 + 16 + col]);
     }
   }
   __syncthreads();
@@ -1619,22 +1690,61 @@ __global__ __launch_bounds__(256) void dense_gA_kernel(const float* __restrict__
 // coefficient group (tile t of the group <-> coefficients 4 c + t: one 16-byte load of a Pd_k row feeds four MFMA column
 // tiles and the four accumulators of a lane are four consecutive coefficients -> 16-byte stores).  Blocks of one k-split
 // run on one XCD (its Pd_k panel stays in that L2).
-__global__ __launch_bounds__(256) void dense_gco_kernel(const float* __restrict__ gvpT, const float* __restrict__ Pd_k, float* __restrict__ out,
-                                                        int N, int nchunks, int Kp, int ngroups, int n_rp, int KS, int cps, int rows_out, int ld_out) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// Round 5, late: the A operand (lane = frame, 16 bytes of the frame's own 83 KB row per load: 64 cache lines per instruction, the four waves
+// of a block -- same frames, different coefficient groups -- each fetching them again) goes through LDS: per 32-k tile the block loads its
+// frames' 128-byte row pieces once, line by line (8 lanes per line), double-buffered, one barrier per tile = per 128 MFMAs of a wave.
+constexpr int GCO_KT = 32, GCO_ROW = GCO_KT + 4;             // k-values per tile; floats per staged frame row (padded: 16-byte reads, stride 144 B)
+constexpr int GCO_RP_FLOATS = 64 * GCO_ROW;                  // one 64-frame row pair of a tile
+constexpr int GCO_THREADS = 320;                             // four MFMA waves + one loader wave
+// The staging is the job of a FIFTH wave: vmcnt counts a wave's loads in order, so an MFMA wave that had requested the next tile's rows (HBM,
+// 2-4 us under load) could not see its next B operand (L2, requested 2 k cycles ahead) arrive before them -- every tile exposed the HBM
+// latency (PMC: 62 % MFMA-busy, the waves waiting 71 % of their cycles).  The loader wave waits for HBM; the MFMA waves only ever wait for L2.
+__global__ __launch_bounds__(GCO_THREADS) void dense_gco_kernel(const float* __restrict__ gvpT, const float* __restrict__ Pd_k, float* __restrict__ out,
+                                                                int N, int nchunks, int Kp, int ngroups, int n_rp, int KS, int cps, int rows_out,
+                                                                int ld_out, int nrp_max) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [2 buffers][nrp_max][64 frames][GCO_ROW]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int items_per_ks = n_rp * ngroups;
   const int bpk = (items_per_ks + 3) / 4;                       // blocks per k-split
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
   const int ks = 8 * (jb / bpk) + xcd;
-  const int item = (jb % bpk) * 4 + wave;
-  if (ks >= KS || item >= items_per_ks) return;
-  const int rp = item / ngroups, grp = item % ngroups;
+  const int item0 = (jb % bpk) * 4;
+  if (ks >= KS || item0 >= items_per_ks) return;                // (block-uniform)
+  const int rp0 = item0 / ngroups;                              // first row pair of the block
+  const int last = item0 + 3 < items_per_ks ? item0 + 3 : items_per_ks - 1;
+  const int nrp = last / ngroups - rp0 + 1;                     // row pairs the block's waves need (<= nrp_max)
   const int c0 = ks * cps, c1 = c0 + cps < nchunks ? c0 + cps : nchunks;
   const size_t Ktot = (size_t)nchunks * 192;
-  const int hi = lane >> 5, ln = lane & 31;
-  int fr[2];
+  const int kb0 = c0 * 192, kb1 = c1 * 192;                     // (multiples of GCO_KT: 192 = 6 x 32)
+  const int buf_floats = nrp_max * GCO_RP_FLOATS;
+
+  if (wave == 4) {
+    // ---- loader: per tile and row pair 64 frames x 128 bytes, a cache line per 8 lanes (lane <-> frame l / 8 + 8 j, piece l % 8) --------------
+    const int sf = lane >> 3, sp = lane & 7;
+    for (int kt = kb0, ib = 0; kt < kb1; kt += GCO_KT, ib ^= 1) {
+      float* buf = smem + ib * buf_floats;
+      for (int q = 0; q < nrp; ++q) {
+        vf4 r[8];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) { const int f = rp * 64 + 32 * m + ln; fr[m] = f < N ? f : N - 1; }
+        for (int j = 0; j < 8; ++j) {
+          const int f = (rp0 + q) * 64 + 8 * j + sf;
+          r[j] = *reinterpret_cast<const vf4*>(gvpT + (size_t)(f < N ? f : N - 1) * Ktot + kt + 4 * sp);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<vf4*>(buf + q * GCO_RP_FLOATS + (8 * j + sf) * GCO_ROW + 4 * sp) = r[j];
+      }
+      // tile kt is staged: the MFMA waves, which have just finished tile kt - GCO_KT out of the other buffer, meet the loader here
+      __syncthreads();
+    }
+    __syncthreads();                                            // (the MFMA waves' barrier behind their last tile)
+    return;
+  }
+
+  const int item = item0 + wave;
+  const bool live = item < items_per_ks;                        // (an idle wave still meets the barriers)
+  const int itc = live ? item : items_per_ks - 1;
+  const int rp = itc / ngroups, grp = itc % ngroups;
+  const int hi = lane >> 5, ln = lane & 31;
   f32x16 acc[2][4];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -1642,12 +1752,8 @@ __global__ __launch_bounds__(256) void dense_gco_kernel(const float* __restrict_
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
-  const float* a0 = gvpT + (size_t)fr[0] * Ktot + 4 * hi;
-  const float* a1 = gvpT + (size_t)fr[1] * Ktot + 4 * hi;
   const float* bp = Pd_k + (size_t)(4 * hi) * Kp + 128 * grp + 4 * ln;
-  auto load = [&](int kb, vf4 (&av)[2], vf4 (&bv)[4]) {
-    av[0] = *reinterpret_cast<const vf4*>(a0 + kb);
-    av[1] = *reinterpret_cast<const vf4*>(a1 + kb);
+  auto load_b = [&](int kb, vf4 (&bv)[4]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = *reinterpret_cast<const vf4*>(bp + (size_t)(kb + e) * Kp);
   };
@@ -1662,24 +1768,34 @@ __global__ __launch_bounds__(256) void dense_gco_kernel(const float* __restrict_
         acc[m][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bv[e].w, acc[m][3], 0, 0, 0);
       }
   };
-  // 8 k-values per iteration (k = kb + 4 hi + e), the next iteration's operands in flight under the 32 MFMAs of the current one
-  const int kb0 = c0 * 192, kb1 = c1 * 192;
-  vf4 avA[2], bvA[4], avB[2], bvB[4];
-  load(kb0, avA, bvA);
-  for (int kb = kb0; kb < kb1; kb += 16) {
-    const int k1 = kb + 8 < kb1 ? kb + 8 : kb;
-    load(k1, avB, bvB);
-    HA_SCHED_FENCE();
-    mma(avA, bvA);
-    HA_SCHED_FENCE();
-    if (kb + 8 < kb1) {
-      const int k2 = kb + 16 < kb1 ? kb + 16 : kb + 8;
-      load(k2, avA, bvA);
+  // 8 k-values per MFMA group (k = kb + 4 hi + e); a tile = 4 groups; the next group's B operands in flight under the MFMAs of the current one
+  const float* arow = smem + (rp - rp0) * GCO_RP_FLOATS + ln * GCO_ROW + 4 * hi;      // + buffer, + 32 m rows, + 8 g
+  vf4 bvA[4], bvB[4];
+  load_b(kb0, bvA);
+  __syncthreads();                                              // tile 0 is staged
+  int ib = 0;
+  for (int kt = kb0; kt < kb1; kt += GCO_KT, ib ^= 1) {
+    const float* ab = arow + ib * buf_floats;
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+      vf4 av[2];
+      load_b(kt + 8 * (g + 1), bvB);
+      av[0] = *reinterpret_cast<const vf4*>(ab + 8 * g);
+      av[1] = *reinterpret_cast<const vf4*>(ab + 32 * GCO_ROW + 8 * g);
       HA_SCHED_FENCE();
-      mma(avB, bvB);
+      mma(av, bvA);
+      HA_SCHED_FENCE();
+      const int kn = kt + 8 * (g + 2) < kb1 ? kt + 8 * (g + 2) : kt;     // (the group after the last one: a harmless re-read)
+      load_b(kn, bvA);
+      av[0] = *reinterpret_cast<const vf4*>(ab + 8 * (g + 1));
+      av[1] = *reinterpret_cast<const vf4*>(ab + 32 * GCO_ROW + 8 * (g + 1));
+      HA_SCHED_FENCE();
+      mma(av, bvB);
       HA_SCHED_FENCE();
     }
+    __syncthreads();                                            // the next tile is staged / this buffer may be overwritten
   }
+  if (!live) return;
   // accumulator register i of lane l: row (i & 3) + 8 (i >> 2) + 4 (l >> 5), column l & 31 <-> coefficients 128 grp + 4 (l & 31) + t
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -1705,14 +1821,33 @@ static DenseBwdPlan dense_bwd_plan(const ha_smpl_model* m, int N, int n_active) 
   P.ngroups = ceil_div(Kc, 128);
   P.ld = P.ngroups * 128;
   P.n_rp = ceil_div(N, 64);
-  // wave target of the dL/dcoeff kernel's K split: ~1.6 waves per SIMD at small N; at large N at least 6 K-splits per (row panel,
-  // column group) -- each wave's chunk loop is a latency chain, and with 2 splits N = 30720 took 19.4 ms against 10.9 ms with 7
-  const int base = 6 * P.n_rp * P.ngroups;
-  const int want = g_dense_bwd_waves > 0 ? g_dense_bwd_waves : (base > 1600 ? base : 1600);
-  int KS = ceil_div(want, P.n_rp * P.ngroups);
-  if (KS < 1) KS = 1;
-  if (KS > P.nchunks) KS = P.nchunks;
-  P.cps = ceil_div(P.nchunks, KS);
+  // K split of the dL/dcoeff kernel.  Its waves are MFMA chains of cps chunks (768 MFMAs of 64 cycles each per chunk) and a k-split's blocks
+  // all run on ONE XCD (ks % 8: its Pd_k panel stays in that L2), so the launch takes  max over XCDs of  ceil(waves on the XCD / 128 SIMDs) x cps
+  // chunk times: pick the split that minimises it (+ a little per split for the partial slabs the reduction reads).  Round 5: N = 1920 went
+  // from 27 splits x 4 chunks (240 waves on three of the XCDs = two rounds, 8 chunk times) to 16 x 7 (120 waves per XCD, 7), 0.488 -> 0.435 ms.
+  // ha_tune_set("dense_bwd_waves", w) overrides with the old rule (about w waves).
+  const int items = P.n_rp * P.ngroups, bpk = ceil_div(items, 4);
+  int cps = 1;
+  if (g_dense_bwd_waves > 0) {
+    int KS = ceil_div(g_dense_bwd_waves, items);
+    KS = KS < 1 ? 1 : (KS > P.nchunks ? P.nchunks : KS);
+    cps = ceil_div(P.nchunks, KS);
+  } else {
+    double best = 1e300;
+    for (int c = 1; c <= P.nchunks; ++c) {
+      const int KS = ceil_div(P.nchunks, c);
+      if ((size_t)KS * N * P.ld > ((size_t)1 << 28) && c < P.nchunks) continue;      // partial slabs: at most 1 GiB
+      int worst = 0;
+      for (int x = 0; x < 8; ++x) {
+        const int nks = KS > x ? (KS - x + 7) / 8 : 0;
+        const int rounds = ceil_div(nks * bpk * 4, 128);
+        worst = rounds > worst ? rounds : worst;
+      }
+      const double cost = (double)worst * c + 0.05 * KS;
+      if (cost < best) { best = cost; cps = c; }
+    }
+  }
+  P.cps = cps;
   P.KS = ceil_div(P.nchunks, P.cps);
   size_t o = 0;
   auto take = [&](size_t n) { const size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
@@ -2024,8 +2159,14 @@ extern "C" int ha_smpl_backward_dense(const ha_smpl_model* m, int N, int n_activ
                      ws + P.off_gvp, ws + P.off_gtl, m->V, m->J, P.nchunks, P.np);
   HA_LAUNCH_CHECK();
   if (g_dense_gA_sparse == 2 && m->gc_joint)
-    hipLaunchKernelGGL(compressed_gA_kernel, dim3(N), dim3(256), (size_t)4 * 64 * 12 * sizeof(float), st, g_verts, v_posed, m->gc_joint, m->gc_w,
-                       m->gc_ng, ws + P.off_gA, m->V, m->Vpad, m->J);
+  {
+    if ((m->V & 1) == 0 && (reinterpret_cast<uintptr_t>(g_verts) & 7) == 0 && (reinterpret_cast<uintptr_t>(v_posed) & 7) == 0)
+      hipLaunchKernelGGL(compressed_gA_kernel<true>, dim3(N), dim3(256), (size_t)(4 * 64 * 12 + 4 * GA_STAGE) * sizeof(float), st, g_verts, v_posed,
+                         m->gc_joint, m->gc_w, m->gc_ng, ws + P.off_gA, m->V, m->Vpad, m->J);
+    else
+      hipLaunchKernelGGL(compressed_gA_kernel<false>, dim3(N), dim3(256), (size_t)(4 * 64 * 12 + 4 * GA_STAGE) * sizeof(float), st, g_verts, v_posed,
+                         m->gc_joint, m->gc_w, m->gc_ng, ws + P.off_gA, m->V, m->Vpad, m->J);
+  }
   else if (g_dense_gA_sparse)
     hipLaunchKernelGGL(sparse_gA_kernel, dim3(N), dim3(256), 0, st, g_verts, v_posed, m->ja_start, m->ja_v, m->ja_w, m->ja_order, ws + P.off_gA,
                        m->V, m->J);
@@ -2036,8 +2177,17 @@ extern "C" int ha_smpl_backward_dense(const ha_smpl_model* m, int N, int n_activ
   {
     const int bpk = ceil_div(P.n_rp * P.ngroups, 4);
     const int nblk = 8 * ceil_div(P.KS, 8) * bpk;
-    hipLaunchKernelGGL(dense_gco_kernel, dim3(nblk), dim3(256), 0, st, ws + P.off_gvp, s0.Pd_k, ws + P.off_gco, N, P.nchunks, Kp, P.ngroups, P.n_rp,
-                       P.KS, P.cps, N, P.ld);
+    // row pairs of 64 frames a block's four waves can span (their items are consecutive (row pair, coefficient group) pairs)
+    const int nrp_max = P.ngroups == 1 ? 4 : (P.ngroups % 4 == 0 ? 1 : 2);
+    const size_t lds_gco = (size_t)2 * nrp_max * GCO_RP_FLOATS * sizeof(float);
+#ifndef HA_SIMT_EMU
+    if (lds_gco > 64 * 1024 && !m->gco_lds_attr_set) {      // (one 128-coefficient group only: four row pairs per block, 74 KB)
+      HA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_gco_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      m->gco_lds_attr_set = true;
+    }
+#endif
+    hipLaunchKernelGGL(dense_gco_kernel, dim3(nblk), dim3(GCO_THREADS), lds_gco, st, ws + P.off_gvp, s0.Pd_k, ws + P.off_gco, N, P.nchunks, Kp, P.ngroups, P.n_rp,
+                       P.KS, P.cps, N, P.ld, nrp_max);
     HA_LAUNCH_CHECK();
   }
   FrameParams p;

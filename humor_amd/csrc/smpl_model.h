@@ -33,6 +33,7 @@ struct VertexSet {
 
 struct ha_smpl_model {
   int device = 0;
+  mutable bool gco_lds_attr_set = false;     // dense_gco_kernel's > 64 KB dynamic-LDS attribute (single-group launches only)
   mutable bool fused_lds_attr_set = false;   // pose_blend_skin_kernel's 80 KB dynamic-LDS attribute has been set on this handle's device
   int V = 0, J = 0, NB = 0, P = 0;
   int Kfull = 0;      // NB + 1 + P
@@ -62,7 +63,7 @@ struct ha_smpl_model {
   // experiment (ha_tune_set("dense_gA_sparse", 2)): per 64-vertex chunk the joints it touches, in groups of 16 slots, and its weights
   // against those slots (SMPL's vertex order is coherent: 8 joints per chunk on average, 17-18 at most -> one or two groups)
   int32_t* gc_joint = nullptr;   // [Vpad/64][32], -1 = unused slot; null when some chunk touches more than 32 joints
-  float* gc_w = nullptr;         // [Vpad/64][64][32]
+  float* gc_w = nullptr;         // [Vpad/64][2 slot groups][4 k-quarters][16 slots][16]: weight of vertex 64 c + 4 e + kq in slot 16 g + s
   int32_t* gc_ng = nullptr;      // [Vpad/64] slot groups in use (1 or 2)
   ha::VertexSet sets[ha::kMaxSubsets];
   // host copies kept for defining subsets later

@@ -47,6 +47,23 @@ def test_dense_backward_kernels(gpu_lib, smplh_npz, smplh_struct, dev, N, hands,
         gpu_lib.call('ha_tune_set', b'dense_gA_sparse', 2)
 
 
+@pytest.mark.parametrize('num_verts', [1101, 1100])
+def test_dense_backward_small_models_odd_vertex_count(gpu_lib, dev, tmp_path, num_verts):
+    """The chunk-compressed dL/dA kernel stages a chunk's 192 + 192 floats with 8-byte loads when the frame stride V * 3 floats is 8-byte
+    aligned (V even) and with scalar loads otherwise; both against the oracle on models with a ragged last 64-vertex chunk."""
+    import numpy as np
+    from humor_amd import synth
+    npz = synth.write_smplh_npz(str(tmp_path / f'model_{num_verts}.npz'), seed=1, num_verts=num_verts)
+    data = np.load(npz)
+
+    class DS:
+        pass
+    ds = DS()
+    for k in data.files:
+        setattr(ds, k, data[k])
+    SC.check_forward_backward(gpu_lib, npz, ds, N=5, device=dev, hands=True, selector=False, algo=2, dense_grad=True)
+
+
 def test_golden_vectors(gpu_lib, smplh_npz, dev):
     SC.check_golden(gpu_lib, smplh_npz, dev)
 

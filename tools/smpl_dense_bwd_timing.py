@@ -63,15 +63,15 @@ def main():
         print(f'  {name}: max |frame - dense| = {(a - b).abs().max().item():.3e}  (scale {a.abs().max().item():.3e})')
     lib.call('ha_tune_set', b'dense_gA_sparse', 0)
     t_mfma = timeit(dense, 20)
-    lib.call('ha_tune_set', b'dense_gA_sparse', 2)
-    t_comp = timeit(dense, 20)
-    g_comp = [t.clone() for t in out['dense']]
     lib.call('ha_tune_set', b'dense_gA_sparse', 1)
+    t_list = timeit(dense, 20)
+    g_list = [t.clone() for t in out['dense']]
+    lib.call('ha_tune_set', b'dense_gA_sparse', 2)
     dense()
     torch.cuda.synchronize()
-    d_comp = max((a - b).abs().max().item() for a, b in zip(g_comp, out['dense']))
-    print(f'  dL/dA as the dense 64-column MFMA product (dense_gA_sparse=0): {t_mfma:.3f} ms; by joint lists (default): {t_dense:.3f} ms; '
-          f'chunk-compressed MFMA product (2, experiment): {t_comp:.3f} ms (max |difference| to the default {d_comp:.2e})')
+    d_comp = max((a - b).abs().max().item() for a, b in zip(g_list, out['dense']))
+    print(f'  dL/dA variants (ha_tune_set dense_gA_sparse): chunk-compressed MFMA product (2, default) {t_dense:.3f} ms; joint lists (1) {t_list:.3f} ms; '
+          f'dense 64-column MFMA product (0) {t_mfma:.3f} ms (max |difference| default vs joint lists {d_comp:.2e})')
     for waves in [int(w) for w in os.environ.get("WAVES", "1600").split(",")]:
         lib.call('ha_tune_set', b'dense_bwd_waves', waves)
         lib.call('ha_smpl_backward_dense_workspace', h.ptr, N, n_active, C.byref(nw))
