@@ -1570,11 +1570,7 @@ __global__ __launch_bounds__(256) void compressed_gA_kernel(const float* __restr
   const int ia = (a < 3 ? a : 0) + 3 * kq, ib = 192 + (b < 3 ? b : 0) + 3 * kq;
   // two chunks ahead: an iteration (~1 k cycles) is shorter than the memory latency under load
   vf2 nxt[4], nx2[4];
-#ifdef HA_SIMT_EMU
-  const int w0 = wave;
-#else
   const int w0 = __builtin_amdgcn_readfirstlane(wave);      // (wave-uniform: the chunk index and its table loads stay scalar)
-#endif
   if (w0 < nch) {
     fetch(w0, nxt);
     fetch(w0 + 4 < nch ? w0 + 4 : w0, nx2);

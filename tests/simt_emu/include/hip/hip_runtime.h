@@ -93,6 +93,9 @@ static inline int __any(int pred) {
   for (int off = 32; off >= 1; off >>= 1) v |= simt_emu::shfl_any(v, simt_emu::lane_id() ^ off);
   return v;
 }
+static inline int __all(int pred) { return !__any(!pred); }
+// (every lane of the wavefront calls it: lane 0's value)
+template <typename T> static inline T __builtin_amdgcn_readfirstlane(T v) { return simt_emu::shfl_any(v, 0); }
 static inline float atomicAdd(float* p, float v) {
   std::atomic_ref<float> r(*p);
   float old = r.load();
