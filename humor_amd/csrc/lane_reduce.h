@@ -14,6 +14,24 @@
 namespace ha {
 namespace lr {
 
+#ifdef HA_SIMT_EMU
+// Host SIMT emulator (CPU test tier): only what the exchange consumers of rollout_persist.hip need (gather_norm / gather_norm_bwd) -- the
+// same sums by shuffles (v + v rotated by 8, 4, 2 inside the 16-lane row: the lanes of equal parity); everything else in this file is
+// gfx950 inline asm and stays out of the emulator build.
+__device__ __forceinline__ float emu_add_ror(float v, int ror) {
+  const int l = (int)(threadIdx.x & 63);
+  return v + __shfl(v, (l & ~15) | ((l + ror) & 15));
+}
+__device__ __forceinline__ void parity_sum2(float (&t)[2]) {
+  for (int ror = 8; ror >= 2; ror >>= 1)
+    for (int i = 0; i < 2; ++i) t[i] = emu_add_ror(t[i], ror);
+}
+__device__ __forceinline__ void parity_sum4(float (&t)[4]) {
+  for (int ror = 8; ror >= 2; ror >>= 1)
+    for (int i = 0; i < 4; ++i) t[i] = emu_add_ror(t[i], ror);
+}
+#else
+
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void swap32(float& a, float& b) {
@@ -232,5 +250,6 @@ __device__ __forceinline__ float block_sum4(const float (&v)[4]) {
   return add_ror8(add_ror4(a + b));
 }
 
+#endif  // !HA_SIMT_EMU
 }  // namespace lr
 }  // namespace ha

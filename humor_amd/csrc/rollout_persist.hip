@@ -31,9 +31,7 @@
 #include <vector>
 
 #include "rot_math.h"
-#ifndef HA_SIMT_EMU
 #include "lane_reduce.h"
-#endif
 
 namespace ha {
 
@@ -156,8 +154,8 @@ struct PersistNet {
   long long launches = 0, launches_bwd = 0;
 };
 
-#ifndef HA_SIMT_EMU
-
+// (the exchange consumers below -- sweeps, slot map, GroupNorm (+ adjoint) -- also compile for the host SIMT emulator: tests/test_rollout_emu.py
+// runs them against PyTorch through the ha_emu_* hooks at the end of this file; everything from the MFMA code on is gfx950 only)
 typedef float pvf4 __attribute__((ext_vector_type(4)));
 typedef unsigned puv4 __attribute__((ext_vector_type(4)));
 
@@ -348,6 +346,8 @@ __device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned 
   norm_pairs<NK, GROUP>(x, gam, bet, xs, tid, stats, row0);
   return true;
 }
+
+#ifndef HA_SIMT_EMU
 
 // one layer's share of a wave: all K chunks against the resident weight registers.  The A operands come from LDS in batches of
 // MB chunks, the next batch's reads issued ahead of the current batch's MFMAs (the compiler otherwise waits for every read right
@@ -1150,6 +1150,8 @@ __device__ __forceinline__ void head_adj(const HeadPrep& o, const RodPrep& p, co
   g_p3 = -g_ry;
 }
 
+#endif  // !HA_SIMT_EMU
+
 // consumer side of an activation adjoint: sweep dL/da (a = ReLU(GroupNorm(h))), the forward's h and statistics, GroupNorm/ReLU
 // adjoint (gn_apply mode 3 of the launch chain: dh = rstd (dxh - mean(dxh) - xh mean(dxh xh))), dh to LDS as [channel][4 rows].
 // The forward's pre-activations and statistics come from HBM / the Infinity Cache (~2 us): they are requested one phase early
@@ -1208,6 +1210,8 @@ __device__ __forceinline__ bool gather_norm_bwd(__amdgpu_buffer_rsrc_t rs, unsig
   }
   return true;
 }
+
+#ifndef HA_SIMT_EMU
 
 template <bool SC1>
 __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd_kernel(PersistBwdArgs a) {
@@ -2135,4 +2139,65 @@ int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_
 #endif
 }
 
+
+#ifdef HA_SIMT_EMU
+// ---- CPU test tier only (host SIMT emulator build; not part of libhumor_amd.so): the exchange consumers on a prepared exchange region --------
+// tests/test_rollout_emu.py fills a region the way publish() does -- the {value, tag} granules of channel c, row pair p at byte
+// ha_emu_xslot(c) * 32 + 16 p -- and checks gather_norm (GroupNorm + ReLU, statistics) and gather_norm_bwd (its adjoint) against PyTorch.
+template <int NQ, int GROUP>
+__global__ void emu_gather_norm_kernel(const unsigned char* xch, unsigned tag, const float* gamma, const float* beta, float* xs_out, float* stats, int row0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int C = NQ * 256;
+  float* gb = smem;
+  float* xs = smem + 4 * C;
+  const int tid = threadIdx.x;
+  gb_fill<true>(gb, gamma, beta, C, tid);
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xch, 0, C * 32, 0x00020000);
+  const bool ok = gather_norm<NQ, GROUP>(rs, 0u, tag, gb, xs, tid, stats, row0);
+  __syncthreads();
+  for (int i = tid; i < 4 * C; i += 256) xs_out[i] = ok ? xs[i] : as_f(0x7fc00000u);
+}
+template <int NQ, int GROUP>
+__global__ void emu_gather_norm_bwd_kernel(const unsigned char* xch, unsigned tag, const float* gamma, const float* beta, const float* ht, const float* stats,
+                                           float* ds_out, int row0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int C = NQ * 256;
+  float* gb = smem;
+  float* ds = smem + 2 * C;
+  const int tid = threadIdx.x;
+  gb_fill<false>(gb, gamma, beta, C, tid);
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xch, 0, C * 32, 0x00020000);
+  GnbRegs<NQ> gr;
+  gnb_issue<NQ, GROUP>(ht, stats, row0, tid, gr);
+  const bool ok = gather_norm_bwd<NQ, GROUP>(rs, 0u, tag, gb, gr, ds, tid);
+  __syncthreads();
+  for (int i = tid; i < 4 * C; i += 256) ds_out[i] = ok ? ds[i] : as_f(0x7fc00000u);
+}
+}  // namespace ha
+
+extern "C" int ha_emu_xslot(int group, int col) { return group == 64 ? ha::xslot<64>(col) : (group == 32 ? ha::xslot<32>(col) : ha::xslot<0>(col)); }
+// group 64: a 1024-channel activation (layers 1 / 2), group 32: the 512-channel one (layer 3)
+extern "C" int ha_emu_gather_norm(int group, const void* xch, unsigned tag, const float* gamma, const float* beta, float* xs_out, float* stats, int row0) {
+  if (group == 64)
+    hipLaunchKernelGGL((ha::emu_gather_norm_kernel<4, 64>), dim3(1), dim3(256), 0, nullptr, static_cast<const unsigned char*>(xch), tag, gamma, beta, xs_out, stats, row0);
+  else if (group == 32)
+    hipLaunchKernelGGL((ha::emu_gather_norm_kernel<2, 32>), dim3(1), dim3(256), 0, nullptr, static_cast<const unsigned char*>(xch), tag, gamma, beta, xs_out, stats, row0);
+  else
+    return HA_ERR_INVALID_ARG;
+  return HA_OK;
+}
+extern "C" int ha_emu_gather_norm_bwd(int group, const void* xch, unsigned tag, const float* gamma, const float* beta, const float* ht, const float* stats,
+                                      float* ds_out, int row0) {
+  if (group == 64)
+    hipLaunchKernelGGL((ha::emu_gather_norm_bwd_kernel<4, 64>), dim3(1), dim3(256), 0, nullptr, static_cast<const unsigned char*>(xch), tag, gamma, beta, ht, stats, ds_out, row0);
+  else if (group == 32)
+    hipLaunchKernelGGL((ha::emu_gather_norm_bwd_kernel<2, 32>), dim3(1), dim3(256), 0, nullptr, static_cast<const unsigned char*>(xch), tag, gamma, beta, ht, stats, ds_out, row0);
+  else
+    return HA_ERR_INVALID_ARG;
+  return HA_OK;
+}
+namespace ha {
+#endif
 }  // namespace ha

@@ -103,6 +103,19 @@ static inline float atomicAdd(float* p, float v) {
   return old;
 }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
+static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+static inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+// buffer descriptor + raw buffer loads (the exchange sweeps of rollout_persist.hip): base pointer + byte offset
+struct __amdgpu_buffer_rsrc_t { const unsigned char* base; };
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(const void* p, int, int, int) { return __amdgpu_buffer_rsrc_t{static_cast<const unsigned char*>(p)}; }
+typedef unsigned emu_uv4 __attribute__((ext_vector_type(4)));
+static inline emu_uv4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int) {
+  emu_uv4 v;
+  std::memcpy(&v, rs.base + voff + soff, 16);
+  return v;
+}
 
 // v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D col = l&31, row = (r&3)+8*(r>>2)+4*(l>>5)
 typedef float f32x16_emu __attribute__((ext_vector_type(16)));

@@ -123,3 +123,61 @@ def test_infer_global_seq_fixture_module_path():
 def test_emu_posterior_gives_parameter_gradients(emu_lib):
     """a training-mode infer_step must leave gradients on the encoder / prior weights (module forward), frozen nets run fused."""
     MC.check_posterior_param_grads(emu_lib, CPU, N=3)
+
+
+@pytest.mark.parametrize('group', [64, 32])
+def test_emu_exchange_consumers_groupnorm_and_adjoint(emu_lib, group):
+    """The consumer side of the persistent kernels' team exchange on the host emulator (rollout_persist.hip: sweep_pairs, the xslot / xchan
+    slot map, norm_pairs, gather_norm, gnb_issue, gather_norm_bwd -- the code that is a third of a persistent step and had no CPU-tier run):
+    an exchange region is filled the way publish() fills it -- {value, tag} granules of channel c, row pair p at byte xslot(c) * 32 + 16 p --
+    and one 256-thread block normalises it.  Checked against PyTorch: GroupNorm(16 groups) + ReLU of the 4 rows as the [channel][4 rows] MFMA
+    operand, the (mean, rstd) statistics in the stash layout [group][32 rows][2], and the GroupNorm / ReLU adjoint of a second, swept dL/da."""
+    import ctypes as C
+    dll = emu_lib._dll
+    nch = 1024 if group == 64 else 512
+    g = torch.Generator().manual_seed(group)
+    h = torch.randn(nch, 4, generator=g) * 1.5 + 0.3                       # pre-activations [channel][row]
+    gamma, beta = torch.rand(nch, generator=g) + 0.5, 0.3 * torch.randn(nch, generator=g)
+    tag, row0 = 41, 8
+
+    def region(vals):
+        words = torch.zeros(nch * 8, dtype=torch.int32)
+        bits = vals.contiguous().view(torch.int32)
+        for c in range(nch):
+            s = dll.ha_emu_xslot(group, c)
+            assert 0 <= s < nch
+            for p in range(2):
+                o = s * 8 + p * 4
+                words[o], words[o + 1], words[o + 2], words[o + 3] = bits[c, 2 * p], tag, bits[c, 2 * p + 1], tag
+        return words
+    slots = sorted(dll.ha_emu_xslot(group, c) for c in range(nch))
+    assert slots == list(range(nch))                                       # a permutation of the region's slots
+    fp = lambda t: t.data_ptr()
+    vp = C.c_void_p
+    xs = torch.zeros(nch * 4)
+    stats = torch.zeros(16 * 32 * 2)
+    xch = region(h)
+    dll.ha_emu_gather_norm.argtypes = [C.c_int, vp, C.c_uint, vp, vp, vp, vp, C.c_int]
+    assert dll.ha_emu_gather_norm(group, fp(xch), tag, fp(gamma), fp(beta), fp(xs), fp(stats), row0) == 0
+    hr = h.t().reshape(4, 16, group).double()                              # [row][group][channel in group]
+    mean, var = hr.mean(2), hr.var(2, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    a_ref = torch.relu((hr - mean[:, :, None]) * rstd[:, :, None] * gamma.double().reshape(16, group) + beta.double().reshape(16, group))
+    a_ref = a_ref.reshape(4, nch).t()                                      # [channel][row]
+    assert (xs.reshape(nch, 4).double() - a_ref).abs().max().item() < 2e-6
+    st = stats.reshape(16, 32, 2)[:, row0:row0 + 4].double()               # [group][4 rows][(mean, rstd)]
+    assert (st[:, :, 0] - mean.t()).abs().max().item() < 1e-6
+    assert ((st[:, :, 1] - rstd.t()).abs() / rstd.t()).max().item() < 1e-6
+    assert stats.reshape(16, 32, 2)[:, :row0].abs().max().item() == 0 and stats.reshape(16, 32, 2)[:, row0 + 4:].abs().max().item() == 0
+    # adjoint: dL/da arrives through the exchange, h ([channel][4 rows]) and the statistics from the forward's stash
+    ga = torch.randn(nch, 4, generator=g)
+    hq = h.clone().double().requires_grad_(True)
+    hq_r = hq.t().reshape(4, 16, group)
+    m2, v2 = hq_r.mean(2, keepdim=True), hq_r.var(2, unbiased=False, keepdim=True)
+    a2 = torch.relu((hq_r - m2) / torch.sqrt(v2 + 1e-5) * gamma.double().reshape(16, group) + beta.double().reshape(16, group)).reshape(4, nch).t()
+    (a2 * ga.double()).sum().backward()
+    ds = torch.zeros(nch * 4)
+    dll.ha_emu_gather_norm_bwd.argtypes = [C.c_int, vp, C.c_uint, vp, vp, vp, vp, vp, C.c_int]
+    assert dll.ha_emu_gather_norm_bwd(group, fp(region(ga)), tag, fp(gamma), fp(beta), fp(h.contiguous()), fp(stats), fp(ds), row0) == 0
+    scale = hq.grad.abs().max().item()
+    assert (ds.reshape(nch, 4).double() - hq.grad).abs().max().item() < 2e-5 * max(1.0, scale)
