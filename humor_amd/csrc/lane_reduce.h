@@ -15,20 +15,44 @@ namespace ha {
 namespace lr {
 
 #ifdef HA_SIMT_EMU
-// Host SIMT emulator (CPU test tier): only what the exchange consumers of rollout_persist.hip need (gather_norm / gather_norm_bwd) -- the
-// same sums by shuffles (v + v rotated by 8, 4, 2 inside the 16-lane row: the lanes of equal parity); everything else in this file is
-// gfx950 inline asm and stays out of the emulator build.
+// Host SIMT emulator (CPU test tier): the PRIMITIVES of this file as shuffles with the semantics stated above (the gfx950 forms below are
+// builtins / inline asm); the composite sums further down are shared source.  tests/test_rollout_emu.py runs them through the ha_emu_* hooks of
+// rollout_persist.hip; tools/microbench/persist_probe.hip runs the real instructions on the GPU against the same host sums.
+__device__ __forceinline__ int emu_lane() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ void swap32(float& a, float& b) {      // a' = {a.lo, b.lo}, b' = {a.hi, b.hi}
+  const int l = emu_lane();
+  const float pa = __shfl(a, l ^ 32), pb = __shfl(b, l ^ 32);
+  if (l < 32) b = pa; else a = pb;
+}
+__device__ __forceinline__ void swap16(float& a, float& b) {      // a' = {a.r0, b.r0, a.r2, b.r2}, b' = {a.r1, b.r1, a.r3, b.r3}
+  const int l = emu_lane();
+  const float pa = __shfl(a, l ^ 16), pb = __shfl(b, l ^ 16);
+  if (((l >> 4) & 1) == 0) b = pa; else a = pb;
+}
 __device__ __forceinline__ float emu_add_ror(float v, int ror) {
-  const int l = (int)(threadIdx.x & 63);
+  const int l = emu_lane();
   return v + __shfl(v, (l & ~15) | ((l + ror) & 15));
 }
-__device__ __forceinline__ void parity_sum2(float (&t)[2]) {
-  for (int ror = 8; ror >= 2; ror >>= 1)
-    for (int i = 0; i < 2; ++i) t[i] = emu_add_ror(t[i], ror);
+__device__ __forceinline__ float add_ror8(float v) { return emu_add_ror(v, 8); }
+__device__ __forceinline__ float add_ror4(float v) { return emu_add_ror(v, 4); }
+__device__ __forceinline__ float add_ror2(float v) { return emu_add_ror(v, 2); }
+__device__ __forceinline__ float add_ror1(float v) { return emu_add_ror(v, 1); }
+template <int N, int R0, int R1>
+__device__ __forceinline__ void emu_stages(float (&t)[N]) {       // (stage by stage over the N values, as the asm blocks order them)
+  for (int ror = R0; ror >= R1; ror >>= 1)
+    for (int i = 0; i < N; ++i) t[i] = emu_add_ror(t[i], ror);
 }
-__device__ __forceinline__ void parity_sum4(float (&t)[4]) {
-  for (int ror = 8; ror >= 2; ror >>= 1)
+__device__ __forceinline__ void row_sum4(float (&t)[4]) { emu_stages<4, 8, 1>(t); }
+__device__ __forceinline__ void row_sum8(float (&t)[8]) { emu_stages<8, 8, 1>(t); }
+__device__ __forceinline__ void parity_sum2(float (&t)[2]) { emu_stages<2, 8, 2>(t); }
+__device__ __forceinline__ void parity_sum4(float (&t)[4]) { emu_stages<4, 8, 2>(t); }
+__device__ __forceinline__ void kblock_sum4(float (&t)[4]) {
+  for (int ror = 4; ror <= 8; ror <<= 1)
     for (int i = 0; i < 4; ++i) t[i] = emu_add_ror(t[i], ror);
+}
+__device__ __forceinline__ void kblock_sum2(float (&t)[2]) {
+  for (int ror = 4; ror <= 8; ror <<= 1)
+    for (int i = 0; i < 2; ++i) t[i] = emu_add_ror(t[i], ror);
 }
 #else
 
@@ -111,6 +135,8 @@ __device__ __forceinline__ void parity_sum4(float (&t)[4]) {
 #undef HA_LR_PS4
 }
 
+#endif  // primitives, part 1 (HA_SIMT_EMU)
+
 template <int N>
 __device__ __forceinline__ void row_sum(float (&t)[N]) {
   if constexpr (N == 4) row_sum4(t);
@@ -183,6 +209,7 @@ __device__ __forceinline__ void half_sum8(float (&v)[8]) {
 // independent values in one asm block: a value's second add reads its first add's result three (two, with the s_nop) instructions
 // later, so the block needs one leading s_nop instead of one per add -- and the four dependent chains overlap instead of running one
 // after the other (a wave that owns a SIMD alone has nobody else to hide the DPP latency behind).
+#ifndef HA_SIMT_EMU
 __device__ __forceinline__ void kblock_sum4(float (&t)[4]) {
 #define HA_LR_KB4(ROR)                                                                \
   "v_add_f32_dpp %0, %0, %0 row_ror:" #ROR " row_mask:0xf bank_mask:0xf\n\t"         \
@@ -201,6 +228,7 @@ __device__ __forceinline__ void kblock_sum2(float (&t)[2]) {
                "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
                : "+v"(t[0]), "+v"(t[1]));
 }
+#endif  // !HA_SIMT_EMU
 // block_sum8 without its last two stages: afterwards out[0], out[1] still have to be summed over the row's four k-blocks (kblock_sum*)
 __device__ __forceinline__ void block_sum8_head(const float (&v)[8], float (&out)[2]) {
   float u[4];
@@ -250,6 +278,5 @@ __device__ __forceinline__ float block_sum4(const float (&v)[4]) {
   return add_ror8(add_ror4(a + b));
 }
 
-#endif  // !HA_SIMT_EMU
 }  // namespace lr
 }  // namespace ha

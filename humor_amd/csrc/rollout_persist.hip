@@ -450,6 +450,8 @@ __device__ __forceinline__ void mma_layer(const float* xs, const float* zs, cons
   }
 }
 
+#endif  // !HA_SIMT_EMU  (publish() below is shared with the emulator build)
+
 // publishes the wave's NCG column groups (columns col0 + 4 g + j) of layer-output `off`.  The k-block partials are summed with the
 // reduce-scatter of lane_reduce.h, which leaves lane (half h, row parity p, column j, k-block 0) with
 //   NCG = 2: column group h, rows 2 p and 2 p + 1  -> ONE 16-byte store of two {value, tag} granules,
@@ -497,6 +499,8 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
     }
   }
 }
+
+#ifndef HA_SIMT_EMU
 
 // The 3x3 helpers of common.h with contraction allowed (the library is built -ffp-contract=off; the glue chains of this file are
 // instruction-issue bound on one or two waves per CU, and a*b + c*d + e*f as mul + 2 fma is 3 instructions instead of 5 -- and rounds
@@ -2175,6 +2179,48 @@ __global__ void emu_gather_norm_bwd_kernel(const unsigned char* xch, unsigned ta
   __syncthreads();
   for (int i = tid; i < 4 * C; i += 256) ds_out[i] = ok ? ds[i] : as_f(0x7fc00000u);
 }
+// lane_reduce.h composites on per-lane inputs (what tools/microbench/persist_probe.hip does on the GPU): in [n][64 lanes] -> out [n_out][64 lanes]
+__global__ void emu_lane_reduce_kernel(int which, const float* in, float* out) {
+  const int l = threadIdx.x & 63;
+  if (which == 0) {             // wave_sum16
+    float v[16];
+    for (int i = 0; i < 16; ++i) v[i] = in[i * 64 + l];
+    lr::wave_sum16(v);
+    for (int i = 0; i < 16; ++i) out[i * 64 + l] = v[i];
+  } else if (which == 1) {      // half_sum8
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = in[i * 64 + l];
+    lr::half_sum8(v);
+    for (int i = 0; i < 8; ++i) out[i * 64 + l] = v[i];
+  } else if (which == 2) {      // block_sum8
+    float v[8], o[2];
+    for (int i = 0; i < 8; ++i) v[i] = in[i * 64 + l];
+    lr::block_sum8(v, o);
+    out[l] = o[0]; out[64 + l] = o[1];
+  } else if (which == 3) {      // block_sum4
+    float v[4];
+    for (int i = 0; i < 4; ++i) v[i] = in[i * 64 + l];
+    out[l] = lr::block_sum4(v);
+  } else {                      // block_sum8_head + kblock_sum2 (the pipelined kernels' split form)
+    float v[8], o[2];
+    for (int i = 0; i < 8; ++i) v[i] = in[i * 64 + l];
+    lr::block_sum8_head(v, o);
+    lr::kblock_sum2(o);
+    out[l] = o[0]; out[64 + l] = o[1];
+  }
+}
+// publish() of every wave of a team for one layer output: wave g (block g / 4) holds the MFMA partials `sums` of its 4 NCG columns x 4 rows
+// (in [g][4 NCG values][64 lanes]); writes the exchange region, the launch-chain slab and the team-layout copy
+template <int NCG, int GW>
+__global__ void emu_publish_kernel(const float* sums_in, const float* bias, unsigned char* xch, unsigned tag, float* slab, float* ht, int row0) {
+  const int lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  float sums[4 * NCG];
+  for (int i = 0; i < 4 * NCG; ++i) sums[i] = sums_in[((size_t)g * 4 * NCG + i) * 64 + lane];
+  const int j4 = lane & 3, h4 = 4 * (lane >> 5);
+  const float b = NCG == 2 ? bias[8 * g + h4 + j4] : bias[4 * g + j4];
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xch, 0, 1 << 20, 0x00020000);
+  publish<NCG, true, GW>(sums, b, 4 * NCG * g, xch, rs, 0u, tag, slab, row0, lane, ht);
+}
 }  // namespace ha
 
 extern "C" int ha_emu_xslot(int group, int col) { return group == 64 ? ha::xslot<64>(col) : (group == 32 ? ha::xslot<32>(col) : ha::xslot<0>(col)); }
@@ -2196,6 +2242,20 @@ extern "C" int ha_emu_gather_norm_bwd(int group, const void* xch, unsigned tag, 
     hipLaunchKernelGGL((ha::emu_gather_norm_bwd_kernel<2, 32>), dim3(1), dim3(256), 0, nullptr, static_cast<const unsigned char*>(xch), tag, gamma, beta, ht, stats, ds_out, row0);
   else
     return HA_ERR_INVALID_ARG;
+  return HA_OK;
+}
+extern "C" int ha_emu_lane_reduce(int which, const float* in, float* out) {
+  hipLaunchKernelGGL(ha::emu_lane_reduce_kernel, dim3(1), dim3(64), 0, nullptr, which, in, out);
+  return HA_OK;
+}
+// ncg 2 / group 64: 128 waves x 8 columns = a 1024-channel activation; ncg 1 / group 32: 128 x 4 = 512; ncg 1 / group 0: `waves` x 4 columns, identity slots
+extern "C" int ha_emu_publish(int ncg, int group, int waves, const float* sums, const float* bias, void* xch, unsigned tag, float* slab, float* ht, int row0) {
+  unsigned char* x = static_cast<unsigned char*>(xch);
+  if (waves % 4 != 0) return HA_ERR_INVALID_ARG;
+  if (ncg == 2 && group == 64) hipLaunchKernelGGL((ha::emu_publish_kernel<2, 64>), dim3(waves / 4), dim3(256), 0, nullptr, sums, bias, x, tag, slab, ht, row0);
+  else if (ncg == 1 && group == 32) hipLaunchKernelGGL((ha::emu_publish_kernel<1, 32>), dim3(waves / 4), dim3(256), 0, nullptr, sums, bias, x, tag, slab, ht, row0);
+  else if (ncg == 1 && group == 0) hipLaunchKernelGGL((ha::emu_publish_kernel<1, 0>), dim3(waves / 4), dim3(256), 0, nullptr, sums, bias, x, tag, slab, ht, row0);
+  else return HA_ERR_INVALID_ARG;
   return HA_OK;
 }
 namespace ha {

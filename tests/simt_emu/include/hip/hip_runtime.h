@@ -111,6 +111,13 @@ static inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
 struct __amdgpu_buffer_rsrc_t { const unsigned char* base; };
 static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(const void* p, int, int, int) { return __amdgpu_buffer_rsrc_t{static_cast<const unsigned char*>(p)}; }
 typedef unsigned emu_uv4 __attribute__((ext_vector_type(4)));
+typedef unsigned emu_uv2 __attribute__((ext_vector_type(2)));
+static inline void __builtin_amdgcn_raw_buffer_store_b128(emu_uv4 v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int) {
+  std::memcpy(const_cast<unsigned char*>(rs.base) + voff + soff, &v, 16);
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b64(emu_uv2 v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int) {
+  std::memcpy(const_cast<unsigned char*>(rs.base) + voff + soff, &v, 8);
+}
 static inline emu_uv4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int) {
   emu_uv4 v;
   std::memcpy(&v, rs.base + voff + soff, 16);

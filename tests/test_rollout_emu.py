@@ -181,3 +181,82 @@ def test_emu_exchange_consumers_groupnorm_and_adjoint(emu_lib, group):
     assert dll.ha_emu_gather_norm_bwd(group, fp(region(ga)), tag, fp(gamma), fp(beta), fp(h.contiguous()), fp(stats), fp(ds), row0) == 0
     scale = hq.grad.abs().max().item()
     assert (ds.reshape(nch, 4).double() - hq.grad).abs().max().item() < 2e-5 * max(1.0, scale)
+
+
+def test_emu_lane_reductions(emu_lib):
+    """lane_reduce.h: the composite cross-lane sums of the persistent kernels (wave_sum16, half_sum8, block_sum8 / block_sum4 and the split form
+    block_sum8_head + kblock_sum2) on the emulator's shuffle forms of their primitives, against host sums -- the reduce-scatter bookkeeping (which
+    lane ends up with which total) is what publish() relies on.  (tools/microbench/persist_probe.hip checks the real instructions on the GPU.)"""
+    import ctypes as C
+    dll = emu_lib._dll
+    dll.ha_emu_lane_reduce.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    g = torch.Generator().manual_seed(7)
+    lanes = torch.arange(64)
+    for which, n_in, n_out in ((0, 16, 16), (1, 8, 8), (2, 8, 2), (3, 4, 1), (4, 8, 2)):
+        x = torch.randn(n_in, 64, generator=g)
+        out = torch.zeros(n_out, 64)
+        assert dll.ha_emu_lane_reduce(which, x.data_ptr(), out.data_ptr()) == 0
+        xd = x.double()
+        if which == 0:
+            ref = xd.sum(1, keepdim=True).expand(16, 64)
+        elif which == 1:
+            ref = torch.stack([xd[:, :32].sum(1), xd[:, 32:].sum(1)], 1)[:, (lanes >= 32).long()]
+        else:
+            # MFMA 4x4x1 accumulators: lane = 16 r + 4 b' + j is the partial of k-block 4 r + b' for column j = lane & 3
+            col_tot = torch.stack([xd[:, (lanes & 3) == j].sum(1) for j in range(4)], 1)          # [value][column]
+            h, p, j = lanes >> 5, (lanes >> 4) & 1, lanes & 3
+            if which == 3:
+                ref = col_tot[2 * h + p, j][None]                                                  # value 2 h + p
+            else:
+                ref = torch.stack([col_tot[4 * h + 2 * p, j], col_tot[4 * h + 2 * p + 1, j]])      # values 4 h + 2 p, 4 h + 2 p + 1
+        assert (out.double() - ref).abs().max().item() < 2e-5, which
+
+
+@pytest.mark.parametrize('ncg,group', [(2, 64), (1, 32), (1, 0)])
+def test_emu_publish_to_consumer_round_trip(emu_lib, ncg, group):
+    """Producer and consumer of one layer hand-off through the REAL publish(): every wave of a team holds the 4x4x1-MFMA partials of its columns
+    (16 k-block partials per (column, row), spread over the lanes as the accumulators are), publish() reduces them, adds the bias and writes the
+    {value, tag} granules, the launch-chain slab and the team-layout copy; gather_norm (the next layer's consumer) reads the region back.  Checks
+    the slot agreement of both sides, the row-pair granules, the slab / team layouts and the sums."""
+    import ctypes as C
+    dll = emu_lib._dll
+    vp = C.c_void_p
+    dll.ha_emu_publish.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_uint, vp, vp, C.c_int]
+    cols_per_wave = 4 * ncg
+    waves = 128 if group else 56
+    nch = waves * cols_per_wave
+    g = torch.Generator().manual_seed(10 * ncg + group)
+    H = torch.randn(nch, 4, generator=g)                                  # totals before the bias [column][row]
+    bias = 0.2 * torch.randn(nch, generator=g)
+    part = torch.randn(16, nch, 4, generator=g)
+    part[15] = H - part[:15].sum(0)                                        # 16 k-block partials that add up to H
+    lanes = torch.arange(64)
+    kb, j = (lanes >> 4) * 4 + ((lanes >> 2) & 3), lanes & 3               # lane = 16 r + 4 b' + j: k-block 4 r + b', column j
+    sums = torch.zeros(waves, 4 * ncg, 64)
+    for w in range(waves):
+        for cg in range(ncg):
+            for i in range(4):
+                sums[w, 4 * cg + i] = part[kb, cols_per_wave * w + 4 * cg + j, i]
+    tag, row0 = 9, 12
+    xch = torch.zeros(1 << 18, dtype=torch.int32)
+    slab = torch.zeros((nch // 4) * 128)
+    ht = torch.zeros(nch * 4)
+    assert dll.ha_emu_publish(ncg, group, waves, sums.data_ptr(), bias.data_ptr(), xch.data_ptr(), tag, slab.data_ptr(), ht.data_ptr(), row0) == 0
+    want = (part.double().sum(0) + bias.double()[:, None])                 # [column][row]
+    assert (ht.reshape(nch, 4).double() - want).abs().max().item() < 2e-5
+    sl = slab.reshape(nch // 4, 32, 4)[:, row0:row0 + 4]                    # [column quad][row][column in quad]
+    assert (sl.permute(0, 2, 1).reshape(nch, 4).double() - want).abs().max().item() < 2e-5
+    words = xch[:nch * 8].reshape(nch, 4, 2)                               # [slot][row][(value, tag)]
+    assert (words[:, :, 1] == tag).all() and (xch[nch * 8:] == 0).all()
+    if group == 0:
+        got = words[:, :, 0].contiguous().view(torch.float32)              # identity slot map (the decoder output: no GroupNorm consumer)
+        assert torch.equal(got, ht.reshape(nch, 4))
+        return
+    gamma, beta = torch.rand(nch, generator=g) + 0.5, 0.3 * torch.randn(nch, generator=g)
+    xs, stats = torch.zeros(nch * 4), torch.zeros(16 * 32 * 2)
+    dll.ha_emu_gather_norm.argtypes = [C.c_int, vp, C.c_uint, vp, vp, vp, vp, C.c_int]
+    assert dll.ha_emu_gather_norm(group, xch.data_ptr(), tag, gamma.data_ptr(), beta.data_ptr(), xs.data_ptr(), stats.data_ptr(), row0) == 0
+    hr = ht.reshape(nch, 4).t().reshape(4, 16, group).double()
+    a_ref = torch.relu((hr - hr.mean(2, keepdim=True)) / torch.sqrt(hr.var(2, unbiased=False, keepdim=True) + 1e-5) * gamma.double().reshape(16, group)
+                       + beta.double().reshape(16, group)).reshape(4, nch).t()
+    assert (xs.reshape(nch, 4).double() - a_ref).abs().max().item() < 2e-6
