@@ -347,8 +347,6 @@ __device__ __forceinline__ bool gather_norm(__amdgpu_buffer_rsrc_t rs, unsigned 
   return true;
 }
 
-#ifndef HA_SIMT_EMU
-
 // one layer's share of a wave: all K chunks against the resident weight registers.  The A operands come from LDS in batches of
 // MB chunks, the next batch's reads issued ahead of the current batch's MFMAs (the compiler otherwise waits for every read right
 // before its first use: one LDS round trip per 4 MFMAs); two accumulators per column group break the 2-pass dependent chain.
@@ -374,6 +372,15 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
 template <int R, bool FIRST, bool VNOP = true, int NWAS = 1, int NWVS = 1>
 __device__ __forceinline__ void mfma_w(pvf4& acc, float av, const float (&wa)[NWAS], const float (&wv)[NWVS]) {
   constexpr int NWA = NWAS;
+#ifdef HA_SIMT_EMU
+  // v_mfma_f32_4x4x1_16b_f32 on the host emulator: 16 independent blocks of four lanes; in block b the lane 4 b + j gets, for the rows i = 0..3,
+  // D[i] (+)= A(lane 4 b + i) * B(lane 4 b + j)
+  const float bw = R < NWA ? wa[R < NWA ? R : 0] : wv[R < NWA ? 0 : R - NWA];
+  const int l = (int)(threadIdx.x & 63);
+  pvf4 d = FIRST ? pvf4{0.f, 0.f, 0.f, 0.f} : acc;
+  for (int i = 0; i < 4; ++i) d[i] = fmaf(__shfl(av, (l & ~3) | i), bw, d[i]);
+  acc = d;
+#else
   if constexpr (R < NWA) {
     if constexpr (FIRST) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&" HA_ACC(acc) : "v"(av), "a"(wa[R]));
     else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+" HA_ACC(acc) : "v"(av), "a"(wa[R]));
@@ -388,6 +395,7 @@ __device__ __forceinline__ void mfma_w(pvf4& acc, float av, const float (&wa)[NW
     if constexpr (FIRST) asm volatile("s_nop 1\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&" HA_ACC(acc) : "v"(av), "v"(wv[R - NWA]));
     else asm volatile("s_nop 1\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+" HA_ACC(acc) : "v"(av), "v"(wv[R - NWA]));
   }
+#endif
 }
 template <int NC_MAIN, int NZ, int NCG, int ROFF, int FIRST, int NWAS, int NWVS>
 __device__ __forceinline__ void mma_batch(const float (&av)[MB], const float (&wa)[NWAS], const float (&wv)[NWVS], pvf4 (&acc)[NCG][8 / NCG]) {
@@ -435,12 +443,14 @@ __device__ __forceinline__ void mma_layer(const float* xs, const float* zs, cons
   MmaSteps<NC_MAIN, NZ, NCG, ROFF, 0, NWAS, NWVS>::run(xs, zs, wa, wv, lane, first, acc);
   // MFMA results -> VALU reads: a hazard the compiler cannot see (the MFMAs are opaque asm to it).  The wait is tied to every
   // accumulator ("+a"), otherwise the scheduler may place an accumulator read between the last MFMA and a free-standing s_nop.
+#ifndef HA_SIMT_EMU
   if constexpr (NCG == 2)
     asm volatile("s_nop 7" : "+" HA_ACC(acc[0][0]), "+" HA_ACC(acc[0][1]), "+" HA_ACC(acc[0][2]), "+" HA_ACC(acc[0][3]), "+" HA_ACC(acc[1][0]), "+" HA_ACC(acc[1][1]), "+" HA_ACC(acc[1][2]), "+" HA_ACC(acc[1][3]));
   else if constexpr (NACC == 8)
     asm volatile("s_nop 7" : "+" HA_ACC(acc[0][0]), "+" HA_ACC(acc[0][1]), "+" HA_ACC(acc[0][2]), "+" HA_ACC(acc[0][3]), "+" HA_ACC(acc[0][4]), "+" HA_ACC(acc[0][5]), "+" HA_ACC(acc[0][6]), "+" HA_ACC(acc[0][7]));
   else
     static_assert(NCG == 2 || NACC == 8, "accumulator fence");
+#endif
 #pragma unroll
   for (int g = 0; g < NCG; ++g) {
 #pragma unroll
@@ -449,8 +459,6 @@ __device__ __forceinline__ void mma_layer(const float* xs, const float* zs, cons
     for (int i = 0; i < 4; ++i) sums[4 * g + i] = acc[g][0][i];
   }
 }
-
-#endif  // !HA_SIMT_EMU  (publish() below is shared with the emulator build)
 
 // publishes the wave's NCG column groups (columns col0 + 4 g + j) of layer-output `off`.  The k-block partials are summed with the
 // reduce-scatter of lane_reduce.h, which leaves lane (half h, row parity p, column j, k-block 0) with
@@ -1851,6 +1859,27 @@ bool persist_take_failure(PersistNet* p) {
 
 unsigned persist_error_word(PersistNet* p) { return (p && p->err_host) ? *reinterpret_cast<volatile unsigned*>(p->err_host) : 0u; }
 
+// Register-stationary packing of forward layer l (weights [Nout][Kin], row-major): wave g of a team, register RO[l] + c NCG + cg, lane (b, j) =
+// W[column (8 | 4) g + 4 cg + j][input 16 c + b] -- the B operand of the wave's c-th v_mfma_f32_4x4x1 of column group cg (main chunks first, then
+// the latent skip's).  (Shared with the emulator test hook ha_emu_persist_layer: tests/test_rollout_emu.py.)
+static void pack_forward_layer(int l, const float* Wl, std::vector<float>& wr) {
+  const int Kin[4] = {P_DIN + P_ZD, P_H0 + P_ZD, P_H1 + P_ZD, P_H2 + P_ZD}, Cmain[4] = {P_DIN, P_H0, P_H1, P_H2};
+  const int NCm[4] = {NC0, NC1, NC2, NC3}, NCGv[4] = {2, 2, 1, 1}, RO[4] = {R0, R1, R2, R3}, Nout[4] = {P_H0, P_H1, P_H2, P_RAW};
+  for (int g = 0; g < NWAVES_TEAM; ++g)
+    for (int c = 0; c < NCm[l] + NCZ; ++c)
+      for (int cg = 0; cg < NCGv[l]; ++cg)
+        for (int ln = 0; ln < 64; ++ln) {
+          const int b = ln >> 2, j = ln & 3;
+          const int col = (NCGv[l] == 2 ? 8 * g : 4 * g) + 4 * cg + j;
+          int k;
+          if (c < NCm[l]) { k = 16 * c + b; if (k >= Cmain[l]) k = -1; }
+          else k = Cmain[l] + 16 * (c - NCm[l]) + b;
+          float v = 0.f;
+          if (col < Nout[l] && k >= 0) v = Wl[(size_t)col * Kin[l] + k];
+          wr[((size_t)g * NREG + RO[l] + c * NCGv[l] + cg) * 64 + ln] = v;
+        }
+}
+
 int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
   *out = nullptr;
 #ifdef HA_SIMT_EMU
@@ -1869,20 +1898,7 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
   const int Kin[4] = {P_DIN + P_ZD, P_H0 + P_ZD, P_H1 + P_ZD, P_H2 + P_ZD}, Cmain[4] = {P_DIN, P_H0, P_H1, P_H2};
   const int NCm[4] = {NC0, NC1, NC2, NC3}, NCGv[4] = {2, 2, 1, 1}, RO[4] = {R0, R1, R2, R3}, Nout[4] = {P_H0, P_H1, P_H2, P_RAW};
   std::vector<float> wr((size_t)NWAVES_TEAM * NREG * 64, 0.f);
-  for (int g = 0; g < NWAVES_TEAM; ++g)
-    for (int l = 0; l < 4; ++l)
-      for (int c = 0; c < NCm[l] + NCZ; ++c)
-        for (int cg = 0; cg < NCGv[l]; ++cg)
-          for (int ln = 0; ln < 64; ++ln) {
-            const int b = ln >> 2, j = ln & 3;
-            const int col = (NCGv[l] == 2 ? 8 * g : 4 * g) + 4 * cg + j;
-            int k;
-            if (c < NCm[l]) { k = 16 * c + b; if (k >= Cmain[l]) k = -1; }
-            else k = Cmain[l] + 16 * (c - NCm[l]) + b;
-            float v = 0.f;
-            if (col < Nout[l] && k >= 0) v = d->w[l][(size_t)col * Kin[l] + k];
-            wr[((size_t)g * NREG + RO[l] + c * NCGv[l] + cg) * 64 + ln] = v;
-          }
+  for (int l = 0; l < 4; ++l) pack_forward_layer(l, d->w[l], wr);
   int rc = p_upload(&p->Wreg, wr);
   if (rc == HA_OK) {
     // adjoint: B operand lane (b, j) of chunk c = W_l[forward output 16 c + b][forward input column]
@@ -2221,6 +2237,42 @@ __global__ void emu_publish_kernel(const float* sums_in, const float* bias, unsi
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xch, 0, 1 << 20, 0x00020000);
   publish<NCG, true, GW>(sums, b, 4 * NCG * g, xch, rs, 0u, tag, slab, row0, lane, ht);
 }
+// ONE forward layer of a team as the persistent kernel computes it: every wave loads its share of the packed weights into its register
+// arrays, multiplies the A operand [channel][4 rows] in LDS with v_mfma_f32_4x4x1 chains (mma_layer) and publishes the result
+template <int L>
+__global__ void emu_layer_kernel(const float* Wreg, const float* bias, const float* x_main, const float* z, unsigned char* xch, unsigned tag, float* slab,
+                                 float* ht, int row0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CM = L == 0 ? P_XPAD : (L == 1 ? P_H0 : (L == 2 ? P_H1 : P_H2));
+  float* xs = smem;
+  float* zs = smem + CM * 4;
+  const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x * 4 + (tid >> 6);
+  for (int i = tid; i < CM * 4; i += 256) xs[i] = x_main[i];
+  for (int i = tid; i < P_ZD * 4; i += 256) zs[i] = z[i];
+  __syncthreads();
+  float wa[NWA], wv[NREG - NWA > 0 ? NREG - NWA : 1];
+  const float* wp = Wreg + (size_t)g * NREG * 64 + lane;
+  for (int r = 0; r < NWA; ++r) wa[r] = wp[(size_t)r * 64];
+  for (int r = NWA; r < NREG; ++r) wv[r - NWA] = wp[(size_t)r * 64];
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xch, 0, 1 << 20, 0x00020000);
+  const int j4 = lane & 3, h4 = 4 * (lane >> 5);
+  if constexpr (L <= 1) {
+    float acc[8];
+    if constexpr (L == 0) mma_layer<NC0, NCZ, 2, R0>(xs, zs, wa, wv, lane, acc);
+    else mma_layer<NC1, NCZ, 2, R1>(xs, zs, wa, wv, lane, acc);
+    publish<2, true, 64>(acc, bias[8 * g + h4 + j4], 8 * g, xch, rs, 0u, tag, slab, row0, lane, ht);
+  } else if constexpr (L == 2) {
+    float acc[4];
+    mma_layer<NC2, NCZ, 1, R2>(xs, zs, wa, wv, lane, acc);
+    publish<1, true, 32>(acc, bias[4 * g + j4], 4 * g, xch, rs, 0u, tag, slab, row0, lane, ht);
+  } else {
+    if (g < L3_WAVES) {
+      float acc[4];
+      mma_layer<NC3, NCZ, 1, R3>(xs, zs, wa, wv, lane, acc);
+      publish<1, true, 0>(acc, bias[4 * g + j4], 4 * g, xch, rs, 0u, tag, slab, row0, lane);
+    }
+  }
+}
 }  // namespace ha
 
 extern "C" int ha_emu_xslot(int group, int col) { return group == 64 ? ha::xslot<64>(col) : (group == 32 ? ha::xslot<32>(col) : ha::xslot<0>(col)); }
@@ -2256,6 +2308,21 @@ extern "C" int ha_emu_publish(int ncg, int group, int waves, const float* sums, 
   else if (ncg == 1 && group == 32) hipLaunchKernelGGL((ha::emu_publish_kernel<1, 32>), dim3(waves / 4), dim3(256), 0, nullptr, sums, bias, x, tag, slab, ht, row0);
   else if (ncg == 1 && group == 0) hipLaunchKernelGGL((ha::emu_publish_kernel<1, 0>), dim3(waves / 4), dim3(256), 0, nullptr, sums, bias, x, tag, slab, ht, row0);
   else return HA_ERR_INVALID_ARG;
+  return HA_OK;
+}
+// layer 0..3 of the default decoder: W [Nout][Cmain + 48] row-major, bias [Nout (padded to the waves' columns)], x_main [Cmain padded to 16][4 rows],
+// z [48][4 rows]; outputs as ha_emu_publish
+extern "C" int ha_emu_persist_layer(int layer, const float* W, const float* bias, const float* x_main, const float* z, void* xch, unsigned tag, float* slab,
+                                    float* ht, int row0) {
+  if (layer < 0 || layer > 3) return HA_ERR_INVALID_ARG;
+  std::vector<float> wr((size_t)ha::NWAVES_TEAM * ha::NREG * 64, 0.f);
+  ha::pack_forward_layer(layer, W, wr);
+  unsigned char* x = static_cast<unsigned char*>(xch);
+  const float* wr_p = wr.data();
+  if (layer == 0) hipLaunchKernelGGL(ha::emu_layer_kernel<0>, dim3(32), dim3(256), 0, nullptr, wr_p, bias, x_main, z, x, tag, slab, ht, row0);
+  else if (layer == 1) hipLaunchKernelGGL(ha::emu_layer_kernel<1>, dim3(32), dim3(256), 0, nullptr, wr_p, bias, x_main, z, x, tag, slab, ht, row0);
+  else if (layer == 2) hipLaunchKernelGGL(ha::emu_layer_kernel<2>, dim3(32), dim3(256), 0, nullptr, wr_p, bias, x_main, z, x, tag, slab, ht, row0);
+  else hipLaunchKernelGGL(ha::emu_layer_kernel<3>, dim3(32), dim3(256), 0, nullptr, wr_p, bias, x_main, z, x, tag, slab, ht, row0);
   return HA_OK;
 }
 namespace ha {

@@ -260,3 +260,40 @@ def test_emu_publish_to_consumer_round_trip(emu_lib, ncg, group):
     a_ref = torch.relu((hr - hr.mean(2, keepdim=True)) / torch.sqrt(hr.var(2, unbiased=False, keepdim=True) + 1e-5) * gamma.double().reshape(16, group)
                        + beta.double().reshape(16, group)).reshape(4, nch).t()
     assert (xs.reshape(nch, 4).double() - a_ref).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize('layer', [0, pytest.param(1, marks=pytest.mark.slow), 2, 3])     # (layer 1: layer 0's code shape again, 25 s)
+def test_emu_persistent_forward_layer_matches_linear(emu_lib, layer):
+    """One decoder layer the way the persistent forward computes it, on the host emulator: the register-stationary weight packing of persist_create
+    (pack_forward_layer), every wave's share of the weights in its register arrays, the A operand [channel][4 rows] in LDS, chains of
+    v_mfma_f32_4x4x1 (emulated: 16 four-lane blocks) over the main input and the latent skip (mma_layer), the k-block reduce-scatter and publish().
+    Against x W^T + b for the team's four rows: the team-layout copy, the launch-chain slab and (layer 3: identity slots) the exchange granules."""
+    import ctypes as C
+    dll = emu_lib._dll
+    vp = C.c_void_p
+    dll.ha_emu_persist_layer.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_uint, vp, vp, C.c_int]
+    cmain = [339, 1024, 1024, 512][layer]
+    cpad = [352, 1024, 1024, 512][layer]
+    nout = [1024, 1024, 512, 216][layer]
+    ncols = [1024, 1024, 512, 216][layer]                                  # columns the publishing waves cover (layer 3: 54 waves x 4)
+    g = torch.Generator().manual_seed(100 + layer)
+    W = torch.randn(nout, cmain + 48, generator=g) / (cmain + 48) ** 0.5
+    bias = torch.zeros(1024)
+    bias[:nout] = 0.1 * torch.randn(nout, generator=g)
+    x = torch.zeros(cpad, 4)
+    x[:cmain] = torch.randn(cmain, 4, generator=g)
+    z = torch.randn(48, 4, generator=g)
+    tag, row0 = 3, 20
+    xch = torch.zeros(1 << 18, dtype=torch.int32)
+    slab = torch.zeros(256 * 128)
+    ht = torch.zeros(1024 * 4)
+    assert dll.ha_emu_persist_layer(layer, W.data_ptr(), bias.data_ptr(), x.data_ptr(), z.data_ptr(), xch.data_ptr(), tag, slab.data_ptr(), ht.data_ptr(), row0) == 0
+    want = W.double()[:, :cmain] @ x.double()[:cmain] + W.double()[:, cmain:] @ z.double() + bias.double()[:nout, None]      # [column][row]
+    sl = slab.reshape(256, 32, 4)[: ncols // 4, row0:row0 + 4].permute(0, 2, 1).reshape(ncols, 4)
+    assert (sl[:nout].double() - want).abs().max().item() < 2e-5
+    if layer < 3:
+        assert (ht.reshape(1024, 4)[:nout].double() - want).abs().max().item() < 2e-5
+    else:
+        words = xch[:ncols * 8].reshape(ncols, 4, 2)
+        assert (words[:, :, 1] == tag).all()
+        assert (words[:nout, :, 0].contiguous().view(torch.float32).double() - want).abs().max().item() < 2e-5
