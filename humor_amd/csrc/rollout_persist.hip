@@ -1859,6 +1859,34 @@ bool persist_take_failure(PersistNet* p) {
 
 unsigned persist_error_word(PersistNet* p) { return (p && p->err_host) ? *reinterpret_cast<volatile unsigned*>(p->err_host) : 0u; }
 
+// Adjoint: B operand lane (b, j) of chunk c = W_l[forward output 16 c + b][forward input column]; per wave NREG_B_ALL registers (the four transposed
+// products, then the dL/dz weights) + BC0_LDS LDS-resident chunks of layer 0.  (Shared with the emulator test hook ha_emu_persist_layer_t.)
+static void pack_backward(const float* const* w, std::vector<float>& wb) {
+  const int Kin[4] = {P_DIN + P_ZD, P_H0 + P_ZD, P_H1 + P_ZD, P_H2 + P_ZD}, Nout[4] = {P_H0, P_H1, P_H2, P_RAW};
+  auto W = [&](int l, int k, int col) -> float { return (k < Nout[l] && col < Kin[l]) ? w[l][(size_t)k * Kin[l] + col] : 0.f; };
+  for (int g = 0; g < NWAVES_TEAM; ++g)
+    for (int ln = 0; ln < 64; ++ln) {
+      const int b = ln >> 2, j = ln & 3;
+      float* dst = wb.data() + (size_t)g * (NREG_B_ALL + BC0_LDS) * 64 + ln;
+      auto put = [&](int reg, float v) { dst[(size_t)reg * 64] = v; };
+      for (int c = 0; c < BC3; ++c) put(BR3 + c, 4 * g + j < P_H2 ? W(3, 16 * c + b, 4 * g + j) : 0.f);
+      for (int c = 0; c < BC2; ++c)
+        for (int cg = 0; cg < 2; ++cg) put(BR2 + c * 2 + cg, W(2, 16 * c + b, 8 * g + 4 * cg + j));
+      for (int c = 0; c < BC1; ++c)
+        for (int cg = 0; cg < 2; ++cg) put(BR1 + c * 2 + cg, W(1, 16 * c + b, 8 * g + 4 * cg + j));
+      for (int c = 0; c < BC0; ++c)
+        put(c < BC0_REG ? BR0 + c : NREG_B_ALL + (c - BC0_REG), (g < L0T_WAVES && 4 * g + j < P_DIN) ? W(0, 16 * c + b, 4 * g + j) : 0.f);
+      if (g < DZ0_WAVES)
+        for (int i = 0; i < DZ0_CH; ++i) put(BRZ0 + i, W(0, 16 * ((g % (BC0 / DZ0_CH)) * DZ0_CH + i) + b, P_DIN + 4 * (g / (BC0 / DZ0_CH)) + j));
+      if (g < DZ1_WAVES)
+        for (int i = 0; i < DZ1_CH; ++i) put(BRZ1 + i, W(1, 16 * ((g % (BC1 / DZ1_CH)) * DZ1_CH + i) + b, P_H0 + 4 * (g / (BC1 / DZ1_CH)) + j));
+      if (g < DZ2_WAVES)
+        for (int i = 0; i < DZ2_CH; ++i) put(BRZ2 + i, W(2, 16 * ((g % (BC2 / DZ2_CH)) * DZ2_CH + i) + b, P_H1 + 4 * (g / (BC2 / DZ2_CH)) + j));
+      if (g < DZ3_WAVES)
+        for (int i = 0; i < DZ3_CH; ++i) put(BRZ3 + i, W(3, 16 * ((g % (BC3 / DZ3_CH)) * DZ3_CH + i) + b, P_H2 + 4 * (g / (BC3 / DZ3_CH)) + j));
+    }
+}
+
 // Register-stationary packing of forward layer l (weights [Nout][Kin], row-major): wave g of a team, register RO[l] + c NCG + cg, lane (b, j) =
 // W[column (8 | 4) g + 4 cg + j][input 16 c + b] -- the B operand of the wave's c-th v_mfma_f32_4x4x1 of column group cg (main chunks first, then
 // the latent skip's).  (Shared with the emulator test hook ha_emu_persist_layer: tests/test_rollout_emu.py.)
@@ -1901,30 +1929,8 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
   for (int l = 0; l < 4; ++l) pack_forward_layer(l, d->w[l], wr);
   int rc = p_upload(&p->Wreg, wr);
   if (rc == HA_OK) {
-    // adjoint: B operand lane (b, j) of chunk c = W_l[forward output 16 c + b][forward input column]
     std::vector<float> wb((size_t)NWAVES_TEAM * (NREG_B_ALL + BC0_LDS) * 64, 0.f);
-    auto W = [&](int l, int k, int col) -> float { return (k < Nout[l] && col < Kin[l]) ? d->w[l][(size_t)k * Kin[l] + col] : 0.f; };
-    for (int g = 0; g < NWAVES_TEAM; ++g)
-      for (int ln = 0; ln < 64; ++ln) {
-        const int b = ln >> 2, j = ln & 3;
-        float* dst = wb.data() + (size_t)g * (NREG_B_ALL + BC0_LDS) * 64 + ln;
-        auto put = [&](int reg, float v) { dst[(size_t)reg * 64] = v; };
-        for (int c = 0; c < BC3; ++c) put(BR3 + c, 4 * g + j < P_H2 ? W(3, 16 * c + b, 4 * g + j) : 0.f);
-        for (int c = 0; c < BC2; ++c)
-          for (int cg = 0; cg < 2; ++cg) put(BR2 + c * 2 + cg, W(2, 16 * c + b, 8 * g + 4 * cg + j));
-        for (int c = 0; c < BC1; ++c)
-          for (int cg = 0; cg < 2; ++cg) put(BR1 + c * 2 + cg, W(1, 16 * c + b, 8 * g + 4 * cg + j));
-        for (int c = 0; c < BC0; ++c)
-          put(c < BC0_REG ? BR0 + c : NREG_B_ALL + (c - BC0_REG), (g < L0T_WAVES && 4 * g + j < P_DIN) ? W(0, 16 * c + b, 4 * g + j) : 0.f);
-        if (g < DZ0_WAVES)
-          for (int i = 0; i < DZ0_CH; ++i) put(BRZ0 + i, W(0, 16 * ((g % (BC0 / DZ0_CH)) * DZ0_CH + i) + b, P_DIN + 4 * (g / (BC0 / DZ0_CH)) + j));
-        if (g < DZ1_WAVES)
-          for (int i = 0; i < DZ1_CH; ++i) put(BRZ1 + i, W(1, 16 * ((g % (BC1 / DZ1_CH)) * DZ1_CH + i) + b, P_H0 + 4 * (g / (BC1 / DZ1_CH)) + j));
-        if (g < DZ2_WAVES)
-          for (int i = 0; i < DZ2_CH; ++i) put(BRZ2 + i, W(2, 16 * ((g % (BC2 / DZ2_CH)) * DZ2_CH + i) + b, P_H1 + 4 * (g / (BC2 / DZ2_CH)) + j));
-        if (g < DZ3_WAVES)
-          for (int i = 0; i < DZ3_CH; ++i) put(BRZ3 + i, W(3, 16 * ((g % (BC3 / DZ3_CH)) * DZ3_CH + i) + b, P_H2 + 4 * (g / (BC3 / DZ3_CH)) + j));
-      }
+    pack_backward(d->w, wb);
     rc = p_upload(&p->Wreg_b, wb);
   }
   if (rc == HA_OK) {
@@ -2273,6 +2279,31 @@ __global__ void emu_layer_kernel(const float* Wreg, const float* bias, const flo
     }
   }
 }
+// ONE transposed layer of the adjoint (L = 3, 2, 1): dL/d(input activation of layer L) [4 rows] = dh_L W_L with the adjoint's packing (pack_backward)
+template <int L>
+__global__ void emu_layer_t_kernel(const float* Wreg_b, const float* dh, unsigned char* xch, unsigned tag, int row0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CM = L == 3 ? P_RAWPAD : (L == 2 ? P_H2 : P_H1);
+  float* sD = smem;
+  const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x * 4 + (tid >> 6);
+  for (int i = tid; i < CM * 4; i += 256) sD[i] = dh[i];
+  __syncthreads();
+  float wa[NWA_B < NREG_B ? NWA_B : NREG_B], wv[NREG_B - NWA_B > 0 ? NREG_B - NWA_B : 1];
+  const float* wp = Wreg_b + (size_t)g * (NREG_B_ALL + BC0_LDS) * 64 + lane;
+  for (int r = 0; r < NWA_B && r < NREG_B; ++r) wa[r] = wp[(size_t)r * 64];
+  for (int r = NWA_B; r < NREG_B; ++r) wv[r - NWA_B] = wp[(size_t)r * 64];
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xch, 0, 1 << 20, 0x00020000);
+  if constexpr (L == 3) {
+    float acc[4];
+    mma_layer<BC3, 0, 1, BR3>(sD, sD, wa, wv, lane, acc);
+    publish<1, true, 32>(acc, 0.f, 4 * g, xch, rs, 0u, tag, nullptr, row0, lane);
+  } else {
+    float acc[8];
+    if constexpr (L == 2) mma_layer<BC2, 0, 2, BR2>(sD, sD, wa, wv, lane, acc);
+    else mma_layer<BC1, 0, 2, BR1>(sD, sD, wa, wv, lane, acc);
+    publish<2, true, 64>(acc, 0.f, 8 * g, xch, rs, 0u, tag, nullptr, row0, lane);
+  }
+}
 }  // namespace ha
 
 extern "C" int ha_emu_xslot(int group, int col) { return group == 64 ? ha::xslot<64>(col) : (group == 32 ? ha::xslot<32>(col) : ha::xslot<0>(col)); }
@@ -2323,6 +2354,21 @@ extern "C" int ha_emu_persist_layer(int layer, const float* W, const float* bias
   else if (layer == 1) hipLaunchKernelGGL(ha::emu_layer_kernel<1>, dim3(32), dim3(256), 0, nullptr, wr_p, bias, x_main, z, x, tag, slab, ht, row0);
   else if (layer == 2) hipLaunchKernelGGL(ha::emu_layer_kernel<2>, dim3(32), dim3(256), 0, nullptr, wr_p, bias, x_main, z, x, tag, slab, ht, row0);
   else hipLaunchKernelGGL(ha::emu_layer_kernel<3>, dim3(32), dim3(256), 0, nullptr, wr_p, bias, x_main, z, x, tag, slab, ht, row0);
+  return HA_OK;
+}
+// transposed layer 3 / 2 / 1 of the adjoint: w = the four forward weight matrices, dh [forward output channels of the layer, padded to 16][4 rows];
+// the result arrives in the exchange region (slot map of the consumer's GroupNorm width: 32 for layer 3, 64 for layers 2 and 1)
+extern "C" int ha_emu_persist_layer_t(int layer, const float* w0, const float* w1, const float* w2, const float* w3, const float* dh, void* xch, unsigned tag,
+                                      int row0) {
+  if (layer < 1 || layer > 3) return HA_ERR_INVALID_ARG;
+  const float* w[4] = {w0, w1, w2, w3};
+  std::vector<float> wb((size_t)ha::NWAVES_TEAM * (ha::NREG_B_ALL + ha::BC0_LDS) * 64, 0.f);
+  ha::pack_backward(w, wb);
+  unsigned char* x = static_cast<unsigned char*>(xch);
+  const float* wb_p = wb.data();
+  if (layer == 3) hipLaunchKernelGGL(ha::emu_layer_t_kernel<3>, dim3(32), dim3(256), 0, nullptr, wb_p, dh, x, tag, row0);
+  else if (layer == 2) hipLaunchKernelGGL(ha::emu_layer_t_kernel<2>, dim3(32), dim3(256), 0, nullptr, wb_p, dh, x, tag, row0);
+  else hipLaunchKernelGGL(ha::emu_layer_t_kernel<1>, dim3(32), dim3(256), 0, nullptr, wb_p, dh, x, tag, row0);
   return HA_OK;
 }
 namespace ha {

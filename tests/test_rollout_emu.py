@@ -297,3 +297,31 @@ def test_emu_persistent_forward_layer_matches_linear(emu_lib, layer):
         words = xch[:ncols * 8].reshape(ncols, 4, 2)
         assert (words[:, :, 1] == tag).all()
         assert (words[:nout, :, 0].contiguous().view(torch.float32).double() - want).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('layer', [3, pytest.param(2, marks=pytest.mark.slow), 1])
+def test_emu_persistent_adjoint_layer_matches_transposed_linear(emu_lib, layer):
+    """One TRANSPOSED layer of the persistent adjoint on the host emulator: pack_backward (the adjoint's register-stationary packing), mma_layer over
+    dh in LDS, publish() into the exchange region the GroupNorm adjoint of the next phase sweeps.  Against dh W for the team's four rows."""
+    import ctypes as C
+    dll = emu_lib._dll
+    vp = C.c_void_p
+    dll.ha_emu_persist_layer_t.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, C.c_uint, C.c_int]
+    kin = [339 + 48, 1024 + 48, 1024 + 48, 512 + 48]
+    nout = [1024, 1024, 512, 216]
+    g = torch.Generator().manual_seed(200 + layer)
+    Ws = [torch.randn(nout[l], kin[l], generator=g) / kin[l] ** 0.5 for l in range(4)]
+    kpad = {3: 224, 2: 512, 1: 1024}[layer]
+    dh = torch.zeros(kpad, 4)
+    dh[:nout[layer]] = torch.randn(nout[layer], 4, generator=g)
+    ncol = kin[layer] - 48                                                 # the layer's main input channels: 512 / 1024 / 1024
+    group = 32 if layer == 3 else 64
+    tag, row0 = 5, 4
+    xch = torch.zeros(1 << 18, dtype=torch.int32)
+    assert dll.ha_emu_persist_layer_t(layer, *[w.data_ptr() for w in Ws], dh.data_ptr(), xch.data_ptr(), tag, row0) == 0
+    want = (dh.double()[:nout[layer]].t() @ Ws[layer].double()[:, :ncol]).t()       # [input channel][row]
+    words = xch[:ncol * 8].reshape(ncol, 4, 2)
+    assert (words[:, :, 1] == tag).all()
+    slots = torch.tensor([dll.ha_emu_xslot(group, c) for c in range(ncol)])
+    got = words[slots][:, :, 0].contiguous().view(torch.float32)
+    assert (got.double() - want).abs().max().item() < 2e-5
