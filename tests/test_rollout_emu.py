@@ -262,7 +262,8 @@ def test_emu_publish_to_consumer_round_trip(emu_lib, ncg, group):
     assert (xs.reshape(nch, 4).double() - a_ref).abs().max().item() < 2e-6
 
 
-@pytest.mark.parametrize('layer', [0, pytest.param(1, marks=pytest.mark.slow), 2, 3])     # (layer 1: layer 0's code shape again, 25 s)
+# (default tier: the two single-column-group layers, ~10 s each; layers 0 / 1 -- two column groups per wave, 17 / 25 s -- with HUMOR_AMD_SLOW=1)
+@pytest.mark.parametrize('layer', [pytest.param(0, marks=pytest.mark.slow), pytest.param(1, marks=pytest.mark.slow), 2, 3])
 def test_emu_persistent_forward_layer_matches_linear(emu_lib, layer):
     """One decoder layer the way the persistent forward computes it, on the host emulator: the register-stationary weight packing of persist_create
     (pack_forward_layer), every wave's share of the weights in its register arrays, the A operand [channel][4 rows] in LDS, chains of
@@ -299,7 +300,7 @@ def test_emu_persistent_forward_layer_matches_linear(emu_lib, layer):
         assert (words[:nout, :, 0].contiguous().view(torch.float32).double() - want).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize('layer', [3, pytest.param(2, marks=pytest.mark.slow), 1])
+@pytest.mark.parametrize('layer', [3, pytest.param(2, marks=pytest.mark.slow), pytest.param(1, marks=pytest.mark.slow)])
 def test_emu_persistent_adjoint_layer_matches_transposed_linear(emu_lib, layer):
     """One TRANSPOSED layer of the persistent adjoint on the host emulator: pack_backward (the adjoint's register-stationary packing), mma_layer over
     dh in LDS, publish() into the exchange region the GroupNorm adjoint of the next phase sweeps.  Against dh W for the team's four rows."""
