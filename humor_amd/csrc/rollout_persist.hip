@@ -1009,6 +1009,8 @@ __device__ __forceinline__ void outer_acc3(float M[9], const float a[3], const f
 #pragma unroll
     for (int k = 0; k < 3; ++k) M[i * 3 + k] = fmaf(a[i], b[k], M[i * 3 + k]);
 }
+#endif  // !HA_SIMT_EMU  (dz_mma / dz_store are shared with the emulator build)
+
 // a dL/dz task (or layer 0's LDS-resident K tail): CH chunks of the activation adjoint against LDS-resident weight vectors.  All
 // operands are read first, then the MFMAs run on min(CH, 8) independent accumulators.
 template <int CH>
@@ -1035,6 +1037,8 @@ __device__ __forceinline__ void dz_store(const float (&acc)[4], float* part, int
     part[(((size_t)t * DZ_SLOTS + slot) * 32 + row0 + row) * P_ZD + 4 * cg + j] = v;
   }
 }
+
+#ifndef HA_SIMT_EMU
 
 // ---------------------------------------------------------------------------------------------------
 // Persistent adjoint: the reverse scan over the S steps as ONE launch, same teams / exchange as the forward.
@@ -1756,6 +1760,8 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
   }
 }
 
+#endif  // !HA_SIMT_EMU  (dz_reduce_kernel is shared with the emulator build)
+
 // g_z[b][t][c] = sum of the DZ_SLOTS partial products, fixed order
 __global__ void dz_reduce_kernel(const float* __restrict__ part, float* __restrict__ g_z, const float* __restrict__ g_z_add, int B, int S) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1765,8 +1771,6 @@ __global__ void dz_reduce_kernel(const float* __restrict__ part, float* __restri
   for (int sl = 0; sl < DZ_SLOTS; ++sl) v += part[(((size_t)t * DZ_SLOTS + sl) * 32 + b) * P_ZD + c];
   g_z[i] = g_z_add ? v + g_z_add[i] : v;
 }
-
-#endif  // !HA_SIMT_EMU
 
 #include "rollout_pipe.inc"
 
@@ -2283,17 +2287,31 @@ __global__ void emu_layer_kernel(const float* Wreg, const float* bias, const flo
 template <int L>
 __global__ void emu_layer_t_kernel(const float* Wreg_b, const float* dh, unsigned char* xch, unsigned tag, int row0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int CM = L == 3 ? P_RAWPAD : (L == 2 ? P_H2 : P_H1);
+  constexpr int CM = L == 3 ? P_RAWPAD : (L == 2 ? P_H2 : (L == 1 ? P_H1 : P_H0));
   float* sD = smem;
   const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x * 4 + (tid >> 6);
   for (int i = tid; i < CM * 4; i += 256) sD[i] = dh[i];
+  float* sWz = smem + CM * 4 + (tid >> 6) * NLW * 64;           // (layer 0: the LDS-resident tail of K)
+  if constexpr (L == 0) {
+    const float* wz = Wreg_b + (size_t)g * (NREG_B_ALL + BC0_LDS) * 64 + lane;
+    for (int r = 0; r < NLW; ++r) sWz[r * 64 + lane] = wz[(size_t)(NREG_B + r) * 64];
+  }
   __syncthreads();
   float wa[NWA_B < NREG_B ? NWA_B : NREG_B], wv[NREG_B - NWA_B > 0 ? NREG_B - NWA_B : 1];
   const float* wp = Wreg_b + (size_t)g * (NREG_B_ALL + BC0_LDS) * 64 + lane;
   for (int r = 0; r < NWA_B && r < NREG_B; ++r) wa[r] = wp[(size_t)r * 64];
   for (int r = NWA_B; r < NREG_B; ++r) wv[r - NWA_B] = wp[(size_t)r * 64];
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xch, 0, 1 << 20, 0x00020000);
-  if constexpr (L == 3) {
+  if constexpr (L == 0) {
+    float acc[4];
+    if (g < L0T_WAVES) {
+      float tail[4];
+      mma_layer<BC0_REG, 0, 1, BR0>(sD, sD, wa, wv, lane, acc);
+      dz_mma<BC0_LDS>(sD + 64 * BC0_REG, sWz + NDZ * 64, lane, tail);
+      for (int i = 0; i < 4; ++i) acc[i] += tail[i];
+    } else { acc[0] = acc[1] = acc[2] = acc[3] = 0.f; }
+    if (g < P_XPAD / 4) publish<1, true, 0>(acc, 0.f, 4 * g, xch, rs, 0u, tag, nullptr, row0, lane);
+  } else if constexpr (L == 3) {
     float acc[4];
     mma_layer<BC3, 0, 1, BR3>(sD, sD, wa, wv, lane, acc);
     publish<1, true, 32>(acc, 0.f, 4 * g, xch, rs, 0u, tag, nullptr, row0, lane);
@@ -2302,6 +2320,42 @@ __global__ void emu_layer_t_kernel(const float* Wreg_b, const float* dh, unsigne
     if constexpr (L == 2) mma_layer<BC2, 0, 2, BR2>(sD, sD, wa, wv, lane, acc);
     else mma_layer<BC1, 0, 2, BR1>(sD, sD, wa, wv, lane, acc);
     publish<2, true, 64>(acc, 0.f, 8 * g, xch, rs, 0u, tag, nullptr, row0, lane);
+  }
+}
+// dL/dz of one step: every wave's K-split partial products of the four layers (LDS-resident weights of pack_backward, dz_mma, dz_store), then
+// dz_reduce_kernel.  dh3 [224][4], dh2 [512][4], dh1 / dh0 [1024][4] = the activation adjoints in the MFMA operand layout
+__global__ void emu_dz_kernel(const float* Wreg_b, const float* dh3, const float* dh2, const float* dh1, const float* dh0, float* dz_part, int row0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sD3 = smem;
+  float* sD2 = sD3 + P_RAWPAD * 4;
+  float* sD1 = sD2 + P_H2 * 4;
+  float* sD0 = sD1 + P_H1 * 4;
+  float* sWzAll = sD0 + P_H0 * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x * 4 + wave;
+  for (int i = tid; i < P_RAWPAD * 4; i += 256) sD3[i] = dh3[i];
+  for (int i = tid; i < P_H2 * 4; i += 256) sD2[i] = dh2[i];
+  for (int i = tid; i < P_H1 * 4; i += 256) sD1[i] = dh1[i];
+  for (int i = tid; i < P_H0 * 4; i += 256) sD0[i] = dh0[i];
+  float* sWz = sWzAll + wave * NLW * 64;
+  const float* wp = Wreg_b + (size_t)g * (NREG_B_ALL + BC0_LDS) * 64 + lane;
+  for (int r = 0; r < NLW; ++r) sWz[r * 64 + lane] = wp[(size_t)(NREG_B + r) * 64];
+  __syncthreads();
+  float accz[4];
+  if (g < DZ3_WAVES) {
+    dz_mma<DZ3_CH>(sD3 + 64 * DZ3_CH * (g % (BC3 / DZ3_CH)), sWz + (BRZ3 - BRZ0) * 64, lane, accz);
+    dz_store(accz, dz_part, 0, DZ_S3 + g % (BC3 / DZ3_CH), g / (BC3 / DZ3_CH), row0, lane);
+  }
+  if (g < DZ2_WAVES) {
+    dz_mma<DZ2_CH>(sD2 + 64 * DZ2_CH * (g % (BC2 / DZ2_CH)), sWz + (BRZ2 - BRZ0) * 64, lane, accz);
+    dz_store(accz, dz_part, 0, DZ_S2 + g % (BC2 / DZ2_CH), g / (BC2 / DZ2_CH), row0, lane);
+  }
+  if (g < DZ1_WAVES) {
+    dz_mma<DZ1_CH>(sD1 + 64 * DZ1_CH * (g % (BC1 / DZ1_CH)), sWz + (BRZ1 - BRZ0) * 64, lane, accz);
+    dz_store(accz, dz_part, 0, DZ_S1 + g % (BC1 / DZ1_CH), g / (BC1 / DZ1_CH), row0, lane);
+  }
+  if (g < DZ0_WAVES) {
+    dz_mma<DZ0_CH>(sD0 + 64 * DZ0_CH * (g % (BC0 / DZ0_CH)), sWz, lane, accz);
+    dz_store(accz, dz_part, 0, DZ_S0 + g % (BC0 / DZ0_CH), g / (BC0 / DZ0_CH), row0, lane);
   }
 }
 }  // namespace ha
@@ -2356,11 +2410,11 @@ extern "C" int ha_emu_persist_layer(int layer, const float* W, const float* bias
   else hipLaunchKernelGGL(ha::emu_layer_kernel<3>, dim3(32), dim3(256), 0, nullptr, wr_p, bias, x_main, z, x, tag, slab, ht, row0);
   return HA_OK;
 }
-// transposed layer 3 / 2 / 1 of the adjoint: w = the four forward weight matrices, dh [forward output channels of the layer, padded to 16][4 rows];
+// transposed layer 3 / 2 / 1 / 0 of the adjoint (0: identity slots, 352 channels of which 339 live): w = the four forward weight matrices, dh [forward output channels of the layer, padded to 16][4 rows];
 // the result arrives in the exchange region (slot map of the consumer's GroupNorm width: 32 for layer 3, 64 for layers 2 and 1)
 extern "C" int ha_emu_persist_layer_t(int layer, const float* w0, const float* w1, const float* w2, const float* w3, const float* dh, void* xch, unsigned tag,
                                       int row0) {
-  if (layer < 1 || layer > 3) return HA_ERR_INVALID_ARG;
+  if (layer < 0 || layer > 3) return HA_ERR_INVALID_ARG;
   const float* w[4] = {w0, w1, w2, w3};
   std::vector<float> wb((size_t)ha::NWAVES_TEAM * (ha::NREG_B_ALL + ha::BC0_LDS) * 64, 0.f);
   ha::pack_backward(w, wb);
@@ -2368,7 +2422,22 @@ extern "C" int ha_emu_persist_layer_t(int layer, const float* w0, const float* w
   const float* wb_p = wb.data();
   if (layer == 3) hipLaunchKernelGGL(ha::emu_layer_t_kernel<3>, dim3(32), dim3(256), 0, nullptr, wb_p, dh, x, tag, row0);
   else if (layer == 2) hipLaunchKernelGGL(ha::emu_layer_t_kernel<2>, dim3(32), dim3(256), 0, nullptr, wb_p, dh, x, tag, row0);
-  else hipLaunchKernelGGL(ha::emu_layer_t_kernel<1>, dim3(32), dim3(256), 0, nullptr, wb_p, dh, x, tag, row0);
+  else if (layer == 1) hipLaunchKernelGGL(ha::emu_layer_t_kernel<1>, dim3(32), dim3(256), 0, nullptr, wb_p, dh, x, tag, row0);
+  else hipLaunchKernelGGL(ha::emu_layer_t_kernel<0>, dim3(32), dim3(256), 0, nullptr, wb_p, dh, x, tag, row0);
+  return HA_OK;
+}
+// dL/dz of ONE step for the team's four rows (sequences row0 .. row0 + 3 of B = 32): g_z [32][1][48]
+extern "C" int ha_emu_persist_dz(const float* w0, const float* w1, const float* w2, const float* w3, const float* dh3, const float* dh2, const float* dh1,
+                                 const float* dh0, float* g_z, int row0) {
+  const float* w[4] = {w0, w1, w2, w3};
+  std::vector<float> wb((size_t)ha::NWAVES_TEAM * (ha::NREG_B_ALL + ha::BC0_LDS) * 64, 0.f);
+  ha::pack_backward(w, wb);
+  std::vector<float> part((size_t)ha::DZ_SLOTS * 32 * ha::P_ZD, 0.f);
+  const float* wb_p = wb.data();
+  float* part_p = part.data();
+  hipLaunchKernelGGL(ha::emu_dz_kernel, dim3(32), dim3(256), 0, nullptr, wb_p, dh3, dh2, dh1, dh0, part_p, row0);
+  const int n = 32 * ha::P_ZD;
+  hipLaunchKernelGGL(ha::dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)part_p, g_z, (const float*)nullptr, 32, 1);
   return HA_OK;
 }
 namespace ha {

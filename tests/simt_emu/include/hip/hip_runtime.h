@@ -179,6 +179,14 @@ static inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f
   return d;
 }
 
+// v_mfma_f32_4x4x1_16b_f32: 16 independent blocks of four lanes; in block b lane 4 b + j gets D[i] = C[i] + A(lane 4 b + i) * B(lane 4 b + j), i = 0..3
+static inline f32x4_emu __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, f32x4_emu c, int, int, int) {
+  const int l = simt_emu::lane_id();
+  f32x4_emu d = c;
+  for (int i = 0; i < 4; ++i) d[i] = fmaf(simt_emu::shfl_any(a, (l & ~3) | i), b, c[i]);
+  return d;
+}
+
 // ---- runtime API subset ---------------------------------------------------------------------------
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }

@@ -300,7 +300,7 @@ def test_emu_persistent_forward_layer_matches_linear(emu_lib, layer):
         assert (words[:nout, :, 0].contiguous().view(torch.float32).double() - want).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize('layer', [3, pytest.param(2, marks=pytest.mark.slow), pytest.param(1, marks=pytest.mark.slow)])
+@pytest.mark.parametrize('layer', [3, pytest.param(2, marks=pytest.mark.slow), pytest.param(1, marks=pytest.mark.slow), pytest.param(0, marks=pytest.mark.slow)])
 def test_emu_persistent_adjoint_layer_matches_transposed_linear(emu_lib, layer):
     """One TRANSPOSED layer of the persistent adjoint on the host emulator: pack_backward (the adjoint's register-stationary packing), mma_layer over
     dh in LDS, publish() into the exchange region the GroupNorm adjoint of the next phase sweeps.  Against dh W for the team's four rows."""
@@ -312,11 +312,11 @@ def test_emu_persistent_adjoint_layer_matches_transposed_linear(emu_lib, layer):
     nout = [1024, 1024, 512, 216]
     g = torch.Generator().manual_seed(200 + layer)
     Ws = [torch.randn(nout[l], kin[l], generator=g) / kin[l] ** 0.5 for l in range(4)]
-    kpad = {3: 224, 2: 512, 1: 1024}[layer]
+    kpad = {3: 224, 2: 512, 1: 1024, 0: 1024}[layer]
     dh = torch.zeros(kpad, 4)
     dh[:nout[layer]] = torch.randn(nout[layer], 4, generator=g)
     ncol = kin[layer] - 48                                                 # the layer's main input channels: 512 / 1024 / 1024
-    group = 32 if layer == 3 else 64
+    group = 32 if layer == 3 else (64 if layer else 0)                     # (layer 0: 32 register-resident K chunks + 24 from LDS; identity slots)
     tag, row0 = 5, 4
     xch = torch.zeros(1 << 18, dtype=torch.int32)
     assert dll.ha_emu_persist_layer_t(layer, *[w.data_ptr() for w in Ws], dh.data_ptr(), xch.data_ptr(), tag, row0) == 0
@@ -326,3 +326,29 @@ def test_emu_persistent_adjoint_layer_matches_transposed_linear(emu_lib, layer):
     slots = torch.tensor([dll.ha_emu_xslot(group, c) for c in range(ncol)])
     got = words[slots][:, :, 0].contiguous().view(torch.float32)
     assert (got.double() - want).abs().max().item() < 2e-5
+
+
+def test_emu_persistent_dz_partials_and_reduction(emu_lib):
+    """dL/dz of one step as the persistent adjoint computes it: 31 K-split partial products per (sequence, latent column group) with the
+    LDS-resident weights of pack_backward (dz_mma, block_sum4, dz_store: slot and row bookkeeping), summed in fixed order by dz_reduce_kernel.
+    Against sum over the four layers of dh_l W_l[:, latent columns] for the team's four rows; the other 28 rows of the 32-row tile stay zero."""
+    import ctypes as C
+    dll = emu_lib._dll
+    vp = C.c_void_p
+    dll.ha_emu_persist_dz.argtypes = [vp] * 9 + [C.c_int]
+    kin = [339 + 48, 1024 + 48, 1024 + 48, 512 + 48]
+    nout = [1024, 1024, 512, 216]
+    g = torch.Generator().manual_seed(77)
+    Ws = [torch.randn(nout[l], kin[l], generator=g) / kin[l] ** 0.5 for l in range(4)]
+    pads = [1024, 1024, 512, 224]
+    dh = []
+    for l in range(4):
+        t = torch.zeros(pads[l], 4)
+        t[:nout[l]] = torch.randn(nout[l], 4, generator=g)
+        dh.append(t)
+    row0 = 16
+    gz = torch.full((32, 48), 7.0)
+    assert dll.ha_emu_persist_dz(*[w.data_ptr() for w in Ws], dh[3].data_ptr(), dh[2].data_ptr(), dh[1].data_ptr(), dh[0].data_ptr(), gz.data_ptr(), row0) == 0
+    want = sum(dh[l].double()[:nout[l]].t() @ Ws[l].double()[:, kin[l] - 48:] for l in range(4))      # [row][48]
+    assert (gz[row0:row0 + 4].double() - want).abs().max().item() < 2e-5
+    assert gz[:row0].abs().max().item() == 0 and gz[row0 + 4:].abs().max().item() == 0
