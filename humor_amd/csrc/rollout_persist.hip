@@ -1863,6 +1863,32 @@ bool persist_take_failure(PersistNet* p) {
 
 unsigned persist_error_word(PersistNet* p) { return (p && p->err_host) ? *reinterpret_cast<volatile unsigned*>(p->err_host) : 0u; }
 
+// Pipelined forward: wave g = 4 m + w of a team belongs to the role of CU m; register c * NCGW + cg = K chunk c of column group cg of the role's
+// layer.  (Shared with the emulator test hook ha_emu_pipe_layer.)
+static void pack_pipe_forward(const float* const* w, std::vector<float>& wp) {
+  const int Kin[4] = {P_DIN + P_ZD, P_H0 + P_ZD, P_H1 + P_ZD, P_H2 + P_ZD}, Cmain[4] = {P_DIN, P_H0, P_H1, P_H2};
+  const int NCm[4] = {NC0, NC1, NC2, NC3}, Nout[4] = {P_H0, P_H1, P_H2, P_RAW};
+  for (int g = 0; g < NWAVES_TEAM; ++g) {
+    const int m = g / 4;
+    if (m >= PRG_M0 && m < PR1_M0) continue;             // (the glue CU holds no weights)
+    const int l = m < PR1_M0 ? 0 : (m < PR2_M0 ? 1 : (m < PR3_M0 ? 2 : 3));
+    const int m0[4] = {PR0_M0, PR1_M0, PR2_M0, PR3_M0}, ncgw[4] = {PF0_CG, PF1_CG, PF2_CG, PF3_CG};
+    const int gw = g - 4 * m0[l];
+    for (int c = 0; c < NCm[l] + NCZ; ++c)
+      for (int cg = 0; cg < ncgw[l]; ++cg)
+        for (int ln = 0; ln < 64; ++ln) {
+          const int b = ln >> 2, j = ln & 3;
+          const int col = 4 * (ncgw[l] * gw + cg) + j;
+          int k;
+          if (c < NCm[l]) { k = 16 * c + b; if (k >= Cmain[l]) k = -1; }
+          else k = Cmain[l] + 16 * (c - NCm[l]) + b;
+          float v = 0.f;
+          if (col < Nout[l] && k >= 0) v = w[l][(size_t)col * Kin[l] + k];
+          wp[((size_t)g * PF_NREG + c * ncgw[l] + cg) * 64 + ln] = v;
+        }
+  }
+}
+
 // Adjoint: B operand lane (b, j) of chunk c = W_l[forward output 16 c + b][forward input column]; per wave NREG_B_ALL registers (the four transposed
 // products, then the dL/dz weights) + BC0_LDS LDS-resident chunks of layer 0.  (Shared with the emulator test hook ha_emu_persist_layer_t.)
 static void pack_backward(const float* const* w, std::vector<float>& wb) {
@@ -1938,26 +1964,8 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
     rc = p_upload(&p->Wreg_b, wb);
   }
   if (rc == HA_OK) {
-    // pipelined forward: wave g = 4 m + w of a team belongs to the role of CU m; register c * NCGW + cg = K chunk c of column group cg
     std::vector<float> wp((size_t)NWAVES_TEAM * PF_NREG * 64, 0.f);
-    for (int g = 0; g < NWAVES_TEAM; ++g) {
-      const int m = g / 4;
-      const int l = m < PR1_M0 ? 0 : (m < PR2_M0 ? 1 : (m < PR3_M0 ? 2 : 3));
-      const int m0[4] = {PR0_M0, PR1_M0, PR2_M0, PR3_M0}, ncgw[4] = {PF0_CG, PF1_CG, PF2_CG, PF3_CG};
-      const int gw = g - 4 * m0[l];
-      for (int c = 0; c < NCm[l] + NCZ; ++c)
-        for (int cg = 0; cg < ncgw[l]; ++cg)
-          for (int ln = 0; ln < 64; ++ln) {
-            const int b = ln >> 2, j = ln & 3;
-            const int col = 4 * (ncgw[l] * gw + cg) + j;
-            int k;
-            if (c < NCm[l]) { k = 16 * c + b; if (k >= Cmain[l]) k = -1; }
-            else k = Cmain[l] + 16 * (c - NCm[l]) + b;
-            float v = 0.f;
-            if (col < Nout[l] && k >= 0) v = d->w[l][(size_t)col * Kin[l] + k];
-            wp[((size_t)g * PF_NREG + c * ncgw[l] + cg) * 64 + ln] = v;
-          }
-    }
+    pack_pipe_forward(d->w, wp);
     rc = p_upload(&p->Wreg_pf, wp);
   }
   if (rc == HA_OK) {
@@ -2358,6 +2366,50 @@ __global__ void emu_dz_kernel(const float* Wreg_b, const float* dh3, const float
     dz_store(accz, dz_part, 0, DZ_S0 + g % (BC0 / DZ0_CH), g / (BC0 / DZ0_CH), row0, lane);
   }
 }
+// ONE forward layer as its ROLE of the pipelined kernels computes it (rollout_pipe.inc): the role's CUs of a team, every wave with its PFx_CG column
+// groups -- role-ordered packing (pack_pipe_forward), pipe_mma, pipe_publish_all with the bias from LDS and the column bound of the last wave
+template <int L>
+__global__ void emu_pipe_layer_kernel(const float* Wreg_pf, const float* bias, const float* x_main, const float* z, unsigned char* xch, unsigned tag,
+                                      float* slab, float* ht, int trow) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CM = L == 0 ? P_XPAD : (L == 1 ? P_H0 : (L == 2 ? P_H1 : P_H2));
+  constexpr int NOUT = L == 0 ? P_H0 : (L == 1 ? P_H1 : (L == 2 ? P_H2 : P_RAW));
+  constexpr int M0 = L == 0 ? PR0_M0 : (L == 1 ? PR1_M0 : (L == 2 ? PR2_M0 : PR3_M0));
+  constexpr int M1 = L == 0 ? PRG_M0 : (L == 1 ? PR2_M0 : (L == 2 ? PR3_M0 : TEAM_CUS));
+  float* xs = smem;
+  float* zs = xs + CM * 4;
+  float* sBias = zs + P_ZD * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = blockIdx.x;
+  for (int i = tid; i < CM * 4; i += 256) xs[i] = x_main[i];
+  for (int i = tid; i < P_ZD * 4; i += 256) zs[i] = z[i];
+  for (int c = tid; c < 1024; c += 256) sBias[c] = bias[c];
+  __syncthreads();
+  if (m < M0 || m >= M1) return;
+  const int gw = (m - M0) * 4 + wave;
+  const float* wp = Wreg_pf + (size_t)(m * 4 + wave) * PF_NREG * 64 + lane;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xch, 0, 1 << 20, 0x00020000);
+  if constexpr (L == 0) {
+    float wa[PNWA], wv[PF0_NREG - PNWA];
+    pipe_load_weights<PF0_NREG>(wp, wa, wv);
+    float sums[PF0_CG][4];
+    pipe_mma<NC0, NCZ, PF0_CG, 1>(xs, zs, wa, wv, lane, sums);
+    pipe_publish_all<PF0_CG, true, 64>(sums, sBias, 4 * PF0_CG * gw, P_H0, xch, rs, 0u, tag, slab, trow, lane, ht);
+  } else if constexpr (L == 1 || L == 2) {
+    float wa[PNWA], wv[PF1_NREG - PNWA];
+    pipe_load_weights<PF1_NREG>(wp, wa, wv);
+    float sums[PF1_CG][4];
+    pipe_mma<NC1, NCZ, PF1_CG, 2>(xs, zs, wa, wv, lane, sums);
+    if constexpr (L == 1) pipe_publish_all<PF1_CG, true, 64>(sums, sBias, 4 * PF1_CG * gw, P_H1, xch, rs, 0u, tag, slab, trow, lane, ht);
+    else pipe_publish_all<PF2_CG, true, 32>(sums, sBias, 4 * PF2_CG * gw, P_H2, xch, rs, 0u, tag, slab, trow, lane, ht);
+  } else {
+    float wa[PF3_NREG < PNWA ? PF3_NREG : PNWA], wv[PF3_NREG - PNWA > 0 ? PF3_NREG - PNWA : 1];
+    pipe_load_weights<PF3_NREG>(wp, wa, wv);
+    float sums[PF3_CG][4];
+    pipe_mma<NC3, NCZ, PF3_CG, 1>(xs, zs, wa, wv, lane, sums);
+    pipe_publish_all<PF3_CG, true, 0>(sums, sBias, 4 * PF3_CG * gw, P_RAW, xch, rs, 0u, tag, slab, trow, lane, nullptr);
+  }
+  (void)NOUT;
+}
 }  // namespace ha
 
 extern "C" int ha_emu_xslot(int group, int col) { return group == 64 ? ha::xslot<64>(col) : (group == 32 ? ha::xslot<32>(col) : ha::xslot<0>(col)); }
@@ -2438,6 +2490,21 @@ extern "C" int ha_emu_persist_dz(const float* w0, const float* w1, const float* 
   hipLaunchKernelGGL(ha::emu_dz_kernel, dim3(32), dim3(256), 0, nullptr, wb_p, dh3, dh2, dh1, dh0, part_p, row0);
   const int n = 32 * ha::P_ZD;
   hipLaunchKernelGGL(ha::dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)part_p, g_z, (const float*)nullptr, 32, 1);
+  return HA_OK;
+}
+// the same layer test for the ROLES of the pipelined kernels (33 .. 256 sequences): w = the four forward weight matrices, bias [1024] of the layer
+extern "C" int ha_emu_pipe_layer(int layer, const float* w0, const float* w1, const float* w2, const float* w3, const float* bias, const float* x_main,
+                                 const float* z, void* xch, unsigned tag, float* slab, float* ht, int trow) {
+  if (layer < 0 || layer > 3) return HA_ERR_INVALID_ARG;
+  const float* w[4] = {w0, w1, w2, w3};
+  std::vector<float> wp((size_t)ha::NWAVES_TEAM * ha::PF_NREG * 64, 0.f);
+  ha::pack_pipe_forward(w, wp);
+  unsigned char* x = static_cast<unsigned char*>(xch);
+  const float* wp_p = wp.data();
+  if (layer == 0) hipLaunchKernelGGL(ha::emu_pipe_layer_kernel<0>, dim3(32), dim3(256), 0, nullptr, wp_p, bias, x_main, z, x, tag, slab, ht, trow);
+  else if (layer == 1) hipLaunchKernelGGL(ha::emu_pipe_layer_kernel<1>, dim3(32), dim3(256), 0, nullptr, wp_p, bias, x_main, z, x, tag, slab, ht, trow);
+  else if (layer == 2) hipLaunchKernelGGL(ha::emu_pipe_layer_kernel<2>, dim3(32), dim3(256), 0, nullptr, wp_p, bias, x_main, z, x, tag, slab, ht, trow);
+  else hipLaunchKernelGGL(ha::emu_pipe_layer_kernel<3>, dim3(32), dim3(256), 0, nullptr, wp_p, bias, x_main, z, x, tag, slab, ht, trow);
   return HA_OK;
 }
 namespace ha {

@@ -352,3 +352,43 @@ def test_emu_persistent_dz_partials_and_reduction(emu_lib):
     want = sum(dh[l].double()[:nout[l]].t() @ Ws[l].double()[:, kin[l] - 48:] for l in range(4))      # [row][48]
     assert (gz[row0:row0 + 4].double() - want).abs().max().item() < 2e-5
     assert gz[:row0].abs().max().item() == 0 and gz[row0 + 4:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize('layer', [pytest.param(0, marks=pytest.mark.slow), pytest.param(1, marks=pytest.mark.slow), pytest.param(2, marks=pytest.mark.slow), 3])
+def test_emu_pipelined_forward_role_matches_linear(emu_lib, layer):
+    """The same layer check for the ROLES of the pipelined kernels (rollout_pipe.inc, 33 .. 256 sequences): role-ordered weight packing
+    (pack_pipe_forward: 5 / 16 / 8 / 2 CUs of a team hold layers 0 .. 3), pipe_mma with 13 / 4 / 4 / 7 column groups per wave, pipe_publish_all
+    (pairs of column groups side by side, bias from LDS, the column bound of a role's last wave)."""
+    import ctypes as C
+    dll = emu_lib._dll
+    vp = C.c_void_p
+    dll.ha_emu_pipe_layer.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint, vp, vp, C.c_int]
+    kin = [339 + 48, 1024 + 48, 1024 + 48, 512 + 48]
+    nouts = [1024, 1024, 512, 216]
+    cmain, cpad, nout = kin[layer] - 48, [352, 1024, 1024, 512][layer], nouts[layer]
+    g = torch.Generator().manual_seed(300 + layer)
+    Ws = [torch.randn(nouts[l], kin[l], generator=g) / kin[l] ** 0.5 for l in range(4)]
+    bias = torch.zeros(1024)
+    bias[:nout] = 0.1 * torch.randn(nout, generator=g)
+    x = torch.zeros(cpad, 4)
+    x[:cmain] = torch.randn(cmain, 4, generator=g)
+    z = torch.randn(48, 4, generator=g)
+    tag, trow = 11, 8
+    xch = torch.zeros(1 << 18, dtype=torch.int32)
+    slab = torch.zeros(264 * 128)
+    ht = torch.zeros(1024 * 4)
+    assert dll.ha_emu_pipe_layer(layer, *[w.data_ptr() for w in Ws], bias.data_ptr(), x.data_ptr(), z.data_ptr(), xch.data_ptr(), tag, slab.data_ptr(),
+                                 ht.data_ptr(), trow) == 0
+    W = Ws[layer].double()
+    want = W[:, :cmain] @ x.double()[:cmain] + W[:, cmain:] @ z.double() + bias.double()[:nout, None]
+    sl = slab.reshape(264, 32, 4)[: nout // 4, trow:trow + 4].permute(0, 2, 1).reshape(nout, 4)
+    assert (sl.double() - want).abs().max().item() < 2e-5
+    assert slab.reshape(264, 32, 4)[nout // 4:].abs().max().item() == 0           # nothing beyond the layer's width (padding column groups are not stored)
+    group = [64, 64, 32, 0][layer]
+    words = xch[:nout * 8].reshape(nout, 4, 2)
+    assert (words[:, :, 1] == tag).all() and (xch[nout * 8:] == 0).all()
+    slots = torch.tensor([dll.ha_emu_xslot(group, c) for c in range(nout)])
+    got = words[slots][:, :, 0].contiguous().view(torch.float32)
+    assert (got.double() - want).abs().max().item() < 2e-5
+    if layer < 3:
+        assert (ht.reshape(1024, 4)[:nout].double() - want).abs().max().item() < 2e-5
