@@ -1863,6 +1863,46 @@ bool persist_take_failure(PersistNet* p) {
 
 unsigned persist_error_word(PersistNet* p) { return (p && p->err_host) ? *reinterpret_cast<volatile unsigned*>(p->err_host) : 0u; }
 
+// Pipelined adjoint: register c * NCGW + cg = K chunk c (forward output channels 16 c .. 16 c + 15 of the layer) of column group cg (forward
+// input columns) of the role's transposed layer; behind them the wave's LDS-resident dL/dz vectors.  (Shared with the emulator test hook.)
+static void pack_pipe_backward(const float* const* w, std::vector<float>& wq) {
+  const int Kin[4] = {P_DIN + P_ZD, P_H0 + P_ZD, P_H1 + P_ZD, P_H2 + P_ZD}, Cmain[4] = {P_DIN, P_H0, P_H1, P_H2}, Nout[4] = {P_H0, P_H1, P_H2, P_RAW};
+  auto W = [&](int l, int k, int col) -> float { return (k >= 0 && k < Nout[l] && col >= 0 && col < Kin[l]) ? w[l][(size_t)k * Kin[l] + col] : 0.f; };
+  const size_t stride = (size_t)(QB_NREG + QB_NLW) * 64;
+  for (int g = 0; g < NWAVES_TEAM; ++g) {
+    const int m = g / 4;
+    if (m >= PRG_M0 && m < PR1_M0) continue;       // the glue CU holds no weights
+    const int l = m < PRG_M0 ? 0 : (m < PR2_M0 ? 1 : (m < PR3_M0 ? 2 : 3));
+    const int m0[4] = {PR0_M0, PR1_M0, PR2_M0, PR3_M0}, ncgw[4] = {QB0_CG, QB1_CG, QB2_CG, QB3_CG}, nch[4] = {BC0, BC1, BC2, BC3};
+    const int gw = g - 4 * m0[l];
+    for (int ln = 0; ln < 64; ++ln) {
+      const int b = ln >> 2, j = ln & 3;
+      float* dst = wq.data() + (size_t)g * stride + ln;
+      for (int c = 0; c < nch[l]; ++c)
+        for (int cg = 0; cg < ncgw[l]; ++cg) {
+          const int col = 4 * (ncgw[l] * gw + cg) + j;
+          dst[(size_t)(c * ncgw[l] + cg) * 64] = col < Cmain[l] ? W(l, 16 * c + b, col) : 0.f;
+        }
+      float* dz = dst + (size_t)QB_NREG * 64;
+      if (l == 3 && gw < 6) {
+        for (int k = 0; k < 2; ++k)
+          for (int i = 0; i < BC3; ++i) dz[(size_t)(k * BC3 + i) * 64] = W(3, 16 * i + b, Cmain[3] + 4 * (2 * gw + k) + j);
+      } else if (l == 2 && gw < 24) {
+        for (int i = 0; i < 16; ++i) dz[(size_t)i * 64] = W(2, 16 * (16 * (gw % 2) + i) + b, Cmain[2] + 4 * (gw / 2) + j);
+      } else if (l == 1 && gw < 48) {
+        for (int i = 0; i < 16; ++i) dz[(size_t)i * 64] = W(1, 16 * (16 * (gw % 4) + i) + b, Cmain[1] + 4 * (gw / 4) + j);
+      } else if (l == 0) {
+        const int zks = gw >> 2, zc0 = 3 * (gw & 3);
+        for (int k = 0; k < 3; ++k)
+          for (int i = 0; i < QZ0_CH; ++i) {
+            const int c = QZ0_CH * zks + i;      // (the 65th chunk of the last K fifth does not exist: zero vector)
+            dz[(size_t)(k * QZ0_CH + i) * 64] = c < BC0 ? W(0, 16 * c + b, Cmain[0] + 4 * (zc0 + k) + j) : 0.f;
+          }
+      }
+    }
+  }
+}
+
 // Pipelined forward: wave g = 4 m + w of a team belongs to the role of CU m; register c * NCGW + cg = K chunk c of column group cg of the role's
 // layer.  (Shared with the emulator test hook ha_emu_pipe_layer.)
 static void pack_pipe_forward(const float* const* w, std::vector<float>& wp) {
@@ -1969,43 +2009,8 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
     rc = p_upload(&p->Wreg_pf, wp);
   }
   if (rc == HA_OK) {
-    // pipelined adjoint: register c * NCGW + cg = K chunk c (forward output channels 16 c .. 16 c + 15 of the layer) of column group cg
-    // (forward input columns) of the role's transposed layer; behind them the wave's LDS-resident dL/dz vectors
-    auto W = [&](int l, int k, int col) -> float { return (k >= 0 && k < Nout[l] && col >= 0 && col < Kin[l]) ? d->w[l][(size_t)k * Kin[l] + col] : 0.f; };
-    const size_t stride = (size_t)(QB_NREG + QB_NLW) * 64;
-    std::vector<float> wq((size_t)NWAVES_TEAM * stride, 0.f);
-    for (int g = 0; g < NWAVES_TEAM; ++g) {
-      const int m = g / 4;
-      if (m >= PRG_M0 && m < PR1_M0) continue;       // the glue CU holds no weights
-      const int l = m < PRG_M0 ? 0 : (m < PR2_M0 ? 1 : (m < PR3_M0 ? 2 : 3));
-      const int m0[4] = {PR0_M0, PR1_M0, PR2_M0, PR3_M0}, ncgw[4] = {QB0_CG, QB1_CG, QB2_CG, QB3_CG}, nch[4] = {BC0, BC1, BC2, BC3};
-      const int gw = g - 4 * m0[l];
-      for (int ln = 0; ln < 64; ++ln) {
-        const int b = ln >> 2, j = ln & 3;
-        float* dst = wq.data() + (size_t)g * stride + ln;
-        for (int c = 0; c < nch[l]; ++c)
-          for (int cg = 0; cg < ncgw[l]; ++cg) {
-            const int col = 4 * (ncgw[l] * gw + cg) + j;
-            dst[(size_t)(c * ncgw[l] + cg) * 64] = col < Cmain[l] ? W(l, 16 * c + b, col) : 0.f;
-          }
-        float* dz = dst + (size_t)QB_NREG * 64;
-        if (l == 3 && gw < 6) {
-          for (int k = 0; k < 2; ++k)
-            for (int i = 0; i < BC3; ++i) dz[(size_t)(k * BC3 + i) * 64] = W(3, 16 * i + b, Cmain[3] + 4 * (2 * gw + k) + j);
-        } else if (l == 2 && gw < 24) {
-          for (int i = 0; i < 16; ++i) dz[(size_t)i * 64] = W(2, 16 * (16 * (gw % 2) + i) + b, Cmain[2] + 4 * (gw / 2) + j);
-        } else if (l == 1 && gw < 48) {
-          for (int i = 0; i < 16; ++i) dz[(size_t)i * 64] = W(1, 16 * (16 * (gw % 4) + i) + b, Cmain[1] + 4 * (gw / 4) + j);
-        } else if (l == 0) {
-          const int zks = gw >> 2, zc0 = 3 * (gw & 3);
-          for (int k = 0; k < 3; ++k)
-            for (int i = 0; i < QZ0_CH; ++i) {
-              const int c = QZ0_CH * zks + i;      // (the 65th chunk of the last K fifth does not exist: zero vector)
-              dz[(size_t)(k * QZ0_CH + i) * 64] = c < BC0 ? W(0, 16 * c + b, Cmain[0] + 4 * (zc0 + k) + j) : 0.f;
-            }
-        }
-      }
-    }
+    std::vector<float> wq((size_t)NWAVES_TEAM * (QB_NREG + QB_NLW) * 64, 0.f);
+    pack_pipe_backward(d->w, wq);
     rc = p_upload(&p->Wreg_pb, wq);
   }
   const int bpad[4] = {P_H0, P_H1, P_H2, P_RAWPAD};
@@ -2410,6 +2415,76 @@ __global__ void emu_pipe_layer_kernel(const float* Wreg_pf, const float* bias, c
   }
   (void)NOUT;
 }
+// One (step, group) of the pipelined ADJOINT's four layer roles (rollout_pipe.inc): every role CU takes its dh (already through the GroupNorm adjoint:
+// tested separately) as the LDS operand, runs its transposed product (pack_pipe_backward, pipe_mma, pipe_publish_all into the adjoint's exchange
+// layout QX_*) and its dL/dz partial products (LDS-resident vectors, pipe_dz_mma, pipe_dz_store)
+__global__ void emu_pipe_layers_t_kernel(const float* Wreg_pb, const float* dh3, const float* dh2, const float* dh1, const float* dh0, unsigned char* xch,
+                                         unsigned tag, float* dz_part, int trow) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = blockIdx.x;
+  float* sWz = smem + P_H0 * 4 + wave * QB_NLW * 64;
+  if (m >= PRG_M0 && m < PR1_M0) return;                       // (the glue adjoint's CU)
+  const float* src = m >= PR3_M0 ? dh3 : (m >= PR2_M0 ? dh2 : (m >= PR1_M0 ? dh1 : dh0));
+  const int nsrc = m >= PR3_M0 ? P_RAWPAD : (m >= PR2_M0 ? P_H2 : P_H0);
+  for (int i = tid; i < P_H0 * 4; i += 256) xs[i] = i < nsrc * 4 ? src[i] : 0.f;
+  const float* wp = Wreg_pb + (size_t)(m * 4 + wave) * (QB_NREG + QB_NLW) * 64 + lane;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xch, 0, 1 << 20, 0x00020000);
+  const int nrows = 32;
+  if (m >= PR3_M0) {
+    const int gw = (m - PR3_M0) * 4 + wave;
+    float wa[QB3_NREG], wv[1];
+    pipe_load_weights<QB3_NREG>(wp, wa, wv);
+    for (int r = 0; r < QZ3_N; ++r) sWz[r * 64 + lane] = wp[(size_t)(QB_NREG + r) * 64];
+    __syncthreads();
+    float sums[QB3_CG][4];
+    pipe_mma<BC3, 0, QB3_CG, 1>(xs, xs, wa, wv, lane, sums);
+    pipe_publish_all<QB3_CG, true, 32>(sums, nullptr, 4 * QB3_CG * gw, P_H2, xch, rs, QX_GA3, tag, nullptr, 0, lane, nullptr);
+    if (gw < 6)
+      for (int k = 0; k < 2; ++k) {
+        float accz[4];
+        pipe_dz_mma<BC3>(xs, sWz + k * BC3 * 64, lane, accz);
+        pipe_dz_store(accz, dz_part, 0, QS_3, 2 * gw + k, nrows, trow, lane);
+      }
+  } else if (m >= PR1_M0) {
+    const bool l2 = m >= PR2_M0;
+    const int gw = (m - (l2 ? PR2_M0 : PR1_M0)) * 4 + wave;
+    float wa[PNWA], wv[1];
+    pipe_load_weights<PNWA>(wp, wa, wv);
+    for (int r = 0; r < QZ2_N; ++r) sWz[r * 64 + lane] = wp[(size_t)(QB_NREG + r) * 64];
+    __syncthreads();
+    const int ndz = l2 ? 24 : 48, nsplit = l2 ? 2 : 4;
+    if (l2) {
+      float sums[QB2_CG][4];
+      pipe_mma<BC2, 0, QB2_CG, 1>(xs, xs, wa, wv, lane, sums);
+      pipe_publish_all<QB2_CG, true, 64>(sums, nullptr, 4 * QB2_CG * gw, P_H1, xch, rs, QX_GA2, tag, nullptr, 0, lane, nullptr);
+    } else {
+      float sums[QB1_CG][4];
+      pipe_mma<BC1, 0, QB1_CG, 2>(xs, xs, wa, wv, lane, sums);
+      pipe_publish_all<QB1_CG, true, 64>(sums, nullptr, 4 * QB1_CG * gw, P_H0, xch, rs, QX_GA1, tag, nullptr, 0, lane, nullptr);
+    }
+    if (gw < ndz) {
+      float accz[4];
+      pipe_dz_mma<16>(xs + 64 * 16 * (gw % nsplit), sWz, lane, accz);
+      pipe_dz_store(accz, dz_part, 0, (l2 ? QS_2 : QS_1) + gw % nsplit, gw / nsplit, nrows, trow, lane);
+    }
+  } else {
+    const int gw = (m - PR0_M0) * 4 + wave;
+    float wa[PNWA], wv[QB0_NREG - PNWA];
+    pipe_load_weights<QB0_NREG>(wp, wa, wv);
+    for (int r = 0; r < QZ0_N; ++r) sWz[r * 64 + lane] = wp[(size_t)(QB_NREG + r) * 64];
+    __syncthreads();
+    const int zks = gw >> 2, zc0 = 3 * (gw & 3);
+    float sums[QB0_CG][4];
+    pipe_mma<BC0, 0, QB0_CG, 2>(xs, xs, wa, wv, lane, sums);
+    pipe_publish_all<QB0_CG, true, 0>(sums, nullptr, 4 * QB0_CG * gw, P_XPAD, xch, rs, QX_GX0, tag, nullptr, 0, lane, nullptr);
+    for (int k = 0; k < 3; ++k) {
+      float accz[4];
+      pipe_dz_mma<QZ0_CH>(xs + 64 * QZ0_CH * zks, sWz + k * QZ0_CH * 64, lane, accz);
+      pipe_dz_store(accz, dz_part, 0, QS_0 + zks, zc0 + k, nrows, trow, lane);
+    }
+  }
+}
 }  // namespace ha
 
 extern "C" int ha_emu_xslot(int group, int col) { return group == 64 ? ha::xslot<64>(col) : (group == 32 ? ha::xslot<32>(col) : ha::xslot<0>(col)); }
@@ -2505,6 +2580,23 @@ extern "C" int ha_emu_pipe_layer(int layer, const float* w0, const float* w1, co
   else if (layer == 1) hipLaunchKernelGGL(ha::emu_pipe_layer_kernel<1>, dim3(32), dim3(256), 0, nullptr, wp_p, bias, x_main, z, x, tag, slab, ht, trow);
   else if (layer == 2) hipLaunchKernelGGL(ha::emu_pipe_layer_kernel<2>, dim3(32), dim3(256), 0, nullptr, wp_p, bias, x_main, z, x, tag, slab, ht, trow);
   else hipLaunchKernelGGL(ha::emu_pipe_layer_kernel<3>, dim3(32), dim3(256), 0, nullptr, wp_p, bias, x_main, z, x, tag, slab, ht, trow);
+  return HA_OK;
+}
+// the four transposed layer roles of the pipelined adjoint for one (step, group): exchange region in the adjoint's layout (returned offsets: bytes of
+// dL/da3, dL/da2, dL/da1, dL/dx), g_z [32][48] for the team's rows trow .. trow + 3
+extern "C" int ha_emu_pipe_layers_t(const float* w0, const float* w1, const float* w2, const float* w3, const float* dh3, const float* dh2, const float* dh1,
+                                    const float* dh0, void* xch, unsigned tag, float* g_z, int trow, unsigned* offsets) {
+  const float* w[4] = {w0, w1, w2, w3};
+  std::vector<float> wq((size_t)ha::NWAVES_TEAM * (ha::QB_NREG + ha::QB_NLW) * 64, 0.f);
+  ha::pack_pipe_backward(w, wq);
+  std::vector<float> part((size_t)ha::QS_SLOTS * 32 * ha::P_ZD, 0.f);
+  const float* wq_p = wq.data();
+  float* part_p = part.data();
+  unsigned char* x = static_cast<unsigned char*>(xch);
+  hipLaunchKernelGGL(ha::emu_pipe_layers_t_kernel, dim3(32), dim3(256), 0, nullptr, wq_p, dh3, dh2, dh1, dh0, x, tag, part_p, trow);
+  const int n = 32 * ha::P_ZD;
+  hipLaunchKernelGGL(ha::pipe_dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)part_p, g_z, (const float*)nullptr, 32, 1, 32);
+  offsets[0] = ha::QX_GA3; offsets[1] = ha::QX_GA2; offsets[2] = ha::QX_GA1; offsets[3] = ha::QX_GX0;
   return HA_OK;
 }
 namespace ha {

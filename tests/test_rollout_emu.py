@@ -392,3 +392,41 @@ def test_emu_pipelined_forward_role_matches_linear(emu_lib, layer):
     assert (got.double() - want).abs().max().item() < 2e-5
     if layer < 3:
         assert (ht.reshape(1024, 4)[:nout].double() - want).abs().max().item() < 2e-5
+
+
+def test_emu_pipelined_adjoint_roles_match_transposed_linear_and_dz(emu_lib):
+    """One (step, group) of the pipelined adjoint's four layer roles on the host emulator: role-ordered packing of the transposed layers and of the
+    LDS-resident dL/dz vectors (pack_pipe_backward), pipe_mma, pipe_publish_all into the adjoint's exchange layout, the 12 K-split dL/dz partial
+    products (pipe_dz_mma / pipe_dz_store) and pipe_dz_reduce_kernel.  Against dh_l W_l (main input columns) and sum_l dh_l W_l (latent columns)."""
+    import ctypes as C
+    dll = emu_lib._dll
+    vp = C.c_void_p
+    dll.ha_emu_pipe_layers_t.argtypes = [vp] * 9 + [C.c_uint, vp, C.c_int, vp]
+    kin = [339 + 48, 1024 + 48, 1024 + 48, 512 + 48]
+    nout = [1024, 1024, 512, 216]
+    g = torch.Generator().manual_seed(500)
+    Ws = [torch.randn(nout[l], kin[l], generator=g) / kin[l] ** 0.5 for l in range(4)]
+    pads = [1024, 1024, 512, 224]
+    dh = []
+    for l in range(4):
+        t = torch.zeros(pads[l], 4)
+        t[:nout[l]] = torch.randn(nout[l], 4, generator=g)
+        dh.append(t)
+    tag, trow = 21, 20
+    xch = torch.zeros(1 << 18, dtype=torch.int32)
+    gz = torch.full((32, 48), 3.0)
+    offs = (C.c_uint * 4)()
+    assert dll.ha_emu_pipe_layers_t(*[w.data_ptr() for w in Ws], dh[3].data_ptr(), dh[2].data_ptr(), dh[1].data_ptr(), dh[0].data_ptr(), xch.data_ptr(), tag,
+                                    gz.data_ptr(), trow, offs) == 0
+    for l, group in ((3, 32), (2, 64), (1, 64), (0, 0)):
+        ncol = kin[l] - 48
+        want = (dh[l].double()[:nout[l]].t() @ Ws[l].double()[:, :ncol]).t()                      # [input channel][row]
+        base = offs[3 - l] // 4
+        words = xch[base:base + ncol * 8].reshape(ncol, 4, 2)
+        assert (words[:, :, 1] == tag).all(), l
+        slots = torch.tensor([dll.ha_emu_xslot(group, c) for c in range(ncol)])
+        got = words[slots][:, :, 0].contiguous().view(torch.float32)
+        assert (got.double() - want).abs().max().item() < 2e-5, l
+    want_z = sum(dh[l].double()[:nout[l]].t() @ Ws[l].double()[:, kin[l] - 48:] for l in range(4))
+    assert (gz[trow:trow + 4].double() - want_z).abs().max().item() < 2e-5
+    assert gz[:trow].abs().max().item() == 0 and gz[trow + 4:].abs().max().item() == 0
