@@ -114,6 +114,9 @@ static_assert(4 * RED_BLOCK <= P_H1 * 4, "reduction scratch fits the dh1 operand
 static_assert(LB_TOTAL * 4 <= 160 * 1024, "the adjoint's LDS fits one CU");
 }  // namespace
 
+extern unsigned g_cu_poison;                 // debug.hip (ha_tune_set "cu_poison")
+int cu_poison_launch(hipStream_t st);
+
 size_t persist_ws_floats() { return (XCH_BYTES + 3) / 4; }
 int persist_dz_slots() { return DZ_SLOTS; }
 
@@ -675,6 +678,12 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
     xs0[c * 4 + i] = v;
     if (writer && c < P_DINP) a.xT[pq(c) + (size_t)r * 4] = v;
   }
+  // The second state buffer: the glue writes channels 0 .. 338 of the buffer it fills, copy_out sends channels 0 .. 339 (P_DINP) of it to
+  // the state slab the prior network reads.  LDS is not cleared between kernels: without this fill the pad channel of every odd step was
+  // whatever the CU's previous kernel left there (round 5: NaN gradients on a fresh box -- 0 x NaN in the prior's first layer -- where the
+  // builder's box held small finite numbers; tools/nan_hunt.py --cu-poison reproduces it anywhere).  The glue record's unused tail likewise.
+  for (int e = tid; e < ROWS * P_XPAD; e += 256) sX[ROWS * P_XPAD + e] = 0.f;
+  if (tid < ROWS * 32) sGL[tid] = 0.f;
   const int zi = tid / P_ZD, zc = tid - zi * P_ZD;          // thread <-> (row, latent channel) for tid < 192
   const bool zlive = tid < ROWS * P_ZD && row0 + zi < a.B;
   if (tid < ROWS * P_ZD) zs[zc * 4 + zi] = zlive ? a.z_seq[((size_t)(row0 + zi) * a.S) * P_ZD + zc] : 0.f;
@@ -2093,6 +2102,7 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
     a.inject = (variant >> 1) & 1;
     a.xch = reinterpret_cast<unsigned char*>(f.ws);
     a.err = p->err_dev;
+    if (g_cu_poison) { const int prc = cu_poison_launch(st); if (prc != HA_OK) return prc; }
     if (variant & 1) hipLaunchKernelGGL(rollout_pipe_fwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), PL_TOTAL * 4, st, a);
     else hipLaunchKernelGGL(rollout_pipe_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), PL_TOTAL * 4, st, a);
     HA_LAUNCH_CHECK();
@@ -2117,6 +2127,7 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
   a.err = p->err_dev;
   a.inject = (variant >> 1) & 1;
   a.hidden_slabs = f.hidden_slabs ? 1 : 0;
+  if (g_cu_poison) { const int prc = cu_poison_launch(st); if (prc != HA_OK) return prc; }
   if (variant & 1) hipLaunchKernelGGL(rollout_persist_fwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
   else hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
   HA_LAUNCH_CHECK();
@@ -2147,6 +2158,7 @@ int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_
     a.t2j = f.t2j; a.g_past0 = f.g_past0; a.dz_part = f.dz_part;
     a.xch = reinterpret_cast<unsigned char*>(f.ws);
     a.err = p->err_dev;
+    if (g_cu_poison) { const int prc = cu_poison_launch(st); if (prc != HA_OK) return prc; }
     if (variant & 1) hipLaunchKernelGGL(rollout_pipe_bwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), QL_TOTAL * 4, st, a);
     else hipLaunchKernelGGL(rollout_pipe_bwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), QL_TOTAL * 4, st, a);
     HA_LAUNCH_CHECK();
@@ -2171,6 +2183,7 @@ int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_
   a.t2j = f.t2j; a.g_past0 = f.g_past0; a.dz_part = f.dz_part;
   a.xch = reinterpret_cast<unsigned char*>(f.ws);
   a.err = p->err_dev;
+  if (g_cu_poison) { const int prc = cu_poison_launch(st); if (prc != HA_OK) return prc; }
   if (variant & 1) hipLaunchKernelGGL(rollout_persist_bwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), LB_TOTAL * 4, st, a);
   else hipLaunchKernelGGL(rollout_persist_bwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), LB_TOTAL * 4, st, a);
   HA_LAUNCH_CHECK();

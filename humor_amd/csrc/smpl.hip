@@ -47,6 +47,7 @@ int g_dense_gA_sparse = 2;   // ha_tune_set("dense_gA_sparse"): dL/dA of the den
                              // chunk touches (205 us at N = 1920), 1 = by joint lists (255 us), 0 = dense 64-column MFMA product (417 us)
 int g_dense_bwd_waves = 0;   // ha_tune_set("dense_bwd_waves"): wave-count target of the dense backward's K split (0 = default)
 extern int g_layer_spb, g_layer_nw, g_layer_finish, g_gemm_rm, g_layer_hsum, g_layer_acc, g_rollout_groups, g_gemm_ks, g_rollout_persist, g_rollout_persist_bwd, g_rollout_persist_inject, g_rollout_pipe, g_rollout_pipe_bwd;   // rollout.hip
+extern unsigned g_cu_poison;   // debug.hip
 }
 extern "C" int ha_tune_set(const char* key, int value) {
   HA_REQUIRE(key, "ha_tune_set: null key");
@@ -66,11 +67,12 @@ extern "C" int ha_tune_set(const char* key, int value) {
   if (strcmp(key, "rollout_pipe") == 0) { ha::g_rollout_pipe = value; return HA_OK; }
   if (strcmp(key, "rollout_pipe_bwd") == 0) { ha::g_rollout_pipe_bwd = value; return HA_OK; }
   if (strcmp(key, "rollout_persist_inject") == 0) { ha::g_rollout_persist_inject = value; return HA_OK; }
+  if (strcmp(key, "cu_poison") == 0) { ha::g_cu_poison = (unsigned)value; return HA_OK; }
   ha::set_error("ha_tune_set: unknown key '%s'", key);
   return HA_ERR_INVALID_ARG;
 }
 extern "C" const char* ha_last_error(void) { return ha::g_err; }
-extern "C" int ha_abi_version(void) { return 2; }
+extern "C" int ha_abi_version(void) { return 3; }
 extern "C" int ha_device_arch(int device, char* buf, int buflen) {
   HA_REQUIRE(buf && buflen > 0, "ha_device_arch: null buffer");
   hipDeviceProp_t prop;

@@ -34,8 +34,12 @@ const char* ha_last_error(void);
 int ha_abi_version(void);
 /* Writes the device's gcnArchName (e.g. "gfx950:sramecc+:xnack-") into buf. */
 int ha_device_arch(int device, char* buf, int buflen);
-/* Development knobs for kernel launch variants (A/B measurements), process-wide: "skin_variant" (-1 = auto), "layer_spb" (K-slices per block of the roll-out layer kernel, 0 = default), "layer_finish" (0 never / 1 auto / 2 always use the GroupNorm finishing pass), "gemm_rm" (row tiles per wave of the batched prior GEMM: 0 by size / 1 / 2), "rollout_persist" / "rollout_persist_bwd" (0 = launch chain; 1 = persistent kernels, 3 = with write-through publishes), "rollout_pipe" / "rollout_pipe_bwd" (batches of more than 32 sequences: 1 = the layer-parallel pipelined persistent kernels, 0 = launch chain; set the adjoint knobs before the forward call), "rollout_persist_inject" (test hook: 1 = the next persistent forwards drop one CU of team 0, so that the failure path -- NaN results, error word -- can be exercised). */
+/* Development knobs for kernel launch variants (A/B measurements), process-wide: "skin_variant" (-1 = auto), "layer_spb" (K-slices per block of the roll-out layer kernel, 0 = default), "layer_finish" (0 never / 1 auto / 2 always use the GroupNorm finishing pass), "gemm_rm" (row tiles per wave of the batched prior GEMM: 0 by size / 1 / 2), "rollout_persist" / "rollout_persist_bwd" (0 = launch chain; 1 = persistent kernels, 3 = with write-through publishes), "rollout_pipe" / "rollout_pipe_bwd" (batches of more than 32 sequences: 1 = the layer-parallel pipelined persistent kernels, 0 = launch chain; set the adjoint knobs before the forward call), "rollout_persist_inject" (test hook: 1 = the next persistent forwards drop one CU of team 0, so that the failure path -- NaN results, error word -- can be exercised), "cu_poison" (test hook: != 0 = every persistent roll-out launch is preceded by a kernel that fills the LDS and the vector registers of every CU with a bit pattern -- 1 = a quiet NaN, else the value itself -- so that a read of state the kernel did not write shows on every box). */
 int ha_tune_set(const char* key, int value);
+/* Test support: fills the LDS and every VGPR / AGPR of all CUs with `pattern` (0 = quiet NaN) on `stream`; with `surviving_words` non-null it then
+ * synchronises the stream and counts the LDS words (of 256 x 40960) a following kernel still finds holding the pattern -- 0 means this box clears
+ * LDS between kernels and the hook cannot show anything. */
+int ha_debug_cu_poison(unsigned int pattern, unsigned int* surviving_words, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SMPL / SMPL+H body model  (replaces smplx==0.1.28 `lbs`, `SMPLH.forward`, `VertexJointSelector` as
