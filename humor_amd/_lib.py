@@ -118,6 +118,7 @@ _SIGS = {
     'ha_humor_rollout_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     'ha_humor_net_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     'ha_humor_persist_status': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint), C.POINTER(C.c_int64)]),
+    'ha_humor_persist_ack': (C.c_int, [C.c_void_p]),
     'ha_mlp_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(MlpDesc), C.c_int, C.c_float]),
     'ha_mlp_destroy': (C.c_int, [C.c_void_p]),
     'ha_mlp_workspace': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
@@ -143,7 +144,7 @@ _SIGS = {
 
 _NO_POISON = {'ha_tune_set', 'ha_debug_cu_poison', 'ha_last_error', 'ha_abi_version', 'ha_device_arch', 'ha_smpl_model_create',
               'ha_smpl_model_destroy', 'ha_smpl_model_info', 'ha_smpl_model_define_subset', 'ha_smpl_workspace', 'ha_humor_net_create',
-              'ha_humor_net_destroy', 'ha_humor_rollout_workspace', 'ha_humor_net_set_option', 'ha_humor_persist_status', 'ha_mlp_create',
+              'ha_humor_net_destroy', 'ha_humor_rollout_workspace', 'ha_humor_net_set_option', 'ha_humor_persist_status', 'ha_humor_persist_ack', 'ha_mlp_create',
               'ha_mlp_destroy', 'ha_mlp_workspace', 'ha_smpl_backward_dense_workspace', 'ha_lbfgs_gram_workspace'}
 
 

@@ -107,7 +107,8 @@ struct ha_humor_net {
   // The stash layout of a call depends on whether the persistent kernels serve it, which in turn depends on mutable state (the tune
   // knob, the asynchronous error word).  A forward call decides ONCE and records the decision for the stash it fills; every later
   // phase of that call and the backward over the same stash use the recorded mode (one host thread per device: no lock).
-  mutable std::unordered_map<const void*, int> stash_mode;
+  struct StashRec { int mode, B, S, knobs; };
+  mutable std::unordered_map<const void*, StashRec> stash_mode;
 };
 
 namespace ha {
@@ -1854,6 +1855,19 @@ static void group_plan(int B, int& ngroups, int& rows_per_group, bool pipelined 
 
 static bool pipelined_call(int B, int mode) { return mode >= 1 && B > 32 && g_rollout_pipe != 0 && g_layer_finish != 2; }
 
+// the process-wide knobs the stash layout depends on, packed: a backward call checks that they are the ones its forward ran with
+static int layout_knobs() {
+  return (g_layer_spb & 0xff) | ((g_layer_finish & 3) << 8) | ((g_layer_acc & 1) << 10) | ((g_layer_hsum & 1) << 11) | ((g_rollout_pipe & 1) << 12) |
+         ((g_rollout_groups & 0xff) << 13);
+}
+// The adjoint of a stash filled by a one-launch forward: mode 2 (no launch-chain slabs) can only be read by the one-launch adjoint -- the
+// stash decides, whatever the adjoint knobs say by now; mode 1 (slabs present) follows the live knobs.
+static bool adjoint_persistent(const StashLayout& L, int mode) {
+  if (!L.single) return false;
+  if (mode == 2) return true;
+  return g_rollout_persist_bwd != 0 && (!L.pipe || g_rollout_pipe_bwd != 0);
+}
+
 static size_t group_stash_floats(const ha_humor_net* net, int rows, int S) {
   // the largest of: persistent mode, launch-chain mode, sampling roll-out (the mode may change between the query and the call)
   const int saved = tl_single_mode;
@@ -1920,6 +1934,12 @@ extern "C" int ha_humor_persist_status(const ha_humor_net* net, int* available, 
   *error_word = persist_error_word(net->persist);
   *launches = persist_launches(net->persist) + (persist_launches_bwd(net->persist) << 32);
   *available = persist_usable(net->persist) ? 1 : 0;
+  return HA_OK;
+}
+
+extern "C" int ha_humor_persist_ack(const ha_humor_net* net) {
+  HA_REQUIRE(net, "ha_humor_persist_ack: null argument");
+  persist_ack_failure(net->persist);
   return HA_OK;
 }
 
@@ -2202,11 +2222,11 @@ static int rollout_backward_impl(const ha_humor_net* net, int B, int S, const fl
     }
   };
 
-  const bool persist_bwd = L.single && g_rollout_persist_bwd != 0 && (!L.pipe || g_rollout_pipe_bwd != 0);
-  HA_REQUIRE(!(!persist_bwd && tl_single_mode == 2),
-             "ha_humor_rollout_backward: this stash was filled by a persistent / pipelined forward without launch-chain slabs (the adjoint knobs said "
-             "the one-launch adjoint would follow) and the adjoint knobs changed since, or the persistent path was disabled by a failure in between "
-             "-- set the knobs before the forward call");
+  const bool persist_bwd = adjoint_persistent(L, tl_single_mode);
+  HA_REQUIRE(!(tl_single_mode == 2 && !(L.single && persist_usable(net->persist))),
+             "ha_humor_rollout_backward: this stash was filled by a persistent / pipelined forward without launch-chain slabs (only the one-launch "
+             "adjoint can read it) and the persistent path has been disabled since (a launch reported a failure, error word 0x%x): repeat the "
+             "forward call -- it will run on the launch chain", persist_error_word(net->persist));
   if (persist_bwd) {
     if (phase == PH_BEGIN) {
       PersistBwd f;
@@ -2362,7 +2382,7 @@ extern "C" int ha_humor_rollout_forward(const ha_humor_net* net, int B, int S, c
   // (one entry per distinct stash address ever seen -- the allocator recycles them, a forward overwrites its entry -- so the map stays
   // small; the wholesale clear is a backstop that a process would need 64 k live stashes to reach)
   if (net->stash_mode.size() > 65536) net->stash_mode.clear();
-  net->stash_mode[stash] = mode;
+  net->stash_mode[stash] = ha_humor_net::StashRec{mode, B, S, layout_knobs()};
   tl_single_mode = mode;
   int rc;
   rc = for_each_group(net->device, B, S, false, (hipStream_t)stream, piped, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {
@@ -2401,7 +2421,12 @@ extern "C" int ha_humor_rollout_backward_ex(const ha_humor_net* net, int B, int 
   DeviceGuard guard(net->device);
   // the mode the forward over this stash recorded (a stash this library has not seen: decided from the live state, as before)
   const auto it = net->stash_mode.find(stash);
-  tl_single_mode = it != net->stash_mode.end() ? it->second : -1;
+  HA_REQUIRE(it != net->stash_mode.end(), "ha_humor_rollout_backward: no forward call of this network has filled this stash");
+  HA_REQUIRE(it->second.B == B && it->second.S == S, "ha_humor_rollout_backward: the stash was filled by a forward call of %d x %d, not %d x %d",
+             it->second.B, it->second.S, B, S);
+  HA_REQUIRE(it->second.knobs == layout_knobs(), "ha_humor_rollout_backward: a layout knob (layer_spb / layer_finish / layer_acc / layer_hsum / "
+             "rollout_pipe / rollout_groups) changed between the forward call that filled this stash and its backward");
+  tl_single_mode = it->second.mode;
   const bool piped = pipelined_call(B, tl_single_mode >= 0 ? tl_single_mode : ((g_rollout_persist != 0 && persist_usable(net->persist)) ? 1 : 0));
   int ng, rpg;
   group_plan(B, ng, rpg, piped);
@@ -2410,10 +2435,10 @@ extern "C" int ha_humor_rollout_backward_ex(const ha_humor_net* net, int B, int 
   tl_groups = 1;
   int rc;
   bool add_in_kernel = false;
-  if (g_z_add && tl_single_mode >= 1 && ng == 1 && g_rollout_persist_bwd != 0) {
+  if (g_z_add && tl_single_mode >= 1 && ng == 1) {
     StashLayout L;
     make_layout(net, B, S, L);
-    add_in_kernel = L.single && (!L.pipe || g_rollout_pipe_bwd != 0);
+    add_in_kernel = adjoint_persistent(L, tl_single_mode);
   }
   tl_gz_add = add_in_kernel ? g_z_add : nullptr;
   rc = for_each_group(net->device, B, S, true, (hipStream_t)stream, piped, [&](int g, int r0, int rows, hipStream_t st, int phase, int t) {

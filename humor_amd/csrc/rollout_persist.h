@@ -54,6 +54,8 @@ void persist_destroy(PersistNet* p);
 bool persist_usable(PersistNet* p);
 // true exactly once after a persistent launch has reported a failure (the caller returns an error: earlier results are invalid)
 bool persist_take_failure(PersistNet* p);
+// the caller has observed the failure through the error word and handled it: persist_take_failure stays false from now on
+void persist_ack_failure(PersistNet* p);
 int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t st);
 int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_t st);
 // error word of the most recent launches (0 = none); valid after the stream has been synchronised

@@ -1870,6 +1870,13 @@ bool persist_take_failure(PersistNet* p) {
   return true;
 }
 
+// The caller has read the error word itself (ha_humor_persist_status) and handled the failure: no entry point needs to return it again.
+void persist_ack_failure(PersistNet* p) {
+  if (!p || !p->err_host || *reinterpret_cast<volatile unsigned*>(p->err_host) == 0) return;
+  p->reported = true;
+  p->disabled = true;
+}
+
 unsigned persist_error_word(PersistNet* p) { return (p && p->err_host) ? *reinterpret_cast<volatile unsigned*>(p->err_host) : 0u; }
 
 // Pipelined adjoint: register c * NCGW + cg = K chunk c (forward output channels 16 c .. 16 c + 15 of the layer) of column group cg (forward

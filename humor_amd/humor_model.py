@@ -436,6 +436,12 @@ class HumorModel(nn.Module):
         h.lib.call('ha_humor_persist_status', h.ptr, C.byref(av), C.byref(err), C.byref(n))
         return av.value, err.value, n.value
 
+    def acknowledge_persistent_failure(self, device):
+        """The caller has read a non-zero error word (persistent_rollout_status) and handled the failure: later roll-out entry points on this
+        network do not report it again (they run on the launch chain)."""
+        h = self._net_handle(device)
+        h.lib.call('ha_humor_persist_ack', h.ptr)
+
     def _cached_handle(self, ref):
         dev = ref.device
         index = (dev.index if dev.index is not None else torch.cuda.current_device()) if dev.type == 'cuda' else 0

@@ -29,6 +29,7 @@ Measured at C4 (32 x 60): 4.9 ms per closure evaluation inside torch.optim.LBFGS
 (stage 1) / 0.46 ms (stage 2) per evaluation including the closure.
 Same algorithm, same decisions in exact arithmetic; fp32 summation order differs, so iterates agree with torch's to rounding."""
 import ctypes as C
+import math
 import time
 
 import torch
@@ -292,8 +293,18 @@ class LBFGS:
         H['M'][2 * H['h']].copy_(g_row_value)
         # (a speculative iteration may have been built on a direction the host then rejects -- curvature test failed: H = y.s / y.y of a
         # vanishing pair -- and hold non-finite rows; dead rows are multiplied by zero coefficients in d = M^T coef, so they must be finite)
-        H['M'][it['pushed']].zero_()
-        H['M'][H['h'] + it['pushed']].zero_()
+        slot, h = it['pushed'], H['h']
+        H['M'][slot].zero_()
+        H['M'][h + slot].zero_()
+        # (... and so must everything ha_lbfgs_gram wrote for the dead slot: its Gram rows / columns, its projections and the coefficient
+        # vector built with it -- ha_lbfgs_coeffs multiplies entries of slots outside `order` by zero, and 0 x NaN poisons every later
+        # direction (advisor, round 5: repeated step() calls at a converged point, y = 0 -> H = 0 / 0))
+        dead = [slot, h + slot]
+        H['G'][dead, :] = 0.0
+        H['G'][:, dead] = 0.0
+        H['P'][dead, :] = 0.0
+        H['Mg'][dead] = 0.0
+        H['coef'].zero_()
         if discard is not None:
             discard()
         self.spec_stats['rolled_back'] += 1
@@ -322,6 +333,9 @@ class LBFGS:
         scal = Hh['scal'][0]
         loss_t = orig_loss.detach().reshape(1).float()
         gg, gmax, gsum, loss = self._scalars(flat_grad, flat_grad, loss_t, scal[:4]).tolist()
+        # host copies of what this call has read anyway (no extra synchronisation): the objective and the largest gradient entry at the
+        # call's first evaluation -- MotionOptimizer.run raises on a non-finite one instead of returning NaN results
+        self.last_loss, self.last_gmax = loss, gmax
         current_evals = 1
         state['func_evals'] += 1
         if gmax <= tolerance_grad:
@@ -494,6 +508,8 @@ class LBFGS:
                 break
 
         assert pending is None
+        if not (math.isfinite(loss) and math.isfinite(gmax)):
+            self.last_loss, self.last_gmax = loss, gmax          # (a later evaluation of this call went non-finite)
         state['d'], state['t'], state['H_diag'] = d, t, H_diag
         state['prev_loss'] = prev_loss
         return orig_loss

@@ -13,6 +13,7 @@ Multi-GPU: pass ``shard=humor_amd.distributed.Shard(B, group)`` -- replicated L-
 of sub-sequences, one packed all-reduce per closure (humor_amd/distributed.py).
 """
 import os
+import math
 import time
 
 import numpy as np
@@ -310,8 +311,23 @@ class MotionOptimizer():
             self._rollout_err0 = err
             for st in self._graph_states:
                 st['graph'], st['failed'] = None, True
+            # this fit is the one the failure aborts: the next fit around the same network must not be handed it again by its first entry point
+            ack = getattr(self.motion_prior, 'acknowledge_persistent_failure', None)
+            if ack is not None:
+                ack(torch.device(self.device))
             raise RuntimeError('humor_amd: the persistent roll-out reported an incomplete launch (error word 0x%x): the objective values of '
                                'this fit are invalid; later evaluations use the launch-chain roll-out' % err)
+
+    def _check_finite(self, optim, stage, it):
+        """Called after every outer iteration with the objective value and the largest gradient entry L-BFGS has just read on the host (no
+        extra synchronisation).  A non-finite one means the iterates are (or are about to become) NaN: the fit is aborted with an error, so
+        that the caller skips the batch (run_fitting.py:437-439) instead of writing NaN results -- round 5 returned a NaN fit silently."""
+        loss, gmax = getattr(optim, 'last_loss', 0.0), getattr(optim, 'last_gmax', 0.0)
+        if not (math.isfinite(loss) and math.isfinite(gmax)):
+            for st in self._graph_states:
+                st['graph'], st['failed'] = None, True
+            raise RuntimeError('humor_amd: non-finite objective in %s, outer iteration %d (loss %r, largest gradient entry %r): the fit is '
+                               'aborted, no results are returned for this batch' % (stage, it, loss, gmax))
 
     def _discard_last_eval(self):
         """humor_amd.lbfgs.LBFGS issues the first trial evaluation of an iteration before it has read the direction's scalars; in the
@@ -415,6 +431,7 @@ class MotionOptimizer():
             self.fitting_loss.cur_optim_step = i
 
             optim.step(closure1)
+            self._check_finite(optim, 'stage 1', i)
         self._mark('stage1', num_iter[0])
         per_stage_outputs['stage1'] = self._stage_snapshot(stages_res_out, 'stage1_results.npz')
 
@@ -428,6 +445,7 @@ class MotionOptimizer():
         self._mark(None)
         for i in range(num_iter[1]):
             optim.step(closure2)
+            self._check_finite(optim, 'stage 2', i)
         self._mark('stage2', num_iter[1])
         per_stage_outputs['stage2'] = self._stage_snapshot(stages_res_out, 'stage2_results.npz')
         stage2_cam = None
@@ -508,6 +526,7 @@ class MotionOptimizer():
                     motion_params, None, short=tune_phase)
             motion_optim.step(closures3[phase])
             self._check_rollout_health()
+            self._check_finite(motion_optim, phase_name, i)
             if self.iter_log is not None:          # (tools/lbfgs_phase_profile.py: a device synchronise per outer iteration)
                 torch.cuda.synchronize()
                 self.iter_log.append((phase_name, time.perf_counter(), self.closure_evals))

@@ -239,6 +239,10 @@ int ha_humor_net_set_option(ha_humor_net* net, const char* key, int value);
  * meaningful once the stream of the last roll-out has been synchronised; *launches = persistent forwards issued so far for this
  * network in the low 32 bits, persistent adjoints in the high 32 bits.  After a failure the library uses the launch chain. */
 int ha_humor_persist_status(const ha_humor_net* net, int* available, unsigned int* error_word, int64_t* launches);
+/* Acknowledges a failure the caller has read through ha_humor_persist_status and handled itself (MotionOptimizer aborts the fit it happened in --
+ * the only detection path for closures replayed from a hipGraph, which never pass an entry point): without it the NEXT roll-out entry point on this
+ * network would return the failure once more, and abort a fit whose evaluations all ran validly on the launch chain.  No-op when the word is 0. */
+int ha_humor_persist_ack(const ha_humor_net* net);
 
 /* ------------------------------------------------------------------------------------------------
  * Frozen MLPs on N independent rows (no weight gradients): VPoser v1.0's decoder / encoder as MotionOptimizer.latent2pose /

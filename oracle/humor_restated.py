@@ -100,11 +100,49 @@ def mlp_params(sd, prefix):
     return lin, gn
 
 
-def mlp_forward(x, lin, gn, skip=None):
-    """Linear -> [GroupNorm(16 groups over channels of a 2-D input) -> ReLU -> (cat skip) -> Linear]*."""
+# ReLU kinks.  The roll-out's gradient is discontinuous wherever a GroupNorm output crosses zero; a unit closer to zero than the rounding
+# of an fp32 evaluation can legitimately sit on either side (two CORRECT fp32 implementations then return gradients that differ by
+# 1e-3 .. 1e-2 of the largest entry).  KinkProbe lets the tests decide such cases from the REFERENCE side: it records, per ReLU site
+# (network, step, layer), the units whose input is within tau[row] of zero, and it can force chosen units on / off -- the one-sided
+# derivatives -- so that a gradient can be required to equal the oracle's on ONE of the branches the oracle itself cannot tell apart.
+_RELU_HOOK = None
+
+
+class KinkProbe:
+    """hook(y, site) -> relu(y).  tau: float or [B] tensor (None: record nothing); force: {site: int8 [B, C], -1 natural / 0 off / 1 on}."""
+
+    def __init__(self, tau=None, force=None):
+        self.tau, self.force, self.near = tau, force or {}, []
+
+    def __call__(self, y, site):
+        mask = y > 0
+        if self.tau is not None:
+            tau = self.tau if not torch.is_tensor(self.tau) else self.tau.to(y.dtype).unsqueeze(1)
+            yd = y.detach()
+            for r, c in (yd.abs() < tau).nonzero().tolist():
+                self.near.append((site, r, c, float(yd[r, c])))
+        f = self.force.get(site)
+        if f is not None:
+            mask = torch.where(f >= 0, f > 0, mask)
+        return y * mask.to(y.dtype)
+
+    def __enter__(self):
+        global _RELU_HOOK
+        self._prev, _RELU_HOOK = _RELU_HOOK, self
+        return self
+
+    def __exit__(self, *exc):
+        global _RELU_HOOK
+        _RELU_HOOK = self._prev
+
+
+def mlp_forward(x, lin, gn, skip=None, site=None):
+    """Linear -> [GroupNorm(16 groups over channels of a 2-D input) -> ReLU -> (cat skip) -> Linear]*.
+    site: (network, step) label of this evaluation for an active KinkProbe (the layer index is appended)."""
     h = F.linear(x, lin[0][0], lin[0][1])
-    for (w, b), (g, be) in zip(lin[1:], gn):
-        h = F.relu(F.group_norm(h, 16, g, be, eps=1e-5))
+    for li, ((w, b), (g, be)) in enumerate(zip(lin[1:], gn)):
+        h = F.group_norm(h, 16, g, be, eps=1e-5)
+        h = F.relu(h) if _RELU_HOOK is None or site is None else _RELU_HOOK(h, site + (li,))
         if skip is not None:
             h = torch.cat([h, skip], dim=1)
         h = F.linear(h, w, b)
@@ -210,11 +248,11 @@ def roll_out(sd, past_in0, z_seq, return_prior=True, eps_seq=None, G0=None, gt0=
     world, pms, pvs = [], [], []
     for t in range(S):
         if return_prior:
-            po = mlp_forward(past_in, pri_lin, pri_gn)
+            po = mlp_forward(past_in, pri_lin, pri_gn, site=('pri', t))
             pms.append(po[:, :LATENT])
             pvs.append(torch.exp(po[:, LATENT:]))
         z = pms[-1] + eps_seq[:, t] * torch.sqrt(pvs[-1]) if sampling else z_seq[:, t]
-        raw = mlp_forward(torch.cat([past_in, z], dim=1), dec_lin, dec_gn, skip=z)
+        raw = mlp_forward(torch.cat([past_in, z], dim=1), dec_lin, dec_gn, skip=z, site=('dec', t))
         pred = decode_compose(past_in, raw, output_delta)
         W = world2aligned(pred[:, 6:15].reshape(B, 3, 3))
         wt = torch.cat([-pred[:, 0:2], zero], dim=1)

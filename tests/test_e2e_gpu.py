@@ -30,6 +30,37 @@ def _gt_joints(npz, dev, B, T, seed):
 
 
 @pytest.mark.parametrize('use_graphs', [False, True])
+@pytest.mark.parametrize('stage', [0, 2])
+def test_non_finite_objective_aborts_the_fit(gpu_lib, dev, smplh_npz, use_graphs, stage):
+    """A fit whose objective turns non-finite raises (run_fitting.py:437-439 then skips the batch) instead of returning NaN results, in
+    every stage, eager and under hipGraph replay.  Stage 1: a NaN observation.  Stage 3: the latent motion is overwritten with NaN behind the
+    optimiser's back after the stage has started (the injection a failed persistent roll-out team would make)."""
+    B, T = 2, 12
+    joints, _ = _gt_joints(smplh_npz, dev, B, T, seed=5)
+    obs = {'joints3d': joints.clone()}
+    opt = FC.build(gpu_lib, dev, 'amass', B, T, smplh_npz)
+    opt.use_graphs = use_graphs
+    if stage == 0:
+        obs['joints3d'][1, 3, 5, 0] = float('nan')
+        with pytest.raises(RuntimeError, match='non-finite objective in stage 1'):
+            opt.run(obs, data_fps=30, lr=1.0, num_iter=[3, 2, 2], lbfgs_max_iter=5)
+        return
+    health = opt._check_rollout_health
+    calls = []
+
+    def poison_after_two():
+        health()
+        calls.append(1)
+        if len(calls) == 2:
+            with torch.no_grad():
+                opt.latent_motion[1, 4, 7] = float('nan')
+    opt._check_rollout_health = poison_after_two
+    with pytest.raises(RuntimeError, match='non-finite objective in stage3'):
+        opt.run(obs, data_fps=30, lr=1.0, num_iter=[3, 3, 6], lbfgs_max_iter=5)
+    assert 2 <= len(calls) <= 4
+
+
+@pytest.mark.parametrize('use_graphs', [False, True])
 def test_amass_style_fit_reduces_joint_error(gpu_lib, dev, smplh_npz, tmp_path, use_graphs):
     """fit_amass_joints-shaped problem (config C2): noisy 3D joints of a known motion; the three stages must reduce the
     joint error substantially and return the reference's result structure; results are written in its npz layout."""

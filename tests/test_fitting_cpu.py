@@ -305,6 +305,44 @@ def test_emu_speculative_lbfgs_is_bit_identical_to_sequential(emu_lib):
     assert out[False][2] == out[True][2]
 
 
+def test_speculative_lbfgs_survives_rollback_of_a_non_finite_iteration(emu_lib):
+    """Advisor, round 5: repeated step() calls at a converged point start with a vanishing pair (y = 0, H = y.s / y.y = 0 / 0); the iteration
+    built on it and the speculative one behind it are non-finite, the host rejects them (curvature test) and rolls the speculation back.
+    The dead slot's Gram rows / projections must not leak NaN into later directions: the speculative run stays finite and equal to the
+    sequential one."""
+    from humor_amd.lbfgs import LBFGS
+    torch.manual_seed(0)
+    n = 30
+    A = torch.randn(n, n)
+    A = A @ A.t() / n + 0.1 * torch.eye(n)
+    b = torch.randn(n)
+
+    def f(x):
+        return 0.5 * x @ A @ x - b @ x + 0.01 * (x ** 4).sum()
+    out = {}
+    for spec in (False, True):
+        p = torch.zeros(n, requires_grad=True)
+        opt = LBFGS([p], max_iter=20, lr=1.0, line_search_fn='strong_wolfe', history_size=3, _lib_override=emu_lib)
+        opt.speculate = spec
+        trace = []
+
+        def closure():
+            p.grad = None
+            l = f(p)
+            l.backward()
+            trace.append(l.item())
+            return l
+        closure.discard_last = lambda: trace.pop()
+        for _ in range(4):
+            opt.step(closure)
+        H = opt._hist
+        out[spec] = (list(trace), p.detach().clone(), bool(torch.isfinite(H['G']).all() and torch.isfinite(H['coef']).all()))
+    assert all(np.isfinite(out[True][0])) and out[True][2], out[True]
+    assert torch.isfinite(out[True][1]).all()
+    assert out[False][0] == out[True][0]
+    assert torch.equal(out[False][1], out[True][1])
+
+
 def test_lbfgs_failed_curvature_test_keeps_the_oldest_pair(emu_lib):
     """With a full history a new pair goes to a spare slot: dropping it (curvature test failed, or a speculative iteration rolled back)
     puts the retired oldest pair back, untouched, as torch.optim.LBFGS keeps it; two allocations can be open at a time and are undone in

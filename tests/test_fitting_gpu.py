@@ -369,6 +369,43 @@ def test_fit_after_an_earlier_persistent_failure_completes_on_the_launch_chain(g
         assert all(torch.isfinite(v).all() for v in final.values())
 
 
+def test_failure_inside_a_replayed_graph_aborts_that_fit_only(gpu_lib, dev, smplh_npz):
+    """a persistent launch that fails inside a REPLAYED hipGraph never passes an entry point; MotionOptimizer finds the
+    error word after the outer iteration (_check_rollout_health), aborts THAT fit and acknowledges the failure (ha_humor_persist_ack), so
+    the next fit around the same HumorModel is not handed the failure again by its first entry point: it completes on the launch chain.
+    Injection: the failure knob is set only while the stage-3 closure is being captured, so the captured persistent forward drops a CU in
+    every replay while every eager evaluation is healthy."""
+    from oracle import closure_cases as CC
+    B, T = 4, 8
+    opt = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz)
+    hm = opt.motion_prior
+    obs = {k: v.clone().to(dev) for k, v in CC.make_case('rgb', B, T, seed=2)['obs'].items()}
+    opt.use_graphs = True
+    inner = opt._stage3_objective
+
+    def objective(*a, **k):
+        capturing = torch.cuda.is_current_stream_capturing()
+        gpu_lib.call('ha_tune_set', b'rollout_persist_inject', 1 if capturing else 0)
+        try:
+            return inner(*a, **k)
+        finally:
+            gpu_lib.call('ha_tune_set', b'rollout_persist_inject', 0)
+    opt._stage3_objective = objective
+    try:
+        with pytest.raises(RuntimeError, match='persistent roll-out reported an incomplete launch|non-finite objective'):
+            opt.run(obs, data_fps=30, lr=1.0, num_iter=[1, 1, 3], lbfgs_max_iter=3)
+    finally:
+        gpu_lib.call('ha_tune_set', b'rollout_persist_inject', 0)
+    if getattr(opt, 'graph_failures', 0):
+        pytest.skip('hipGraph capture of the closure is not available on this box')
+    av, err, _ = hm.persistent_rollout_status(dev)
+    assert av == 0 and err != 0, (av, hex(err))
+    for _ in range(2):                                           # the next "batches" around the same HumorModel complete (launch chain)
+        opt2 = FC.build(gpu_lib, dev, 'rgb', B, T, smplh_npz, hm=hm)
+        final, _stages = opt2.run(obs, data_fps=30, lr=1.0, num_iter=[1, 1, 2], lbfgs_max_iter=3)
+        assert all(torch.isfinite(v).all() for v in final.values())
+
+
 def test_stage3_closure_beyond_32_sequences_pipelined_equals_launch_chain(gpu_lib, dev, smplh_npz):
     """A stage-3 objective of 40 overlapping sub-sequences (roll-out on the pipelined persistent kernels, rollout_pipe.inc) against the same
     objective with the roll-out on the launch chain (ha_tune_set "rollout_persist" 0): loss and every gradient."""
