@@ -155,9 +155,12 @@ HA_HD void w2a_bwd(const W2A& o, const float gW[9], float& g_p0, float& g_p3) {
   const float g_az = gaa[2];
   const float g_s = o.angle * g_az;
   const float g_angle = o.s * g_az;
-  const float g_xp = -g_angle / sqrtf(1.0f - o.xp * o.xp);
-  const float g_u = (o.u >= -1.0f && o.u <= 1.0f) ? g_xp : 0.f;
+  // d acos(u) / du = -1 / sqrt(1 - u^2).  With u = rx / d, d = nrm + eps:  1 - u^2 = (ry^2 + eps (2 nrm + eps)) / d^2 -- a sum of
+  // non-negative terms.  The literal 1 - u u cancels: within 1e-2 rad of the heading singularity (1 - u^2 ~ 1e-4) one rounding of u u is
+  // a 6e-4 relative error of the gradient (round 6: the rows every fp32 path missed the tight bars on; the fp32 reference has that error too)
   const float d = o.nrm + 1e-6f;
+  const float g_xp = -g_angle * d / sqrtf(o.ry * o.ry + 1e-6f * (2.0f * o.nrm + 1e-6f));
+  const float g_u = (o.u >= -1.0f && o.u <= 1.0f) ? g_xp : 0.f;
   float g_rx = g_u / d;
   float g_ry = 0.f;
   const float g_nrm = -g_u * o.rx / (d * d);

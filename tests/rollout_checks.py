@@ -49,9 +49,10 @@ def oracle_grads(sd, past, z, objective, dtype=torch.float64, probe=None):
     return w.detach(), pm.detach(), pv.detach(), [x.detach() for x in g]
 
 
-def _ulp_perturb(v, gen):
-    """v with every entry moved by one fp32 ulp up or down (random sign)."""
-    return (v * (1.0 + ((torch.rand(v.shape, generator=gen) > 0.5).float() * 2 - 1) * 2.0 ** -23)).float()
+def _perturb_rows(v, amp, gen):
+    """v (float64, [B, ...]) with every entry moved by a uniform relative amount in [-amp[row], amp[row]]."""
+    a = amp.reshape(-1, *([1] * (v.dim() - 1)))
+    return v * (1.0 + (torch.rand(v.shape, generator=gen, dtype=torch.float64) * 2 - 1) * a)
 
 
 def kink_aware_grad_check(sd, past, z, objective, world_gpu, g_gpu, grad_rtol=GRAD_RTOL, max_units=6, npert=6):
@@ -61,10 +62,11 @@ def kink_aware_grad_check(sd, past, z, objective, world_gpu, g_gpu, grad_rtol=GR
           (tau = max(4e-6, 8 x the sequence's largest state deviation from fp64)) are the ones an fp32 evaluation may legitimately put on
           the other side; the sequence passes if the kernel's gradient equals the oracle's -- at the same flat bar -- for ONE on / off
           assignment of those units (<= 2^max_units batched oracle evaluations; the sequences are independent);
-      (b) conditioning: a sequence whose gradient the fp32 ORACLE itself cannot reproduce -- its fp32 evaluation is >= grad_rtol / 4 from its
-          fp64 one, or moves by that much under 1-ulp perturbations of the inputs (npert draws) -- has no meaningful flat bar (heading within
-          1e-2 rad of the acos singularity: the gradient moves 1e4 x as much as the states); it is reported as `unstable`, must stay within
-          30 x the bar, and at most max(1, 10 %) of the sequences may be.
+      (b) conditioning: the gradient of a sequence can follow the oracle's no better than the oracle's own gradient holds still when its
+          inputs move by as much as the kernel's forward values are off (a deviation the forward bar allows): relative input perturbations
+          of amplitude max(1 ulp, 2 x the sequence's state deviation) are applied to the fp64 oracle (npert draws); where ITS gradient moves
+          by >= grad_rtol / 4 the sequence is ill-conditioned (heading within 1e-2 rad of the acos singularity: the gradient moves 1e4 x as
+          much as the states) -- reported as `unstable`, it must stay within 30 x the bar, and at most max(1, 10 %) of the sequences may be.
     Anything else fails.  Returns the report."""
     B = past.shape[0]
     w64, _, _, g64 = oracle_grads(sd, past, z, objective)
@@ -111,21 +113,22 @@ def kink_aware_grad_check(sd, past, z, objective, world_gpu, g_gpu, grad_rtol=GR
         if b not in left:
             report['rows_on_other_branch'].append((b, round(e_nat[b].item(), 6), round(best[b], 6), len(units[b]), float(tau[b])))
     if left:
-        # (b) can the fp32 oracle itself reproduce these sequences' gradients?
-        _, _, _, g32 = oracle_grads(sd, past, z, objective, dtype=torch.float32)
-        moved = row_err(g64, g32)
+        # (b) how far does the ORACLE's gradient move when its inputs move as much as the kernel's forward values are off?
+        wmax = w64.abs().reshape(B, -1).amax(1).clamp(min=1.0)
+        amp = torch.clamp(2.0 * dev / wmax, min=2.0 ** -23)
+        moved = torch.zeros(B, dtype=torch.float64)
         gen = torch.Generator().manual_seed(12345)
         for _ in range(npert):
-            _, _, _, gp = oracle_grads(sd, _ulp_perturb(past.detach().float(), gen), _ulp_perturb(z.detach().float(), gen), objective, dtype=torch.float32)
-            moved = torch.maximum(moved, row_err(g32, gp))
+            _, _, _, gp = oracle_grads(sd, _perturb_rows(past.detach().double(), amp, gen), _perturb_rows(z.detach().double(), amp, gen), objective)
+            moved = torch.maximum(moved, row_err(g64, gp))
         for b in left:
             rec = (b, round(e_nat[b].item(), 6), round(best[b], 6), len(units[b]), float(tau[b]), round(moved[b].item(), 6))
             if moved[b].item() >= grad_rtol / 4 and best[b] < 30 * grad_rtol:
                 report['unstable'].append(rec)
             else:
                 report['unresolved'].append(rec)
-    assert not report['unresolved'], ('gradient differs from the fp64 oracle on every reachable ReLU branch of a sequence the fp32 oracle '
-                                      'reproduces (row, natural error, best branch error, near-kink units, tau, oracle fp32 movement)', report)
+    assert not report['unresolved'], ('gradient differs from the fp64 oracle on every reachable ReLU branch of a sequence whose oracle gradient '
+                                      'holds still (row, natural error, best branch error, near-kink units, tau, oracle movement under input perturbation)', report)
     assert len(report['unstable']) <= max(1, B // 10), ('too many sequences beyond the flat bar, even if ill-conditioned', report)
     return report
 
@@ -187,7 +190,7 @@ def check_rollout(lib, device, B, S, seed=0, with_prior=True, weight_scale=1.0, 
         if rep['rows_on_other_branch'] or rep['unstable']:
             print(f'check_rollout {B}x{S} seed {seed}: sequences on another ReLU branch than the fp64 oracle '
                   f'(row, natural error, error on the matching branch, near-kink units, tau): {rep["rows_on_other_branch"]}; '
-                  f'sequences the fp32 oracle cannot reproduce (.., its own movement): {rep["unstable"]}')
+                  f'ill-conditioned sequences (.., the oracle\'s own movement under input perturbations of the kernel\'s forward deviation): {rep["unstable"]}')
     else:
         # the adjoint of a long chain is amplified like the forward error: judge both fp32 gradients against fp64
         g_ref = torch.autograd.grad(objective(w_ref, pm_r, pv_r), [past_c, z_c])

@@ -13,13 +13,14 @@ CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 
 
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+    # (rollout_persist.hip is compiled through rollout_persist_emu.cpp, which includes it and adds the ha_emu_* test hooks)
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip') and f != 'rollout_persist.hip')
 
 
 def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
-    srcs = sources() + [os.path.join(HERE, 'simt_emu.cpp')]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc'))] + \
+    srcs = sources() + [os.path.join(HERE, 'simt_emu.cpp'), os.path.join(HERE, 'rollout_persist_emu.cpp')]
+    deps = srcs + [os.path.join(CSRC, 'rollout_persist.hip')] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc'))] + \
         [os.path.join(HERE, 'include', 'hip', 'hip_runtime.h'), os.path.join(ROOT, 'include', 'humor_amd.h')]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
