@@ -149,3 +149,54 @@ def uncanonicalize_world(world, R0, t0, t2j):
     Rroot = torch.einsum('bij,bsjk->bsik', Rt, world[:, :, 6:15].reshape(B, S, 3, 3)).reshape(B, S, 9)
     return torch.cat([rot(world[:, :, 0:3]) - t0.unsqueeze(1), rot(world[:, :, 3:6]), Rroot, rot(world[:, :, 15:18]),
                       world[:, :, 18:207], joints.reshape(B, S, 66), jvel.reshape(B, S, 66), world[:, :, 339:348]], dim=2)
+
+
+def window_to_local(win, W, wt, t2j):
+    """The frame change of HumorModel.apply_world2local_trans(invert=False) (humor_model.py:696-772) on a window of states: win = {name:
+    [B, S, d]} with rotations as 9-d matrices, W [B,3,3] the new frame's rotation, wt [B,3] its translation, t2j [B,3] the root-to-joint
+    offset.  Positions: W (p + wt) (joints about t2j), directions / rotations: W v, W R; the body pose is frame-independent."""
+    B = W.shape[0]
+    out = {}
+    for k, v in win.items():
+        S = v.shape[1]
+        if k == 'trans':
+            out[k] = torch.einsum('bij,bsj->bsi', W, v + wt.unsqueeze(1))
+        elif k in ('trans_vel', 'root_orient_vel'):
+            out[k] = torch.einsum('bij,bsj->bsi', W, v)
+        elif k == 'root_orient':
+            out[k] = torch.einsum('bij,bsjk->bsik', W, v.reshape(B, S, 3, 3)).reshape(B, S, 9)
+        elif k == 'joints':
+            J = v.shape[2] // 3
+            p = v.reshape(B, S, J, 3) + wt.view(B, 1, 1, 3) + t2j.view(B, 1, 1, 3)
+            out[k] = (torch.einsum('bij,bskj->bski', W, p) - t2j.view(B, 1, 1, 3)).reshape(B, S, J * 3)
+        elif k == 'joints_vel':
+            J = v.shape[2] // 3
+            out[k] = torch.einsum('bij,bskj->bski', W, v.reshape(B, S, J, 3)).reshape(B, S, J * 3)
+        else:
+            out[k] = v
+    return out
+
+
+def window_to_world(win, G, gt, t2j):
+    """The inverse direction (invert=True): G^T p - gt (joints: G^T (p + t2j) - t2j - gt), G^T v, G^T R."""
+    B = G.shape[0]
+    Gt = G.transpose(1, 2)
+    out = {}
+    for k, v in win.items():
+        S = v.shape[1]
+        if k == 'trans':
+            out[k] = torch.einsum('bij,bsj->bsi', Gt, v) - gt.unsqueeze(1)
+        elif k in ('trans_vel', 'root_orient_vel'):
+            out[k] = torch.einsum('bij,bsj->bsi', Gt, v)
+        elif k == 'root_orient':
+            out[k] = torch.einsum('bij,bsjk->bsik', Gt, v.reshape(B, S, 3, 3)).reshape(B, S, 9)
+        elif k == 'joints':
+            J = v.shape[2] // 3
+            p = torch.einsum('bij,bskj->bski', Gt, v.reshape(B, S, J, 3) + t2j.view(B, 1, 1, 3))
+            out[k] = (p - t2j.view(B, 1, 1, 3) - gt.view(B, 1, 1, 3)).reshape(B, S, J * 3)
+        elif k == 'joints_vel':
+            J = v.shape[2] // 3
+            out[k] = torch.einsum('bij,bskj->bski', Gt, v.reshape(B, S, J, 3)).reshape(B, S, J * 3)
+        else:
+            out[k] = v
+    return out

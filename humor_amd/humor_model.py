@@ -10,7 +10,10 @@ The roll-out kernels implement the configuration the fitting pipeline uses (in_r
 steps_in=1, 'smpl+joints(+contacts)', output_delta=True) and its output variants: out_rot_rep='6d' / '9d' (humor_model.py:476-484) and
 output_delta=False (the decoder emits the state itself, :331-347); these take the launch-chain kernels, the persistent roll-out is
 built for the residual 216-wide decoder.
-Other configurations raise NotImplementedError instead of silently running somewhere else.
+The INPUT variants -- in_rot_rep 'aa' / '6d' (:462-478, 970-981) and steps_in > 1 (:838-850, 946-957) -- are off the fitting path (the released
+checkpoint is 'mat' / 1): roll_out serves them with a step loop of on-device PyTorch operations (_roll_out_generic: prior through the fused MLP
+kernels, decoder through its module), pinned to reference fixtures (tests/golden/rollout_inrep.npz).  model_use_smpl_joint_inputs (a training-time
+option that needs one SMPL model file per gender) raises NotImplementedError.
 """
 import ctypes as C
 
@@ -331,16 +334,50 @@ class HumorModel(nn.Module):
         s_p[:, 2, 2] = torch.det(torch.matmul(u, vh))
         return torch.matmul(torch.matmul(u, s_p), vh)
 
+    def _rep_to_rotmat(self, x, rep):
+        """[N, rot_dim] in representation `rep` -> [N,3,3] (convert_to_rotmat, humor/utils/transforms.py:60-73); 'mat' / '9d'-as-matrix passes through."""
+        from .frames import _rodrigues_torch
+        if rep == 'mat':
+            return x.reshape(-1, 3, 3)
+        if rep == 'aa':
+            return _rodrigues_torch(x.reshape(-1, 3))
+        if rep == '6d':
+            v = x.reshape(-1, 3, 2)
+            a1, a2 = v[:, :, 0], v[:, :, 1]
+            b1 = torch.nn.functional.normalize(a1)
+            b2 = torch.nn.functional.normalize(a2 - (b1 * a2).sum(1, keepdim=True) * b1)
+            return torch.stack((b1, b2, torch.cross(b1, b2, dim=1)), dim=-1)
+        raise ValueError(rep)
+
+    def _last_step_as_mat(self, past_in):
+        """The most recent input step of past_in [B, steps_in * D_in] with its rotations as matrices: [B, 339] in the 'mat' layout
+        (humor_model.py:462-478)."""
+        B = past_in.size(0)
+        step = past_in.reshape(B, self.steps_in, -1)[:, -1]
+        if self.in_rot_rep == 'mat':
+            return step
+        w = self.input_rot_dim
+        parts, o = [], 0
+        for n, d in zip(self.data_names, self.input_dim_list):
+            v = step[:, o:o + d]
+            o += d
+            if n == 'root_orient':
+                v = self._rep_to_rotmat(v, self.in_rot_rep).reshape(B, 9)
+            elif n == 'pose_body':
+                v = self._rep_to_rotmat(v.reshape(B * NUM_BODY_JOINTS, w), self.in_rot_rep).reshape(B, NUM_BODY_JOINTS * 9)
+            parts.append(v)
+        return torch.cat(parts, dim=1)
+
     def decode(self, z, past_in):
         """One decoder evaluation + residual composition in plain PyTorch (humor_model.py:445-498): the canonical-frame state after
-        one step, [B, 339 (+9 contact logits)].  Off the hot path: roll_out runs the same arithmetic in the HIP kernels."""
+        one step, [B, 339 (+9 contact logits)], rotations as matrices.  Off the hot path: roll_out runs the same arithmetic in the HIP
+        kernels for the fitting configuration; the input variants (in_rot_rep 'aa' / '6d', steps_in > 1) come through here."""
         B = z.size(0)
         past_in = past_in.reshape(B, -1)
         raw = self.decoder(torch.cat([past_in, z], dim=1))
         if not self.output_delta:
             return raw                       # the network's output is the state itself; split_output converts its rotations
-        if self.in_rot_rep != 'mat':
-            raise NotImplementedError("decode implements in_rot_rep='mat'")
+        past_in = self._last_step_as_mat(past_in)
         w = self.output_rot_dim
         o_root, o_rvel, o_body, o_j = 6, 6 + w, 9 + w, 9 + 22 * w
         dR = self._delta_rotmat(raw[:, o_root:o_root + w])
@@ -456,6 +493,9 @@ class HumorModel(nn.Module):
         (use_mean: z_t = mu_t; forward only).  eps_seq [B,S,48] is an extension for reproducible sampling (default: randn).
         Returns a dict of world-frame [B, num_steps, D] tensors (rotations as matrices), optionally (prior mean, var).
         '''
+        if self.in_rot_rep != 'mat' or self.steps_in != 1:
+            return self._roll_out_generic(x_past, init_input_dict, num_steps, use_mean, z_seq, return_prior, return_z, canonicalize_input,
+                                          uncanonicalize_output, eps_seq)
         self._check_rollout_config()
         if x_past is not None:
             past_in = x_past.reshape(x_past.size(0), -1)
@@ -505,6 +545,110 @@ class HumorModel(nn.Module):
             out['z'] = z_out
         if return_prior:
             return out, (pm, pv)
+        return out
+
+    def _window_as_input(self, win):
+        """Window {name: [B, S, d]} (rotations as matrices) -> past_in [B, S * D_in] with the rotations in in_rot_rep (humor_model.py:970-981:
+        'aa' through rotation_matrix_to_angle_axis, '6d' = the first six entries of the row-major matrix, as the reference slices them)."""
+        from . import ops
+        parts = []
+        for k in self.data_names:
+            v = win[k]
+            B, S = v.shape[0], v.shape[1]
+            if k in ('root_orient', 'pose_body') and self.in_rot_rep != 'mat':
+                nj = v.shape[2] // 9
+                if self.in_rot_rep == 'aa':
+                    v = ops.rotation_matrix_to_angle_axis(v.reshape(B * S * nj, 3, 3), _lib_override=self._lib).reshape(B, S, nj * 3)
+                else:
+                    v = v.reshape(B, S, nj, 9)[:, :, :, :6].reshape(B, S, nj * 6)
+            parts.append(v)
+        return torch.cat(parts, dim=2).reshape(parts[0].shape[0], -1)
+
+    def _roll_out_generic(self, x_past, init_input_dict, num_steps, use_mean, z_seq, return_prior, return_z, canonicalize_input,
+                          uncanonicalize_output, eps_seq):
+        """HumorModel.roll_out (humor_model.py:785-1017) for the input variants the roll-out kernels do not implement: in_rot_rep 'aa' / '6d'
+        and steps_in > 1 (the released checkpoint and every fitting configuration use 'mat' / 1: those run the HIP kernels above).  The same
+        arithmetic as a step loop of on-device PyTorch operations (differentiable): prior through the fused MLP kernels when the network is
+        frozen, decoder through its module, the frame changes of the whole input window per step (frames.window_to_local), the world-frame
+        outputs from the accumulated transform.  init_input_dict holds the window {name: [B, <= steps_in, d]} with rotations as MATRICES, x_past
+        the same window in the input representation [B, <= steps_in, D_in] (the reference needs both for in_rot_rep != 'mat': test_humor.py:
+        210-224; here x_past alone is enough)."""
+        from . import frames
+        names = self.data_names
+        if init_input_dict is not None:
+            win = {k: init_input_dict[k] for k in names}
+        elif x_past is not None:
+            B0, S0 = x_past.shape[0], x_past.shape[1]
+            win, o = {}, 0
+            for k, d in zip(names, self.input_dim_list):
+                v = x_past[:, :, o:o + d]
+                o += d
+                if k in ('root_orient', 'pose_body') and self.in_rot_rep != 'mat':
+                    nj = d // self.input_rot_dim
+                    v = self._rep_to_rotmat(v.reshape(B0 * S0 * nj, self.input_rot_dim), self.in_rot_rep).reshape(B0, S0, nj * 9)
+                win[k] = v
+        else:
+            raise ValueError('roll_out needs the initial state: x_past [B, steps_in, D] or init_input_dict {name: [B, steps_in, d]}')
+        ref = win[names[0]]
+        B, dt, dev = ref.shape[0], ref.dtype, ref.device
+        zero = torch.zeros(B, 1, dtype=dt, device=dev)
+        W0 = wt0 = None
+        if canonicalize_input:
+            W0 = frames.world2aligned_mat(win['root_orient'][:, -1].reshape(B, 3, 3))
+            wt0 = torch.cat([-win['trans'][:, -1, :2], zero], dim=1)
+            t2j0 = torch.cat([-(win['joints'][:, -1, :2] + wt0[:, :2]), zero], dim=1) if self.need_trans2joint else torch.zeros(B, 3, dtype=dt, device=dev)
+            win = frames.window_to_local(win, W0, wt0, t2j0)
+        pad = self.steps_in - ref.shape[1]
+        if pad > 0:
+            win = {k: torch.cat([torch.zeros(B, pad, v.shape[2], dtype=dt, device=dev), v], dim=1) for k, v in win.items()}
+        if x_past is None or canonicalize_input:
+            past_in = self._window_as_input(win)
+        else:
+            xp = x_past
+            if xp.shape[1] < self.steps_in:
+                xp = torch.cat([torch.zeros(B, self.steps_in - xp.shape[1], xp.shape[2], dtype=dt, device=dev), xp], dim=1)
+            past_in = xp.reshape(B, -1)
+        G = torch.eye(3, dtype=dt, device=dev).unsqueeze(0).repeat(B, 1, 1)
+        gt = torch.zeros(B, 3, dtype=dt, device=dev)
+        if canonicalize_input and uncanonicalize_output:
+            G, gt = W0, wt0
+        t2j = torch.cat([-win['joints'][:, -1, :2], zero], dim=1) if self.need_trans2joint else torch.zeros(B, 3, dtype=dt, device=dev)
+        dims = list(self.delta_output_dim_list)
+        out_names = names + (self.aux_out_data_names or [])
+        world, pms, pvs, zs = [], [], [], []
+        for t in range(num_steps):
+            pm = pv = None
+            if return_prior or z_seq is None:
+                pm, pv = self.prior(past_in) if self.use_conditional_prior else (torch.zeros(B, self.latent_size, dtype=dt, device=dev),
+                                                                                  torch.ones(B, self.latent_size, dtype=dt, device=dev))
+                pms.append(pm)
+                pvs.append(pv)
+            if z_seq is not None:
+                z = z_seq[:, t]
+            elif use_mean:
+                z = pm
+            else:
+                eps = eps_seq[:, t] if eps_seq is not None else torch.randn(B, self.latent_size, dtype=dt, device=dev)
+                z = pm + eps * torch.sqrt(pv)
+            zs.append(z)
+            state = self.decode(z, past_in)
+            if not self.output_delta:
+                state = torch.cat([v.reshape(B, -1) for v in self.split_output(state).values()], dim=1)
+            pred = dict(zip(out_names, (v.unsqueeze(1) for v in torch.split(state, dims, dim=1))))
+            win = {k: torch.cat([win[k][:, 1:], pred[k]], dim=1) for k in names}
+            W = frames.world2aligned_mat(pred['root_orient'][:, 0].reshape(B, 3, 3))
+            wt = torch.cat([-pred['trans'][:, 0, :2], zero], dim=1)
+            win = frames.window_to_local(win, W, wt, t2j)
+            wd = frames.window_to_world(pred, G, gt, t2j)
+            world.append(wd)
+            gt = torch.cat([-wd['trans'][:, 0, :2], zero], dim=1)
+            G = torch.matmul(G, W)
+            past_in = self._window_as_input(win)
+        out = {k: torch.cat([w[k] for w in world], dim=1) for k in out_names}
+        if return_z:
+            out['z'] = torch.stack(zs, dim=1)
+        if return_prior:
+            return out, (torch.stack(pms, dim=1), torch.stack(pvs, dim=1))
         return out
 
     # ------------------------------------------------------------------------------------------------

@@ -338,6 +338,11 @@ class LBFGS:
         self.last_loss, self.last_gmax = loss, gmax
         current_evals = 1
         state['func_evals'] += 1
+        if not math.isfinite(loss):
+            # (ha_lbfgs_scalars' maximum ignores NaN: a NaN gradient reads as max|g| = 0 -- "converged".  Nothing useful can follow a
+            # non-finite objective; the caller is told through last_loss)
+            self.last_gmax = float('nan')
+            return orig_loss
         if gmax <= tolerance_grad:
             return orig_loss
         d, t = state.get('d'), state.get('t')

@@ -146,7 +146,7 @@ def _mlp_keys(prefix, sizes, skip=0):
 
 
 def humor_state_dict(seed=0, weight_scale=1.0, latent=HUMOR_LATENT, in_dim=HUMOR_IN_DIM, out_dim=HUMOR_OUT_DIM,
-                     randomize_gn=True, out_scale=1.0, yaw_rate=None):
+                     randomize_gn=True, out_scale=1.0, yaw_rate=None, past_steps=1):
     """Random weights in the reference checkpoint's key layout.  Linear layers use PyTorch's default
     kaiming-uniform bound 1/sqrt(fan_in); GroupNorm affine is perturbed around (1, 0) when
     ``randomize_gn`` so the affine path is exercised by parity tests.
@@ -158,9 +158,10 @@ def humor_state_dict(seed=0, weight_scale=1.0, latent=HUMOR_LATENT, in_dim=HUMOR
     model at 30 fps -- small per-frame deltas, bounded state -- and fp32 stays within ~1e-5 of fp64 over 119 steps."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
-    specs = (_mlp_keys('encoder', [2 * in_dim, 1024, 1024, 1024, 1024, 2 * latent]) +
-             _mlp_keys('decoder', [in_dim + latent, 1024, 1024, 512, out_dim], skip=latent) +
-             _mlp_keys('prior_net', [in_dim, 1024, 1024, 1024, 1024, 2 * latent]))
+    past = past_steps * in_dim      # HumorModel(steps_in=past_steps): the networks see the last `past_steps` states (humor_model.py:175-206)
+    specs = (_mlp_keys('encoder', [past + in_dim, 1024, 1024, 1024, 1024, 2 * latent]) +
+             _mlp_keys('decoder', [past + latent, 1024, 1024, 512, out_dim], skip=latent) +
+             _mlp_keys('prior_net', [past, 1024, 1024, 1024, 1024, 2 * latent]))
     for key, shape in specs:
         if len(shape) == 2:
             bound = weight_scale / math.sqrt(shape[1])

@@ -412,6 +412,63 @@ def check_rollout_rotrep_golden(lib, device, rep):
     return ew, e0, ez
 
 
+INREP_CASES = [('aa', 1), ('6d', 1), ('mat', 2), ('aa', 2)]
+
+
+def check_rollout_inrep(lib, device, rep, steps_in):
+    """HumorModel's input variants (in_rot_rep 'aa' / '6d', steps_in = 2) against the reference-generated fixture tests/golden/rollout_inrep.npz
+    (oracle/make_golden_inrep.py: world states, prior outputs, gradients w.r.t. the latent sequence and the initial window), driven like the
+    reference (x_past in the input representation + init_input_dict with matrix rotations).  Flat bars 1e-4 / 1e-3."""
+    from humor_amd import synth as SY
+    gold = golden('rollout_inrep.npz')
+    tag = f'{rep}_{steps_in}'
+    rot_w = {'aa': 3, '6d': 6, 'mat': 9}[rep]
+    in_dim = 3 + 3 + rot_w + 3 + 21 * rot_w + 66 + 66
+    sd = SY.humor_state_dict(seed=0, in_dim=in_dim, past_steps=steps_in, **SY.CONTRACTIVE)
+    hm = HumorModel(in_rot_rep=rep, out_rot_rep='aa', latent_size=48, model_data_config='smpl+joints+contacts', steps_in=steps_in, _lib_override=lib)
+    hm.load_state_dict(sd)
+    hm = hm.to(device).eval()
+    # on the device the frozen prior goes through the fused MLP kernels (ha_mlp_*); on host tensors the parameters stay trainable, which keeps
+    # the prior on its PyTorch module (the emulator build of the GEMM kernels would take minutes per case here)
+    for p in hm.parameters():
+        p.requires_grad_(device.type != 'cuda')
+    t = lambda k: torch.from_numpy(gold[f'{tag}_{k}']).to(device)
+    win0, z = t('win0').requires_grad_(True), t('z').requires_grad_(True)
+    B, S = z.shape[0], z.shape[1]
+    names, dims = ['trans', 'trans_vel', 'root_orient', 'root_orient_vel', 'pose_body', 'joints', 'joints_vel'], [3, 3, 9, 3, 189, 66, 66]
+    d, o = {}, 0
+    for k, n in zip(names, dims):
+        d[k] = win0[:, :, o:o + n]
+        o += n
+    parts = []
+    for k in names:
+        v = d[k]
+        if k in ('root_orient', 'pose_body') and rep != 'mat':
+            nj = v.shape[2] // 9
+            if rep == 'aa':
+                v = ops.rotation_matrix_to_angle_axis(v.reshape(B * steps_in * nj, 3, 3), _lib_override=lib).reshape(B, steps_in, nj * 3)
+            else:
+                v = v.reshape(B, steps_in, nj, 9)[:, :, :, :6].reshape(B, steps_in, nj * 6)
+        parts.append(v)
+    x_past = torch.cat(parts, dim=2)
+    pred, (pm, pv) = hm.roll_out(x_past, d, S, z_seq=z, return_prior=True)
+    world = torch.cat([pred[k] for k in names + ['contacts']], 2)
+    e = {'world': (world - t('world')).abs().max().item(), 'pm': (pm - t('pm')).abs().max().item(),
+         'pv': ((pv - t('pv')).abs() / t('pv').abs().clamp(min=1.0)).max().item()}
+    assert max(e.values()) < FWD_TOL, e
+    g = torch.autograd.grad((world * t('gw')).sum() + (pm * t('gm')).sum() + (pv * t('gv')).sum(), [win0, z])
+    for name, got, ref in (('g_win', g[0], t('g_win')), ('g_z', g[1], t('g_z'))):
+        e[name] = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+        assert e[name] < GRAD_RTOL, (name, e)
+    # the roll-out continues where the reference's cannot (second step with in_rot_rep != 'mat'): finite, and its first step is the one-step result
+    if rep != 'mat':
+        z2 = torch.cat([z.detach(), 0.5 * z.detach()], dim=1)
+        two = hm.roll_out(x_past.detach(), {k: v.detach() for k, v in d.items()}, 2, z_seq=z2)
+        assert all(torch.isfinite(v).all() for v in two.values()) and two['trans'].shape[1] == 2
+        assert (two['trans'][:, :1].detach() - pred['trans'].detach()).abs().max().item() < 1e-6
+    return e
+
+
 def check_rotations_golden(lib, device):
     gd = golden('rotations.npz')
     aa = torch.tensor(gd['aa']).to(device).requires_grad_(True)

@@ -16,6 +16,13 @@ def test_emu_rotation_kernels(emu_lib):
     RC.check_rot_to_aa_near_pi(emu_lib, CPU, n=900)
 
 
+@pytest.mark.parametrize('rep,steps_in', RC.INREP_CASES)
+def test_rollout_input_variants_match_reference_fixture(emu_lib, rep, steps_in):
+    """HumorModel(in_rot_rep='aa' | '6d', steps_in=2) (humor_model.py:104-135, 462-478, 960-981) against the reference-generated fixture; on host
+    tensors (decoder / prior modules in PyTorch, R -> axis-angle through the emulator build of the rotation kernel)."""
+    print(rep, steps_in, RC.check_rollout_inrep(emu_lib, CPU, rep, steps_in))
+
+
 @pytest.mark.slow
 def test_emu_rollout_two_steps(emu_lib):
     # MFMA layer kernel (all four prologue modes), glue forward/backward, dz / past_in0 collection

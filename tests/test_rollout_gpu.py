@@ -81,6 +81,13 @@ def test_rollout_output_rotation_representations(gpu_lib, dev, rep):
     print(rep, RC.check_rollout_rotrep_golden(gpu_lib, dev, rep))
 
 
+@pytest.mark.parametrize('rep,steps_in', RC.INREP_CASES)
+def test_rollout_input_variants(gpu_lib, dev, rep, steps_in):
+    """HumorModel(in_rot_rep='aa' | '6d', steps_in=2) on the device (prior through the fused MLP kernels, R -> axis-angle through its HIP kernel)
+    against the reference-generated fixture: flat 1e-4 / 1e-3 bars."""
+    print(rep, steps_in, RC.check_rollout_inrep(gpu_lib, dev, rep, steps_in))
+
+
 @pytest.mark.parametrize('name', ['c4', 'c3', 'c5'])
 def test_rollout_baseline_lengths_flat_tolerance(gpu_lib, dev, fwd_path, name):
     """59 / 89 / 119 steps against the reference's own outputs (tests/golden/rollout_long.npz): flat 1e-4 on every step's
