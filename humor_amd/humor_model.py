@@ -575,6 +575,8 @@ class HumorModel(nn.Module):
         210-224; here x_past alone is enough)."""
         from . import frames
         names = self.data_names
+        if x_past is not None and x_past.dim() == 2:
+            x_past = x_past.reshape(x_past.shape[0], -1, self.input_data_dim)
         if init_input_dict is not None:
             win = {k: init_input_dict[k] for k in names}
         elif x_past is not None:

@@ -1,6 +1,8 @@
 // TEST INFRASTRUCTURE ONLY -- runtime of the host SIMT emulator (see include/hip/hip_runtime.h).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 namespace ha { alignas(16) float smem[40960]; }   // 160 KiB "LDS", one block resident at a time
 
 namespace simt_emu {
@@ -13,6 +15,12 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   if (block.y != 1 || block.z != 1 || nthreads % 64 != 0) {
     std::fprintf(stderr, "simt_emu: only 1-D blocks of whole waves are supported\n");
     std::abort();
+  }
+  // LDS is not cleared between kernels on the hardware, and a kernel that reads a word it never wrote sees whatever the previous tenant of the
+  // CU left there (round 5: NaN gradients on one box, green on another).  Every emulated launch therefore starts on NaN-filled "LDS".
+  {
+    const unsigned nanbits = 0x7fc00000u;
+    for (size_t i = 0; i < sizeof(ha::smem) / sizeof(float); ++i) std::memcpy(&ha::smem[i], &nanbits, 4);
   }
   BlockCtx ctx;
   std::barrier<> block_bar(nthreads);

@@ -89,8 +89,11 @@ def test_rollout_refuses_cpu():
     hm = HumorModel(in_rot_rep='mat', out_rot_rep='aa', model_data_config='smpl+joints+contacts')
     with pytest.raises((HumorAmdError, RuntimeError)):
         hm.roll_out(torch.zeros(2, 339), None, 2, z_seq=torch.zeros(2, 2, 48))
+    # the input variants run off the kernel path, but their R -> axis-angle conversion is a HIP kernel too: host tensors are refused there as well
+    with pytest.raises((HumorAmdError, RuntimeError)):
+        HumorModel(in_rot_rep='aa', out_rot_rep='aa').roll_out(torch.zeros(2, 207), None, 2, z_seq=torch.zeros(2, 2, 48))
     with pytest.raises(NotImplementedError):
-        HumorModel(in_rot_rep='aa', out_rot_rep='aa').roll_out(torch.zeros(2, 300), None, 2, z_seq=torch.zeros(2, 2, 48))
+        HumorModel(in_rot_rep='mat', out_rot_rep='aa', model_use_smpl_joint_inputs=True)
 
 
 @pytest.mark.slow

@@ -57,13 +57,14 @@ def test_rollout_small_batches_on_poisoned_state(gpu_lib, dev, fwd_path, B):
     n = C.c_uint()
     gpu_lib.call('ha_debug_cu_poison', 1, C.byref(n), None)
     assert n.value > 0, 'this box clears LDS between kernels: the poison hook cannot show anything'
-    gpu_lib.call('ha_tune_set', b'cu_poison', 1)
+    import os
+    pattern = int(os.environ.get('HUMOR_AMD_CU_POISON') or '1', 0)
+    gpu_lib.call('ha_tune_set', b'cu_poison', pattern)
     try:
         for S in range(1, 9):
             RC.check_rollout(gpu_lib, dev, B=B, S=S, seed=8 * B + S)
     finally:
-        import os
-        gpu_lib.call('ha_tune_set', b'cu_poison', 1 if os.environ.get('HUMOR_AMD_CU_POISON') else 0)
+        gpu_lib.call('ha_tune_set', b'cu_poison', pattern if os.environ.get('HUMOR_AMD_CU_POISON') else 0)
 
 
 def test_rollout_without_prior(gpu_lib, dev, fwd_path):
