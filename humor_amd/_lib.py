@@ -142,12 +142,6 @@ _SIGS = {
 }
 
 
-_NO_POISON = {'ha_tune_set', 'ha_debug_cu_poison', 'ha_last_error', 'ha_abi_version', 'ha_device_arch', 'ha_smpl_model_create',
-              'ha_smpl_model_destroy', 'ha_smpl_model_info', 'ha_smpl_model_define_subset', 'ha_smpl_workspace', 'ha_humor_net_create',
-              'ha_humor_net_destroy', 'ha_humor_rollout_workspace', 'ha_humor_net_set_option', 'ha_humor_persist_status', 'ha_humor_persist_ack', 'ha_mlp_create',
-              'ha_mlp_destroy', 'ha_mlp_workspace', 'ha_smpl_backward_dense_workspace', 'ha_lbfgs_gram_workspace'}
-
-
 class HumorAmdError(RuntimeError):
     pass
 
@@ -162,7 +156,6 @@ class Lib:
                 f'__graft_entry__.build()).  humor_amd has no CPU/PyTorch fallback for its kernels.')
         self.path = path
         self.emulator = emulator
-        self.poison_calls = 0       # HUMOR_AMD_CU_POISON (get_lib): bit pattern written to every CU's LDS / registers in front of every compute entry point
         self._dll = C.CDLL(path)
         missing = []
         for name, (res, args) in _SIGS.items():
@@ -181,10 +174,6 @@ class Lib:
         return name not in self.missing
 
     def call(self, name, *args):
-        if self.poison_calls and name not in _NO_POISON:
-            # test tier: the first kernel of this entry point starts on CUs whose LDS / vector registers hold NaN patterns
-            import torch
-            self._dll.ha_debug_cu_poison(self.poison_calls, None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         rc = getattr(self._dll, name)(*args)
         if rc != HA_OK:
             msg = self._dll.ha_last_error()
@@ -216,12 +205,11 @@ def get_lib():
         if v:                                                            # (an empty value means unset, as for HUMOR_AMD_LIB)
             _lib.call('ha_tune_set', b'rollout_persist', int(v))
         # HUMOR_AMD_CU_POISON=1 (test tier, tools/nan_hunt.py): LDS and vector registers are not cleared between kernels -- a kernel that
-        # reads a word it never wrote sees the previous kernel's data, which differs from box to box.  With this set every compute entry
-        # point (and every persistent roll-out launch inside one) is preceded by a kernel that fills them with NaN patterns.
+        # reads a word it never wrote sees the previous kernel's data, which differs from box to box.  With this set every kernel launch of
+        # the library is preceded by a kernel that fills them with NaN patterns (another value = that bit pattern; humor_amd/csrc/debug.hip).
         v = os.environ.get('HUMOR_AMD_CU_POISON')
         if v and int(v, 0):
             _lib.call('ha_tune_set', b'cu_poison', int(v, 0) if int(v, 0) < 2 ** 31 else int(v, 0) - 2 ** 32)
-            _lib.poison_calls = int(v, 0)
     return _lib
 
 

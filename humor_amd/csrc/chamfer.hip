@@ -109,9 +109,9 @@ extern "C" int ha_chamfer_forward(int b, int n, const float* xyz1, int m, const 
   if (b == 0) return HA_OK;
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = 3 * CH_CHUNK * sizeof(float);
-  hipLaunchKernelGGL(chamfer_nn_kernel, dim3(ceil_div(n, 256), b), dim3(256), lds, st, n, xyz1, m, xyz2, dist1, idx1);
+  HA_LAUNCH(chamfer_nn_kernel, dim3(ceil_div(n, 256), b), dim3(256), lds, st, n, xyz1, m, xyz2, dist1, idx1);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(chamfer_nn_kernel, dim3(ceil_div(m, 256), b), dim3(256), lds, st, m, xyz2, n, xyz1, dist2, idx2);
+  HA_LAUNCH(chamfer_nn_kernel, dim3(ceil_div(m, 256), b), dim3(256), lds, st, m, xyz2, n, xyz1, dist2, idx2);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -125,9 +125,9 @@ extern "C" int ha_chamfer_backward(int b, int n, const float* xyz1, int m, const
   hipStream_t st = (hipStream_t)stream;
   // pass 1 writes grad_xyz1 (own points of direction 1) and needs grad_xyz2 zeroed for its scattered half; pass 2 accumulates both
   zero_async(grad_xyz2, (size_t)b * m * 3 * sizeof(float), st);      // (a kernel: see common.h)
-  hipLaunchKernelGGL(chamfer_grad_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, n, xyz1, m, xyz2, grad_dist1, idx1, grad_xyz1, grad_xyz2, 0);
+  HA_LAUNCH(chamfer_grad_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, n, xyz1, m, xyz2, grad_dist1, idx1, grad_xyz1, grad_xyz2, 0);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(chamfer_grad_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, st, m, xyz2, n, xyz1, grad_dist2, idx2, grad_xyz2, grad_xyz1, 1);
+  HA_LAUNCH(chamfer_grad_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, st, m, xyz2, n, xyz1, grad_dist2, idx2, grad_xyz2, grad_xyz1, 1);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

@@ -48,10 +48,20 @@ static __global__ void zero_words_kernel(unsigned* __restrict__ p, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0u;
 }
+// Every kernel launch of the library goes through HA_LAUNCH: with ha_tune_set("cu_poison") (test tier, debug.hip) a kernel that fills the LDS and
+// the vector registers of every CU with a bit pattern runs in front of it -- a kernel that reads state it did not write then fails on every box.
+extern unsigned g_cu_poison;
+int cu_poison_launch(hipStream_t st);
+#define HA_LAUNCH(kernel, grid, block, lds, st, ...)                          \
+  do {                                                                        \
+    if (ha::g_cu_poison) (void)ha::cu_poison_launch(st);                      \
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);            \
+  } while (0)
+
 static inline void zero_async(void* p, size_t bytes, hipStream_t st) {
   const size_t n = bytes / 4;       // (every caller clears whole floats)
   if (n == 0) return;
-  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(p), n);
+  HA_LAUNCH(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(p), n);
 }
 
 #define HA_CHECK_HIP(expr)                                                                        \

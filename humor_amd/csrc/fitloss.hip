@@ -408,9 +408,9 @@ extern "C" int ha_fit_loss(const ha_fit_args* args, void* stream) {
   HA_REQUIRE(!a.prev_tail || (a.cam_verts && a.overlap), "ha_fit_loss: a halo tail needs cam_verts and the overlap table");
   HA_REQUIRE(!a.gmm_gx || (a.gmm_nll && a.gmm_D >= 1 && a.gmm_nseg >= 1 && a.gmm_nseg <= 4), "ha_fit_loss: the folded init-state prior needs gmm_nll, gmm_D and 1..4 segments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(fit_loss_kernel, dim3(a.B * a.T), dim3(64), (128 + 66) * sizeof(float), st, a);
+  HA_LAUNCH(fit_loss_kernel, dim3(a.B * a.T), dim3(64), (128 + 66) * sizeof(float), st, a);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fit_reduce_kernel, dim3(1), dim3(1024), (NT + 1) * sizeof(float), st, a);
+  HA_LAUNCH(fit_reduce_kernel, dim3(1), dim3(1024), (NT + 1) * sizeof(float), st, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

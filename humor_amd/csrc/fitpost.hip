@@ -209,7 +209,7 @@ extern "C" int ha_rollout_post_forward(const ha_rollout_post_args* args, void* s
   HA_REQUIRE(a.trans && a.root_orient && a.pose_body && a.joints && a.contacts_conf && a.contacts, "ha_rollout_post_forward: null output");
   HA_REQUIRE((a.c2p_R == nullptr) == (a.c2p_t == nullptr), "ha_rollout_post_forward: c2p_R and c2p_t go together");
   HA_REQUIRE(!a.c2p_R || (a.cam_trans && a.cam_root_orient), "ha_rollout_post_forward: camera-frame outputs missing");
-  hipLaunchKernelGGL(rollout_post_fwd_kernel, dim3(a.B * (a.S + 1)), dim3(64), 0, (hipStream_t)stream, a);
+  HA_LAUNCH(rollout_post_fwd_kernel, dim3(a.B * (a.S + 1)), dim3(64), 0, (hipStream_t)stream, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -222,9 +222,9 @@ extern "C" int ha_rollout_post_backward(const ha_rollout_post_args* args, void* 
   HA_REQUIRE(a.g_world && a.g_trans0 && a.g_root0 && a.g_pose0 && a.g_joints0 && a.partial, "ha_rollout_post_backward: null output");
   HA_REQUIRE(!a.c2p_R || (a.g_c2p_R && a.g_c2p_t), "ha_rollout_post_backward: cam2prior gradient outputs missing");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(rollout_post_bwd_kernel, dim3(a.B * (a.S + 1)), dim3(64), 0, st, a);
+  HA_LAUNCH(rollout_post_bwd_kernel, dim3(a.B * (a.S + 1)), dim3(64), 0, st, a);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rollout_post_reduce_kernel, dim3(a.B), dim3(64), 0, st, a);
+  HA_LAUNCH(rollout_post_reduce_kernel, dim3(a.B), dim3(64), 0, st, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

@@ -285,7 +285,7 @@ extern "C" int ha_fit_pre_forward(const ha_fit_pre_args* args, void* stream) {
   HA_REQUIRE(a.B >= 1, "ha_fit_pre_forward: B must be >= 1");
   HA_REQUIRE(a.floor && a.trans0 && a.root0 && a.pose0 && a.jcam && a.trans_vel && a.joints_vel && a.root_orient_vel, "ha_fit_pre_forward: null input");
   HA_REQUIRE(a.past_in && a.trans_p && a.root_p && a.joints_p && a.c2p_R && a.c2p_t && a.root_height, "ha_fit_pre_forward: null output");
-  hipLaunchKernelGGL(fit_pre_fwd_kernel, dim3(a.B), dim3(64), 0, (hipStream_t)stream, a);
+  HA_LAUNCH(fit_pre_fwd_kernel, dim3(a.B), dim3(64), 0, (hipStream_t)stream, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -297,7 +297,7 @@ extern "C" int ha_fit_pre_backward(const ha_fit_pre_args* args, void* stream) {
   HA_REQUIRE(a.floor && a.trans0 && a.root0 && a.pose0 && a.jcam, "ha_fit_pre_backward: null input");
   HA_REQUIRE(a.g_floor && a.g_trans0 && a.g_root0 && a.g_pose0 && a.g_jcam && a.g_trans_vel && a.g_joints_vel && a.g_root_orient_vel,
              "ha_fit_pre_backward: null gradient output");
-  hipLaunchKernelGGL(fit_pre_bwd_kernel, dim3(a.B), dim3(64), 0, (hipStream_t)stream, a);
+  HA_LAUNCH(fit_pre_bwd_kernel, dim3(a.B), dim3(64), 0, (hipStream_t)stream, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

@@ -151,9 +151,9 @@ extern "C" int ha_gmm_nll(const ha_gmm_args* args, void* stream) {
   HA_REQUIRE(a.means && a.Linv && a.LinvT && a.cst && a.lp && a.gpart && a.nll && a.g_x, "ha_gmm_nll: null tensor");
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = ((size_t)(2 + GMM_WAVES) * a.D + GMM_WAVES) * sizeof(float);
-  hipLaunchKernelGGL(gmm_comp_kernel, dim3(a.B * a.K), dim3(GMM_WAVES * 64), lds, st, a);
+  HA_LAUNCH(gmm_comp_kernel, dim3(a.B * a.K), dim3(GMM_WAVES * 64), lds, st, a);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gmm_mix_kernel, dim3(a.B), dim3(256), 64 * sizeof(float), st, a);
+  HA_LAUNCH(gmm_mix_kernel, dim3(a.B), dim3(256), 64 * sizeof(float), st, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

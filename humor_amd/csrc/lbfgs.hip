@@ -311,9 +311,9 @@ extern "C" int ha_lbfgs_gram(int n, int rows, const float* M, int i0, int i1, in
   HA_REQUIRE(n >= 1 && rows >= 1 && M && part && P, "ha_lbfgs_gram: bad argument");
   HA_REQUIRE(i0 >= 0 && i1 >= 0 && i2 >= 0, "ha_lbfgs_gram: negative row index");
   const int nb = ceil_div(n, GR_CW);
-  hipLaunchKernelGGL(lbfgs_gram_partial_kernel, dim3(nb, 8), dim3(256), 0, (hipStream_t)stream, M, n, rows, i0, i1, i2, part);
+  HA_LAUNCH(lbfgs_gram_partial_kernel, dim3(nb, 8), dim3(256), 0, (hipStream_t)stream, M, n, rows, i0, i1, i2, part);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(lbfgs_gram_reduce_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, part, nb, rows, P);
+  HA_LAUNCH(lbfgs_gram_reduce_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, part, nb, rows, P);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -327,7 +327,7 @@ extern "C" int ha_lbfgs_gram_workspace(int n, int rows, int64_t* part_floats) {
 extern "C" int ha_lbfgs_scalars(int n, const float* a, const float* b, const float* extra, float* out, void* stream) {
   using namespace ha;
   HA_REQUIRE(n >= 1 && a && b && out, "ha_lbfgs_scalars: bad argument");
-  hipLaunchKernelGGL(lbfgs_scalars_kernel, dim3(1), dim3(1024), 48 * sizeof(float), (hipStream_t)stream, n, a, b, extra, out);
+  HA_LAUNCH(lbfgs_scalars_kernel, dim3(1), dim3(1024), 48 * sizeof(float), (hipStream_t)stream, n, a, b, extra, out);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -347,7 +347,7 @@ extern "C" int ha_lbfgs_pair_coeffs(int hist, int num_old, const int32_t* order,
   }
   a.G = G; a.Mg = Mg; a.coef = coef;
   a.P = P; a.slot = slot; a.Gw = G; a.Mgw = Mg; a.scal = scal;
-  hipLaunchKernelGGL(lbfgs_coeffs_kernel, dim3(1), dim3(256), LB_COEFF_LDS, (hipStream_t)stream, a);
+  HA_LAUNCH(lbfgs_coeffs_kernel, dim3(1), dim3(256), LB_COEFF_LDS, (hipStream_t)stream, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -366,7 +366,7 @@ extern "C" int ha_lbfgs_coeffs(int hist, int num_old, const int32_t* order, cons
     a.order[i] = order[i];
   }
   a.G = G; a.Mg = Mg; a.h_diag = h_diag; a.h_diag_dev = h_diag_dev; a.coef = coef;
-  hipLaunchKernelGGL(lbfgs_coeffs_kernel, dim3(1), dim3(256), LB_COEFF_LDS, (hipStream_t)stream, a);
+  HA_LAUNCH(lbfgs_coeffs_kernel, dim3(1), dim3(256), LB_COEFF_LDS, (hipStream_t)stream, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

@@ -139,7 +139,7 @@ extern "C" int ha_rigid_image_forward(const ha_rigid_image_args* args, void* str
   HA_REQUIRE(a.N >= 1 && a.J >= 1 && a.V >= 0, "ha_rigid_image_forward: N, J must be >= 1 and V >= 0");
   HA_REQUIRE(a.joints && a.root && a.trans && a.root2 && a.trans2 && a.joints2, "ha_rigid_image_forward: null tensor");
   HA_REQUIRE(a.V == 0 || (a.verts && a.verts2), "ha_rigid_image_forward: vertex tensors missing");
-  hipLaunchKernelGGL(rigid_image_fwd_kernel, dim3(a.N), dim3(rigid_threads(a)), 0, (hipStream_t)stream, a);
+  HA_LAUNCH(rigid_image_fwd_kernel, dim3(a.N), dim3(rigid_threads(a)), 0, (hipStream_t)stream, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -151,7 +151,7 @@ extern "C" int ha_rigid_image_backward(const ha_rigid_image_args* args, void* st
   HA_REQUIRE(a.joints && a.root && a.trans && a.root2 && a.trans2, "ha_rigid_image_backward: forward tensors missing");
   HA_REQUIRE(a.g_joints && a.g_root && a.g_trans && a.g_root2 && a.g_trans2, "ha_rigid_image_backward: null gradient output");
   HA_REQUIRE(a.V == 0 || (a.verts && a.g_verts), "ha_rigid_image_backward: vertex tensors missing");
-  hipLaunchKernelGGL(rigid_image_bwd_kernel, dim3(a.N), dim3(rigid_threads(a)), 4 * RG_NRED * sizeof(float), (hipStream_t)stream, a);
+  HA_LAUNCH(rigid_image_bwd_kernel, dim3(a.N), dim3(rigid_threads(a)), 4 * RG_NRED * sizeof(float), (hipStream_t)stream, a);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }

@@ -1307,14 +1307,14 @@ __global__ __launch_bounds__(256) void glue_bwd_kernel(GlueParams p) {
 
 static inline void launch_glue_fwd(int rotw, bool delta, int rows, hipStream_t st, const GlueParams& g) {
   const size_t lds = S_TOTAL_BWD * sizeof(float);
-#define HA_GLUE_FWD(R, D) hipLaunchKernelGGL((glue_fwd_kernel<R, D>), dim3(rows), dim3(192), lds, st, g)
+#define HA_GLUE_FWD(R, D) HA_LAUNCH((glue_fwd_kernel<R, D>), dim3(rows), dim3(192), lds, st, g)
   if (delta) { if (rotw == 3) HA_GLUE_FWD(3, true); else if (rotw == 6) HA_GLUE_FWD(6, true); else HA_GLUE_FWD(9, true); }
   else { if (rotw == 3) HA_GLUE_FWD(3, false); else if (rotw == 6) HA_GLUE_FWD(6, false); else HA_GLUE_FWD(9, false); }
 #undef HA_GLUE_FWD
 }
 static inline void launch_glue_bwd(int rotw, bool delta, int rows, hipStream_t st, const GlueParams& g) {
   const size_t lds = S_TOTAL_BWD * sizeof(float);
-#define HA_GLUE_BWD(R, D) hipLaunchKernelGGL((glue_bwd_kernel<R, D>), dim3(rows), dim3(256), lds, st, g)
+#define HA_GLUE_BWD(R, D) HA_LAUNCH((glue_bwd_kernel<R, D>), dim3(rows), dim3(256), lds, st, g)
   if (delta) { if (rotw == 3) HA_GLUE_BWD(3, true); else if (rotw == 6) HA_GLUE_BWD(6, true); else HA_GLUE_BWD(9, true); }
   else { if (rotw == 3) HA_GLUE_BWD(3, false); else if (rotw == 6) HA_GLUE_BWD(6, false); else HA_GLUE_BWD(9, false); }
 #undef HA_GLUE_BWD
@@ -1747,7 +1747,7 @@ static int launch_layers(LayerLaunch& LL, const StashLayout& L, float* stash, hi
       T.hsrc = nullptr; T.nsplit_h = 0;
     }
     if (fb) {
-      hipLaunchKernelGGL(gn_finish_kernel, dim3(fb), dim3(256), 4 * 32 * 8 * sizeof(float), st, F);
+      HA_LAUNCH(gn_finish_kernel, dim3(fb), dim3(256), 4 * 32 * 8 * sizeof(float), st, F);
       HA_LAUNCH_CHECK();
     }
   }
@@ -1756,8 +1756,8 @@ static int launch_layers(LayerLaunch& LL, const StashLayout& L, float* stash, hi
   T0.nblocks *= LL.RT;
   // (8-wave blocks need a register diet first: 256-VGPR cap at 2 waves/SIMD -> scratch spills, measured 4x slower)
   const bool lean = L.finish && T0.mode == 0 && T0.nsplit_src <= 1;
-  if (lean) hipLaunchKernelGGL((mlp_layer_kernel<4, true>), grid, dim3(256), 4 * 1024 * sizeof(float), st, LL);
-  else hipLaunchKernelGGL((mlp_layer_kernel<4, false>), grid, dim3(256), 4 * 1024 * sizeof(float), st, LL);
+  if (lean) HA_LAUNCH((mlp_layer_kernel<4, true>), grid, dim3(256), 4 * 1024 * sizeof(float), st, LL);
+  else HA_LAUNCH((mlp_layer_kernel<4, false>), grid, dim3(256), 4 * 1024 * sizeof(float), st, LL);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -1777,9 +1777,9 @@ static int launch_prior_gemm(GemmTask& T, hipStream_t st) {
   T.per_xcd = ceil_div(T.nwork, 8);
   const dim3 grid(T.per_xcd * 8), block(256);
   const size_t lds = 4 * GEMM_LDS_WAVE * sizeof(float);
-  if (rm == 2) hipLaunchKernelGGL(prior_gemm_kernel<2>, grid, block, lds, st, T);
-  else if (ks == 2) hipLaunchKernelGGL((prior_gemm_kernel<1, 2>), grid, block, lds, st, T);
-  else hipLaunchKernelGGL(prior_gemm_kernel<1>, grid, block, lds, st, T);
+  if (rm == 2) HA_LAUNCH(prior_gemm_kernel<2>, grid, block, lds, st, T);
+  else if (ks == 2) HA_LAUNCH((prior_gemm_kernel<1, 2>), grid, block, lds, st, T);
+  else HA_LAUNCH(prior_gemm_kernel<1>, grid, block, lds, st, T);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -2032,11 +2032,11 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
   }
   if (phase == PH_BEGIN) {
     if (L.acc) zero_async(stash + L.steps, (size_t)(S + 1) * L.per_step * sizeof(float), st);
-    hipLaunchKernelGGL(transpose_in_kernel, dim3(256), dim3(256), 0, st, z_seq, stash + L.zT, B, S, ZD, ZD, RT);
+    HA_LAUNCH(transpose_in_kernel, dim3(256), dim3(256), 0, st, z_seq, stash + L.zT, B, S, ZD, ZD, RT);
     HA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, x_ptr(0), B, 1, D_IN, D_INP, RT);
+    HA_LAUNCH(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, x_ptr(0), B, 1, D_IN, D_INP, RT);
     HA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
+    HA_LAUNCH(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
     HA_LAUNCH_CHECK();
     return HA_OK;
   }
@@ -2083,7 +2083,7 @@ static int rollout_forward_impl(const ha_humor_net* net, int B, int S, const flo
     q.pri_pad = net->pri[np - 1].Nout_pad;
     q.pri_out0 = stash + L.pri_h[np - 1]; q.step_stride = (size_t)RT * q.pri_pad * 32; q.pri_nsplit = 1;
     q.prior_mu = prior_mu; q.prior_var = prior_var;
-    hipLaunchKernelGGL(prior_io_kernel, dim3(rows, S), dim3(64), 0, st, q);
+    HA_LAUNCH(prior_io_kernel, dim3(rows, S), dim3(64), 0, st, q);
     HA_LAUNCH_CHECK();
   }
   return HA_OK;
@@ -2100,9 +2100,9 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
   const int RT = L.RT, rows = RT * 32;
   auto step_ptr = [&](int t) { return stash + L.steps + (size_t)t * L.per_step; };
   auto x_ptr = [&](int t) { return stash + L.xT + (size_t)t * RT * D_INP * 32; };
-  hipLaunchKernelGGL(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, x_ptr(0), B, 1, D_IN, D_INP, RT);
+  HA_LAUNCH(transpose_in_kernel, dim3(64), dim3(256), 0, st, past_in0, x_ptr(0), B, 1, D_IN, D_INP, RT);
   HA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
+  HA_LAUNCH(init_state_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, past_in0, step_ptr(0) + L.off_G, stash + L.t2j, B, rows);
   HA_LAUNCH_CHECK();
   const PackedLayer& DL = net->dec[net->n_dec - 1];
   const PackedLayer& PL = net->pri[net->n_pri - 1];
@@ -2125,7 +2125,7 @@ extern "C" int ha_humor_rollout_sample(const ha_humor_net* net, int B, int S, co
     sp_.B = B; sp_.S = S; sp_.t = t; sp_.RT = RT;
     sp_.pri_out = stash + L.smp_pri[net->n_pri - 1]; sp_.pri_nsplit = L.nsf_pri[net->n_pri - 1]; sp_.pri_pad = PL.Nout_pad;
     sp_.eps = eps_seq; sp_.zT_t = zT; sp_.z_out = z_out;
-    hipLaunchKernelGGL(sample_z_kernel, dim3(rows), dim3(64), 0, st, sp_);
+    HA_LAUNCH(sample_z_kernel, dim3(rows), dim3(64), 0, st, sp_);
     HA_LAUNCH_CHECK();
     for (int l = 0; l < net->n_dec; ++l) {
       LayerLaunch LL;
@@ -2165,7 +2165,7 @@ static int prior_adjoint_all(const ha_humor_net* net, const StashLayout& L, int 
   q.pri_out0 = stash + L.pri_h[np - 1]; q.step_stride = (size_t)RT * q.pri_pad * 32; q.pri_nsplit = 1;
   q.g_prior_mu = g_prior_mu; q.g_prior_var = g_prior_var;
   q.g_pri_all = stash + L.g_pri_out;
-  hipLaunchKernelGGL(prior_io_kernel, dim3(RT * 32, S), dim3(64), 0, st, q);
+  HA_LAUNCH(prior_io_kernel, dim3(RT * 32, S), dim3(64), 0, st, q);
   HA_LAUNCH_CHECK();
   return prior_backward_batched(net, L, stash, S, st);
 }
@@ -2451,7 +2451,7 @@ extern "C" int ha_humor_rollout_backward_ex(const ha_humor_net* net, int B, int 
   tl_gz_add = nullptr;
   if (rc == HA_OK && g_z_add && !add_in_kernel) {
     const int n = B * S * ZD;
-    hipLaunchKernelGGL(add_inplace_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, g_z_seq, g_z_add, n);
+    HA_LAUNCH(add_inplace_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, g_z_seq, g_z_add, n);
     HA_LAUNCH_CHECK();
   }
   return rc;
@@ -2462,7 +2462,7 @@ extern "C" int ha_humor_rollout_backward_ex(const ha_humor_net* net, int B, int 
   do {                                                                                    \
     HA_REQUIRE(n >= 0, NAME ": n must be >= 0");                                          \
     if (n == 0) return HA_OK;                                                             \
-    hipLaunchKernelGGL(KERNEL, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, n, __VA_ARGS__); \
+    HA_LAUNCH(KERNEL, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, n, __VA_ARGS__); \
     HA_LAUNCH_CHECK();                                                                    \
     return HA_OK;                                                                         \
   } while (0)
@@ -2645,7 +2645,7 @@ extern "C" int ha_mlp_forward(const ha_mlp* m, int N, const float* x, int tail, 
   DeviceGuard guard(m->device);
   hipStream_t st = (hipStream_t)stream;
   const MlpLayout W = mlp_layout(m, N);
-  hipLaunchKernelGGL(transpose_in_kernel, dim3(ceil_div((int)((size_t)W.nrt * m->in_pad * 32), 256)), dim3(256), 0, st, x, ws + W.xT, N, 1, m->in_dim,
+  HA_LAUNCH(transpose_in_kernel, dim3(ceil_div((int)((size_t)W.nrt * m->in_pad * 32), 256)), dim3(256), 0, st, x, ws + W.xT, N, 1, m->in_dim,
                      m->in_pad, W.nrt);
   HA_LAUNCH_CHECK();
   for (int l = 0; l < m->n; ++l) {
@@ -2675,7 +2675,7 @@ extern "C" int ha_mlp_forward(const ha_mlp* m, int N, const float* x, int tail, 
   }
   const int C = m->out_dim, Cpad = m->L[m->n - 1].Nout_pad;
   const size_t items = tail == HA_MLP_TAIL_NONE ? (size_t)N * C : (size_t)N * (C / 6);
-  hipLaunchKernelGGL(mlp_out_kernel, dim3((unsigned)ceil_div((int)items, 256)), dim3(256), 0, st, ws + W.out, y, N, C, Cpad, tail);
+  HA_LAUNCH(mlp_out_kernel, dim3((unsigned)ceil_div((int)items, 256)), dim3(256), 0, st, ws + W.out, y, N, C, Cpad, tail);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -2690,7 +2690,7 @@ extern "C" int ha_mlp_backward(const ha_mlp* m, int N, const float* g_y, int tai
   // the adjoint of the output goes to pp[(n-1)&1]; layer l's task reads pp[l&1] and writes pp[(l-1)&1]
   float* g_out = ws + W.pp[(m->n - 1) & 1];
   const size_t items = tail == HA_MLP_TAIL_NONE ? (size_t)W.nrt * 32 * Cpad : (size_t)W.nrt * 32 * ceil_div(Cpad, 6);
-  hipLaunchKernelGGL(mlp_gout_kernel, dim3((unsigned)ceil_div((int)items, 256)), dim3(256), 0, st, g_y, ws + W.out, g_out, N, W.nrt, C, Cpad, tail);
+  HA_LAUNCH(mlp_gout_kernel, dim3((unsigned)ceil_div((int)items, 256)), dim3(256), 0, st, g_y, ws + W.out, g_out, N, W.nrt, C, Cpad, tail);
   HA_LAUNCH_CHECK();
   for (int l = m->n - 1; l >= 0; --l) {
     const PackedLayer& P = m->L[l];
@@ -2710,7 +2710,7 @@ extern "C" int ha_mlp_backward(const ha_mlp* m, int N, const float* g_y, int tai
     int rc = launch_prior_gemm(T, st);
     if (rc != HA_OK) return rc;
   }
-  hipLaunchKernelGGL(mlp_out_kernel, dim3((unsigned)ceil_div((int)((size_t)N * m->in_dim), 256)), dim3(256), 0, st, ws + W.gx, g_x, N, m->in_dim,
+  HA_LAUNCH(mlp_out_kernel, dim3((unsigned)ceil_div((int)((size_t)N * m->in_dim), 256)), dim3(256), 0, st, ws + W.gx, g_x, N, m->in_dim,
                      m->L[0].Nin_pad, 0);
   HA_LAUNCH_CHECK();
   return HA_OK;

@@ -114,9 +114,6 @@ static_assert(4 * RED_BLOCK <= P_H1 * 4, "reduction scratch fits the dh1 operand
 static_assert(LB_TOTAL * 4 <= 160 * 1024, "the adjoint's LDS fits one CU");
 }  // namespace
 
-extern unsigned g_cu_poison;                 // debug.hip (ha_tune_set "cu_poison")
-int cu_poison_launch(hipStream_t st);
-
 size_t persist_ws_floats() { return (XCH_BYTES + 3) / 4; }
 int persist_dz_slots() { return DZ_SLOTS; }
 
@@ -2069,7 +2066,7 @@ int persist_create(PersistNet** out, int device, const ha_mlp_desc* d) {
       memset(&a, 0, sizeof(a));
       a.xch = xch;
       a.err = p->err_dev;
-      hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, 0, a);
+      HA_LAUNCH(rollout_persist_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, 0, a);
       e = hipDeviceSynchronize();
     }
     unsigned cnt[NTEAMS] = {0};
@@ -2110,9 +2107,8 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
     a.inject = (variant >> 1) & 1;
     a.xch = reinterpret_cast<unsigned char*>(f.ws);
     a.err = p->err_dev;
-    if (g_cu_poison) { const int prc = cu_poison_launch(st); if (prc != HA_OK) return prc; }
-    if (variant & 1) hipLaunchKernelGGL(rollout_pipe_fwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), PL_TOTAL * 4, st, a);
-    else hipLaunchKernelGGL(rollout_pipe_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), PL_TOTAL * 4, st, a);
+    if (variant & 1) HA_LAUNCH(rollout_pipe_fwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), PL_TOTAL * 4, st, a);
+    else HA_LAUNCH(rollout_pipe_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), PL_TOTAL * 4, st, a);
     HA_LAUNCH_CHECK();
     ++p->launches;
     return HA_OK;
@@ -2135,9 +2131,8 @@ int persist_forward(PersistNet* p, const PersistFwd& f, int variant, hipStream_t
   a.err = p->err_dev;
   a.inject = (variant >> 1) & 1;
   a.hidden_slabs = f.hidden_slabs ? 1 : 0;
-  if (g_cu_poison) { const int prc = cu_poison_launch(st); if (prc != HA_OK) return prc; }
-  if (variant & 1) hipLaunchKernelGGL(rollout_persist_fwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
-  else hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
+  if (variant & 1) HA_LAUNCH(rollout_persist_fwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
+  else HA_LAUNCH(rollout_persist_fwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), L_TOTAL * 4, st, a);
   HA_LAUNCH_CHECK();
   ++p->launches;
   return HA_OK;
@@ -2166,12 +2161,11 @@ int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_
     a.t2j = f.t2j; a.g_past0 = f.g_past0; a.dz_part = f.dz_part;
     a.xch = reinterpret_cast<unsigned char*>(f.ws);
     a.err = p->err_dev;
-    if (g_cu_poison) { const int prc = cu_poison_launch(st); if (prc != HA_OK) return prc; }
-    if (variant & 1) hipLaunchKernelGGL(rollout_pipe_bwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), QL_TOTAL * 4, st, a);
-    else hipLaunchKernelGGL(rollout_pipe_bwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), QL_TOTAL * 4, st, a);
+    if (variant & 1) HA_LAUNCH(rollout_pipe_bwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), QL_TOTAL * 4, st, a);
+    else HA_LAUNCH(rollout_pipe_bwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), QL_TOTAL * 4, st, a);
     HA_LAUNCH_CHECK();
     const int n = f.B * f.S * P_ZD;
-    hipLaunchKernelGGL(pipe_dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)f.dz_part, f.g_z, f.g_z_add, f.B, f.S, a.NG * 32);
+    HA_LAUNCH(pipe_dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)f.dz_part, f.g_z, f.g_z_add, f.B, f.S, a.NG * 32);
     HA_LAUNCH_CHECK();
     ++p->launches_bwd;
     return HA_OK;
@@ -2191,12 +2185,11 @@ int persist_backward(PersistNet* p, const PersistBwd& f, int variant, hipStream_
   a.t2j = f.t2j; a.g_past0 = f.g_past0; a.dz_part = f.dz_part;
   a.xch = reinterpret_cast<unsigned char*>(f.ws);
   a.err = p->err_dev;
-  if (g_cu_poison) { const int prc = cu_poison_launch(st); if (prc != HA_OK) return prc; }
-  if (variant & 1) hipLaunchKernelGGL(rollout_persist_bwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), LB_TOTAL * 4, st, a);
-  else hipLaunchKernelGGL(rollout_persist_bwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), LB_TOTAL * 4, st, a);
+  if (variant & 1) HA_LAUNCH(rollout_persist_bwd_kernel<true>, dim3(NTEAMS * TEAM_CUS), dim3(256), LB_TOTAL * 4, st, a);
+  else HA_LAUNCH(rollout_persist_bwd_kernel<false>, dim3(NTEAMS * TEAM_CUS), dim3(256), LB_TOTAL * 4, st, a);
   HA_LAUNCH_CHECK();
   const int n = f.B * f.S * P_ZD;
-  hipLaunchKernelGGL(dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)f.dz_part, f.g_z, f.g_z_add, f.B, f.S);
+  HA_LAUNCH(dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)f.dz_part, f.g_z, f.g_z_add, f.B, f.S);
   HA_LAUNCH_CHECK();
   ++p->launches_bwd;
   return HA_OK;

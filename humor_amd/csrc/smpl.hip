@@ -1907,7 +1907,7 @@ extern "C" int ha_lbs_skin(const ha_smpl_model* m, int N, const float* v_posed, 
   const int diag = (sv >> 3) & 3;
   const int nb = (int)((total + 256 * nw - 1) / (256 * nw));
   const size_t lds = (size_t)(2 * m->J * 12 + 256 * nw * 3) * sizeof(float);
-#define HA_SKIN(NTV, D, NWV) hipLaunchKernelGGL((lbs_skin_wave_kernel<NTV, D, NWV>), dim3(nb), dim3(64 * NWV), lds, (hipStream_t)stream, \
+#define HA_SKIN(NTV, D, NWV) HA_LAUNCH((lbs_skin_wave_kernel<NTV, D, NWV>), dim3(nb), dim3(64 * NWV), lds, (hipStream_t)stream, \
                                                v_posed, A, transl, m->w4, m->idx4, verts, N, m->V, m->J)
   if (diag == 1) HA_SKIN(true, 1, 8);
   else if (diag == 2) HA_SKIN(true, 2, 8);
@@ -1949,7 +1949,7 @@ extern "C" int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_ac
   const int blocks = ceil_div(N, FW);
   if (algo == 1) {
     p.verts = verts;
-    hipLaunchKernelGGL(smpl_frame_fwd_kernel, dim3(blocks), dim3(FW * 64), lds, st, p);
+    HA_LAUNCH(smpl_frame_fwd_kernel, dim3(blocks), dim3(FW * 64), lds, st, p);
     HA_LAUNCH_CHECK();
     return HA_OK;
   }
@@ -1958,7 +1958,7 @@ extern "C" int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_ac
   p.nchunks = 0;
   p.coeffT = ws_coeff;
   p.Npad = ceil_div(N, 64) * 64;
-  hipLaunchKernelGGL(smpl_frame_fwd_kernel, dim3(blocks), dim3(FW * 64), lds, st, p);
+  HA_LAUNCH(smpl_frame_fwd_kernel, dim3(blocks), dim3(FW * 64), lds, st, p);
   HA_LAUNCH_CHECK();
   if (!verts) return HA_OK;
   {
@@ -1978,12 +1978,12 @@ extern "C" int ha_smpl_forward(const ha_smpl_model* m, int slot, int N, int n_ac
       }
 #endif
       HA_REQUIRE(lds_f <= 80 * 1024, "ha_smpl_forward: algo 3 keeps the A matrices of 32 frames in LDS (J <= 53)");
-      hipLaunchKernelGGL((pose_blend_skin_kernel<4, true>), dim3(n_groups * (p.Npad / 32)), dim3(256), lds_f, st, ws_coeff, p.Npad, KQ,
+      HA_LAUNCH((pose_blend_skin_kernel<4, true>), dim3(n_groups * (p.Npad / 32)), dim3(256), lds_f, st, ws_coeff, p.Npad, KQ,
                            ceil_div(m->Kfull_pad / 2, 4), m->Pd_m, N, m->V, n_vt, n_groups, A_out, transl, m->w4, m->idx4, verts, m->J);
       HA_LAUNCH_CHECK();
       return HA_OK;
     }
-    hipLaunchKernelGGL(pose_blend_mfma_kernel, dim3(n_vtg8 * n_ft), dim3(256), 0, st, ws_coeff, p.Npad, KQ, ceil_div(m->Kfull_pad / 2, 4),
+    HA_LAUNCH(pose_blend_mfma_kernel, dim3(n_vtg8 * n_ft), dim3(256), 0, st, ws_coeff, p.Npad, KQ, ceil_div(m->Kfull_pad / 2, 4),
                        m->Pd_m, ws_vposed, N, m->V, n_vt, n_ft);
     HA_LAUNCH_CHECK();
   }
@@ -2004,7 +2004,7 @@ extern "C" int ha_smpl_backward(const ha_smpl_model* m, int slot, int N, int n_a
   p.g_verts = g_verts; p.g_joints = g_joints;
   p.g_pose = g_pose; p.g_betas = g_betas; p.g_transl = g_transl;
   const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + kXchFloats) * sizeof(float);
-  hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
+  HA_LAUNCH(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -2024,7 +2024,7 @@ extern "C" int ha_smpl_forward_split(const ha_smpl_model* m, int slot, int N, in
   p.joints = joints_ext; p.verts = verts_tail ? verts_tail : joints_ext;   // (non-null = "evaluate the vertex set")
   p.n_head = n_head; p.jstride = m->J + n_head;
   const size_t lds = ((size_t)FW * (((m->Kfull_pad + 3) & ~3) + m->J * 12) + kXchFloats) * sizeof(float);
-  hipLaunchKernelGGL(smpl_frame_fwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
+  HA_LAUNCH(smpl_frame_fwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -2045,7 +2045,7 @@ extern "C" int ha_smpl_backward_split(const ha_smpl_model* m, int slot, int N, i
   p.g_pose = g_pose; p.g_betas = g_betas; p.g_transl = g_transl;
   p.n_head = n_head; p.jstride = m->J + n_head;
   const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + kXchFloats) * sizeof(float);
-  hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
+  HA_LAUNCH(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -2070,7 +2070,7 @@ extern "C" int ha_smpl_forward_parts(const ha_smpl_model* m, int slot, int N, in
   p.joints = joints_ext; p.verts = verts_tail ? verts_tail : joints_ext;
   p.n_head = n_head; p.jstride = m->J + n_head;
   const size_t lds = ((size_t)FW * (((m->Kfull_pad + 3) & ~3) + m->J * 12) + kXchFloats) * sizeof(float);
-  hipLaunchKernelGGL(smpl_frame_fwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
+  HA_LAUNCH(smpl_frame_fwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -2097,7 +2097,7 @@ extern "C" int ha_smpl_backward_parts(const ha_smpl_model* m, int slot, int N, i
   p.add_root = add_root; p.add_body = add_body; p.add_betas = add_betas; p.add_transl = add_transl;
   p.n_head = n_head; p.jstride = m->J + n_head;
   const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + kXchFloats) * sizeof(float);
-  hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
+  HA_LAUNCH(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, (hipStream_t)stream, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -2124,7 +2124,7 @@ __global__ __launch_bounds__(256) void seq_sum_add_kernel(const float* __restric
 
 extern "C" int ha_seq_sum_add(int B, int T, int W, const float* src, const float* add1, const float* add2, float* out, void* stream) {
   HA_REQUIRE(src && out && B >= 1 && T >= 1 && W >= 1 && W <= 64, "ha_seq_sum_add: need src, out, B, T >= 1 and 1 <= W <= 64");
-  hipLaunchKernelGGL(seq_sum_add_kernel, dim3(B), dim3(256), 256 * sizeof(float), (hipStream_t)stream, src, add1, add2, out, T, W);
+  HA_LAUNCH(seq_sum_add_kernel, dim3(B), dim3(256), 256 * sizeof(float), (hipStream_t)stream, src, add1, add2, out, T, W);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
@@ -2153,23 +2153,23 @@ extern "C" int ha_smpl_backward_dense(const ha_smpl_model* m, int N, int n_activ
   HA_REQUIRE(P.np <= 64, "ha_smpl_backward_dense: V=%d too large for the partial-sum layout", m->V);
   const VertexSet& s0 = m->sets[0];
   const int Kp = ceil_div(m->Kfull, 128) * 128;
-  hipLaunchKernelGGL(dense_gvp_kernel, dim3(P.np / 4, N), dim3(256), (size_t)m->J * 12 * sizeof(float), st, g_verts, A, m->w4, m->idx4,
+  HA_LAUNCH(dense_gvp_kernel, dim3(P.np / 4, N), dim3(256), (size_t)m->J * 12 * sizeof(float), st, g_verts, A, m->w4, m->idx4,
                      ws + P.off_gvp, ws + P.off_gtl, m->V, m->J, P.nchunks, P.np);
   HA_LAUNCH_CHECK();
   if (g_dense_gA_sparse == 2 && m->gc_joint)
   {
     if ((m->V & 1) == 0 && (reinterpret_cast<uintptr_t>(g_verts) & 7) == 0 && (reinterpret_cast<uintptr_t>(v_posed) & 7) == 0)
-      hipLaunchKernelGGL(compressed_gA_kernel<true>, dim3(N), dim3(256), (size_t)(4 * 64 * 12 + 4 * GA_STAGE) * sizeof(float), st, g_verts, v_posed,
+      HA_LAUNCH(compressed_gA_kernel<true>, dim3(N), dim3(256), (size_t)(4 * 64 * 12 + 4 * GA_STAGE) * sizeof(float), st, g_verts, v_posed,
                          m->gc_joint, m->gc_w, m->gc_ng, ws + P.off_gA, m->V, m->Vpad, m->J);
     else
-      hipLaunchKernelGGL(compressed_gA_kernel<false>, dim3(N), dim3(256), (size_t)(4 * 64 * 12 + 4 * GA_STAGE) * sizeof(float), st, g_verts, v_posed,
+      HA_LAUNCH(compressed_gA_kernel<false>, dim3(N), dim3(256), (size_t)(4 * 64 * 12 + 4 * GA_STAGE) * sizeof(float), st, g_verts, v_posed,
                          m->gc_joint, m->gc_w, m->gc_ng, ws + P.off_gA, m->V, m->Vpad, m->J);
   }
   else if (g_dense_gA_sparse)
-    hipLaunchKernelGGL(sparse_gA_kernel, dim3(N), dim3(256), 0, st, g_verts, v_posed, m->ja_start, m->ja_v, m->ja_w, m->ja_order, ws + P.off_gA,
+    HA_LAUNCH(sparse_gA_kernel, dim3(N), dim3(256), 0, st, g_verts, v_posed, m->ja_start, m->ja_v, m->ja_w, m->ja_order, ws + P.off_gA,
                        m->V, m->J);
   else
-    hipLaunchKernelGGL(dense_gA_kernel, dim3(N), dim3(256), (size_t)4 * 64 * 12 * sizeof(float), st, g_verts, v_posed, m->Wd, ws + P.off_gA, m->V,
+    HA_LAUNCH(dense_gA_kernel, dim3(N), dim3(256), (size_t)4 * 64 * 12 * sizeof(float), st, g_verts, v_posed, m->Wd, ws + P.off_gA, m->V,
                        m->Vpad, m->J);
   HA_LAUNCH_CHECK();
   {
@@ -2184,7 +2184,7 @@ extern "C" int ha_smpl_backward_dense(const ha_smpl_model* m, int N, int n_activ
       m->gco_lds_attr_set = true;
     }
 #endif
-    hipLaunchKernelGGL(dense_gco_kernel, dim3(nblk), dim3(GCO_THREADS), lds_gco, st, ws + P.off_gvp, s0.Pd_k, ws + P.off_gco, N, P.nchunks, Kp, P.ngroups, P.n_rp,
+    HA_LAUNCH(dense_gco_kernel, dim3(nblk), dim3(GCO_THREADS), lds_gco, st, ws + P.off_gvp, s0.Pd_k, ws + P.off_gco, N, P.nchunks, Kp, P.ngroups, P.n_rp,
                        P.KS, P.cps, N, P.ld, nrp_max);
     HA_LAUNCH_CHECK();
   }
@@ -2197,7 +2197,7 @@ extern "C" int ha_smpl_backward_dense(const ha_smpl_model* m, int N, int n_activ
   p.gA_in = ws + P.off_gA; p.gco_part = ws + P.off_gco; p.gco_ks = P.KS; p.gco_rows = N; p.gco_ld = P.ld;
   p.gtl_part = ws + P.off_gtl; p.gtl_np = P.np;
   const size_t lds = ((size_t)FW * bwd_wave_floats((m->Kfull_pad + 3) & ~3, m->J) + kXchFloats) * sizeof(float);
-  hipLaunchKernelGGL(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, st, p);
+  HA_LAUNCH(smpl_frame_bwd_kernel, dim3(ceil_div(N, FW)), dim3(FW * 64), lds, st, p);
   HA_LAUNCH_CHECK();
   return HA_OK;
 }
