@@ -246,12 +246,13 @@ def test_persistent_forward_matches_launch_chain(gpu_lib, dev, variant):
         print('persistent vs chain', B, S, variant, RC.check_persistent_vs_chain(gpu_lib, dev, B, S, seed=B, variant=variant))
 
 
-@pytest.mark.parametrize('B,S', [(64, 12), (40, 5), (100, 7), (256, 20), (300, 4)])
+@pytest.mark.parametrize('B,S', [(64, 12), (40, 5), (100, 7), (256, 20), (300, 4), (260, 3), (288, 3)])
 def test_pipelined_rollout_matches_launch_chain(gpu_lib, dev, B, S):
     """roll-outs of more than 32 sequences on the layer-parallel pipelined persistent kernels (rollout_pipe.inc: forward and
     adjoint, one launch each per chunk of <= 256 sequences) against the 5-launches-per-step chain on the same inputs -- world states,
     prior outputs and every gradient, for the pipelined forward + launch-chain adjoint and for pipelined forward + pipelined adjoint;
-    partial last tiles (40, 100), full tiles (64, 256) and two chunks (300)."""
+    partial last tiles (40, 100), full tiles (64, 256), two chunks (300), and a chunk of 256 whose tail of 4 / 32 sequences goes to the B <= 32
+    kernels from inside the chunk loop (260, 288: ADVICE r5)."""
     print('pipelined vs chain', B, S, RC.check_persistent_vs_chain(gpu_lib, dev, B, S, seed=B, variant=1, launches_per_call=(B + 255) // 256))
 
 
