@@ -89,6 +89,44 @@ def test_rollout_input_variants(gpu_lib, dev, rep, steps_in):
     print(rep, steps_in, RC.check_rollout_inrep(gpu_lib, dev, rep, steps_in))
 
 
+@pytest.mark.parametrize('canon,uncanon', [(False, False), (True, False), (True, True)])
+def test_generic_step_loop_equals_the_kernel_path(gpu_lib, dev, canon, uncanon):
+    """The on-device step loop that serves HumorModel's input variants (_roll_out_generic) is a second implementation of the whole roll-out: in
+    the fitting configuration ('mat' / 1), where the HIP kernels run, both must agree -- world states, prior outputs, gradients -- with and
+    without canonicalize_input / uncanonicalize_output (humor_model.py:808-858)."""
+    hm, _ = RC.make_model(gpu_lib, dev, seed=9, contractive=True)
+    for p in hm.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(19)
+    B, S = 5, 6
+    past = RC.canonical_state(B, g)
+    if canon:                         # a world-frame start: the canonical state turned about z and moved
+        th = torch.rand(B, generator=g) * 2.0
+        Rz = torch.zeros(B, 3, 3)
+        Rz[:, 0, 0], Rz[:, 0, 1], Rz[:, 1, 0], Rz[:, 1, 1], Rz[:, 2, 2] = th.cos(), -th.sin(), th.sin(), th.cos(), 1.0
+        off = torch.cat([torch.randn(B, 2, generator=g), torch.zeros(B, 1)], 1)
+        rot = lambda v: torch.einsum('bij,bj->bi', Rz, v)
+        joints = torch.einsum('bij,bkj->bki', Rz, past[:, 207:273].reshape(B, 22, 3)) + off.unsqueeze(1)
+        past = torch.cat([rot(past[:, 0:3]) + off, rot(past[:, 3:6]), torch.matmul(Rz, past[:, 6:15].reshape(B, 3, 3)).reshape(B, 9), rot(past[:, 15:18]),
+                          past[:, 18:207], joints.reshape(B, 66), torch.einsum('bij,bkj->bki', Rz, past[:, 273:339].reshape(B, 22, 3)).reshape(B, 66)], 1)
+    past, z = past.to(dev), (0.5 * torch.randn(B, S, 48, generator=g)).to(dev)
+    gw, gm = torch.randn(B, S, 348, generator=g).to(dev), torch.randn(B, S, 48, generator=g).to(dev)
+    res = []
+    for generic in (False, True):
+        p, zz = past.clone().requires_grad_(True), z.clone().requires_grad_(True)
+        x_past = p.reshape(B, 1, 339)
+        if generic:
+            out, (pm, pv) = hm._roll_out_generic(x_past, None, S, False, zz, True, False, canon, uncanon, None)
+        else:
+            out, (pm, pv) = hm.roll_out(x_past, None, S, z_seq=zz, return_prior=True, canonicalize_input=canon, uncanonicalize_output=uncanon)
+        w = RC.world_of(out)
+        ((w * gw).sum() + (pm * gm).sum() + pv.sum()).backward()
+        res.append((w.detach(), pm.detach(), pv.detach(), p.grad.clone(), zz.grad.clone()))
+    for name, a, b, tol in zip(('world', 'pm', 'pv', 'g_past', 'g_z'), res[0], res[1], (2e-5, 2e-5, 2e-5, 3e-4, 3e-4)):
+        e = (a - b).abs().max().item() / max(1.0, a.abs().max().item())
+        assert e <= tol, (name, e)
+
+
 @pytest.mark.parametrize('name', ['c4', 'c3', 'c5'])
 def test_rollout_baseline_lengths_flat_tolerance(gpu_lib, dev, fwd_path, name):
     """59 / 89 / 119 steps against the reference's own outputs (tests/golden/rollout_long.npz): flat 1e-4 on every step's
