@@ -92,6 +92,20 @@ def test_emu_stage12_objectives(emu_lib, smplh_npz, kind):
                 assert np.abs(v.detach().numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (kind, stage, k)
 
 
+def test_emu_non_finite_objective_aborts_the_fit(emu_lib, smplh_npz):
+    """MotionOptimizer.run raises when the objective L-BFGS has just read on the host is non-finite (here: a NaN observation, stage 1) instead of
+    carrying NaN into its results; LBFGS.step returns after the ONE evaluation that showed it (the GPU tier repeats this in stage 3 and under
+    hipGraph replay: tests/test_e2e_gpu.py::test_non_finite_objective_aborts_the_fit)."""
+    B, T = 2, 4
+    case = CC.make_case('amass', B, T, seed=3)
+    opt = FC.build(emu_lib, CPU, 'amass', B, T, smplh_npz)
+    obs = {k: v.clone() for k, v in case['obs'].items()}
+    obs['joints3d'][1, 2, 5, 0] = float('nan')
+    with pytest.raises(RuntimeError, match='non-finite objective in stage 1'):
+        opt.run(obs, data_fps=30, lr=1.0, num_iter=[2, 1, 1], lbfgs_max_iter=3)
+    assert opt.closure_evals == 1
+
+
 def _sharded_worker(rank, world, port, npz, emu_path, out, B=4):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
