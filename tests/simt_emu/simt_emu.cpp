@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- runtime of the host SIMT emulator (see include/hip/hip_runtime.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 
 namespace ha { alignas(16) float smem[40960]; }   // 160 KiB "LDS", one block resident at a time
@@ -20,7 +21,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   // CU left there (round 5: NaN gradients on one box, green on another).  Every emulated launch therefore starts on NaN-filled "LDS".
   {
     const unsigned nanbits = 0x7fc00000u;
-    for (size_t i = 0; i < sizeof(ha::smem) / sizeof(float); ++i) std::memcpy(&ha::smem[i], &nanbits, 4);
+    float nanv;
+    std::memcpy(&nanv, &nanbits, 4);
+    std::fill(ha::smem, ha::smem + sizeof(ha::smem) / sizeof(float), nanv);
   }
   BlockCtx ctx;
   std::barrier<> block_bar(nthreads);

@@ -319,6 +319,7 @@ def test_emu_speculative_lbfgs_is_bit_identical_to_sequential(emu_lib):
     assert out[False][2] == out[True][2]
 
 
+@pytest.mark.slow          # (a minute on the emulator; the speculative issue is off by default)
 def test_speculative_lbfgs_survives_rollback_of_a_non_finite_iteration(emu_lib):
     """Advisor, round 5: repeated step() calls at a converged point start with a vanishing pair (y = 0, H = y.s / y.y = 0 / 0); the iteration
     built on it and the speculative one behind it are non-finite, the host rejects them (curvature test) and rolls the speculation back.
