@@ -58,6 +58,21 @@ int cu_poison_launch(hipStream_t st);
     hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);            \
   } while (0)
 
+// The kernel's dynamic LDS.  gfx950: the usual extern array.  Host emulator (CPU test tier): the block's own buffer -- the persistent roll-out
+// kernels run with the 32 blocks of a team resident at the same time there (tests/simt_emu: resident teams), one LDS each.
+#ifdef HA_SIMT_EMU
+#define HA_DYN_LDS(name) float* const name = simt_emu::block_lds()
+#else
+#define HA_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) float name[]
+#endif
+
+// two values made opaque to the optimiser (it must not hoist what depends on them out of a loop); the constraint letter differs on the host
+#ifdef HA_SIMT_EMU
+#define HA_OPAQUE2(a, b) asm volatile("" : "+r"(a), "+r"(b))
+#else
+#define HA_OPAQUE2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#endif
+
 static inline void zero_async(void* p, size_t bytes, hipStream_t st) {
   const size_t n = bytes / 4;       // (every caller clears whole floats)
   if (n == 0) return;

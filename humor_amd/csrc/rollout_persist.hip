@@ -508,7 +508,6 @@ __device__ __forceinline__ void publish(const float (&sums)[4 * NCG], float bias
   }
 }
 
-#ifndef HA_SIMT_EMU
 
 // The 3x3 helpers of common.h with contraction allowed (the library is built -ffp-contract=off; the glue chains of this file are
 // instruction-issue bound on one or two waves per CU, and a*b + c*d + e*f as mul + 2 fma is 3 instructions instead of 5 -- and rounds
@@ -550,7 +549,7 @@ __device__ __forceinline__ void mat3_tvec(const float A[9], const float v[3], fl
 // rodrigues() of common.h with ONE argument reduction for sine and cosine and the norm / its reciprocal from v_sqrt_f32 / v_rcp_f32
 // (1 ulp each, arguments >= 1e-8: no denormals).  The glue is a dependent chain on one lane per sequence: the IEEE sqrtf and division
 // are ~10 dependent instructions each, and the unit axis they produce differs from the correctly rounded one by an ulp or two.
-#ifdef HA_GLUE_IEEE      // (A/B builds only: correctly rounded division / square root in the glue chains)
+#if defined(HA_GLUE_IEEE) || defined(HA_SIMT_EMU)      // (A/B builds and the host emulator: correctly rounded division / square root in the glue chains)
 __device__ __forceinline__ float hw_rcp(float x) { return 1.0f / x; }
 __device__ __forceinline__ float hw_sqrt(float x) { return sqrtf(x); }
 #else
@@ -607,9 +606,18 @@ __device__ __forceinline__ float w2a_sc(const float pR[9], float W[9]) {
   return angle;
 }
 
+// the XCD this block runs on (HW_REG_XCC_ID) and the host-mapped error word; host emulator: one team, blocks 0 .. 31 on "XCD" 0
+#ifdef HA_SIMT_EMU
+__device__ __forceinline__ unsigned xcc_id() { return (unsigned)(blockIdx.x / TEAM_CUS) & 7u; }
+__device__ __forceinline__ void err_store(unsigned* err, unsigned v) { std::atomic_ref<unsigned>(*err).store(v); }
+#else
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }
+__device__ __forceinline__ void err_store(unsigned* err, unsigned v) { __hip_atomic_store(err, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+#endif
+
 template <bool SC1>
 __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd_kernel(PersistArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  HA_DYN_LDS(smem);
   float* xs0 = smem + L_XS0;
   float* xs1 = smem + L_XS1;
   float* xs2 = smem + L_XS2;
@@ -626,7 +634,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
 
   // ---- team formation: a block belongs to the XCD it runs on ------------------------------------------------------------
   if (tid == 0) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;       // HW_REG_XCC_ID
+    const unsigned xcc = xcc_id();
     unsigned* cnt = reinterpret_cast<unsigned*>(a.xch);
     misc[0] = (int)xcc;
     misc[1] = (int)atomicAdd(cnt + xcc, 1u);
@@ -636,7 +644,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
   // (block-uniform values out of LDS: readfirstlane keeps them -- and the buffer descriptor built from them -- in SGPRs)
   const int team = __builtin_amdgcn_readfirstlane(misc[0]), m = __builtin_amdgcn_readfirstlane(misc[1]);
   if (m >= TEAM_CUS) {        // more than 32 blocks on this XCD: another XCD is short of one, its team will time out
-    if (tid == 0) __hip_atomic_store(a.err, 0x100u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) err_store(a.err, 0x100u | (unsigned)team);
     return;
   }
   if (a.S == 0) return;       // residency / placement probe
@@ -1003,7 +1011,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_fwd
       const int i = (int)(e / ((size_t)a.S * P_STATE));
       if (row0 + i < a.B) a.world[(size_t)row0 * a.S * P_STATE + e] = nanv;
     }
-    if (tid == 0) __hip_atomic_store(a.err, 0x200u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) err_store(a.err, 0x200u | (unsigned)team);
   }
 }
 
@@ -1015,7 +1023,6 @@ __device__ __forceinline__ void outer_acc3(float M[9], const float a[3], const f
 #pragma unroll
     for (int k = 0; k < 3; ++k) M[i * 3 + k] = fmaf(a[i], b[k], M[i * 3 + k]);
 }
-#endif  // !HA_SIMT_EMU  (dz_mma / dz_store are shared with the emulator build)
 
 // a dL/dz task (or layer 0's LDS-resident K tail): CH chunks of the activation adjoint against LDS-resident weight vectors.  All
 // operands are read first, then the MFMAs run on min(CH, 8) independent accumulators.
@@ -1044,7 +1051,6 @@ __device__ __forceinline__ void dz_store(const float (&acc)[4], float* part, int
   }
 }
 
-#ifndef HA_SIMT_EMU
 
 // ---------------------------------------------------------------------------------------------------
 // Persistent adjoint: the reverse scan over the S steps as ONE launch, same teams / exchange as the forward.
@@ -1173,7 +1179,6 @@ __device__ __forceinline__ void head_adj(const HeadPrep& o, const RodPrep& p, co
   g_p3 = -g_ry;
 }
 
-#endif  // !HA_SIMT_EMU
 
 // consumer side of an activation adjoint: sweep dL/da (a = ReLU(GroupNorm(h))), the forward's h and statistics, GroupNorm/ReLU
 // adjoint (gn_apply mode 3 of the launch chain: dh = rstd (dxh - mean(dxh) - xh mean(dxh xh))), dh to LDS as [channel][4 rows].
@@ -1234,11 +1239,10 @@ __device__ __forceinline__ bool gather_norm_bwd(__amdgpu_buffer_rsrc_t rs, unsig
   return true;
 }
 
-#ifndef HA_SIMT_EMU
 
 template <bool SC1>
 __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd_kernel(PersistBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  HA_DYN_LDS(smem);
   float* sD3 = smem + LB_D3;
   float* sD2 = smem + LB_D2;
   float* sD1 = smem + LB_D1;
@@ -1250,7 +1254,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
   if (tid == 0) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    const unsigned xcc = xcc_id();
     unsigned* cnt = reinterpret_cast<unsigned*>(a.xch);
     misc[0] = (int)xcc;
     misc[1] = (int)atomicAdd(cnt + xcc, 1u);
@@ -1259,7 +1263,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
   __syncthreads();
   const int team = __builtin_amdgcn_readfirstlane(misc[0]), m = __builtin_amdgcn_readfirstlane(misc[1]);
   if (m >= TEAM_CUS) {
-    if (tid == 0) __hip_atomic_store(a.err, 0x300u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) err_store(a.err, 0x300u | (unsigned)team);
     return;
   }
   const int g = m * 4 + wave;
@@ -1403,7 +1407,7 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
     int gi = 2 * (wave & 1) + (lane >> 5), gv = lane & 31;                // sequence of the team, rotation / vector task of this lane
     // (opaque to the optimiser: otherwise every lane-dependent LDS offset below is hoisted out of the step loop and lives in a VGPR for
     // the whole launch -- the register file holds the weights, and the allocator then starts copying weights around, tests/test_build.py)
-    asm volatile("" : "+v"(gi), "+v"(gv));
+    HA_OPAQUE2(gi, gv);
     {
       const float* X = cur + PF_X + gi * P_XPAD;
       const float* RW = cur + PF_RAW + gi * P_RAWPAD;
@@ -1763,11 +1767,10 @@ __global__ __launch_bounds__(256) HA_WAVES_PER_EU(1, 1) void rollout_persist_bwd
       const int tt = (int)(e / (ROWS * P_ZD)), r = (int)(e % (ROWS * P_ZD));
       a.dz_part[(((size_t)tt * DZ_SLOTS) * 32 + row0) * P_ZD + r] = nanv;          // slot 0 of every step
     }
-    if (tid == 0) __hip_atomic_store(a.err, 0x400u | (unsigned)team, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) err_store(a.err, 0x400u | (unsigned)team);
   }
 }
 
-#endif  // !HA_SIMT_EMU  (dz_reduce_kernel is shared with the emulator build)
 
 // g_z[b][t][c] = sum of the DZ_SLOTS partial products, fixed order
 __global__ void dz_reduce_kernel(const float* __restrict__ part, float* __restrict__ g_z, const float* __restrict__ g_z_add, int B, int S) {

@@ -469,6 +469,49 @@ def check_rollout_inrep(lib, device, rep, steps_in):
     return e
 
 
+def check_persistent_kernels_whole_team(emu_lib, B, S, seed=0):
+    """The B <= 32 persistent roll-out kernels AS A WHOLE on the host emulator (tests/simt_emu: resident teams): the 32 blocks of one XCD team run
+    at the same time, one OS thread per work-item, every block on its own NaN-filled LDS, every buffer the kernels write NaN-filled.  Forward:
+    team formation, the step loop, the four exchange hand-offs per step through tagged granules, consumer-side GroupNorm, the glue chains, copy_out;
+    then the one-launch adjoint over the forward's stash (reverse scan, GroupNorm / glue adjoints, dL/dz partials + reduction).  Against the
+    oracle at the flat bars; the state slabs the prior reads and the decoder outputs must be finite for every live row -- the pad channel of the
+    ODD steps is where round 5's uninitialised LDS buffer showed (removing that fix makes this check fail: 3 non-finite entries per odd step)."""
+    import ctypes as C
+    dll = emu_lib._dll
+    sd = synth.humor_state_dict(seed=seed)
+    g = torch.Generator().manual_seed(seed + 5)
+    past = canonical_state(B, g).requires_grad_(True)
+    z = torch.randn(B, S, 48, generator=g).requires_grad_(True)
+    gw = torch.randn(B, S, 348, generator=g)
+    f = lambda t: np.ascontiguousarray(t.detach().float().numpy())
+    arrs = [f(sd[f'decoder.net.{i}.weight']) for i in (0, 3, 6, 9)] + [f(sd[f'decoder.net.{i}.bias']) for i in (0, 3, 6, 9)]
+    for i in (1, 4, 7):
+        arrs += [f(sd[f'decoder.net.{i}.weight']), f(sd[f'decoder.net.{i}.bias'])]
+    pin, zin, gwn = f(past), f(z), f(gw)
+    world, xT, raw = np.zeros((B, S, 348), np.float32), np.zeros((S + 1, 85, 32, 4), np.float32), np.zeros((S, 56, 32, 4), np.float32)
+    g_past, g_z = np.zeros((B, 339), np.float32), np.zeros((B, S, 48), np.float32)
+    err, errb = C.c_uint(0), C.c_uint(0)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    fn = dll.ha_emu_persist_team
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 19 + [C.POINTER(C.c_uint), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint)]
+    assert fn(B, S, *[P(a) for a in arrs], P(pin), P(zin), P(world), P(xT), P(raw), C.byref(err), P(gwn), P(g_past), P(g_z), C.byref(errb)) == 0
+    assert err.value == 0 and errb.value == 0, (hex(err.value), hex(errb.value))
+    w_ref, _ = H.roll_out(sd, past, z)
+    (w_ref * gw).sum().backward()
+    e = {'world': float(np.abs(world - w_ref.detach().numpy()).max())}
+    assert np.isfinite(world).all() and e['world'] < FWD_TOL, e
+    live = xT[:, :, :B, :]
+    bad = [int((~np.isfinite(live[t])).sum()) for t in range(S + 1)]
+    assert not any(bad), ('non-finite entries in the state slabs of the live rows, by step', bad)
+    assert np.isfinite(raw[:, :54, :B, :]).all()
+    for name, got, ref in (('g_past', g_past, past.grad.numpy()), ('g_z', g_z, z.grad.numpy())):
+        assert np.isfinite(got).all(), name
+        e[name] = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+        assert e[name] < GRAD_RTOL, e
+    return e
+
+
 def check_rotations_golden(lib, device):
     gd = golden('rotations.npz')
     aa = torch.tensor(gd['aa']).to(device).requires_grad_(True)

@@ -13,6 +13,7 @@
 #define HA_SIMT_EMU 1
 #include <atomic>
 #include <barrier>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -56,6 +57,8 @@ struct BlockCtx {
 };
 extern thread_local BlockCtx* t_ctx;
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+extern int g_resident_blocks;      // > 0: the next launches run all their blocks concurrently (teams of the persistent kernels), own LDS each
+float* block_lds();                // the calling work-item's block's dynamic LDS
 inline int wave_id() { return (int)(t_threadIdx.x >> 6); }
 inline int lane_id() { return (int)(t_threadIdx.x & 63); }
 inline void wave_sync() { t_ctx->wave_bar[wave_id()]->arrive_and_wait(); }
@@ -106,7 +109,12 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
 static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
-static inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+// (resident teams: a polling work-item sleeps instead of spinning -- thousands of OS threads share a few cores with the producers they wait for)
+static inline void __builtin_amdgcn_s_sleep(int) {
+  if (simt_emu::g_resident_blocks > 0) std::this_thread::sleep_for(std::chrono::milliseconds(20));
+  else std::this_thread::yield();
+}
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return std::atomic_ref<unsigned>(*p).fetch_add(v); }
 // buffer descriptor + raw buffer loads (the exchange sweeps of rollout_persist.hip): base pointer + byte offset
 struct __amdgpu_buffer_rsrc_t { const unsigned char* base; };
 static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(const void* p, int, int, int) { return __amdgpu_buffer_rsrc_t{static_cast<const unsigned char*>(p)}; }

@@ -425,3 +425,100 @@ extern "C" int ha_emu_pipe_layers_t(const float* w0, const float* w1, const floa
   offsets[0] = ha::QX_GA3; offsets[1] = ha::QX_GA2; offsets[2] = ha::QX_GA1; offsets[3] = ha::QX_GX0;
   return HA_OK;
 }
+
+static int emu_persist_team(int B, int S, const float* const* w, const float* const* bs, const float* const* gam, const float* const* bet,
+                            const float* past_in0, const float* z_seq, float* world, float* xT, float* raw, unsigned* err,
+                            const float* g_world, float* g_past, float* g_z, unsigned* err_bwd) {
+  using namespace ha;
+  if (B < 1 || B > ROWS || S < 1) return HA_ERR_INVALID_ARG;
+  std::vector<float> wr((size_t)NWAVES_TEAM * NREG * 64, 0.f);
+  for (int l = 0; l < 4; ++l) pack_forward_layer(l, w[l], wr);
+  const int bpad[4] = {P_H0, P_H1, P_H2, P_RAWPAD}, nout[4] = {P_H0, P_H1, P_H2, P_RAW};
+  std::vector<float> bias[4];
+  for (int l = 0; l < 4; ++l) {
+    bias[l].assign(bpad[l], 0.f);
+    for (int i = 0; i < nout[l]; ++i) bias[l][i] = bs[l][i];
+  }
+  // a private stash: per step [G 32 x 12 | slabs 1024, 1024, 512, 224 x 32 | statistics 3 x 16 x 32 x 2 | glue record 32 x 32 | team layout 32 x (1024, 1024, 512)]
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t r = o; o += (n + 63) / 64 * 64; return r; };
+  PersistArgs a;
+  memset(&a, 0, sizeof(a));
+  a.off_G = take(32 * 12);
+  for (int l = 0; l < 4; ++l) a.off_dec[l] = take((size_t)bpad[l] * 32);
+  for (int l = 0; l < 3; ++l) a.off_gn[l] = take(16 * 32 * 2);
+  a.off_gl = take(32 * 32);
+  for (int l = 0; l < 3; ++l) a.off_ht[l] = take((size_t)32 * nout[l]);
+  a.per_step = o;
+  const unsigned nanbits = 0x7fc00000u;
+  float nanv;
+  memcpy(&nanv, &nanbits, 4);
+  // (every buffer the kernels write starts NaN-filled, like the GPU tier's poisoned allocations)
+  std::vector<float> steps((size_t)(S + 1) * a.per_step, nanv), xTv((size_t)(S + 1) * P_DINP * 32, nanv), t2j(32 * 3, nanv);
+  std::vector<unsigned char> xch(XCH_BYTES, 0);
+  std::vector<float> worldv((size_t)B * S * P_STATE, nanv);
+  unsigned errw = 0;
+  a.B = B; a.S = S;
+  a.Wreg = wr.data();
+  for (int l = 0; l < 4; ++l) a.bias[l] = bias[l].data();
+  for (int l = 0; l < 3; ++l) { a.gamma[l] = gam[l]; a.beta[l] = bet[l]; }
+  a.past_in0 = past_in0; a.z_seq = z_seq; a.world = worldv.data(); a.xT = xTv.data(); a.steps = steps.data();
+  a.t2j = t2j.data();
+  a.xch = xch.data();
+  a.err = &errw;
+  a.hidden_slabs = 1;
+  simt_emu::g_resident_blocks = TEAM_CUS;
+  hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(TEAM_CUS), dim3(256), 0, nullptr, a);
+  simt_emu::g_resident_blocks = 0;
+  memcpy(world, worldv.data(), worldv.size() * sizeof(float));
+  memcpy(xT, xTv.data(), xTv.size() * sizeof(float));
+  for (int t = 0; t < S; ++t) memcpy(raw + (size_t)t * P_RAWPAD * 32, steps.data() + (size_t)t * a.per_step + a.off_dec[3], (size_t)P_RAWPAD * 32 * sizeof(float));
+  *err = errw;
+  if (!g_world) return HA_OK;
+  // ---- the adjoint over the forward's stash (no prior part: gx_pri = null) -----------------------------------------------------------------
+  std::vector<float> wb((size_t)NWAVES_TEAM * (NREG_B_ALL + BC0_LDS) * 64, 0.f);
+  pack_backward(w, wb);
+  PersistBwdArgs q;
+  memset(&q, 0, sizeof(q));
+  q.B = B; q.S = S;
+  q.Wreg = wb.data();
+  for (int l = 0; l < 3; ++l) { q.gamma[l] = gam[l]; q.beta[l] = bet[l]; }
+  q.g_world = g_world; q.gx_pri = nullptr; q.gxp_pad = 0;
+  q.xT = xTv.data(); q.steps = steps.data(); q.per_step = a.per_step; q.off_G = a.off_G;
+  for (int l = 0; l < 4; ++l) q.off_dec[l] = a.off_dec[l];
+  for (int l = 0; l < 3; ++l) { q.off_gn[l] = a.off_gn[l]; q.off_ht[l] = a.off_ht[l]; }
+  q.off_gl = a.off_gl;
+  q.t2j = t2j.data();
+  std::vector<float> gpast((size_t)B * P_DIN, nanv), dzp((size_t)S * DZ_SLOTS * 32 * P_ZD, nanv), gz((size_t)B * S * P_ZD, nanv);
+  q.g_past0 = gpast.data(); q.dz_part = dzp.data();
+  std::fill(xch.begin(), xch.end(), (unsigned char)0);
+  q.xch = xch.data();
+  unsigned errb = 0;
+  q.err = &errb;
+  simt_emu::g_resident_blocks = TEAM_CUS;
+  hipLaunchKernelGGL(rollout_persist_bwd_kernel<false>, dim3(TEAM_CUS), dim3(256), 0, nullptr, q);
+  simt_emu::g_resident_blocks = 0;
+  const int n = B * S * P_ZD;
+  hipLaunchKernelGGL(dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)dzp.data(), gz.data(), (const float*)nullptr, B, S);
+  memcpy(g_past, gpast.data(), gpast.size() * sizeof(float));
+  memcpy(g_z, gz.data(), gz.size() * sizeof(float));
+  *err_bwd = errb;
+  return HA_OK;
+}
+
+// ---- the WHOLE persistent kernels (B <= 4: one team) with the team's 32 blocks resident at the same time ---------------------------------------
+// Forward: team formation from the block index, the step loop, every exchange hand-off through tagged granules, GroupNorm on the consumer side, the
+// glue chains, copy_out -- every block on its own NaN-filled LDS, every output buffer NaN-filled.  w / b: the decoder's four Linear layers
+// ([out][in] row-major, biases), g / be: the GroupNorm affines of layers 1 .. 3.  Outputs: world [B][S][348], xT [(S + 1)][340][32] (the state
+// slabs the prior network reads: quad layout), raw [S][224][32] (decoder outputs, quad layout), err (the kernel's error word).
+// With g_world [B][S][348] != null the one-launch ADJOINT runs over the forward's stash: g_past [B][339], g_z [B][S][48], err_bwd.
+extern "C" int ha_emu_persist_team(int B, int S, const float* w0, const float* w1, const float* w2, const float* w3, const float* b0, const float* b1,
+                                   const float* b2, const float* b3, const float* g1, const float* be1, const float* g2, const float* be2,
+                                   const float* g3, const float* be3, const float* past_in0, const float* z_seq, float* world, float* xT, float* raw,
+                                   unsigned* err, const float* g_world, float* g_past, float* g_z, unsigned* err_bwd) {
+  const float* w[4] = {w0, w1, w2, w3};
+  const float* bs[4] = {b0, b1, b2, b3};
+  const float* gam[3] = {g1, g2, g3};
+  const float* bet[3] = {be1, be2, be3};
+  return emu_persist_team(B, S, w, bs, gam, bet, past_in0, z_seq, world, xT, raw, err, g_world, g_past, g_z, err_bwd);
+}
