@@ -512,6 +512,48 @@ def check_persistent_kernels_whole_team(emu_lib, B, S, seed=0):
     return e
 
 
+def check_pipelined_kernels_whole_team(emu_lib, B, S, seed=0):
+    """The pipelined roll-out kernels (rollout_pipe.inc, 32 < B <= 256) as a whole on the host emulator, for ONE resident team: layer roles on
+    5 / 16 / 8 / 2 CUs + the glue CU, NG = ceil(B / 32) groups of four sequences flowing through them, forward and one-launch adjoint, on NaN-filled
+    LDS and buffers.  Team 0 owns sequences 32 g + 0 .. 3 of every tile g: those rows against the oracle at the flat bars (the other teams are not
+    resident; their rows stay NaN)."""
+    import ctypes as C
+    dll = emu_lib._dll
+    NG = (B + 31) // 32
+    rows = [32 * g + i for g in range(NG) for i in range(4) if 32 * g + i < B]
+    sd = synth.humor_state_dict(seed=seed)
+    g = torch.Generator().manual_seed(seed + 5)
+    past = canonical_state(B, g).requires_grad_(True)
+    z = torch.randn(B, S, 48, generator=g).requires_grad_(True)
+    gw = torch.randn(B, S, 348, generator=g)
+    f = lambda t: np.ascontiguousarray(t.detach().float().numpy())
+    arrs = [f(sd[f'decoder.net.{i}.weight']) for i in (0, 3, 6, 9)] + [f(sd[f'decoder.net.{i}.bias']) for i in (0, 3, 6, 9)]
+    for i in (1, 4, 7):
+        arrs += [f(sd[f'decoder.net.{i}.weight']), f(sd[f'decoder.net.{i}.bias'])]
+    pin, zin, gwn = f(past), f(z), f(gw)
+    world, xT = np.zeros((B, S, 348), np.float32), np.zeros((S + 1, NG, 85, 32, 4), np.float32)
+    g_past, g_z = np.zeros((B, 339), np.float32), np.zeros((B, S, 48), np.float32)
+    err, errb = C.c_uint(0), C.c_uint(0)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    fn = dll.ha_emu_pipe_team
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 18 + [C.POINTER(C.c_uint), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint)]
+    assert fn(B, S, *[P(a) for a in arrs], P(pin), P(zin), P(world), P(xT), C.byref(err), P(gwn), P(g_past), P(g_z), C.byref(errb)) == 0
+    assert err.value == 0 and errb.value == 0, (hex(err.value), hex(errb.value))
+    w_ref, _ = H.roll_out(sd, past, z)
+    (w_ref * gw).sum().backward()
+    e = {'world': float(np.abs(world[rows] - w_ref.detach().numpy()[rows]).max())}
+    assert np.isfinite(world[rows]).all() and e['world'] < FWD_TOL, e
+    nl = [min(4, B - 32 * gg) for gg in range(NG)]
+    bad = [int(sum((~np.isfinite(xT[t, gg, :, :nl[gg], :])).sum() for gg in range(NG))) for t in range(S + 1)]
+    assert not any(bad), ('non-finite entries in the state slabs of the live rows, by step', bad)
+    for name, got, ref in (('g_past', g_past, past.grad.numpy()), ('g_z', g_z, z.grad.numpy())):
+        assert np.isfinite(got[rows]).all(), name
+        e[name] = float(np.abs(got[rows] - ref[rows]).max() / max(1.0, np.abs(ref).max()))
+        assert e[name] < GRAD_RTOL, e
+    return e
+
+
 def check_rotations_golden(lib, device):
     gd = golden('rotations.npz')
     aa = torch.tensor(gd['aa']).to(device).requires_grad_(True)

@@ -522,3 +522,90 @@ extern "C" int ha_emu_persist_team(int B, int S, const float* w0, const float* w
   const float* bet[3] = {be1, be2, be3};
   return emu_persist_team(B, S, w, bs, gam, bet, past_in0, z_seq, world, xT, raw, err, g_world, g_past, g_z, err_bwd);
 }
+
+// ---- the WHOLE pipelined kernels (32 < B <= 256) for ONE team: rows 4 team .. 4 team + 3 of every 32-row tile, i.e. with team 0 resident the
+// sequences 32 g + 0 .. 3 of the NG = ceil(B / 32) tiles (the other teams' rows stay NaN in the outputs and are not compared).  Layer roles 5 / 16 /
+// 8 / 2 CUs + the glue CU, groups flowing through them, forward and one-launch adjoint.  Buffers: world [B][S][348], xT [(S + 1)][NG][340][32],
+// g_past [B][339], g_z [B][S][48].
+extern "C" int ha_emu_pipe_team(int B, int S, const float* w0, const float* w1, const float* w2, const float* w3, const float* b0, const float* b1,
+                                const float* b2, const float* b3, const float* g1, const float* be1, const float* g2, const float* be2,
+                                const float* g3, const float* be3, const float* past_in0, const float* z_seq, float* world, float* xT,
+                                unsigned* err, const float* g_world, float* g_past, float* g_z, unsigned* err_bwd) {
+  using namespace ha;
+  if (B <= NTEAMS * ROWS || B > 32 * PG_MAX || S < 1) return HA_ERR_INVALID_ARG;
+  const float* w[4] = {w0, w1, w2, w3};
+  const float* bs[4] = {b0, b1, b2, b3};
+  const float* gam[3] = {g1, g2, g3};
+  const float* bet[3] = {be1, be2, be3};
+  const int NG = (B + 31) / 32;
+  std::vector<float> wp((size_t)NWAVES_TEAM * PF_NREG * 64, 0.f);
+  pack_pipe_forward(w, wp);
+  const int bpad[4] = {P_H0, P_H1, P_H2, P_RAWPAD}, nout[4] = {P_H0, P_H1, P_H2, P_RAW};
+  std::vector<float> bias[4];
+  for (int l = 0; l < 4; ++l) {
+    bias[l].assign(bpad[l], 0.f);
+    for (int i = 0; i < nout[l]; ++i) bias[l][i] = bs[l][i];
+  }
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t r = o; o += (n + 63) / 64 * 64; return r; };
+  PipeArgs a;
+  memset(&a, 0, sizeof(a));
+  const size_t RT = NG;
+  a.off_G = take(RT * 32 * 12);
+  for (int l = 0; l < 4; ++l) { a.off_dec[l] = take(RT * bpad[l] * 32); a.dec_pad[l] = bpad[l]; }
+  for (int l = 0; l < 3; ++l) a.off_gn[l] = take(RT * 16 * 32 * 2);
+  a.off_gl = take(RT * 32 * 32);
+  for (int l = 0; l < 3; ++l) a.off_ht[l] = take(RT * 32 * nout[l]);
+  a.per_step = o;
+  const unsigned nanbits = 0x7fc00000u;
+  float nanv;
+  memcpy(&nanv, &nanbits, 4);
+  std::vector<float> steps((size_t)(S + 1) * a.per_step, nanv), xTv((size_t)(S + 1) * NG * P_DINP * 32, nanv), t2j((size_t)NG * 32 * 3, nanv);
+  std::vector<unsigned char> xch(PX_BYTES, 0);
+  std::vector<float> worldv((size_t)B * S * P_STATE, nanv);
+  unsigned errw = 0;
+  a.B = B; a.S = S; a.NG = NG;
+  a.Wreg = wp.data();
+  for (int l = 0; l < 4; ++l) a.bias[l] = bias[l].data();
+  for (int l = 0; l < 3; ++l) { a.gamma[l] = gam[l]; a.beta[l] = bet[l]; }
+  a.past_in0 = past_in0; a.z_seq = z_seq; a.world = worldv.data(); a.xT = xTv.data(); a.steps = steps.data();
+  a.t2j = t2j.data();
+  a.hidden_slabs = 1;
+  a.xch = xch.data();
+  a.err = &errw;
+  simt_emu::g_resident_blocks = TEAM_CUS;
+  hipLaunchKernelGGL(rollout_pipe_fwd_kernel<false>, dim3(TEAM_CUS), dim3(256), 0, nullptr, a);
+  simt_emu::g_resident_blocks = 0;
+  memcpy(world, worldv.data(), worldv.size() * sizeof(float));
+  memcpy(xT, xTv.data(), xTv.size() * sizeof(float));
+  *err = errw;
+  if (!g_world) return HA_OK;
+  std::vector<float> wq((size_t)NWAVES_TEAM * (QB_NREG + QB_NLW) * 64, 0.f);
+  pack_pipe_backward(w, wq);
+  PipeBwdArgs q;
+  memset(&q, 0, sizeof(q));
+  q.B = B; q.S = S; q.NG = NG;
+  q.Wreg = wq.data();
+  for (int l = 0; l < 3; ++l) { q.gamma[l] = gam[l]; q.beta[l] = bet[l]; }
+  q.g_world = g_world; q.gx_pri = nullptr; q.gxp_pad = 0;
+  q.xT = xTv.data(); q.steps = steps.data(); q.per_step = a.per_step; q.off_G = a.off_G; q.off_gl = a.off_gl;
+  for (int l = 0; l < 4; ++l) { q.off_dec[l] = a.off_dec[l]; q.dec_pad[l] = a.dec_pad[l]; }
+  for (int l = 0; l < 3; ++l) { q.off_gn[l] = a.off_gn[l]; q.off_ht[l] = a.off_ht[l]; }
+  q.t2j = t2j.data();
+  std::vector<float> gpast((size_t)B * P_DIN, nanv), dzp((size_t)S * QS_SLOTS * NG * 32 * P_ZD, nanv), gz((size_t)B * S * P_ZD, nanv);
+  q.g_past0 = gpast.data(); q.dz_part = dzp.data();
+  std::fill(xch.begin(), xch.end(), (unsigned char)0);
+  q.xch = xch.data();
+  unsigned errb = 0;
+  q.err = &errb;
+  simt_emu::g_resident_blocks = TEAM_CUS;
+  hipLaunchKernelGGL(rollout_pipe_bwd_kernel<false>, dim3(TEAM_CUS), dim3(256), 0, nullptr, q);
+  simt_emu::g_resident_blocks = 0;
+  const int n = B * S * P_ZD;
+  hipLaunchKernelGGL(pipe_dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)dzp.data(), gz.data(), (const float*)nullptr, B, S, NG * 32);
+  memcpy(g_past, gpast.data(), gpast.size() * sizeof(float));
+  memcpy(g_z, gz.data(), gz.size() * sizeof(float));
+  *err_bwd = errb;
+  return HA_OK;
+}
+

@@ -31,6 +31,14 @@ def test_emu_persistent_kernels_whole_team(emu_lib, B, S):
     print(B, S, RC.check_persistent_kernels_whole_team(emu_lib, B, S, seed=B + S))
 
 
+@pytest.mark.slow          # (~2 minutes per case on the emulator)
+@pytest.mark.parametrize('B,S', [(36, 2), (33, 3)])
+def test_emu_pipelined_kernels_whole_team(emu_lib, B, S):
+    """The pipelined kernels for more than 32 sequences as a whole in the CPU tier: one resident team (layer roles + glue CU, two groups in flight),
+    forward and one-launch adjoint against the oracle (RC.check_pipelined_kernels_whole_team); 33: a tile with one live row."""
+    print(B, S, RC.check_pipelined_kernels_whole_team(emu_lib, B, S, seed=B + S))
+
+
 @pytest.mark.slow
 def test_emu_rollout_two_steps(emu_lib):
     # MFMA layer kernel (all four prologue modes), glue forward/backward, dz / past_in0 collection
