@@ -8,7 +8,9 @@
 // humor_amd raises if libhumor_amd.so (the gfx950 build) is missing.
 //
 // Model: one OS thread per work-item of a block (blocks run one after another), std::barrier for
-// __syncthreads, a per-wave exchange buffer + barrier for cross-lane ops.  Wave size 64.
+// __syncthreads, a per-wave exchange buffer + barrier for cross-lane ops.  Wave size 64.  Every launch starts on
+// NaN-filled LDS.  Resident teams (simt_emu::g_resident_blocks > 0): ALL blocks of the launch run at the same time,
+// each with its own context and LDS -- the persistent roll-out kernels hand activations from block to block.
 #pragma once
 #define HA_SIMT_EMU 1
 #include <atomic>
