@@ -430,7 +430,8 @@ static int emu_persist_team(int B, int S, const float* const* w, const float* co
                             const float* past_in0, const float* z_seq, float* world, float* xT, float* raw, unsigned* err,
                             const float* g_world, float* g_past, float* g_z, unsigned* err_bwd) {
   using namespace ha;
-  if (B < 1 || B > ROWS || S < 1) return HA_ERR_INVALID_ARG;
+  if (B < 1 || B > ROWS * NTEAMS || S < 1) return HA_ERR_INVALID_ARG;
+  const int nteams = (B + ROWS - 1) / ROWS;          // one resident team per four sequences (team = block index / 32 on the emulator)
   std::vector<float> wr((size_t)NWAVES_TEAM * NREG * 64, 0.f);
   for (int l = 0; l < 4; ++l) pack_forward_layer(l, w[l], wr);
   const int bpad[4] = {P_H0, P_H1, P_H2, P_RAWPAD}, nout[4] = {P_H0, P_H1, P_H2, P_RAW};
@@ -467,8 +468,8 @@ static int emu_persist_team(int B, int S, const float* const* w, const float* co
   a.xch = xch.data();
   a.err = &errw;
   a.hidden_slabs = 1;
-  simt_emu::g_resident_blocks = TEAM_CUS;
-  hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(TEAM_CUS), dim3(256), 0, nullptr, a);
+  simt_emu::g_resident_blocks = TEAM_CUS * nteams;
+  hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(TEAM_CUS * nteams), dim3(256), 0, nullptr, a);
   simt_emu::g_resident_blocks = 0;
   memcpy(world, worldv.data(), worldv.size() * sizeof(float));
   memcpy(xT, xTv.data(), xTv.size() * sizeof(float));
@@ -495,8 +496,8 @@ static int emu_persist_team(int B, int S, const float* const* w, const float* co
   q.xch = xch.data();
   unsigned errb = 0;
   q.err = &errb;
-  simt_emu::g_resident_blocks = TEAM_CUS;
-  hipLaunchKernelGGL(rollout_persist_bwd_kernel<false>, dim3(TEAM_CUS), dim3(256), 0, nullptr, q);
+  simt_emu::g_resident_blocks = TEAM_CUS * nteams;
+  hipLaunchKernelGGL(rollout_persist_bwd_kernel<false>, dim3(TEAM_CUS * nteams), dim3(256), 0, nullptr, q);
   simt_emu::g_resident_blocks = 0;
   const int n = B * S * P_ZD;
   hipLaunchKernelGGL(dz_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, (const float*)dzp.data(), gz.data(), (const float*)nullptr, B, S);
@@ -506,7 +507,7 @@ static int emu_persist_team(int B, int S, const float* const* w, const float* co
   return HA_OK;
 }
 
-// ---- the WHOLE persistent kernels (B <= 4: one team) with the team's 32 blocks resident at the same time ---------------------------------------
+// ---- the WHOLE persistent kernels (one team per four sequences) with every team's 32 blocks resident at the same time ---------------------------------------
 // Forward: team formation from the block index, the step loop, every exchange hand-off through tagged granules, GroupNorm on the consumer side, the
 // glue chains, copy_out -- every block on its own NaN-filled LDS, every output buffer NaN-filled.  w / b: the decoder's four Linear layers
 // ([out][in] row-major, biases), g / be: the GroupNorm affines of layers 1 .. 3.  Outputs: world [B][S][348], xT [(S + 1)][340][32] (the state
