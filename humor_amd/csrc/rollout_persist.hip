@@ -78,7 +78,11 @@ constexpr int L_SGL = L_SG + 2 * L_GSZ, L_T2J = L_SGL + ROWS * 32, L_ZERO = L_T2
 constexpr int COPY_WORLD = ROWS * P_STATE, COPY_XT = ROWS * P_DINP, COPY_G = ROWS * 12, COPY_GL = ROWS * 32;
 constexpr int COPY_TOTAL = COPY_WORLD + COPY_XT + COPY_G + COPY_GL;
 constexpr int COPY_PER_CU = (COPY_TOTAL + TEAM_CUS - 1) / TEAM_CUS;
+#ifdef HA_SIMT_EMU
+static int SPIN_LIMIT = 40000;           // (host emulator: a poll sleeps 20 ms; the failure-protocol test lowers the bound -- tests/simt_emu/rollout_persist_emu.cpp)
+#else
 constexpr int SPIN_LIMIT = 40000;        // bounded waits (~1 us per spin)
+#endif
 
 // ---- persistent adjoint: transposed layers, K chunks = forward output channels / 16 ---------------------------------------------
 constexpr int BC3 = P_RAWPAD / 16, BC2 = P_H2 / 16, BC1 = P_H1 / 16, BC0 = P_H0 / 16;

@@ -426,6 +426,15 @@ extern "C" int ha_emu_pipe_layers_t(const float* w0, const float* w1, const floa
   return HA_OK;
 }
 
+// test knobs of the whole-kernel hooks: the failure injection of ha_tune_set("rollout_persist_inject") (member 3 of team 0 leaves at once) and the
+// bound of the kernels' waits in polls (a poll sleeps 20 ms on the emulator: 1500 polls = 30 s, far more than a healthy hand-off takes at these sizes)
+static int g_emu_inject = 0;
+extern "C" int ha_emu_persist_knobs(int inject, int spin_limit) {
+  g_emu_inject = inject;
+  ha::SPIN_LIMIT = spin_limit > 0 ? spin_limit : 40000;
+  return HA_OK;
+}
+
 static int emu_persist_team(int B, int S, const float* const* w, const float* const* bs, const float* const* gam, const float* const* bet,
                             const float* past_in0, const float* z_seq, float* world, float* xT, float* raw, unsigned* err,
                             const float* g_world, float* g_past, float* g_z, unsigned* err_bwd) {
@@ -468,6 +477,7 @@ static int emu_persist_team(int B, int S, const float* const* w, const float* co
   a.xch = xch.data();
   a.err = &errw;
   a.hidden_slabs = 1;
+  a.inject = g_emu_inject;
   simt_emu::g_resident_blocks = TEAM_CUS * nteams;
   hipLaunchKernelGGL(rollout_persist_fwd_kernel<false>, dim3(TEAM_CUS * nteams), dim3(256), 0, nullptr, a);
   simt_emu::g_resident_blocks = 0;
