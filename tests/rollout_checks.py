@@ -545,6 +545,37 @@ def check_persistent_failure_protocol_whole_team(emu_lib, B=6, S=1, seed=0):
     return e
 
 
+def check_pipelined_failure_protocol_whole_team(emu_lib, B=33, S=1, seed=0):
+    """The same protocol in the pipelined forward (one resident team): a layer-0 CU that leaves at once -> every row the team owns, in EVERY tile, is NaN
+    and the error word is 0x600 | team."""
+    import ctypes as C
+    dll = emu_lib._dll
+    NG = (B + 31) // 32
+    rows = [32 * g + i for g in range(NG) for i in range(4) if 32 * g + i < B]
+    sd = synth.humor_state_dict(seed=seed)
+    g = torch.Generator().manual_seed(seed + 5)
+    past, z = canonical_state(B, g), torch.randn(B, S, 48, generator=g)
+    f = lambda t: np.ascontiguousarray(t.detach().float().numpy())
+    arrs = [f(sd[f'decoder.net.{i}.weight']) for i in (0, 3, 6, 9)] + [f(sd[f'decoder.net.{i}.bias']) for i in (0, 3, 6, 9)]
+    for i in (1, 4, 7):
+        arrs += [f(sd[f'decoder.net.{i}.weight']), f(sd[f'decoder.net.{i}.bias'])]
+    pin, zin = f(past), f(z)
+    world, xT = np.zeros((B, S, 348), np.float32), np.zeros((S + 1, NG, 85, 32, 4), np.float32)
+    err, errb = C.c_uint(0), C.c_uint(0)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    fn = dll.ha_emu_pipe_team
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 18 + [C.POINTER(C.c_uint), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint)]
+    dll.ha_emu_persist_knobs(1, 1500)
+    try:
+        assert fn(B, S, *[P(a) for a in arrs], P(pin), P(zin), P(world), P(xT), C.byref(err), None, None, None, C.byref(errb)) == 0
+    finally:
+        dll.ha_emu_persist_knobs(0, 0)
+    assert err.value == 0x600, hex(err.value)
+    assert np.isnan(world[rows]).all(), 'the incomplete team\'s rows must be NaN in every tile'
+    return rows
+
+
 def check_pipelined_kernels_whole_team(emu_lib, B, S, seed=0):
     """The pipelined roll-out kernels (rollout_pipe.inc, 32 < B <= 256) as a whole on the host emulator, for ONE resident team: layer roles on
     5 / 16 / 8 / 2 CUs + the glue CU, NG = ceil(B / 32) groups of four sequences flowing through them, forward and one-launch adjoint, on NaN-filled

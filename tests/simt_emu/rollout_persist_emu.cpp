@@ -582,6 +582,7 @@ extern "C" int ha_emu_pipe_team(int B, int S, const float* w0, const float* w1, 
   a.past_in0 = past_in0; a.z_seq = z_seq; a.world = worldv.data(); a.xT = xTv.data(); a.steps = steps.data();
   a.t2j = t2j.data();
   a.hidden_slabs = 1;
+  a.inject = g_emu_inject;
   a.xch = xch.data();
   a.err = &errw;
   simt_emu::g_resident_blocks = TEAM_CUS;

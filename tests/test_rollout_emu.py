@@ -31,11 +31,12 @@ def test_emu_persistent_kernels_whole_team(emu_lib, B, S):
     print(B, S, RC.check_persistent_kernels_whole_team(emu_lib, B, S, seed=B + S))
 
 
-@pytest.mark.slow          # (~1.5 minutes: two resident teams + 30 s of bounded waits)
+@pytest.mark.slow          # (~3 minutes: resident teams + 30 s of bounded waits, persistent then pipelined forward)
 def test_emu_persistent_failure_protocol_whole_team(emu_lib):
     """The bounded-wait failure protocol of the persistent forward in the CPU tier: a team member that never publishes -> that team's rows NaN, error
     word 0x200 | team, the other resident team unaffected (RC.check_persistent_failure_protocol_whole_team)."""
     print(RC.check_persistent_failure_protocol_whole_team(emu_lib))
+    print('pipelined: NaN rows', RC.check_pipelined_failure_protocol_whole_team(emu_lib))
 
 
 @pytest.mark.slow          # (~2 minutes per case on the emulator)
