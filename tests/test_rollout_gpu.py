@@ -294,6 +294,36 @@ def test_pipelined_rollout_matches_launch_chain(gpu_lib, dev, B, S):
     print('pipelined vs chain', B, S, RC.check_persistent_vs_chain(gpu_lib, dev, B, S, seed=B, variant=1, launches_per_call=(B + 255) // 256))
 
 
+@pytest.mark.parametrize('B', [260, 288, 100])
+def test_pipelined_forward_with_the_launch_chain_adjoint_knob(gpu_lib, dev, B):
+    """ha_tune_set("rollout_pipe_bwd", 0) -- pipelined forward (hidden slabs written), launch-chain adjoint for the pipelined chunks; with 260 /
+    288 sequences the tail of 4 / 32 goes to the B <= 32 kernels, whose one-launch adjoint reads a stash that carries slabs (mode 1).  Against the launch
+    chain in both directions."""
+    hm, _ = RC.make_model(gpu_lib, dev, seed=B, contractive=True)
+    g = torch.Generator().manual_seed(B)
+    S = 3
+    past, z = RC.canonical_state(B, g).to(dev), torch.randn(B, S, 48, generator=g).to(dev)
+    gw = torch.randn(B, S, 348, generator=g).to(dev)
+    res = []
+    try:
+        for persist, pipe_bwd in ((0, 1), (1, 0)):
+            gpu_lib.call('ha_tune_set', b'rollout_persist', persist)
+            gpu_lib.call('ha_tune_set', b'rollout_pipe_bwd', pipe_bwd)
+            p, zz = past.clone().requires_grad_(True), z.clone().requires_grad_(True)
+            out, (pm, pv) = hm.roll_out(p, None, S, z_seq=zz, return_prior=True)
+            w = RC.world_of(out)
+            ((w * gw).sum() + pm.sum() + pv.sum()).backward()
+            res.append((w.detach(), pm.detach(), p.grad.clone(), zz.grad.clone()))
+    finally:
+        gpu_lib.call('ha_tune_set', b'rollout_persist', 1)
+        gpu_lib.call('ha_tune_set', b'rollout_pipe_bwd', 1)
+    for name, a, b, tol in zip(('world', 'pm', 'g_past', 'g_z'), res[0], res[1], (2e-5, 2e-5, 3e-4, 3e-4)):
+        e = (a - b).abs().reshape(B, -1).amax(1) / max(1.0, a.abs().max().item())
+        assert torch.isfinite(b).all(), name
+        # (per sequence; at most one sequence on another ReLU branch per case: the kink bar of the pipelined-vs-chain test)
+        assert (e > tol).sum().item() <= 1 and e.max().item() <= RC.KINK_RTOL, (name, e.max().item(), int((e > tol).sum()))
+
+
 def test_pipelined_rollout_determinism_and_reuse(gpu_lib, dev):
     """Back-to-back pipelined launches on one network (fresh stash each): bit-identical results in both directions, no stale granules."""
     hm, _ = RC.make_model(gpu_lib, dev, contractive=True)
